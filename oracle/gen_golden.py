@@ -1,0 +1,110 @@
+"""Generate golden vectors under tests/golden/ by RUNNING THE REFERENCE ITSELF.
+
+Build-container only: imports the unmodified reference modules from /root/reference
+(through the omegaconf/kornia stand-ins in oracle/stubs) on CPU fp32, feeds them seeded
+inputs and seeded weights (shared with the oracle through the reference's own
+state_dict names) and stores inputs, outputs, losses and gradients as small .npz
+fixtures.  /root/reference does not exist on the GPU box; tests only read the .npz.
+
+    python oracle/gen_golden.py            # rewrites tests/golden/*.npz
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle", "stubs"))
+sys.path.append("/root/reference")
+
+from glue_factory_amd.synthetic import make_pairs  # noqa: E402
+from oracle import lightglue_oracle as lgo  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def _np(d, prefix=""):
+    out = {}
+    for k, v in d.items():
+        if torch.is_tensor(v):
+            out[prefix + k] = v.detach().cpu().numpy()
+    return out
+
+
+def ref_lightglue(n_layers, dim, heads, params, filter_threshold=0.0):
+    from gluefactory.models.matchers.lightglue import LightGlue
+
+    model = LightGlue({"n_layers": n_layers, "descriptor_dim": dim, "input_dim": dim,
+                       "num_heads": heads, "weights": None, "flash": False,
+                       "checkpointed": False, "filter_threshold": filter_threshold})
+    missing = model.load_state_dict(params, strict=True)  # asserts the state_dict contract
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return model
+
+
+def gen_lightglue(name, batch, n0, n1, n_layers, dim, heads, seed, size, store_params):
+    torch.manual_seed(seed)
+    params = lgo.init_params(n_layers, dim, heads, seed=seed)
+    data = make_pairs(batch, n0, n1, dim=dim, size=size, seed=seed + 1)
+    model = ref_lightglue(n_layers, dim, heads, params, filter_threshold=0.0)
+    out = {}
+    # ---- eval forward (plain path: no early stop / pruning)
+    model.eval()
+    with torch.no_grad():
+        pe = model(data)
+    out.update(_np({k: pe[k] for k in ("matches0", "matches1", "matching_scores0",
+                                       "matching_scores1", "log_assignment")}, "eval."))
+    # ---- train step: forward + loss + backward
+    model.train()
+    pred = model(data)
+    losses, _ = model.loss(pred, {**pred, **data})
+    losses["total"].mean().backward()
+    out.update(_np({k: pred[k] for k in ("matches0", "matches1", "matching_scores0",
+                                         "matching_scores1", "log_assignment",
+                                         "ref_descriptors0", "ref_descriptors1")}, "train."))
+    out.update(_np({k: v for k, v in losses.items() if torch.is_tensor(v)}, "loss."))
+    grads = {k: p.grad for k, p in model.named_parameters()}
+    if store_params:
+        out.update(_np(params, "param."))
+        out.update(_np(grads, "grad."))
+    else:
+        # parameters are regenerated from the seed by the test; keep checksums + small grads
+        out["param_checksum"] = np.array([float(sum(v.double().abs().sum() for v in params.values()))])
+        for k, g in grads.items():
+            out["gradnorm." + k] = np.array([float(g.double().norm())])
+            if g.numel() <= 1024:
+                out["grad." + k] = g.numpy()
+    out.update(_np({k: v for k, v in data.items() if torch.is_tensor(v)}, "data."))
+    out["data.image_size0"] = data["view0"]["image_size"].numpy()
+    out["data.image_size1"] = data["view1"]["image_size"].numpy()
+    out["meta"] = np.array([batch, n0, n1, n_layers, dim, heads, seed, size[0], size[1]])
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+    print(name, "total loss", losses["total"].tolist(),
+          "matches", (pred["matches0"] > -1).sum(1).tolist())
+
+
+def gen_gt(name, batch, n0, n1, seed):
+    from gluefactory.geometry.gt_generation import gt_matches_from_homography
+
+    data = make_pairs(batch, n0, n1, dim=8, size=(640, 480), seed=seed, with_gt=False)
+    ref = gt_matches_from_homography(data["keypoints0"], data["keypoints1"], data["H_0to1"],
+                                     pos_th=3.0, neg_th=3.0)
+    out = _np({k: data[k] for k in ("keypoints0", "keypoints1", "H_0to1")}, "data.")
+    out.update(_np(ref, "gt."))
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+    print(name, "positives", ref["assignment"].sum((1, 2)).tolist())
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    gen_lightglue("lightglue_small", batch=2, n0=40, n1=48, n_layers=2, dim=64, heads=4,
+                  seed=11, size=(640, 480), store_params=True)
+    gen_lightglue("lightglue_d256", batch=1, n0=72, n1=64, n_layers=2, dim=256, heads=4,
+                  seed=23, size=(1024, 1024), store_params=False)
+    gen_gt("gt_homography", batch=2, n0=96, n1=80, seed=5)
+
+
+if __name__ == "__main__":
+    main()

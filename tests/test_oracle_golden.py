@@ -1,0 +1,76 @@
+"""Pin the CPU oracle against outputs of the reference itself (tests/golden/*.npz,
+produced by oracle/gen_golden.py from /root/reference).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_data, load_golden
+from oracle import lightglue_oracle as lgo
+
+TOL = dict(rtol=1e-4, atol=1e-4)  # north_star: within 1e-4 fp32
+
+
+def _params(z):
+    meta = z["meta"]
+    n_layers, dim, heads, seed = int(meta[3]), int(meta[4]), int(meta[5]), int(meta[6])
+    if any(k.startswith("param.") for k in z):
+        p = {k[6:]: torch.from_numpy(v) for k, v in z.items() if k.startswith("param.")}
+    else:
+        p = lgo.init_params(n_layers, dim, heads, seed=seed)
+        chk = float(sum(v.double().abs().sum() for v in p.values()))
+        assert abs(chk - float(z["param_checksum"][0])) < 1e-6 * chk
+    return p, n_layers, heads
+
+
+@pytest.mark.parametrize("name", ["lightglue_small", "lightglue_d256"])
+def test_forward_eval_matches_reference(name):
+    z = load_golden(name)
+    p, L, H = _params(z)
+    data = golden_data(z)
+    with torch.no_grad():
+        pred = lgo.forward(p, data, L, H, filter_threshold=0.0, training=False)
+    np.testing.assert_allclose(pred["log_assignment"].numpy(), z["eval.log_assignment"], **TOL)
+    np.testing.assert_array_equal(pred["matches0"].numpy(), z["eval.matches0"])
+    np.testing.assert_array_equal(pred["matches1"].numpy(), z["eval.matches1"])
+    np.testing.assert_allclose(pred["matching_scores0"].numpy(), z["eval.matching_scores0"], **TOL)
+    np.testing.assert_allclose(pred["matching_scores1"].numpy(), z["eval.matching_scores1"], **TOL)
+
+
+@pytest.mark.parametrize("name", ["lightglue_small", "lightglue_d256"])
+def test_train_step_matches_reference(name):
+    z = load_golden(name)
+    p, L, H = _params(z)
+    data = golden_data(z)
+    pred, losses, grads = lgo.train_step_grads(p, data, L, H)
+    for k in ("log_assignment", "ref_descriptors0", "ref_descriptors1", "matching_scores0"):
+        np.testing.assert_allclose(pred[k].detach().numpy(), z["train." + k], **TOL)
+    np.testing.assert_array_equal(pred["matches0"].numpy(), z["train.matches0"])
+    loss_keys = [k[5:] for k in z if k.startswith("loss.")]
+    assert set(loss_keys) >= {"total", "last", "nll_pos", "nll_neg", "confidence", "row_norm",
+                              "num_matchable", "num_unmatchable", "assignment_nll"}
+    for k in loss_keys:
+        np.testing.assert_allclose(losses[k].detach().numpy(), z["loss." + k], **TOL)
+    n_checked = 0
+    for k, g in grads.items():
+        if "grad." + k in z:
+            ref = z["grad." + k]
+            scale = max(np.abs(ref).max(), 1e-6)
+            np.testing.assert_allclose(g.numpy() / scale, ref / scale, rtol=1e-3, atol=2e-4,
+                                       err_msg=k)
+            n_checked += 1
+        if "gradnorm." + k in z:
+            ref = float(z["gradnorm." + k][0])
+            assert abs(float(g.double().norm()) - ref) <= 1e-3 * ref + 1e-7, k
+    assert n_checked > 10
+
+
+def test_fp64_oracle_close_to_fp32_reference():
+    """The oracle in fp64 is the tie-breaker for kernel tests; it must sit within the
+    fp32 noise of the fp32 reference run."""
+    z = load_golden("lightglue_small")
+    p, L, H = _params(z)
+    p64 = {k: v.double() for k, v in p.items()}
+    data = golden_data(z, dtype=torch.float64)
+    with torch.no_grad():
+        pred = lgo.forward(p64, data, L, H, training=False)
+    np.testing.assert_allclose(pred["log_assignment"].numpy(), z["eval.log_assignment"], **TOL)
