@@ -1,0 +1,382 @@
+// Assignment head kernels: row/column log-sum-exp, arg-max, materialisation and backward of the
+// double-softmax log assignment with dustbins, all streaming S = a b^T through MFMA tiles so
+// that no N x N similarity tensor is ever read from HBM.
+//
+// Replaces (reference) gluefactory/models/matchers/lightglue.py:256-268
+// (sigmoid_log_double_softmax), :278-287 (MatchAssignment: the `sim` einsum), :293-309
+// (filter_matches), :81-94 (TokenConfidence.loss arg-maxes) and the dense passes of
+// gluefactory/models/utils/losses.py:6-73; gluestick.py:772-783 uses the same kernels with a
+// bin column bias.
+//
+// Common structure: one workgroup = 4 waves owns 128 rows of the "owner" matrix (fragments kept
+// in registers: D/16 k-steps), and streams the other matrix through LDS in 64-row tiles.  The
+// tile is computed as C[tile_row][owner] so every reduction over the streamed axis is
+// lane-local (see gf_common.h).  Kernels that write N x N data make the owner the CONTIGUOUS
+// (column) index of the output so a half-wave writes 32 consecutive elements of one row.
+#include "gf_common.h"
+#include "gf_amd.h"
+
+namespace {
+
+template <typename T, int D> struct ALay {
+    static constexpr int VEC = 16 / sizeof(T);
+    static constexpr int CPR = D / VEC;
+    static constexpr int LDR = D + VEC;
+    static constexpr int TILE = 64 * LDR;  // elements
+};
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <typename T, int D>
+__device__ __forceinline__ void stage_rows(T* lds, const T* g, int row0, int nmax) {
+    using L = ALay<T, D>;
+    for (int c = threadIdx.x; c < 64 * L::CPR; c += 256) {
+        int r = c / L::CPR, cc = c % L::CPR;
+        int gr = min(row0 + r, nmax - 1);
+        u32x4 v = *reinterpret_cast<const u32x4*>(g + (int64_t)gr * D + cc * L::VEC);
+        *reinterpret_cast<u32x4*>(lds + r * L::LDR + cc * L::VEC) = v;
+    }
+}
+
+template <typename T, int D>
+__device__ __forceinline__ void load_owner(Frag<T> (&f)[D / 16], const T* rowptr, int hi) {
+#pragma unroll
+    for (int s = 0; s < D / 16; ++s) f[s] = ld_frag8(rowptr + 16 * s + 8 * hi);
+}
+
+template <typename T, int D>
+__device__ __forceinline__ void mma_tile(f32x16& acc, const T* lds, int i0, const Frag<T> (&f)[D / 16],
+                                         int l31, int hi) {
+    using L = ALay<T, D>;
+    const T* base = lds + (i0 + l31) * L::LDR + 8 * hi;
+#pragma unroll
+    for (int s = 0; s < D / 16; ++s) mma32(acc, ld_frag8(base + 16 * s), f[s]);
+}
+
+struct HeadParams {
+    const void* own;   // owner matrix  [B, No, D]
+    const void* oth;   // streamed matrix [B, Ns, D]
+    int B, No, Ns;
+    const float* sbias;  // per streamed row  [B, Ns] or null
+    const float* obias;  // per owner row     [B, No] or null
+    float alpha;
+    // outputs / extra inputs (kernel specific)
+    float* f0; float* f1; int64_t* i0;
+    const float* g0; const float* g1; const float* g2; const float* g3;
+    const float* G; int64_t ldg; float galpha; float corner;
+    void* out;
+};
+
+#define GF_HEAD_PROLOGUE(T, D)                                                                   \
+    using L = ALay<T, D>;                                                                         \
+    extern __shared__ __attribute__((aligned(16))) char smem[];                                   \
+    T* tile = reinterpret_cast<T*>(smem);                                                         \
+    float* vec0 = reinterpret_cast<float*>(tile + L::TILE);                                       \
+    float* vec1 = vec0 + 64;                                                                      \
+    const int nob = (p.No + 127) / 128;                                                           \
+    const int lb = xcd_remap(blockIdx.x, nob * p.B);                                              \
+    const int ob = lb % nob, b = lb / nob;                                                        \
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;                                   \
+    const int l31 = lane & 31, hi = lane >> 5;                                                    \
+    const int orow = ob * 128 + wave * 32 + l31;                                                  \
+    const int old_ = min(orow, p.No - 1);                                                         \
+    const T* ownp = reinterpret_cast<const T*>(p.own) + (int64_t)b * p.No * D;                    \
+    const T* othp = reinterpret_cast<const T*>(p.oth) + (int64_t)b * p.Ns * D;                    \
+    Frag<T> of[D / 16];                                                                           \
+    load_owner<T, D>(of, ownp + (int64_t)old_ * D, hi);                                           \
+    (void)vec1;
+
+// lse[b, owner] = log sum_s exp(own . oth_s + sbias_s)
+template <typename T, int D>
+__global__ __launch_bounds__(256) void rows_lse_kernel(HeadParams p) {
+    GF_HEAD_PROLOGUE(T, D)
+    float m = GF_NEG_BIG, lsum = 0.f;
+    for (int s0 = 0; s0 < p.Ns; s0 += 64) {
+        __syncthreads();
+        stage_rows<T, D>(tile, othp, s0, p.Ns);
+        if (threadIdx.x < 64) {
+            int si = s0 + threadIdx.x;
+            vec0[threadIdx.x] = (si < p.Ns) ? (p.sbias ? p.sbias[(int64_t)b * p.Ns + si] * GF_LOG2E : 0.f)
+                                            : -INFINITY;
+        }
+        __syncthreads();
+        f32x16 s[2];
+        float mx = GF_NEG_BIG;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+            mma_tile<T, D>(s[kb], tile, kb * 32, of, l31, hi);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 b4 = *reinterpret_cast<const f32x4*>(vec0 + kb * 32 + 8 * g + 4 * hi);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float x = s[kb][4 * g + e] * GF_LOG2E + b4[e];
+                    s[kb][4 * g + e] = x;
+                    mx = fmaxf(mx, x);
+                }
+            }
+        }
+        mx = fmaxf(mx, xhalf(mx));
+        const float mnew = fmaxf(m, mx);
+        float ps = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ps += fast_exp2(s[kb][r] - mnew);
+        lsum = lsum * fast_exp2(m - mnew) + ps;
+        m = mnew;
+    }
+    lsum += xhalf(lsum);
+    if (orow < p.No && hi == 0) p.f0[(int64_t)b * p.No + orow] = (m + fast_log2(lsum)) * GF_LN2;
+}
+
+// max / argmax over streamed rows of alpha * own.oth_s + sbias_s
+template <typename T, int D>
+__global__ __launch_bounds__(256) void rows_argmax_kernel(HeadParams p) {
+    GF_HEAD_PROLOGUE(T, D)
+    float best = -INFINITY;
+    int bidx = 0x7fffffff;
+    for (int s0 = 0; s0 < p.Ns; s0 += 64) {
+        __syncthreads();
+        stage_rows<T, D>(tile, othp, s0, p.Ns);
+        if (threadIdx.x < 64) {
+            int si = s0 + threadIdx.x;
+            vec0[threadIdx.x] = (si < p.Ns) ? (p.sbias ? p.sbias[(int64_t)b * p.Ns + si] : 0.f) : -INFINITY;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            f32x16 s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+            mma_tile<T, D>(s, tile, kb * 32, of, l31, hi);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 b4 = *reinterpret_cast<const f32x4*>(vec0 + kb * 32 + 8 * g + 4 * hi);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float x = p.alpha * s[4 * g + e] + b4[e];
+                    int idx = s0 + kb * 32 + 8 * g + 4 * hi + e;
+                    if (x > best || (x == best && idx < bidx)) { best = x; bidx = idx; }
+                }
+            }
+        }
+    }
+    float ob_ = xhalf(best);
+    int oi = __shfl_xor(bidx, 32);
+    if (ob_ > best || (ob_ == best && oi < bidx)) { best = ob_; bidx = oi; }
+    if (orow < p.No && hi == 0) {
+        p.f0[(int64_t)b * p.No + orow] = best;
+        p.i0[(int64_t)b * p.No + orow] = (bidx == 0x7fffffff) ? 0 : bidx;
+    }
+}
+
+// out[b, s, o] = alpha * oth_s . own_o + sbias_s + obias_o  (+ dustbin row / column / corner)
+// owner = column index of `out` ([B, Ns+1, No+1]); streamed = row index.
+template <typename T, int D>
+__global__ __launch_bounds__(256) void assign_write_kernel(HeadParams p) {
+    GF_HEAD_PROLOGUE(T, D)
+    float* out = reinterpret_cast<float*>(p.out) + (int64_t)b * (p.Ns + 1) * (p.No + 1);
+    const int64_t ldo = p.No + 1;
+    const float ocb = p.obias ? p.obias[(int64_t)b * p.No + old_] : 0.f;
+    for (int s0 = 0; s0 < p.Ns; s0 += 64) {
+        __syncthreads();
+        stage_rows<T, D>(tile, othp, s0, p.Ns);
+        if (threadIdx.x < 64) {
+            int si = min(s0 + (int)threadIdx.x, p.Ns - 1);
+            vec0[threadIdx.x] = p.sbias ? p.sbias[(int64_t)b * p.Ns + si] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            f32x16 s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+            mma_tile<T, D>(s, tile, kb * 32, of, l31, hi);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 b4 = *reinterpret_cast<const f32x4*>(vec0 + kb * 32 + 8 * g + 4 * hi);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    int si = s0 + kb * 32 + 8 * g + 4 * hi + e;
+                    if (si < p.Ns && orow < p.No)
+                        out[(int64_t)si * ldo + orow] = p.alpha * s[4 * g + e] + b4[e] + ocb;
+                }
+            }
+        }
+    }
+    // dustbins: last row for the owned columns, last column by the first block, corner once
+    if (orow < p.No && hi == 0) out[(int64_t)p.Ns * ldo + orow] = p.g1 ? p.g1[(int64_t)b * p.No + orow] : 0.f;
+    if (ob == 0) {
+        for (int si = threadIdx.x; si < p.Ns; si += 256)
+            out[(int64_t)si * ldo + p.No] = p.g0 ? p.g0[(int64_t)b * p.Ns + si] : 0.f;
+        if (threadIdx.x == 0) out[(int64_t)p.Ns * ldo + p.No] = p.corner;
+    }
+}
+
+// dS[b, s, o] = galpha * G[b,s,o] + exp(S - r_s) * gr_s + exp(S - c_o) * gc_o   (S = oth_s . own_o)
+template <typename T, int D>
+__global__ __launch_bounds__(256) void dual_softmax_bwd_kernel(HeadParams p) {
+    GF_HEAD_PROLOGUE(T, D)
+    T* dS = reinterpret_cast<T*>(p.out) + (int64_t)b * p.Ns * p.No;
+    const float c2 = p.g1[(int64_t)b * p.No + old_] * GF_LOG2E;   // column normaliser of the owner
+    const float gco = p.g3[(int64_t)b * p.No + old_];
+    const float* Gb = p.G ? p.G + (int64_t)b * (p.Ns + 1) * p.ldg : nullptr;
+    for (int s0 = 0; s0 < p.Ns; s0 += 64) {
+        __syncthreads();
+        stage_rows<T, D>(tile, othp, s0, p.Ns);
+        if (threadIdx.x < 64) {
+            int si = s0 + threadIdx.x;
+            bool ok = si < p.Ns;
+            vec0[threadIdx.x] = ok ? p.g0[(int64_t)b * p.Ns + si] * GF_LOG2E : INFINITY;  // r_s
+            vec1[threadIdx.x] = ok ? p.g2[(int64_t)b * p.Ns + si] : 0.f;                  // gr_s
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            f32x16 s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+            mma_tile<T, D>(s, tile, kb * 32, of, l31, hi);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 r4 = *reinterpret_cast<const f32x4*>(vec0 + kb * 32 + 8 * g + 4 * hi);
+                f32x4 g4 = *reinterpret_cast<const f32x4*>(vec1 + kb * 32 + 8 * g + 4 * hi);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    int si = s0 + kb * 32 + 8 * g + 4 * hi + e;
+                    if (si < p.Ns && orow < p.No) {
+                        float x = s[4 * g + e] * GF_LOG2E;
+                        float v = fast_exp2(x - r4[e]) * g4[e] + fast_exp2(x - c2) * gco;
+                        if (Gb) v += p.galpha * Gb[(int64_t)si * p.ldg + orow];
+                        dS[(int64_t)si * p.No + orow] = from_f32<T>(v);
+                    }
+                }
+            }
+        }
+    }
+}
+
+__global__ void filter_matches_kernel(const float* max0, const int64_t* arg0, const int64_t* arg1, float th,
+                                      int64_t* m0, int64_t* m1, float* s0, float* s1, int B, int M, int N) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t tot = (int64_t)B * (M + N);
+    if (t >= tot) return;
+    int b = t / (M + N);
+    int k = t % (M + N);
+    const int64_t* a0 = arg0 + (int64_t)b * M;
+    const int64_t* a1 = arg1 + (int64_t)b * N;
+    if (k < M) {
+        int64_t j = a0[k];
+        bool mutual = (a1[j] == k);
+        float sc = mutual ? __expf(max0[(int64_t)b * M + k]) : 0.f;
+        s0[(int64_t)b * M + k] = sc;
+        m0[(int64_t)b * M + k] = (mutual && sc > th) ? j : -1;
+    } else {
+        int j = k - M;
+        int64_t i = a1[j];
+        bool mutual = (a0[i] == j);
+        float sc = mutual ? __expf(max0[(int64_t)b * M + i]) : 0.f;
+        s1[(int64_t)b * N + j] = sc;
+        m1[(int64_t)b * N + j] = (mutual && sc > th) ? i : -1;
+    }
+}
+
+template <typename T, int D> size_t head_lds() { return ALay<T, D>::TILE * sizeof(T) + 128 * sizeof(float); }
+
+template <typename K> int set_lds(K kern, size_t bytes) {
+    if (bytes > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
+}
+
+enum { K_LSE, K_ARGMAX, K_WRITE, K_BWD };
+
+template <typename T, int D> int launch_td(int which, const HeadParams& p, hipStream_t st) {
+    const int total = ((p.No + 127) / 128) * p.B;
+    const size_t lds = head_lds<T, D>();
+#define GF_LAUNCH(kern)                                             \
+    {                                                               \
+        if (int e = set_lds(kern<T, D>, lds)) return e;             \
+        kern<T, D><<<dim3(total), dim3(256), lds, st>>>(p);         \
+        return (int)hipGetLastError();                              \
+    }
+    switch (which) {
+        case K_LSE: GF_LAUNCH(rows_lse_kernel)
+        case K_ARGMAX: GF_LAUNCH(rows_argmax_kernel)
+        case K_WRITE: GF_LAUNCH(assign_write_kernel)
+        default: GF_LAUNCH(dual_softmax_bwd_kernel)
+    }
+#undef GF_LAUNCH
+}
+
+template <typename T> int launch_t(int which, const HeadParams& p, int D, hipStream_t st) {
+    switch (D) {
+        case 64: return launch_td<T, 64>(which, p, st);
+        case 128: return launch_td<T, 128>(which, p, st);
+        case 256: return launch_td<T, 256>(which, p, st);
+        default: return GF_ERR_UNSUPPORTED;
+    }
+}
+
+int launch(int which, const HeadParams& p, int D, int dtype, void* stream) {
+    if (p.B <= 0 || p.No <= 0 || p.Ns <= 0) return GF_ERR_SHAPE;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == GF_F32) return launch_t<float>(which, p, D, st);
+    if (dtype == GF_BF16) return launch_t<bf16_t>(which, p, D, st);
+    return GF_ERR_DTYPE;
+}
+
+}  // namespace
+
+extern "C" int gf_rows_lse(const void* a, const void* b, const float* colbias, float* lse,
+                           int B, int M, int N, int D, int dtype, void* stream) {
+    HeadParams p = {};
+    p.own = a; p.oth = b; p.B = B; p.No = M; p.Ns = N; p.sbias = colbias; p.f0 = lse;
+    return launch(K_LSE, p, D, dtype, stream);
+}
+
+extern "C" int gf_rows_argmax(const void* a, const void* b, const float* colbias, float alpha,
+                              float* rowmax, int64_t* rowarg,
+                              int B, int M, int N, int D, int dtype, void* stream) {
+    HeadParams p = {};
+    p.own = a; p.oth = b; p.B = B; p.No = M; p.Ns = N; p.sbias = colbias; p.alpha = alpha;
+    p.f0 = rowmax; p.i0 = rowarg;
+    return launch(K_ARGMAX, p, D, dtype, stream);
+}
+
+extern "C" int gf_assign_write(const void* a, const void* b, const float* rowbias, const float* colbias,
+                               const float* bin_col, const float* bin_row, float alpha, float corner,
+                               float* out, int B, int M, int N, int D, int dtype, void* stream) {
+    // owner = columns (b rows), streamed = rows (a rows)
+    HeadParams p = {};
+    p.own = b; p.oth = a; p.B = B; p.No = N; p.Ns = M; p.sbias = rowbias; p.obias = colbias;
+    p.alpha = alpha; p.corner = corner; p.g0 = bin_col; p.g1 = bin_row; p.out = out;
+    return launch(K_WRITE, p, D, dtype, stream);
+}
+
+extern "C" int gf_dual_softmax_bwd(const void* a, const void* b, const float* r, const float* c,
+                                   const float* gr, const float* gc, const float* G, int64_t ldg,
+                                   float galpha, void* dS, int B, int M, int N, int D, int dtype,
+                                   void* stream) {
+    HeadParams p = {};
+    p.own = b; p.oth = a; p.B = B; p.No = N; p.Ns = M;
+    p.g0 = r; p.g1 = c; p.g2 = gr; p.g3 = gc; p.G = G; p.ldg = ldg; p.galpha = galpha; p.out = dS;
+    return launch(K_BWD, p, D, dtype, stream);
+}
+
+extern "C" int gf_filter_matches(const float* max0, const int64_t* arg0, const int64_t* arg1, float th,
+                                 int64_t* m0, int64_t* m1, float* s0, float* s1,
+                                 int B, int M, int N, void* stream) {
+    if (B <= 0 || M <= 0 || N <= 0) return GF_ERR_SHAPE;
+    int64_t tot = (int64_t)B * (M + N);
+    int blocks = (int)((tot + 255) / 256);
+    filter_matches_kernel<<<dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
+        max0, arg0, arg1, th, m0, m1, s0, s1, B, M, N);
+    return (int)hipGetLastError();
+}

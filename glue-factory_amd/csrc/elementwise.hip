@@ -1,0 +1,310 @@
+// Memory-bound fused elementwise kernels of the transformer block (HBM-roofline class):
+//   * rotary embedding of the q,k thirds of the fused Wqkv output, in place, + its backward
+//     (reference: gluefactory/models/matchers/lightglue.py:42-49, 159-160);
+//   * LayerNorm(affine) + exact GELU of the FFN hidden, forward and backward
+//     (reference: lightglue.py:143-148, the ffn.1 / ffn.2 modules).
+// One wave per row/token, 4 waves per workgroup, grid-stride; fp32 math, T in / T out.
+#include "gf_common.h"
+#include "gf_amd.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------- rotary
+// qkv: [B*N, 3, H, D]; lane -> (half = q|k, pair i); loop over heads.
+template <typename T, bool INVERSE, bool WITH_DTHETA>
+__global__ __launch_bounds__(256) void rotary_kernel(T* qkv, const T* yrot, const float* cs, float* dtheta,
+                                                     int64_t tokens, int H, int D) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int npair = D / 2;
+    for (int64_t tok = (int64_t)blockIdx.x * 4 + wave; tok < tokens; tok += (int64_t)gridDim.x * 4) {
+        // generic in D: work items = 2 (q,k) * npair, strided over the 64 lanes
+        for (int w = lane; w < 2 * npair; w += 64) {
+            const int half = w / npair, i = w % npair;
+            const f32x2 csv = *reinterpret_cast<const f32x2*>(cs + tok * D + 2 * i);
+            const float c = csv[0], s = INVERSE ? -csv[1] : csv[1];
+            float acc = 0.f;
+            T* base = qkv + tok * 3 * H * D + (int64_t)half * H * D + 2 * i;
+            const T* ybase = WITH_DTHETA ? yrot + tok * 3 * H * D + (int64_t)half * H * D + 2 * i : nullptr;
+            for (int h = 0; h < H; ++h) {
+                float x0 = to_f32(base[h * D]), x1 = to_f32(base[h * D + 1]);
+                if (WITH_DTHETA) {
+                    float y0 = to_f32(ybase[h * D]), y1 = to_f32(ybase[h * D + 1]);
+                    acc += x1 * y0 - x0 * y1;  // x = upstream gradient here
+                }
+                base[h * D] = from_f32<T>(x0 * c - x1 * s);
+                base[h * D + 1] = from_f32<T>(x1 * c + x0 * s);
+            }
+            if (WITH_DTHETA) {
+                // q and k halves of the same pair live in different lanes (or different w): atomics
+                // would be non-deterministic, so reduce through the other half explicitly.
+                // npair <= 32 -> lanes l and l+npair hold (q,i) and (k,i) when 2*npair <= 64.
+                float other = __shfl(acc, (lane + npair) & 63);
+                if (2 * npair <= 64) {
+                    if (half == 0) dtheta[tok * npair + i] = acc + other;
+                } else {
+                    atomicAdd(&dtheta[tok * npair + i], acc);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------- LN + GELU
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+__device__ __forceinline__ float gelu_f(float z) { return 0.5f * z * (1.f + erff(z * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad(float z) {
+    return 0.5f * (1.f + erff(z * 0.70710678118654752f)) + z * 0.3989422804014327f * __expf(-0.5f * z * z);
+}
+
+template <typename T> struct Chunk { static constexpr int VEC = 16 / sizeof(T); };
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <typename T, int NCH>
+__device__ __forceinline__ void load_row(float (&x)[NCH][16 / sizeof(T)], const T* row, int C, int lane) {
+    constexpr int VEC = 16 / sizeof(T);
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        int col = (ch * 64 + lane) * VEC;
+        if (col < C) {
+            union { u32x4 u; T e[VEC]; } v;
+            v.u = *reinterpret_cast<const u32x4*>(row + col);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) x[ch][e] = to_f32(v.e[e]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) x[ch][e] = 0.f;
+        }
+    }
+}
+template <typename T, int NCH>
+__device__ __forceinline__ void store_row(T* row, const float (&y)[NCH][16 / sizeof(T)], int C, int lane) {
+    constexpr int VEC = 16 / sizeof(T);
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        int col = (ch * 64 + lane) * VEC;
+        if (col < C) {
+            union { u32x4 u; T e[VEC]; } v;
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v.e[e] = from_f32<T>(y[ch][e]);
+            *reinterpret_cast<u32x4*>(row + col) = v.u;
+        }
+    }
+}
+
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void ln_gelu_fwd_kernel(const T* x, const float* gamma, const float* beta, T* y,
+                                                          float* mean, float* rstd, int R, int C, float eps) {
+    constexpr int VEC = 16 / sizeof(T);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float g[NCH][VEC], bt[NCH][VEC];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            int col = (ch * 64 + lane) * VEC + e;
+            g[ch][e] = col < C ? gamma[col] : 0.f;
+            bt[ch][e] = col < C ? beta[col] : 0.f;
+        }
+    for (int row = blockIdx.x * 4 + wave; row < R; row += gridDim.x * 4) {
+        float v[NCH][VEC];
+        load_row<T, NCH>(v, x + (int64_t)row * C, C, lane);
+        float s = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) s += v[ch][e];
+        const float mu = wave_sum(s) / C;
+        float q = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                int col = (ch * 64 + lane) * VEC + e;
+                float d = col < C ? v[ch][e] - mu : 0.f;
+                q += d * d;
+            }
+        const float rs = rsqrtf(wave_sum(q) / C + eps);
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) v[ch][e] = gelu_f((v[ch][e] - mu) * rs * g[ch][e] + bt[ch][e]);
+        store_row<T, NCH>(y + (int64_t)row * C, v, C, lane);
+        if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    }
+}
+
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void ln_gelu_bwd_kernel(const T* x, const float* gamma, const float* beta,
+                                                          const float* mean, const float* rstd, const T* dy, T* dx,
+                                                          float* dgamma_part, float* dbeta_part, int R, int C) {
+    constexpr int VEC = 16 / sizeof(T);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = reinterpret_cast<float*>(smem);  // [4 waves][2][NCH*64*VEC]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float g[NCH][VEC], bt[NCH][VEC], dg[NCH][VEC], db[NCH][VEC];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            int col = (ch * 64 + lane) * VEC + e;
+            g[ch][e] = col < C ? gamma[col] : 0.f;
+            bt[ch][e] = col < C ? beta[col] : 0.f;
+            dg[ch][e] = 0.f;
+            db[ch][e] = 0.f;
+        }
+    for (int row = blockIdx.x * 4 + wave; row < R; row += gridDim.x * 4) {
+        float v[NCH][VEC], d[NCH][VEC];
+        load_row<T, NCH>(v, x + (int64_t)row * C, C, lane);
+        load_row<T, NCH>(d, dy + (int64_t)row * C, C, lane);
+        const float mu = mean[row], rs = rstd[row];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                int col = (ch * 64 + lane) * VEC + e;
+                float xh = (v[ch][e] - mu) * rs;
+                float z = xh * g[ch][e] + bt[ch][e];
+                float dz = col < C ? d[ch][e] * gelu_grad(z) : 0.f;
+                dg[ch][e] += dz * xh;
+                db[ch][e] += dz;
+                float dxh = dz * g[ch][e];
+                v[ch][e] = xh;
+                d[ch][e] = dxh;
+                s1 += dxh;
+                s2 += dxh * xh;
+            }
+        const float m1 = wave_sum(s1) / C, m2 = wave_sum(s2) / C;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) d[ch][e] = rs * (d[ch][e] - m1 - v[ch][e] * m2);
+        store_row<T, NCH>(dx + (int64_t)row * C, d, C, lane);
+    }
+    // reduce the 4 waves' column partials through LDS, one partial row per block
+    constexpr int W = NCH * 64 * VEC;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            int col = (ch * 64 + lane) * VEC + e;
+            red[(wave * 2 + 0) * W + col] = dg[ch][e];
+            red[(wave * 2 + 1) * W + col] = db[ch][e];
+        }
+    __syncthreads();
+    for (int col = threadIdx.x; col < C; col += 256) {
+        float a = 0.f, b2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { a += red[(w * 2) * W + col]; b2 += red[(w * 2 + 1) * W + col]; }
+        dgamma_part[(int64_t)blockIdx.x * C + col] = a;
+        dbeta_part[(int64_t)blockIdx.x * C + col] = b2;
+    }
+}
+
+int ln_blocks(int R) {
+    int nb = (R + 3) / 4;
+    return nb < 1 ? 1 : (nb > 1024 ? 1024 : nb);
+}
+
+template <typename T> int ln_nch(int C) {
+    constexpr int VEC = 16 / sizeof(T);
+    if (C % VEC) return -1;
+    int chunks = C / VEC;
+    if (chunks <= 64) return 1;
+    if (chunks <= 128) return 2;
+    if (chunks <= 256) return 4;
+    return -1;
+}
+
+template <typename T>
+int ln_fwd_t(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int R, int C,
+             float eps, hipStream_t st) {
+    int nb = ln_blocks(R);
+    const T* xp = reinterpret_cast<const T*>(x);
+    T* yp = reinterpret_cast<T*>(y);
+    switch (ln_nch<T>(C)) {
+        case 1: ln_gelu_fwd_kernel<T, 1><<<nb, 256, 0, st>>>(xp, gamma, beta, yp, mean, rstd, R, C, eps); break;
+        case 2: ln_gelu_fwd_kernel<T, 2><<<nb, 256, 0, st>>>(xp, gamma, beta, yp, mean, rstd, R, C, eps); break;
+        case 4: ln_gelu_fwd_kernel<T, 4><<<nb, 256, 0, st>>>(xp, gamma, beta, yp, mean, rstd, R, C, eps); break;
+        default: return GF_ERR_UNSUPPORTED;
+    }
+    return (int)hipGetLastError();
+}
+
+template <typename T>
+int ln_bwd_t(const void* x, const float* gamma, const float* beta, const float* mean, const float* rstd,
+             const void* dy, void* dx, float* dgp, float* dbp, int R, int C, hipStream_t st) {
+    constexpr int VEC = 16 / sizeof(T);
+    int nb = ln_blocks(R);
+    const T* xp = reinterpret_cast<const T*>(x);
+    const T* dyp = reinterpret_cast<const T*>(dy);
+    T* dxp = reinterpret_cast<T*>(dx);
+    int nch = ln_nch<T>(C);
+    if (nch < 0) return GF_ERR_UNSUPPORTED;
+    size_t lds = (size_t)8 * nch * 64 * VEC * sizeof(float);
+    switch (nch) {
+        case 1: ln_gelu_bwd_kernel<T, 1><<<nb, 256, lds, st>>>(xp, gamma, beta, mean, rstd, dyp, dxp, dgp, dbp, R, C); break;
+        case 2: ln_gelu_bwd_kernel<T, 2><<<nb, 256, lds, st>>>(xp, gamma, beta, mean, rstd, dyp, dxp, dgp, dbp, R, C); break;
+        default: ln_gelu_bwd_kernel<T, 4><<<nb, 256, lds, st>>>(xp, gamma, beta, mean, rstd, dyp, dxp, dgp, dbp, R, C); break;
+    }
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" int gf_rotary_qk(void* qkv, const float* cs, int B, int N, int H, int D, int inverse,
+                            int dtype, void* stream) {
+    if (B <= 0 || N <= 0 || H <= 0 || D <= 0 || (D & 1)) return GF_ERR_SHAPE;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    int64_t tokens = (int64_t)B * N;
+    int nb = (int)((tokens + 3) / 4 > 4096 ? 4096 : (tokens + 3) / 4);
+    if (dtype == GF_F32) {
+        if (inverse) rotary_kernel<float, true, false><<<nb, 256, 0, st>>>((float*)qkv, nullptr, cs, nullptr, tokens, H, D);
+        else rotary_kernel<float, false, false><<<nb, 256, 0, st>>>((float*)qkv, nullptr, cs, nullptr, tokens, H, D);
+    } else if (dtype == GF_BF16) {
+        if (inverse) rotary_kernel<bf16_t, true, false><<<nb, 256, 0, st>>>((bf16_t*)qkv, nullptr, cs, nullptr, tokens, H, D);
+        else rotary_kernel<bf16_t, false, false><<<nb, 256, 0, st>>>((bf16_t*)qkv, nullptr, cs, nullptr, tokens, H, D);
+    } else return GF_ERR_DTYPE;
+    return (int)hipGetLastError();
+}
+
+extern "C" int gf_rotary_qk_bwd(void* dqkv, const void* qkv_rot, const float* cs, float* dtheta,
+                                int B, int N, int H, int D, int dtype, void* stream) {
+    if (B <= 0 || N <= 0 || H <= 0 || D <= 0 || (D & 1)) return GF_ERR_SHAPE;
+    if (D > 64) return GF_ERR_UNSUPPORTED;  // keeps the q/k pair reduction inside one wave pass
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    int64_t tokens = (int64_t)B * N;
+    int nb = (int)((tokens + 3) / 4 > 4096 ? 4096 : (tokens + 3) / 4);
+    if (dtype == GF_F32)
+        rotary_kernel<float, true, true><<<nb, 256, 0, st>>>((float*)dqkv, (const float*)qkv_rot, cs, dtheta, tokens, H, D);
+    else if (dtype == GF_BF16)
+        rotary_kernel<bf16_t, true, true><<<nb, 256, 0, st>>>((bf16_t*)dqkv, (const bf16_t*)qkv_rot, cs, dtheta, tokens, H, D);
+    else return GF_ERR_DTYPE;
+    return (int)hipGetLastError();
+}
+
+extern "C" int gf_ln_gelu_nblk(int R) { return ln_blocks(R); }
+
+extern "C" int gf_ln_gelu_fwd(const void* x, const float* gamma, const float* beta, void* y,
+                              float* mean, float* rstd, int R, int C, float eps, int dtype, void* stream) {
+    if (R <= 0 || C <= 0) return GF_ERR_SHAPE;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == GF_F32) return ln_fwd_t<float>(x, gamma, beta, y, mean, rstd, R, C, eps, st);
+    if (dtype == GF_BF16) return ln_fwd_t<bf16_t>(x, gamma, beta, y, mean, rstd, R, C, eps, st);
+    return GF_ERR_DTYPE;
+}
+
+extern "C" int gf_ln_gelu_bwd(const void* x, const float* gamma, const float* beta, const float* mean,
+                              const float* rstd, const void* dy, void* dx, float* dgamma_part,
+                              float* dbeta_part, int R, int C, int dtype, void* stream) {
+    if (R <= 0 || C <= 0) return GF_ERR_SHAPE;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == GF_F32) return ln_bwd_t<float>(x, gamma, beta, mean, rstd, dy, dx, dgamma_part, dbeta_part, R, C, st);
+    if (dtype == GF_BF16) return ln_bwd_t<bf16_t>(x, gamma, beta, mean, rstd, dy, dx, dgamma_part, dbeta_part, R, C, st);
+    return GF_ERR_DTYPE;
+}

@@ -1,0 +1,398 @@
+"""LightGlue matcher on the MI355X hot path (drop-in for gluefactory.models.matchers.lightglue).
+
+Same plugin surface as the reference module (gluefactory/models/matchers/lightglue.py:312-630):
+``LightGlue(conf)``, ``forward(data) -> pred`` and ``loss(pred, data) -> (losses, metrics)``,
+the same ``default_conf`` keys, ``required_data_keys`` and ``state_dict`` names/shapes
+(SURVEY.md §8 note S), exported as ``__main_model__`` so that
+``model.matcher.name: glue_factory_amd.matchers.lightglue`` in a glue-factory yaml is the whole
+integration.
+
+What runs where
+  * linear layers: hipBLASLt through torch (plain library GEMMs);
+  * rotary + self attention, bidirectional cross attention (forward and backward):
+    hand-written MFMA flash kernels (csrc/attention.hip), fed by the fused projections in
+    place — no [B,H,N,N] tensor exists;
+  * LayerNorm+GELU of the FFN: one fused HIP kernel each way (csrc/elementwise.hip);
+  * assignment heads (lightglue.py:256-309): row/column log-sum-exp, arg-max and the
+    materialised log-assignment from MFMA tiles of md0 md1^T (csrc/assignment.hip).  The L
+    training heads never build the (N+1)^2 matrix: the NLL (utils/losses.py:6-73) is evaluated
+    on the ground-truth positives and the two dustbin vectors, which is exactly the dense
+    weighted sum because the weight matrix is zero elsewhere.
+Compute dtype: fp32 (exact-fp32 MFMA, parity mode) by default, bf16 with fp32 statistics when
+``conf.mp`` is set or the call happens under ``torch.autocast``.  There is no CPU path.
+"""
+import math
+import warnings
+from pathlib import Path
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .. import ops
+from ..conf import Conf
+from ..metrics import matcher_metrics
+
+
+def normalize_keypoints(kpts, size=None):
+    """(k - size/2) / (max(size)/2), fp32 (lightglue.py:27-39)."""
+    kpts = kpts.float()
+    if size is None:
+        size = 1 + kpts.max(-2).values - kpts.min(-2).values
+    elif not isinstance(size, torch.Tensor):
+        size = torch.tensor(size, device=kpts.device, dtype=kpts.dtype)
+    size = size.to(kpts)
+    shift = size / 2
+    scale = size.max(-1).values / 2
+    return (kpts - shift[..., None, :]) / scale[..., None, None]
+
+
+class _PosEnc(nn.Module):
+    """Holds posenc.Wr (lightglue.py:52-65); returns the pair angles and interleaved (cos, sin)."""
+
+    def __init__(self, in_dim, head_dim):
+        super().__init__()
+        self.Wr = nn.Linear(in_dim, head_dim // 2, bias=False)
+        nn.init.normal_(self.Wr.weight.data, mean=0.0, std=1.0)
+
+    def forward(self, kpts):
+        theta = F.linear(kpts, self.Wr.weight.float())            # [B,N,hd/2] fp32
+        with torch.no_grad():
+            cs = torch.stack((torch.cos(theta), torch.sin(theta)), -1).flatten(-2).contiguous()
+        return theta, cs
+
+
+def _ffn_modules(dim):
+    return nn.Sequential(nn.Linear(2 * dim, 2 * dim), nn.LayerNorm(2 * dim, elementwise_affine=True),
+                         nn.GELU(), nn.Linear(2 * dim, dim))
+
+
+def _lin(x, layer):
+    return F.linear(x, layer.weight.to(x.dtype), None if layer.bias is None else layer.bias.to(x.dtype))
+
+
+def _ffn(ffn, x, msg):
+    h = _lin(torch.cat([x, msg], -1), ffn[0])
+    h = ops.ln_gelu(h, ffn[1].weight, ffn[1].bias, ffn[1].eps)
+    return x + _lin(h, ffn[3])
+
+
+class SelfBlock(nn.Module):
+    def __init__(self, dim, heads):
+        super().__init__()
+        self.heads, self.head_dim = heads, dim // heads
+        self.Wqkv = nn.Linear(dim, 3 * dim, bias=True)
+        self.out_proj = nn.Linear(dim, dim, bias=True)
+        self.ffn = _ffn_modules(dim)
+        # reference channel order of Wqkv's output is (head, channel, {q,k,v}); the kernels want
+        # ({q,k,v}, head, channel): gather the weight rows instead of shuffling activations.
+        h, c = heads, self.head_dim
+        perm = (torch.arange(h)[None, :, None] * (3 * c) + torch.arange(c)[None, None, :] * 3
+                + torch.arange(3)[:, None, None]).reshape(-1)
+        self.register_buffer("_perm", perm, persistent=False)
+
+    def forward(self, x, theta, cs):
+        b, n, d = x.shape
+        w = self.Wqkv.weight.index_select(0, self._perm).to(x.dtype)
+        bias = self.Wqkv.bias.index_select(0, self._perm).to(x.dtype)
+        qkv = F.linear(x, w, bias).view(b, n, 3, self.heads, self.head_dim)
+        ctx = ops.self_attention_rotary(qkv, theta, cs)           # [b,n,H,hd]
+        msg = _lin(ctx.view(b, n, d), self.out_proj)
+        return _ffn(self.ffn, x, msg)
+
+
+class CrossBlock(nn.Module):
+    def __init__(self, dim, heads):
+        super().__init__()
+        self.heads, self.head_dim = heads, dim // heads
+        self.to_qk = nn.Linear(dim, dim, bias=True)
+        self.to_v = nn.Linear(dim, dim, bias=True)
+        self.to_out = nn.Linear(dim, dim, bias=True)
+        self.ffn = _ffn_modules(dim)
+
+    def _proj(self, x):
+        w = torch.cat([self.to_qk.weight, self.to_v.weight], 0).to(x.dtype)
+        bias = torch.cat([self.to_qk.bias, self.to_v.bias], 0).to(x.dtype)
+        return F.linear(x, w, bias).view(x.shape[0], x.shape[1], 2, self.heads, self.head_dim)
+
+    def forward_stacked(self, x):
+        """x [2B,N,C]: image 0 in the first half of the batch, image 1 in the second."""
+        b2, n, d = x.shape
+        m = ops.cross_attention_stacked(self._proj(x))
+        return _ffn(self.ffn, x, _lin(m.view(b2, n, d), self.to_out))
+
+    def forward(self, x0, x1):
+        m0, m1 = ops.cross_attention(self._proj(x0), self._proj(x1))
+        m0 = _lin(m0.view(x0.shape), self.to_out)
+        m1 = _lin(m1.view(x1.shape), self.to_out)
+        return _ffn(self.ffn, x0, m0), _ffn(self.ffn, x1, m1)
+
+
+class TransformerLayer(nn.Module):
+    def __init__(self, dim, heads):
+        super().__init__()
+        self.self_attn = SelfBlock(dim, heads)
+        self.cross_attn = CrossBlock(dim, heads)
+
+
+class MatchAssignment(nn.Module):
+    """final_proj + matchability and the double-softmax statistics (lightglue.py:271-290)."""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.dim = dim
+        self.matchability = nn.Linear(dim, 1, bias=True)
+        self.final_proj = nn.Linear(dim, dim, bias=True)
+
+    def stats(self, d0, d1):
+        """Everything the log assignment is made of, without the matrix:
+        A_ij = 2 md0_i.md1_j - r_i - c_j + lz0_i + lz1_j,  A_i,n = bin0_i,  A_m,j = bin1_j."""
+        s = self.dim ** -0.25
+        w = (self.final_proj.weight * s).to(d0.dtype)
+        bias = (self.final_proj.bias * s).to(d0.dtype)
+        md0, md1 = F.linear(d0, w, bias), F.linear(d1, w, bias)
+        z0 = _lin(d0, self.matchability).squeeze(-1).float()
+        z1 = _lin(d1, self.matchability).squeeze(-1).float()
+        r, c = ops.dual_lse(md0, md1)
+        return {"md0": md0, "md1": md1, "r": r, "c": c,
+                "lz0": F.logsigmoid(z0), "lz1": F.logsigmoid(z1),
+                "bin0": F.logsigmoid(-z0), "bin1": F.logsigmoid(-z1)}
+
+    @staticmethod
+    def materialize(h):
+        return ops.assign_write(h["md0"], h["md1"], h["lz0"] - h["r"], h["lz1"] - h["c"],
+                                h["bin0"], h["bin1"], alpha=2.0, corner=0.0)
+
+    @staticmethod
+    @torch.no_grad()
+    def argmaxes(h):
+        """Row / column maxima of the core (value in the full log-assignment, index), plus the
+        arg-max over the full row / column INCLUDING its dustbin entry."""
+        n, m = h["md1"].shape[1], h["md0"].shape[1]
+        v0, a0 = ops.rows_argmax(h["md0"], h["md1"], h["lz1"] - h["c"], alpha=2.0)
+        v1, a1 = ops.rows_argmax(h["md1"], h["md0"], h["lz0"] - h["r"], alpha=2.0)
+        max0 = v0 - h["r"] + h["lz0"]
+        max1 = v1 - h["c"] + h["lz1"]
+        full0 = torch.where(h["bin0"] > max0, torch.full_like(a0, n), a0)
+        full1 = torch.where(h["bin1"] > max1, torch.full_like(a1, m), a1)
+        return {"max0": max0, "arg0": a0, "arg1": a1, "full0": full0, "full1": full1}
+
+    def get_matchability(self, desc):
+        return torch.sigmoid(_lin(desc, self.matchability)).squeeze(-1)
+
+
+class TokenConfidence(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.token = nn.Sequential(nn.Linear(dim, 1), nn.Sigmoid())
+
+    def logits(self, desc):
+        return _lin(desc.detach(), self.token[0]).squeeze(-1).float()
+
+    def forward(self, desc0, desc1):
+        return torch.sigmoid(self.logits(desc0)), torch.sigmoid(self.logits(desc1))
+
+
+class LightGlue(nn.Module):
+    default_conf = {
+        "name": "lightglue",
+        "input_dim": 256,
+        "add_scale_ori": False,
+        "descriptor_dim": 256,
+        "n_layers": 9,
+        "num_heads": 4,
+        "flash": False,            # accepted for yaml compatibility: attention is always flash-style
+        "mp": False,               # bf16 compute with fp32 statistics
+        "depth_confidence": -1,
+        "width_confidence": -1,
+        "filter_threshold": 0.0,
+        "checkpointed": False,     # accepted; activations are kept (288 GB HBM), never recomputed
+        "weights": None,
+        "weights_from_version": "v0.1_arxiv",
+        "loss": {"gamma": 1.0, "fn": "nll", "nll_balancing": 0.5},
+    }
+    required_data_keys = ["keypoints0", "keypoints1", "descriptors0", "descriptors1"]
+
+    def __init__(self, conf=None):
+        super().__init__()
+        self.conf = conf = Conf.merge(self.default_conf, conf or {})
+        d, h, n = conf.descriptor_dim, conf.num_heads, conf.n_layers
+        if d % h or d // h != 64:
+            raise NotImplementedError("the HIP attention kernels are built for head_dim == 64")
+        self.input_proj = (nn.Linear(conf.input_dim, d, bias=True) if conf.input_dim != d
+                           else nn.Identity())
+        self.posenc = _PosEnc(2 + 2 * conf.add_scale_ori, d // h)
+        self.transformers = nn.ModuleList([TransformerLayer(d, h) for _ in range(n)])
+        self.log_assignment = nn.ModuleList([MatchAssignment(d) for _ in range(n)])
+        self.token_confidence = nn.ModuleList([TokenConfidence(d) for _ in range(n - 1)])
+        self.register_buffer("confidence_thresholds", torch.Tensor(
+            [min(max(0.8 + 0.1 * math.exp(-4.0 * i / n), 0.0), 1.0) for i in range(n)]))
+        if conf.weights is not None:
+            self._load_weights(conf.weights)
+        if conf.depth_confidence > 0 or conf.width_confidence > 0:
+            warnings.warn("adaptive depth/width (eval-only early stop and point pruning) is not "
+                          "part of the training hot path and is ignored", stacklevel=2)
+
+    def _load_weights(self, weights):
+        path = Path(weights)
+        if not path.exists():
+            raise FileNotFoundError(f"weights file {weights} not found (no network on this target)")
+        sd = torch.load(str(path), map_location="cpu")
+        for i in range(self.conf.n_layers):  # legacy key layout (lightglue.py:384-391)
+            sd = {k.replace(f"self_attn.{i}", f"transformers.{i}.self_attn")
+                  if not k.startswith("transformers.") else k: v for k, v in sd.items()}
+            sd = {k.replace(f"cross_attn.{i}", f"transformers.{i}.cross_attn")
+                  if not k.startswith("transformers.") else k: v for k, v in sd.items()}
+        self.load_state_dict(sd, strict=False)
+
+    # ------------------------------------------------------------------ forward
+    def _compute_dtype(self):
+        if self.conf.mp or torch.is_autocast_enabled():
+            return torch.bfloat16
+        return torch.float32
+
+    def forward(self, data):
+        for key in self.required_data_keys:
+            assert key in data, f"Missing key {key} in data"
+        if not data["keypoints0"].is_cuda:
+            raise RuntimeError("glue_factory_amd.LightGlue runs on the MI355X HIP path only "
+                               "(move the batch to the GPU; there is no CPU fallback)")
+        T = self._compute_dtype()  # read the autocast state before switching it off
+        with torch.autocast(device_type="cuda", enabled=False):
+            return self._forward(data, T)
+
+    def _forward(self, data, T):
+        conf = self.conf
+        kpts0, kpts1 = data["keypoints0"], data["keypoints1"]
+        b, m, _ = kpts0.shape
+        n = kpts1.shape[1]
+        size0 = size1 = None
+        if "view0" in data and "view1" in data:
+            size0 = data["view0"].get("image_size")
+            size1 = data["view1"].get("image_size")
+        kpts0 = normalize_keypoints(kpts0, size0)
+        kpts1 = normalize_keypoints(kpts1, size1)
+        if conf.add_scale_ori:
+            def cat_so(k, sc, o):
+                return torch.cat([k, sc if sc.dim() == 3 else sc[..., None],
+                                  o if o.dim() == 3 else o[..., None]], -1)
+            kpts0 = cat_so(kpts0, data["scales0"].float(), data["oris0"].float())
+            kpts1 = cat_so(kpts1, data["scales1"].float(), data["oris1"].float())
+        desc0, desc1 = data["descriptors0"], data["descriptors1"]
+        assert desc0.shape[-1] == conf.input_dim and desc1.shape[-1] == conf.input_dim
+        desc0, desc1 = desc0.to(T).contiguous(), desc1.to(T).contiguous()
+        if not isinstance(self.input_proj, nn.Identity):
+            desc0, desc1 = _lin(desc0, self.input_proj), _lin(desc1, self.input_proj)
+
+        stacked = m == n
+        all0, all1 = [], []
+        if stacked:   # both images share every GEMM / kernel launch
+            x = torch.cat([desc0, desc1], 0)
+            theta, cs = self.posenc(torch.cat([kpts0, kpts1], 0))
+            for i, layer in enumerate(self.transformers):
+                x = layer.self_attn(x, theta, cs)
+                x = layer.cross_attn.forward_stacked(x)
+                if self.training or i == conf.n_layers - 1:
+                    all0.append(x[:b])
+                    all1.append(x[b:])
+            desc0, desc1 = x[:b], x[b:]
+        else:
+            th0, cs0 = self.posenc(kpts0)
+            th1, cs1 = self.posenc(kpts1)
+            for i, layer in enumerate(self.transformers):
+                desc0 = layer.self_attn(desc0, th0, cs0)
+                desc1 = layer.self_attn(desc1, th1, cs1)
+                desc0, desc1 = layer.cross_attn(desc0, desc1)
+                if self.training or i == conf.n_layers - 1:
+                    all0.append(desc0)
+                    all1.append(desc1)
+
+        head = self.log_assignment[conf.n_layers - 1].stats(desc0, desc1)
+        scores = MatchAssignment.materialize(head)
+        am = MatchAssignment.argmaxes(head)
+        m0, m1, ms0, ms1 = ops.filter_matches(am["max0"], am["arg0"], am["arg1"], conf.filter_threshold)
+        return {
+            "matches0": m0, "matches1": m1,
+            "matching_scores0": ms0, "matching_scores1": ms1,
+            "ref_descriptors0": torch.stack(all0, 1), "ref_descriptors1": torch.stack(all1, 1),
+            "log_assignment": scores,
+            "prune0": torch.ones_like(ms0) * conf.n_layers,
+            "prune1": torch.ones_like(ms1) * conf.n_layers,
+            # private: final-layer arg-maxes incl. dustbins, reused by loss() for the confidence targets
+            "_final_argmax0": am["full0"], "_final_argmax1": am["full1"],
+        }
+
+    # ------------------------------------------------------------------ loss
+    @staticmethod
+    def _gt_sparse(data):
+        """COO positives and dustbin masks of the dense weight matrix of
+        utils/losses.py:62-73 (weights = gt_assignment, (gt_matches0==-1), (gt_matches1==-1))."""
+        pos = data["gt_assignment"].nonzero(as_tuple=True)     # (b, i, j), one sync per step
+        neg0 = (data["gt_matches0"] == -1).float()
+        neg1 = (data["gt_matches1"] == -1).float()
+        bsz = data["gt_assignment"].shape[0]
+        num_pos = torch.zeros(bsz, device=neg0.device).index_add_(
+            0, pos[0], torch.ones_like(pos[0], dtype=torch.float32)).clamp(min=1.0)
+        return {"pos": pos, "neg0": neg0, "neg1": neg1, "num_pos": num_pos,
+                "n0": neg0.sum(-1).clamp(min=1.0), "n1": neg1.sum(-1).clamp(min=1.0)}
+
+    def _nll(self, h, gt):
+        """weight_loss of utils/losses.py:6-25 on the non-zero weights only."""
+        bi, ii, ji = gt["pos"]
+        dot = (h["md0"][bi, ii].float() * h["md1"][bi, ji].float()).sum(-1)
+        a_pos = 2.0 * dot - h["r"][bi, ii] - h["c"][bi, ji] + h["lz0"][bi, ii] + h["lz1"][bi, ji]
+        nll_pos = -torch.zeros_like(gt["num_pos"]).index_add_(0, bi, a_pos) / gt["num_pos"]
+        nll_neg = -((h["bin0"] * gt["neg0"]).sum(-1) + (h["bin1"] * gt["neg1"]).sum(-1)) / (gt["n0"] + gt["n1"])
+        bal = self.conf.loss.nll_balancing
+        nll = bal * nll_pos + (1 - bal) * nll_neg
+        return nll, {"assignment_nll": nll, "nll_pos": nll_pos, "nll_neg": nll_neg,
+                     "num_matchable": gt["num_pos"], "num_unmatchable": (gt["n0"] + gt["n1"]) / 2.0}
+
+    def loss(self, pred, data):
+        with torch.autocast(device_type="cuda", enabled=False):
+            return self._loss(pred, data)
+
+    def _loss(self, pred, data):
+        rd0, rd1 = pred["ref_descriptors0"], pred["ref_descriptors1"]
+        L = rd0.shape[1]
+        gt = self._gt_sparse(data)
+
+        def head(i):
+            return self.log_assignment[i].stats(rd0[:, i], rd1[:, i])
+
+        nll, stats = self._nll(head(L - 1), gt)
+        losses = {"total": nll, "last": nll.clone().detach(), **stats}
+        if self.training:
+            losses["confidence"] = 0.0
+        with torch.no_grad():
+            losses["row_norm"] = pred["log_assignment"].exp()[:, :-1].sum(2).mean(1)
+        if "_final_argmax0" in pred:
+            fin0, fin1 = pred["_final_argmax0"], pred["_final_argmax1"]
+        else:  # pred built elsewhere: read the arg-maxes off the materialised matrix
+            la = pred["log_assignment"].detach()
+            fin0, fin1 = la[:, :-1, :].max(-1).indices, la[:, :, :-1].max(-2).indices
+
+        sum_weights = 1.0
+        gamma = self.conf.loss.gamma
+        for i in range(L - 1):
+            h = head(i)
+            nll_i, _ = self._nll(h, gt)
+            weight = gamma ** (L - i - 1) if gamma > 0.0 else i + 1
+            sum_weights += weight
+            losses["total"] = losses["total"] + nll_i * weight
+            am = MatchAssignment.argmaxes(h)
+            tc = self.token_confidence[i]
+            bce = F.binary_cross_entropy_with_logits
+            conf_i = (bce(tc.logits(rd0[:, i]), (am["full0"] == fin0).float(), reduction="none").mean(-1)
+                      + bce(tc.logits(rd1[:, i]), (am["full1"] == fin1).float(), reduction="none").mean(-1)) / 2.0
+            losses["confidence"] = losses["confidence"] + conf_i / (L - 1)
+        losses["total"] = losses["total"] / sum_weights
+        if self.training:
+            losses["total"] = losses["total"] + losses["confidence"]
+            metrics = {}
+        else:
+            metrics = matcher_metrics(pred, data)
+        return losses, metrics
+
+
+__main_model__ = LightGlue

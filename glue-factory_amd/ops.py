@@ -1,0 +1,361 @@
+"""torch.autograd.Function wrappers around the HIP launchers of libgf_amd.so.
+
+PyTorch is plumbing here (device memory, streams, autograd graph); every op below calls the
+C ABI of include/gf_amd.h through ctypes with raw device pointers and the current HIP stream.
+There is no CPU or eager fallback: a non-CUDA tensor or a missing library raises.
+"""
+import torch
+
+from . import lib as _lib
+
+F32, BF16 = 0, 1
+
+
+def _dt(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise RuntimeError(f"glue_factory_amd kernels take float32 or bfloat16, got {t.dtype}")
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("glue_factory_amd ops need tensors on a HIP device (no CPU fallback)")
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _s3(t):
+    """(batch, token, head) element strides of a [B,N,H,D] view with contiguous D."""
+    assert t.dim() == 4 and t.stride(3) == 1, "attention operands must be [B,N,H,D] with contiguous D"
+    return _lib.strides(t.stride(0), t.stride(1), t.stride(2))
+
+
+# ------------------------------------------------------------------------------ attention
+def attn_fwd_raw(q, k, v, scale, out=None, lse=None):
+    _chk(q, k, v)
+    B, Nq, H, D = q.shape
+    Nk = k.shape[1]
+    o = torch.empty((B, Nq, H, D), dtype=q.dtype, device=q.device) if out is None else out
+    if lse is None:
+        lse = torch.empty((B, H, Nq), dtype=torch.float32, device=q.device)
+    _lib.check(_lib.load().gf_attn_fwd(_p(q), _p(k), _p(v), _p(o), _p(lse), B, H, Nq, Nk, D,
+                                       _s3(q), _s3(k), _s3(v), _s3(o), float(scale), _dt(q),
+                                       _stream()), "gf_attn_fwd")
+    return o, lse
+
+
+def attn_bwd_raw(q, k, v, o, do, lse, dq, dk, dv, scale):
+    B, Nq, H, D = q.shape
+    Nk = k.shape[1]
+    if do.stride(3) != 1:
+        do = do.contiguous()
+    delta = torch.empty_like(lse)
+    _lib.check(_lib.load().gf_attn_bwd(_p(q), _p(k), _p(v), _p(o), _p(do), _p(lse), _p(delta),
+                                       _p(dq), _p(dk), _p(dv), B, H, Nq, Nk, D,
+                                       _s3(q), _s3(k), _s3(v), _s3(o), _s3(do), _s3(dq), _s3(dk),
+                                       _s3(dv), float(scale), _dt(q), _stream()), "gf_attn_bwd")
+
+
+class _Attention(torch.autograd.Function):
+    """o = softmax(scale q k^T) v on [B,N,H,D] views (generic entry, used by SuperGlue/GlueStick)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, scale):
+        o, lse = attn_fwd_raw(q, k, v, scale)
+        ctx.save_for_backward(q, k, v, o, lse)
+        ctx.scale = scale
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o, lse = ctx.saved_tensors
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        dq, dk, dv = (t.contiguous() for t in (dq, dk, dv))
+        attn_bwd_raw(q, k, v, o, do, lse, dq, dk, dv, ctx.scale)
+        return dq, dk, dv, None
+
+
+def attention(q, k, v, scale=None):
+    scale = q.shape[-1] ** -0.5 if scale is None else scale
+    return _Attention.apply(q, k, v, scale)
+
+
+class _SelfAttentionRotary(torch.autograd.Function):
+    """Rotary(q,k) + self attention on the fused projection qkv [B,N,3,H,D].
+
+    qkv is the private output buffer of the Wqkv GEMM: it is rotated IN PLACE (nobody else
+    reads it) and kept for the backward.  theta [B,N,D/2] are the pair angles (differentiable,
+    they carry the gradient to posenc.Wr); cs [B,N,D] = interleaved (cos, sin) of theta."""
+
+    @staticmethod
+    def forward(ctx, qkv, theta, cs):
+        _chk(qkv, cs)
+        B, N, three, H, D = qkv.shape
+        assert three == 3 and qkv.is_contiguous() and cs.is_contiguous() and cs.dtype == torch.float32
+        L = _lib.load()
+        _lib.check(L.gf_rotary_qk(_p(qkv), _p(cs), B, N, H, D, 0, _dt(qkv), _stream()), "gf_rotary_qk")
+        o, lse = attn_fwd_raw(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], D ** -0.5)
+        ctx.save_for_backward(qkv, cs, o, lse)
+        ctx.theta_dtype = theta.dtype
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, cs, o, lse = ctx.saved_tensors
+        B, N, _, H, D = qkv.shape
+        dqkv = torch.empty_like(qkv)
+        attn_bwd_raw(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], o, do, lse,
+                     dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2], D ** -0.5)
+        dtheta = torch.empty((B, N, D // 2), dtype=torch.float32, device=qkv.device)
+        _lib.check(_lib.load().gf_rotary_qk_bwd(_p(dqkv), _p(qkv), _p(cs), _p(dtheta), B, N, H, D,
+                                                _dt(qkv), _stream()), "gf_rotary_qk_bwd")
+        return dqkv, dtheta.to(ctx.theta_dtype), None
+
+
+def self_attention_rotary(qkv, theta, cs):
+    return _SelfAttentionRotary.apply(qkv, theta, cs)
+
+
+class _CrossAttention(torch.autograd.Function):
+    """Bidirectional cross attention with shared qk projection.
+
+    p0, p1: [B,N_i,2,H,D] fused (to_qk, to_v) projections of image 0 / 1.
+    m0 = softmax(qk0 qk1^T / sqrt(D)) v1,  m1 = softmax(qk1 qk0^T / sqrt(D)) v0."""
+
+    @staticmethod
+    def forward(ctx, p0, p1):
+        D = p0.shape[-1]
+        m0, lse0 = attn_fwd_raw(p0[:, :, 0], p1[:, :, 0], p1[:, :, 1], D ** -0.5)
+        m1, lse1 = attn_fwd_raw(p1[:, :, 0], p0[:, :, 0], p0[:, :, 1], D ** -0.5)
+        ctx.save_for_backward(p0, p1, m0, m1, lse0, lse1)
+        return m0, m1
+
+    @staticmethod
+    def backward(ctx, dm0, dm1):
+        p0, p1, m0, m1, lse0, lse1 = ctx.saved_tensors
+        D = p0.shape[-1]
+        d0, d1 = torch.empty_like(p0), torch.empty_like(p1)
+        tk0, tk1 = torch.empty_like(p0[:, :, 0]), torch.empty_like(p1[:, :, 0])
+        tk0, tk1 = tk0.contiguous(), tk1.contiguous()
+        # direction 0->1: q = qk0, k = qk1, v = v1
+        attn_bwd_raw(p0[:, :, 0], p1[:, :, 0], p1[:, :, 1], m0, dm0, lse0,
+                     d0[:, :, 0], tk1, d1[:, :, 1], D ** -0.5)
+        # direction 1->0: q = qk1, k = qk0, v = v0
+        attn_bwd_raw(p1[:, :, 0], p0[:, :, 0], p0[:, :, 1], m1, dm1, lse1,
+                     d1[:, :, 0], tk0, d0[:, :, 1], D ** -0.5)
+        d0[:, :, 0] += tk0
+        d1[:, :, 0] += tk1
+        return d0, d1
+
+
+class _CrossAttentionStacked(torch.autograd.Function):
+    """Same as _CrossAttention for equal keypoint counts, on the batch-stacked projection
+    p [2B,N,2,H,D] (image 0 in the first half); returns the stacked messages [2B,N,H,D] so
+    the following to_out GEMM runs once over both images without a concat."""
+
+    @staticmethod
+    def forward(ctx, p):
+        B2, N, _, H, D = p.shape
+        B = B2 // 2
+        m = torch.empty((B2, N, H, D), dtype=p.dtype, device=p.device)
+        lse = torch.empty((B2, H, N), dtype=torch.float32, device=p.device)
+        p0, p1 = p[:B], p[B:]
+        attn_fwd_raw(p0[:, :, 0], p1[:, :, 0], p1[:, :, 1], D ** -0.5, out=m[:B], lse=lse[:B])
+        attn_fwd_raw(p1[:, :, 0], p0[:, :, 0], p0[:, :, 1], D ** -0.5, out=m[B:], lse=lse[B:])
+        ctx.save_for_backward(p, m, lse)
+        return m
+
+    @staticmethod
+    def backward(ctx, dm):
+        p, m, lse = ctx.saved_tensors
+        B2, N, _, H, D = p.shape
+        B = B2 // 2
+        if not dm.is_contiguous():
+            dm = dm.contiguous()
+        d = torch.empty_like(p)
+        tk = torch.empty((B2, N, H, D), dtype=p.dtype, device=p.device)
+        p0, p1, d0, d1 = p[:B], p[B:], d[:B], d[B:]
+        attn_bwd_raw(p0[:, :, 0], p1[:, :, 0], p1[:, :, 1], m[:B], dm[:B], lse[:B],
+                     d0[:, :, 0], tk[B:], d1[:, :, 1], D ** -0.5)
+        attn_bwd_raw(p1[:, :, 0], p0[:, :, 0], p0[:, :, 1], m[B:], dm[B:], lse[B:],
+                     d1[:, :, 0], tk[:B], d0[:, :, 1], D ** -0.5)
+        d[:, :, 0] += tk
+        return d
+
+
+def cross_attention(p0, p1):
+    return _CrossAttention.apply(p0, p1)
+
+
+def cross_attention_stacked(p):
+    return _CrossAttentionStacked.apply(p)
+
+
+# ------------------------------------------------------------------------------ LN + GELU
+class _LnGelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        _chk(x, gamma, beta)
+        C = x.shape[-1]
+        x2 = x.reshape(-1, C)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        R = x2.shape[0]
+        g32, b32 = gamma.float().contiguous(), beta.float().contiguous()
+        y = torch.empty_like(x2)
+        mean = torch.empty(R, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(R, dtype=torch.float32, device=x.device)
+        _lib.check(_lib.load().gf_ln_gelu_fwd(_p(x2), _p(g32), _p(b32), _p(y), _p(mean), _p(rstd),
+                                              R, C, float(eps), _dt(x2), _stream()), "gf_ln_gelu_fwd")
+        ctx.save_for_backward(x2, g32, b32, mean, rstd)
+        ctx.shape = x.shape
+        ctx.pdtypes = (gamma.dtype, beta.dtype)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, g32, b32, mean, rstd = ctx.saved_tensors
+        R, C = x2.shape
+        dy2 = dy.reshape(R, C)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        L = _lib.load()
+        nblk = L.gf_ln_gelu_nblk(R)
+        dx = torch.empty_like(x2)
+        dgp = torch.empty((nblk, C), dtype=torch.float32, device=x2.device)
+        dbp = torch.empty((nblk, C), dtype=torch.float32, device=x2.device)
+        _lib.check(L.gf_ln_gelu_bwd(_p(x2), _p(g32), _p(b32), _p(mean), _p(rstd), _p(dy2), _p(dx),
+                                    _p(dgp), _p(dbp), R, C, _dt(x2), _stream()), "gf_ln_gelu_bwd")
+        return (dx.view(ctx.shape), dgp.sum(0).to(ctx.pdtypes[0]), dbp.sum(0).to(ctx.pdtypes[1]), None)
+
+
+def ln_gelu(x, gamma, beta, eps=1e-5):
+    return _LnGelu.apply(x, gamma, beta, eps)
+
+
+# ------------------------------------------------------------------------------ assignment head
+def _mat3(t):
+    assert t.dim() == 3
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def rows_lse(a, b, colbias=None):
+    """lse[b,i] = log sum_j exp(a_i . b_j + colbias_j); no autograd (see dual_lse)."""
+    _chk(a, b, colbias)
+    a, b = _mat3(a), _mat3(b)
+    B, M, D = a.shape
+    N = b.shape[1]
+    out = torch.empty((B, M), dtype=torch.float32, device=a.device)
+    cb = None if colbias is None else colbias.float().contiguous()
+    _lib.check(_lib.load().gf_rows_lse(_p(a), _p(b), _p(cb), _p(out), B, M, N, D, _dt(a), _stream()),
+               "gf_rows_lse")
+    return out
+
+
+@torch.no_grad()
+def rows_argmax(a, b, colbias=None, alpha=1.0):
+    """max_j / argmax_j of alpha * a_i . b_j + colbias_j  ->  ([B,M] float, [B,M] int64)."""
+    _chk(a, b, colbias)
+    a, b = _mat3(a), _mat3(b)
+    B, M, D = a.shape
+    N = b.shape[1]
+    vmax = torch.empty((B, M), dtype=torch.float32, device=a.device)
+    arg = torch.empty((B, M), dtype=torch.int64, device=a.device)
+    cb = None if colbias is None else colbias.float().contiguous()
+    _lib.check(_lib.load().gf_rows_argmax(_p(a), _p(b), _p(cb), float(alpha), _p(vmax), _p(arg),
+                                          B, M, N, D, _dt(a), _stream()), "gf_rows_argmax")
+    return vmax, arg
+
+
+class _DualLSE(torch.autograd.Function):
+    """(r, c) = (LSE_j S_ij, LSE_i S_ij) for S = a b^T, never materialising S.
+    Backward: dS = P_row * gr + P_col * gc (written once in the compute dtype), then two GEMMs."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _mat3(a), _mat3(b)
+        r = rows_lse(a, b)
+        c = rows_lse(b, a)
+        ctx.save_for_backward(a, b, r, c)
+        return r, c
+
+    @staticmethod
+    def backward(ctx, gr, gc):
+        a, b, r, c = ctx.saved_tensors
+        B, M, D = a.shape
+        N = b.shape[1]
+        gr = torch.zeros_like(r) if gr is None else gr.float().contiguous()
+        gc = torch.zeros_like(c) if gc is None else gc.float().contiguous()
+        dS = torch.empty((B, M, N), dtype=a.dtype, device=a.device)
+        _lib.check(_lib.load().gf_dual_softmax_bwd(_p(a), _p(b), _p(r), _p(c), _p(gr), _p(gc), None, 0,
+                                                   0.0, _p(dS), B, M, N, D, _dt(a), _stream()),
+                   "gf_dual_softmax_bwd")
+        da = torch.bmm(dS, b)
+        db = torch.bmm(dS.transpose(1, 2), a)
+        return da, db
+
+
+def dual_lse(a, b):
+    return _DualLSE.apply(a, b)
+
+
+class _AssignWrite(torch.autograd.Function):
+    """out[b,i,j] = alpha a_i.b_j + rowbias_i + colbias_j, plus dustbin column/row/corner."""
+
+    @staticmethod
+    def forward(ctx, a, b, rowbias, colbias, bin_col, bin_row, alpha, corner):
+        _chk(a, b, rowbias, colbias, bin_col, bin_row)
+        a, b = _mat3(a), _mat3(b)
+        B, M, D = a.shape
+        N = b.shape[1]
+        rb, cb, bc, br = (t.float().contiguous() for t in (rowbias, colbias, bin_col, bin_row))
+        out = torch.empty((B, M + 1, N + 1), dtype=torch.float32, device=a.device)
+        _lib.check(_lib.load().gf_assign_write(_p(a), _p(b), _p(rb), _p(cb), _p(bc), _p(br),
+                                               float(alpha), float(corner), _p(out), B, M, N, D,
+                                               _dt(a), _stream()), "gf_assign_write")
+        ctx.save_for_backward(a, b)
+        ctx.alpha = alpha
+        ctx.dts = (rowbias.dtype, colbias.dtype, bin_col.dtype, bin_row.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, G):
+        # Dense upstream gradient: only reached when somebody differentiates through the
+        # materialised matrix (never in the training step, whose loss heads are sparse).
+        a, b = ctx.saved_tensors
+        core = G[:, :-1, :-1]
+        g = (ctx.alpha * core).to(a.dtype)
+        da = torch.bmm(g, b)
+        db = torch.bmm(g.transpose(1, 2), a)
+        d = ctx.dts
+        return (da, db, core.sum(2).to(d[0]), core.sum(1).to(d[1]), G[:, :-1, -1].to(d[2]),
+                G[:, -1, :-1].to(d[3]), None, None)
+
+
+def assign_write(a, b, rowbias, colbias, bin_col, bin_row, alpha=2.0, corner=0.0):
+    return _AssignWrite.apply(a, b, rowbias, colbias, bin_col, bin_row, alpha, corner)
+
+
+@torch.no_grad()
+def filter_matches(max0, arg0, arg1, th):
+    """Mutual-NN filter from the row/column arg-max vectors -> (m0, m1, s0, s1)."""
+    _chk(max0, arg0, arg1)
+    B, M = arg0.shape
+    N = arg1.shape[1]
+    max0, arg0, arg1 = max0.float().contiguous(), arg0.contiguous(), arg1.contiguous()
+    m0 = torch.empty((B, M), dtype=torch.int64, device=arg0.device)
+    m1 = torch.empty((B, N), dtype=torch.int64, device=arg0.device)
+    s0 = torch.empty((B, M), dtype=torch.float32, device=arg0.device)
+    s1 = torch.empty((B, N), dtype=torch.float32, device=arg0.device)
+    _lib.check(_lib.load().gf_filter_matches(_p(max0), _p(arg0), _p(arg1), float(th), _p(m0), _p(m1),
+                                             _p(s0), _p(s1), B, M, N, _stream()), "gf_filter_matches")
+    return m0, m1, s0, s1

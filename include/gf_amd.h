@@ -1,0 +1,143 @@
+/* gf_amd.h — C ABI of libgf_amd.so, the MI355X (gfx950) matcher hot-path library.
+ *
+ * The reference (cvg/glue-factory) is pure Python on PyTorch and has no FFI of its own; the
+ * entry points below are what its matcher modules would bind for the hot path, one per fused
+ * op, each citing the reference lines it replaces (paths relative to /root/reference).
+ * INTEGRATION.md shows the ctypes stubs a glue-factory maintainer would add.
+ *
+ * Conventions
+ *  - Plain pointers to DEVICE memory owned by the caller (PyTorch's caching allocator in the
+ *    shipped host code); the library allocates nothing and keeps no global state.
+ *  - `stream` is a hipStream_t passed as void*; every call only enqueues kernels on it (no host
+ *    synchronisation, hipGraph-capturable).
+ *  - `dtype`: GF_DTYPE_F32 (exact fp32 MFMA, parity mode) or GF_DTYPE_BF16 (bf16 operands, fp32
+ *    accumulation and statistics, perf mode).  Statistics / scores / indices are always
+ *    float / float / int64.
+ *  - Strides are in ELEMENTS; the innermost (channel) dimension is contiguous.  Base pointers
+ *    and strides must keep 16-byte alignment of every row (GF_ERR_ALIGN otherwise).
+ *  - Return value: 0 on success, a negative GF_ERR_* for rejected arguments, or a positive
+ *    hipError_t from the launch.
+ */
+#ifndef GF_AMD_H
+#define GF_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GF_DTYPE_F32 0
+#define GF_DTYPE_BF16 1
+
+#define GF_ERR_UNSUPPORTED (-1) /* e.g. head_dim != 64 */
+#define GF_ERR_SHAPE (-2)
+#define GF_ERR_ALIGN (-3)
+#define GF_ERR_DTYPE (-4)
+
+/* ABI version; bumped on any signature change. */
+int gf_abi_version(void);
+
+/* ---- multi-head attention over keypoints --------------------------------------------------
+ * softmax(scale * q k^T) v, flash style (no N x N tensor in HBM).
+ * Replaces gluefactory/models/matchers/lightglue.py:97-128 (Attention), :161 (SelfBlock),
+ * :203-216 (CrossBlock: call twice, (qk0,qk1,v1) and (qk1,qk0,v0)),
+ * gluefactory_nonfree/superglue.py:112-116 and gluefactory/models/matchers/gluestick.py:524-529.
+ * q [B,Nq,H,D], k/v [B,Nk,H,D], o [B,Nq,H,D] with strides {batch, token, head}; D == 64.
+ * lse [B,H,Nq] = log sum_j exp(scale * q_i.k_j)  (saved for the backward). */
+int gf_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
+                int B, int H, int Nq, int Nk, int D,
+                const int64_t* q_strides, const int64_t* k_strides,
+                const int64_t* v_strides, const int64_t* o_strides,
+                float scale, int dtype, void* stream);
+
+/* Backward of gf_attn_fwd (what autograd derives from the lines above).  delta [B,H,Nq] is
+ * workspace (rowsum(dout * o)), written by the call. */
+int gf_attn_bwd(const void* q, const void* k, const void* v, const void* o,
+                const void* dout, const float* lse, float* delta,
+                void* dq, void* dk, void* dv,
+                int B, int H, int Nq, int Nk, int D,
+                const int64_t* q_strides, const int64_t* k_strides,
+                const int64_t* v_strides, const int64_t* o_strides,
+                const int64_t* do_strides, const int64_t* dq_strides,
+                const int64_t* dk_strides, const int64_t* dv_strides,
+                float scale, int dtype, void* stream);
+
+/* ---- assignment head: double softmax with dustbins ------------------------------------------
+ * S = a b^T with a [B,M,D], b [B,N,D] (the final_proj outputs, already scaled by D^-1/4),
+ * D % 16 == 0, D <= 256, rows contiguous (row stride D, batch strides M*D / N*D).
+ *
+ * gf_rows_lse: lse[b,i] = log sum_j exp(S_ij + colbias[b,j])   (colbias may be NULL)
+ *   Called twice — (a,b) and (b,a) — it gives the row and column normalisers of
+ *   lightglue.py:262-263 (log_softmax over dim 2 of sim and of sim^T); with colbias it also
+ *   serves the bin-augmented softmax of gluestick.py:772-783 by the caller adding the bin. */
+int gf_rows_lse(const void* a, const void* b, const float* colbias, float* lse,
+                int B, int M, int N, int D, int dtype, void* stream);
+
+/* gf_rows_argmax: for every row i of a: max_j / argmax_j over j < N of
+ *   (alpha * S_ij + colbias[b,j])        -> rowmax[b,i] (float), rowarg[b,i] (int64)
+ * With alpha = 2, colbias_j = logsigmoid(z1_j) - c_j this is the row arg-max of the core of the
+ * log assignment (lightglue.py:295 `scores[:, :-1, :-1].max(2)`, and the per-layer arg-max of
+ * TokenConfidence.loss lightglue.py:81-94) without materialising it; called with (b,a) it
+ * gives the column arg-max. */
+int gf_rows_argmax(const void* a, const void* b, const float* colbias, float alpha,
+                   float* rowmax, int64_t* rowarg,
+                   int B, int M, int N, int D, int dtype, void* stream);
+
+/* gf_assign_write: materialise the log assignment (lightglue.py:256-268)
+ *   out[b,i,j] = alpha*S_ij + rowbias[b,i] + colbias[b,j]      i<M, j<N
+ *   out[b,i,N] = bin_col[b,i];  out[b,M,j] = bin_row[b,j];  out[b,M,N] = corner
+ * out is [B, M+1, N+1] fp32 contiguous.  LightGlue: alpha=2, rowbias = logsig(z0) - r,
+ * colbias = logsig(z1) - c, bin_col = logsig(-z0), bin_row = logsig(-z1), corner = 0.
+ * GlueStick (gluestick.py:772-783): alpha=1, rowbias=-r/2, colbias=-c/2, bins from the caller. */
+int gf_assign_write(const void* a, const void* b, const float* rowbias, const float* colbias,
+                    const float* bin_col, const float* bin_row, float alpha, float corner,
+                    float* out, int B, int M, int N, int D, int dtype, void* stream);
+
+/* gf_dual_softmax_bwd: the N x N part of the head's backward.  With r_i = LSE_j S_ij and
+ * c_j = LSE_i S_ij (gf_rows_lse), gr = dL/dr and gc = dL/dc:
+ *   dS[b,i,j] = galpha * G[b,i,j] + exp(S_ij - r_i) * gr[b,i] + exp(S_ij - c_j) * gc[b,j]
+ * written in `dtype` ([B,M,N] contiguous) for the two GEMMs dA = dS b, dB = dS^T a.
+ * G (fp32, rows of stride ldg inside a [B, M+1, ldg] buffer, i.e. the upstream gradient of the
+ * materialised log assignment) may be NULL: in the sparse-loss training path the positives'
+ * direct term reaches a/b through autograd of a gather in the host code. */
+int gf_dual_softmax_bwd(const void* a, const void* b, const float* r, const float* c,
+                        const float* gr, const float* gc, const float* G, int64_t ldg,
+                        float galpha, void* dS, int B, int M, int N, int D, int dtype,
+                        void* stream);
+
+/* ---- mutual nearest neighbour filter (lightglue.py:293-309, superglue.py:301-311,
+ * gluestick.py:321-334) from the row/column arg-max vectors:
+ * max0 [B,M] (log-score of the row maximum), arg0 [B,M], arg1 [B,N] ->
+ * m0 [B,M], m1 [B,N] (int64, -1 = unmatched), s0 [B,M], s1 [B,N]. */
+int gf_filter_matches(const float* max0, const int64_t* arg0, const int64_t* arg1, float th,
+                      int64_t* m0, int64_t* m1, float* s0, float* s1,
+                      int B, int M, int N, void* stream);
+
+/* ---- fused elementwise ops of the transformer block ---------------------------------------
+ * Rotary embedding applied in place to the q and k thirds of a fused [B,N,3,H,D] projection
+ * (lightglue.py:42-49,159-160): cs [B,N,D] holds cos in the even and sin in the odd slot of
+ * each pair (one angle per pair).  `inverse` applies the transpose rotation (backward). */
+int gf_rotary_qk(void* qkv, const float* cs, int B, int N, int H, int D, int inverse,
+                 int dtype, void* stream);
+/* Backward of the rotation: dqkv holds the gradients w.r.t. the ROTATED q,k (first two thirds,
+ * rotated back in place) and qkv_rot the rotated values saved by the forward;
+ * dtheta [B,N,D/2] (fp32) receives the gradient w.r.t. the pair angles
+ * sum_{q,k,heads} (g_odd * y_even - g_even * y_odd), which autograd carries to posenc.Wr. */
+int gf_rotary_qk_bwd(void* dqkv, const void* qkv_rot, const float* cs, float* dtheta,
+                     int B, int N, int H, int D, int dtype, void* stream);
+/* LayerNorm(affine) + GELU(erf) over rows of x [R, C] (lightglue.py:143-148 ffn.1, ffn.2):
+ * y = gelu(ln(x) * gamma + beta); saves mean / rstd [R] for the backward. */
+int gf_ln_gelu_fwd(const void* x, const float* gamma, const float* beta, void* y,
+                   float* mean, float* rstd, int R, int C, float eps, int dtype, void* stream);
+/* Backward: dx [R,C]; dgamma/dbeta partial sums [nblk, C] fp32 (nblk = gf_ln_gelu_nblk(R)),
+ * reduced by the caller. */
+int gf_ln_gelu_nblk(int R);
+int gf_ln_gelu_bwd(const void* x, const float* gamma, const float* beta, const float* mean,
+                   const float* rstd, const void* dy, void* dx, float* dgamma_part,
+                   float* dbeta_part, int R, int C, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GF_AMD_H */

@@ -1,0 +1,103 @@
+"""CPU-only checks: the C-ABI library builds/loads and exports every symbol declared in
+include/gf_amd.h; config object, plugin registry and BaseModel semantics; the product path
+fails loudly without a GPU (no fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "gf_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gf_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from glue_factory_amd import lib
+    if not os.path.exists(lib.LIB_PATH):
+        lib.build()
+    so = ctypes.CDLL(lib.LIB_PATH)
+    declared = _declared_symbols()
+    assert len(declared) >= 12
+    for name in declared:
+        assert hasattr(so, name), f"{name} declared in gf_amd.h but not exported"
+    assert set(declared) == set(lib.SIGNATURES), set(declared) ^ set(lib.SIGNATURES)
+    assert lib.load().gf_abi_version() == lib.ABI_VERSION
+
+
+def test_conf_semantics():
+    from glue_factory_amd.conf import Conf, ConfError
+    base = Conf.create({"a": 1, "loss": {"gamma": 1.0, "fn": "nll"}, "layers": ["self", "cross"]})
+    c = Conf.merge(base, {"a": 2, "loss": {"gamma": 0.5}})
+    assert c.a == 2 and c.loss.gamma == 0.5 and c.loss.fn == "nll" and c["layers"] == ["self", "cross"]
+    assert base.a == 1  # merge does not alias
+    c.set_struct(True)
+    with pytest.raises(ConfError):
+        c.unknown
+    with pytest.raises(ConfError):
+        c["new"] = 1
+    with pytest.raises(ConfError):
+        Conf.merge(c, {"nope": 1})
+    c.set_readonly(True)
+    with pytest.raises(ConfError):
+        c.a = 5
+    assert c.to_container() == {"a": 2, "loss": {"gamma": 0.5, "fn": "nll"}, "layers": ["self", "cross"]}
+    d = Conf.from_dotlist(["model.matcher.n_layers=4", "train.lr=1e-4", "x=true"])
+    assert d.model.matcher.n_layers == 4 and d.x is True
+
+
+def test_registry_and_base_model():
+    from glue_factory_amd.base_model import BaseModel, get_model
+
+    LG = get_model("glue_factory_amd.matchers.lightglue")
+    assert LG.__name__ == "LightGlue"
+    assert get_model("matchers.lightglue") is LG and get_model("lightglue") is LG
+    with pytest.raises(RuntimeError):
+        get_model("does.not.exist")
+
+    class Child(BaseModel):
+        default_conf = {"k": 3, "nested": {"x": 1}}
+        required_data_keys = ["view0"]
+
+        def _init(self, conf):
+            self.lin = torch.nn.Linear(2, 2)
+            self.bn = torch.nn.BatchNorm1d(2)
+
+        def _forward(self, data):
+            return {"y": data["view0"]}
+
+        def loss(self, pred, data):
+            raise NotImplementedError
+
+    m = Child({"nested": {"x": 5}, "trainable": False, "freeze_batch_normalization": True, "extra": 1})
+    assert m.conf.k == 3 and m.conf.nested.x == 5 and m.conf.name is None and m.conf.extra == 1
+    assert all(not p.requires_grad for p in m.parameters())
+    m.train()
+    assert m.training and not m.bn.training
+    with pytest.raises(AssertionError):
+        m({})
+    assert m({"view0": 1}) == {"y": 1}
+    assert not m.is_initialized()
+    m.load_state_dict(m.state_dict())
+    assert m.is_initialized()
+
+
+def test_lightglue_conf_state_dict_and_no_cpu_fallback():
+    from glue_factory_amd.matchers.lightglue import LightGlue
+    from oracle import lightglue_oracle as lgo
+    m = LightGlue({"n_layers": 2, "checkpointed": True, "flash": False})
+    ref = lgo.init_params(2, 256, 4, seed=0)
+    sd = m.state_dict()
+    assert set(sd) == set(ref) and all(sd[k].shape == ref[k].shape for k in ref)
+    torch.testing.assert_close(sd["confidence_thresholds"], ref["confidence_thresholds"])
+    data = {"keypoints0": torch.rand(1, 8, 2), "keypoints1": torch.rand(1, 8, 2),
+            "descriptors0": torch.rand(1, 8, 256), "descriptors1": torch.rand(1, 8, 256)}
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(data)
+    with pytest.raises(NotImplementedError):
+        LightGlue({"descriptor_dim": 128, "num_heads": 4})

@@ -1,0 +1,230 @@
+"""HIP kernels (through the C ABI + autograd wrappers) vs fp64 torch restatements of the same
+math.  fp32 mode: 1e-4 (north_star tolerance); bf16 mode: loose bounds, reported."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from glue_factory_amd import ops
+
+DEV = "cuda"
+
+
+def _attn_ref(q, k, v, scale):
+    # q [B,Nq,H,D] fp64
+    s = torch.einsum("bqhd,bkhd->bhqk", q, k) * scale
+    p = torch.softmax(s, -1)
+    return torch.einsum("bhqk,bkhd->bqhd", p, v), torch.logsumexp(s, -1)
+
+
+def _tols(dtype):
+    return dict(rtol=1e-4, atol=1e-4) if dtype == torch.float32 else dict(rtol=5e-2, atol=5e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,Nq,Nk", [(2, 4, 128, 128), (1, 2, 100, 77), (2, 4, 300, 513), (1, 1, 1, 1)])
+def test_attention_fwd_bwd(dtype, B, H, Nq, Nk):
+    D = 64
+    g = torch.Generator().manual_seed(B * 1000 + Nq + Nk)
+    q, k, v, do = (torch.randn(B, n, H, D, generator=g, dtype=torch.float64)
+                   for n in (Nq, Nk, Nk, Nq))
+    # asymmetric content (transpose-detecting): scale rows / channels differently
+    k = k * (1 + torch.arange(D, dtype=torch.float64) / D)
+    v = v + torch.arange(Nk, dtype=torch.float64)[None, :, None, None] / Nk
+    qd, kd, vd, dod = (t.to(DEV, dtype) for t in (q, k, v, do))
+    qr, kr, vr = (t.to(torch.float64).cpu().requires_grad_(True) for t in (qd, kd, vd))
+    oref, lse_ref = _attn_ref(qr, kr, vr, D ** -0.5)
+    (oref * dod.cpu().double()).sum().backward()
+
+    qd, kd, vd = (t.requires_grad_(True) for t in (qd, kd, vd))
+    o = ops.attention(qd, kd, vd)
+    (o * dod).sum().backward()
+    torch.testing.assert_close(o.detach().cpu().double(), oref.detach(), **_tols(dtype))
+    for name, a, b in (("dq", qd.grad, qr.grad), ("dk", kd.grad, kr.grad), ("dv", vd.grad, vr.grad)):
+        scale = max(b.abs().max().item(), 1e-6)
+        torch.testing.assert_close(a.cpu().double() / scale, b / scale, msg=lambda m: f"{name}: {m}",
+                                   **_tols(dtype))
+    _, lse = ops.attn_fwd_raw(qd.detach(), kd.detach(), vd.detach(), D ** -0.5)
+    torch.testing.assert_close(lse.cpu().double(), lse_ref.detach(), rtol=1e-4,
+                               atol=1e-4 if dtype == torch.float32 else 3e-2)
+
+
+def test_attention_strided_views_and_spike():
+    """q,k,v as strided views of one fused buffer; one key spikes (forces the online rescale)."""
+    B, N, H, D = 2, 200, 4, 64
+    g = torch.Generator().manual_seed(3)
+    qkv = torch.randn(B, N, 3, H, D, generator=g, dtype=torch.float64)
+    qkv[:, 150, 1] *= 12.0   # late spike: running max jumps in the third 64-key tile
+    d = qkv.to(DEV, torch.float32)
+    o = ops.attention(d[:, :, 0], d[:, :, 1], d[:, :, 2])
+    ref, _ = _attn_ref(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], D ** -0.5)
+    torch.testing.assert_close(o.cpu().double(), ref, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_self_attention_rotary(dtype):
+    B, N, H, D = 2, 96, 4, 64
+    g = torch.Generator().manual_seed(5)
+    qkv = torch.randn(B, N, 3, H, D, generator=g).to(DEV, dtype)
+    theta = (torch.randn(B, N, D // 2, generator=g) * 2).to(DEV).requires_grad_(True)
+    do = torch.randn(B, N, H, D, generator=g).to(DEV, dtype)
+    # reference in fp64 on the CPU
+    x = qkv.detach().cpu().double().requires_grad_(True)
+    th = theta.detach().cpu().double().requires_grad_(True)
+    cos, sin = torch.cos(th).repeat_interleave(2, -1), torch.sin(th).repeat_interleave(2, -1)
+
+    def rot(t):  # t [B,N,H,D]
+        te, to = t[..., 0::2], t[..., 1::2]
+        r = torch.stack((-to, te), -1).flatten(-2)
+        return t * cos[:, :, None] + r * sin[:, :, None]
+
+    oref, _ = _attn_ref(rot(x[:, :, 0]), rot(x[:, :, 1]), x[:, :, 2], D ** -0.5)
+    (oref * do.cpu().double()).sum().backward()
+
+    qkv_in = qkv.clone().requires_grad_(True)
+    work = qkv_in * 1.0   # non-leaf private buffer, rotated in place by the op
+    cs = torch.stack((torch.cos(theta), torch.sin(theta)), -1).flatten(-2).detach().contiguous()
+    o = ops.self_attention_rotary(work, theta, cs)
+    (o * do).sum().backward()
+    tol = _tols(dtype)
+    torch.testing.assert_close(o.detach().cpu().double(), oref.detach(), **tol)
+    sc = x.grad.abs().max().item()
+    torch.testing.assert_close(qkv_in.grad.cpu().double() / sc, x.grad / sc, **tol)
+    sc = th.grad.abs().max().item()
+    torch.testing.assert_close(theta.grad.cpu().double() / sc, th.grad / sc, **tol)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_cross_attention_both_forms(dtype):
+    B, N, H, D = 2, 130, 4, 64
+    g = torch.Generator().manual_seed(7)
+    p = torch.randn(2 * B, N, 2, H, D, generator=g).to(DEV, dtype)
+    dm = torch.randn(2 * B, N, H, D, generator=g).to(DEV, dtype)
+    x = p.detach().cpu().double().requires_grad_(True)
+    m0, _ = _attn_ref(x[:B, :, 0], x[B:, :, 0], x[B:, :, 1], D ** -0.5)
+    m1, _ = _attn_ref(x[B:, :, 0], x[:B, :, 0], x[:B, :, 1], D ** -0.5)
+    mref = torch.cat([m0, m1], 0)
+    (mref * dm.cpu().double()).sum().backward()
+    ps = p.clone().requires_grad_(True)
+    m = ops.cross_attention_stacked(ps)
+    (m * dm).sum().backward()
+    tol = _tols(dtype)
+    torch.testing.assert_close(m.detach().cpu().double(), mref.detach(), **tol)
+    sc = x.grad.abs().max().item()
+    torch.testing.assert_close(ps.grad.cpu().double() / sc, x.grad / sc, **tol)
+    # unstacked form with different keypoint counts
+    p0 = torch.randn(B, 70, 2, H, D, generator=g).to(DEV, dtype).requires_grad_(True)
+    p1 = torch.randn(B, 129, 2, H, D, generator=g).to(DEV, dtype).requires_grad_(True)
+    a0, a1 = ops.cross_attention(p0, p1)
+    (a0.sum() + 2 * a1.sum()).backward()
+    x0 = p0.detach().cpu().double().requires_grad_(True)
+    x1 = p1.detach().cpu().double().requires_grad_(True)
+    r0, _ = _attn_ref(x0[:, :, 0], x1[:, :, 0], x1[:, :, 1], D ** -0.5)
+    r1, _ = _attn_ref(x1[:, :, 0], x0[:, :, 0], x0[:, :, 1], D ** -0.5)
+    (r0.sum() + 2 * r1.sum()).backward()
+    torch.testing.assert_close(a0.detach().cpu().double(), r0.detach(), **tol)
+    torch.testing.assert_close(a1.detach().cpu().double(), r1.detach(), **tol)
+    for a, b in ((p0.grad, x0.grad), (p1.grad, x1.grad)):
+        sc = b.abs().max().item()
+        torch.testing.assert_close(a.cpu().double() / sc, b / sc, **tol)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("R,C", [(37, 512), (256, 512), (5, 128)])
+def test_ln_gelu(dtype, R, C):
+    g = torch.Generator().manual_seed(R + C)
+    x = (torch.randn(R, C, generator=g) * 2 + 0.3).to(DEV, dtype)
+    gamma = (1 + 0.2 * torch.randn(C, generator=g)).to(DEV).requires_grad_(True)
+    beta = (0.2 * torch.randn(C, generator=g)).to(DEV).requires_grad_(True)
+    dy = torch.randn(R, C, generator=g).to(DEV, dtype)
+    xr = x.detach().cpu().double().requires_grad_(True)
+    gr, br = (t.detach().cpu().double().requires_grad_(True) for t in (gamma, beta))
+    yref = torch.nn.functional.gelu(torch.nn.functional.layer_norm(xr, (C,), gr, br, 1e-5))
+    (yref * dy.cpu().double()).sum().backward()
+    xs = x.clone().requires_grad_(True)
+    y = ops.ln_gelu(xs, gamma, beta, 1e-5)
+    (y * dy).sum().backward()
+    tol = _tols(dtype)
+    torch.testing.assert_close(y.detach().cpu().double(), yref.detach(), **tol)
+    for a, b in ((xs.grad, xr.grad), (gamma.grad, gr.grad), (beta.grad, br.grad)):
+        sc = b.abs().max().item()
+        torch.testing.assert_close(a.cpu().double() / sc, b / sc, **tol)
+
+
+def _head_inputs(B, M, N, D, dtype, seed):
+    g = torch.Generator().manual_seed(seed)
+    a = (torch.randn(B, M, D, generator=g) * 0.6).to(DEV, dtype)
+    b = (torch.randn(B, N, D, generator=g) * 0.6).to(DEV, dtype)
+    z0 = torch.randn(B, M, generator=g).to(DEV)
+    z1 = torch.randn(B, N, generator=g).to(DEV)
+    return a, b, z0, z1
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,M,N,D", [(2, 128, 128, 256), (1, 100, 171, 256), (2, 65, 40, 64), (1, 1, 3, 128)])
+def test_assignment_head(dtype, B, M, N, D):
+    from oracle.lightglue_oracle import log_double_softmax
+    a, b, z0, z1 = _head_inputs(B, M, N, D, dtype, 11 + M + N)
+    ar, br = (t.detach().cpu().double().requires_grad_(True) for t in (a, b))
+    z0r, z1r = (t.detach().cpu().double().requires_grad_(True) for t in (z0, z1))
+    sim = ar @ br.transpose(1, 2)
+    ref = log_double_softmax(sim, z0r, z1r)
+
+    ad, bd = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    z0d, z1d = z0.clone().requires_grad_(True), z1.clone().requires_grad_(True)
+    r, c = ops.dual_lse(ad, bd)
+    lz0, lz1 = torch.nn.functional.logsigmoid(z0d), torch.nn.functional.logsigmoid(z1d)
+    out = ops.assign_write(ad, bd, lz0 - r, lz1 - c, torch.nn.functional.logsigmoid(-z0d),
+                           torch.nn.functional.logsigmoid(-z1d), alpha=2.0, corner=0.0)
+    tol = dict(rtol=1e-4, atol=1e-4) if dtype == torch.float32 else dict(rtol=2e-2, atol=8e-2)
+    torch.testing.assert_close(r.detach().cpu().double(), sim.logsumexp(2).detach(), **tol)
+    torch.testing.assert_close(c.detach().cpu().double(), sim.logsumexp(1).detach(), **tol)
+    torch.testing.assert_close(out.detach().cpu().double(), ref.detach(), **tol)
+    # dense backward through the materialised matrix + the two normalisers
+    G = torch.randn(B, M + 1, N + 1, generator=torch.Generator().manual_seed(1)).to(DEV)
+    (out * G).sum().backward()
+    (ref * G.cpu().double()).sum().backward()
+    for name, x, y in (("a", ad.grad, ar.grad), ("b", bd.grad, br.grad), ("z0", z0d.grad, z0r.grad),
+                       ("z1", z1d.grad, z1r.grad)):
+        sc = max(y.abs().max().item(), 1e-9)
+        torch.testing.assert_close(x.cpu().double() / sc, y / sc, msg=lambda m: f"{name}: {m}",
+                                   **(_tols(dtype)))
+    # arg-maxes of the core and mutual-NN filter
+    if dtype == torch.float32:
+        core = ref[:, :-1, :-1].detach()
+        h = {"md0": a, "md1": b, "r": r.detach(), "c": c.detach(), "lz0": lz0.detach(),
+             "lz1": lz1.detach(), "bin0": torch.nn.functional.logsigmoid(-z0),
+             "bin1": torch.nn.functional.logsigmoid(-z1)}
+        from glue_factory_amd.matchers.lightglue import MatchAssignment
+        am = MatchAssignment.argmaxes(h)
+        torch.testing.assert_close(am["max0"].cpu().double(), core.max(2).values, rtol=1e-4, atol=1e-4)
+        assert torch.equal(am["arg0"].cpu(), core.max(2).indices)
+        assert torch.equal(am["arg1"].cpu(), core.max(1).indices)
+        assert torch.equal(am["full0"].cpu(), ref[:, :-1, :].detach().max(-1).indices)
+        assert torch.equal(am["full1"].cpu(), ref[:, :, :-1].detach().max(-2).indices)
+        from oracle.lightglue_oracle import filter_matches
+        for th in (0.0, 1e-4):
+            m0, m1, s0, s1 = ops.filter_matches(am["max0"], am["arg0"], am["arg1"], th)
+            rm0, rm1, rs0, rs1 = filter_matches(ref.detach(), th)
+            assert torch.equal(m0.cpu(), rm0) and torch.equal(m1.cpu(), rm1)
+            torch.testing.assert_close(s0.cpu().double(), rs0, rtol=1e-4, atol=1e-6)
+            torch.testing.assert_close(s1.cpu().double(), rs1, rtol=1e-4, atol=1e-6)
+
+
+def test_rows_lse_colbias_and_large_logits():
+    """colbias path (GlueStick bin) and +-large logits: LSE must stay finite and exact."""
+    B, M, N, D = 1, 70, 90, 64
+    a, b, _, _ = _head_inputs(B, M, N, D, torch.float32, 99)
+    a = a * 6.0   # |S| up to ~ 100
+    cb = torch.randn(B, N, device=DEV) * 3
+    out = ops.rows_lse(a, b, cb)
+    ref = (a.cpu().double() @ b.cpu().double().transpose(1, 2) + cb.cpu().double()[:, None]).logsumexp(2)
+    torch.testing.assert_close(out.cpu().double(), ref, rtol=1e-5, atol=1e-3)
+
+
+def test_ops_reject_cpu_tensors():
+    with pytest.raises(RuntimeError):
+        ops.attention(torch.zeros(1, 4, 1, 64), torch.zeros(1, 4, 1, 64), torch.zeros(1, 4, 1, 64))

@@ -1,0 +1,120 @@
+"""End-to-end parity of the HIP LightGlue (through the plugin surface) against the CPU oracle and
+the reference-generated golden vectors.  fp32 mode: 1e-4; bf16 mode: loose, reported."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_data, load_golden
+
+pytestmark = pytest.mark.gpu
+
+from oracle import lightglue_oracle as lgo  # noqa: E402
+
+
+def _model(params, n_layers, **kw):
+    from glue_factory_amd.base_model import get_model
+    M = get_model("glue_factory_amd.matchers.lightglue")
+    model = M({"n_layers": n_layers, "filter_threshold": 0.0, **kw})
+    res = model.load_state_dict(params, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    return model.cuda()
+
+
+def _to_cuda(d):
+    from glue_factory_amd.synthetic import to_device
+    return to_device(d, "cuda")
+
+
+def _margin_mask(la, k):
+    """rows whose top-2 gap in the oracle exceeds k (arg-max is discontinuous at ties)."""
+    top2 = la.topk(2, dim=-1).values
+    return (top2[..., 0] - top2[..., 1]) > k
+
+
+def test_golden_d256_eval_and_train_step():
+    z = load_golden("lightglue_d256")
+    meta = z["meta"]
+    L, dim, heads, seed = int(meta[3]), int(meta[4]), int(meta[5]), int(meta[6])
+    params = lgo.init_params(L, dim, heads, seed=seed)
+    data = golden_data(z)
+    model = _model(params, L)
+    cdata = _to_cuda(data)
+    model.eval()
+    with torch.no_grad():
+        pe = model(cdata)
+    np.testing.assert_allclose(pe["log_assignment"].cpu().numpy(), z["eval.log_assignment"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_array_equal(pe["matches0"].cpu().numpy(), z["eval.matches0"])
+    np.testing.assert_array_equal(pe["matches1"].cpu().numpy(), z["eval.matches1"])
+    np.testing.assert_allclose(pe["matching_scores0"].cpu().numpy(), z["eval.matching_scores0"], rtol=1e-3, atol=1e-6)
+
+    model.train()
+    pred = model(cdata)
+    losses, metrics = model.loss(pred, {**pred, **cdata})
+    assert metrics == {}
+    losses["total"].mean().backward()
+    for k in ("log_assignment", "ref_descriptors0", "ref_descriptors1"):
+        np.testing.assert_allclose(pred[k].detach().cpu().numpy(), z["train." + k], rtol=1e-4, atol=1e-4, err_msg=k)
+    for k in [k[5:] for k in z if k.startswith("loss.")]:
+        np.testing.assert_allclose(losses[k].detach().cpu().numpy(), z["loss." + k], rtol=1e-4, atol=1e-4, err_msg=k)
+    checked = 0
+    for k, p in model.named_parameters():
+        assert p.grad is not None, f"{k} got no gradient (DDP would hang)"
+        if "gradnorm." + k in z:
+            ref = float(z["gradnorm." + k][0])
+            assert abs(float(p.grad.double().norm()) - ref) <= 2e-3 * ref + 1e-7, (k, float(p.grad.norm()), ref)
+            checked += 1
+        if "grad." + k in z:
+            ref = z["grad." + k]
+            sc = max(np.abs(ref).max(), 1e-9)
+            np.testing.assert_allclose(p.grad.cpu().numpy() / sc, ref / sc, rtol=1e-3, atol=1e-3, err_msg=k)
+    assert checked > 40
+
+
+@pytest.mark.parametrize("n0,n1", [(192, 192), (150, 201)])
+def test_train_step_vs_oracle_fp32(n0, n1):
+    from glue_factory_amd.synthetic import make_pairs
+    L = 3
+    params = lgo.init_params(L, 256, 4, seed=n0)
+    data = make_pairs(2, n0, n1, dim=256, size=(640, 480), seed=n1)
+    odata = dict(data, image_size0=data["view0"]["image_size"], image_size1=data["view1"]["image_size"])
+    pred_o, loss_o, grads_o = lgo.train_step_grads(params, odata, L, 4)
+    model = _model(params, L).train()
+    cdata = _to_cuda(data)
+    pred = model(cdata)
+    losses, _ = model.loss(pred, {**pred, **cdata})
+    losses["total"].mean().backward()
+    torch.testing.assert_close(pred["log_assignment"].cpu(), pred_o["log_assignment"].detach(), rtol=1e-4, atol=1e-4)
+    ok = _margin_mask(pred_o["log_assignment"].detach()[:, :-1, :-1], 1e-3)
+    assert torch.equal(pred["matches0"].cpu()[ok], pred_o["matches0"][ok])
+    for k, v in loss_o.items():
+        torch.testing.assert_close(losses[k].detach().cpu(), v.detach(), rtol=1e-4, atol=1e-4, msg=lambda m: f"{k}: {m}")
+    for k, p in model.named_parameters():
+        ref = grads_o[k]
+        sc = max(ref.abs().max().item(), 1e-9)
+        torch.testing.assert_close(p.grad.cpu() / sc, ref / sc, rtol=2e-3, atol=2e-3, msg=lambda m: f"{k}: {m}")
+
+
+def test_train_step_bf16_close_to_oracle():
+    """perf mode (autocast bf16): same plumbing, looser numbers; reports the error."""
+    from glue_factory_amd.synthetic import make_pairs
+    L = 3
+    params = lgo.init_params(L, 256, 4, seed=2)
+    data = make_pairs(2, 256, dim=256, size=(640, 480), seed=3)
+    odata = dict(data, image_size0=data["view0"]["image_size"], image_size1=data["view1"]["image_size"])
+    pred_o, loss_o, grads_o = lgo.train_step_grads(params, odata, L, 4)
+    model = _model(params, L).train()
+    cdata = _to_cuda(data)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        pred = model(cdata)
+        losses, _ = model.loss(pred, {**pred, **cdata})
+    losses["total"].mean().backward()
+    assert pred["ref_descriptors0"].dtype == torch.bfloat16
+    err = (pred["log_assignment"].cpu() - pred_o["log_assignment"].detach()).abs().max().item()
+    rel = ((losses["total"].cpu() - loss_o["total"].detach()).abs() / loss_o["total"].detach().abs()).max().item()
+    print(f"bf16: max|dlog_assignment|={err:.3e} rel loss err={rel:.3e}")
+    assert err < 0.5 and rel < 2e-2
+    cos = []
+    for k, p in model.named_parameters():
+        a, b = p.grad.cpu().flatten().double(), grads_o[k].flatten().double()
+        cos.append(torch.nn.functional.cosine_similarity(a, b, dim=0).item())
+    assert min(cos) > 0.9, min(cos)
