@@ -1,0 +1,118 @@
+"""Data-parallel train step around a BaseModel-style module (one process per GPU).
+
+Mirrors the semantics of the reference hot loop (gluefactory/train.py:465-517): zero_grad,
+autocast forward, ``loss_fn(pred, data)``, mean of ``losses["total"]``, cross-rank agreement on
+whether the loss is differentiable (all_reduce PRODUCT, train.py:482-488), backward (DDP bucketed
+gradient all-reduce over RCCL/xGMI overlapped with the backward), optional gradient clipping,
+optimizer step.  Image pairs are independent, so the batch shards across ranks with no
+data-path collective; the only collectives are the gradient all-reduce, the 4-byte flag and the
+logging reduce (train.py:525-531).
+
+The same code runs on CPU with the ``gloo`` backend for tests (any module with the
+forward/loss interface), and on GPUs with ``nccl`` (= RCCL on ROCm).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend=None, init_method=None, rank=None, world_size=None):
+    """Join the process group.  Defaults come from the torchrun environment (RANK, WORLD_SIZE,
+    LOCAL_RANK, MASTER_ADDR/PORT); ``init_method='file://...'`` reproduces the reference's
+    single-node file rendezvous (train.py:276-281)."""
+    world_size = int(os.environ.get("WORLD_SIZE", "1")) if world_size is None else world_size
+    rank = int(os.environ.get("RANK", "0")) if rank is None else rank
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world_size == 1:
+        return 0, 1, local
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    kw = {}
+    if backend == "nccl":
+        torch.cuda.set_device(local)
+        kw["device_id"] = torch.device("cuda", local)
+    if init_method is not None:
+        dist.init_process_group(backend, init_method=init_method, rank=rank, world_size=world_size, **kw)
+    else:
+        dist.init_process_group(backend, **kw)
+    return rank, world_size, local
+
+
+def shard_batch(data, rank, world_size):
+    """Slice every batched tensor of a (nested) batch dict: global batch -> this rank's pairs
+    (what DistributedSampler + batch_size // n_gpus do in train.py:285-288)."""
+    if isinstance(data, dict):
+        return {k: shard_batch(v, rank, world_size) for k, v in data.items()}
+    if torch.is_tensor(data) and data.dim() > 0:
+        b = data.shape[0]
+        assert b % world_size == 0, f"global batch {b} not divisible by world size {world_size}"
+        per = b // world_size
+        return data[rank * per:(rank + 1) * per]
+    return data
+
+
+class TrainStep:
+    """step(data) -> dict of detached per-sample losses; one optimiser update per call."""
+
+    def __init__(self, model, optimizer, amp_dtype=None, clip_grad=None, device_ids=None,
+                 bucket_cap_mb=16, find_unused_parameters=False):
+        self.model = model
+        self.optimizer = optimizer
+        self.amp_dtype = amp_dtype
+        self.clip_grad = clip_grad
+        self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.fwd_model = model
+        if self.distributed:
+            from torch.nn.parallel import DistributedDataParallel as DDP
+            # ~47 MB of fp32 gradients for LightGlue: 16 MB buckets let the all-reduce of the
+            # assignment/confidence heads (first gradients of the backward) start while the
+            # transformer backward is still running; loss() is called on the bare module (as the
+            # reference binds loss_fn before wrapping, train.py:334-339).
+            self.fwd_model = DDP(model, device_ids=device_ids, bucket_cap_mb=bucket_cap_mb,
+                                 gradient_as_bucket_view=True,
+                                 find_unused_parameters=find_unused_parameters)
+        p = next(model.parameters())
+        self.device_type = p.device.type
+        self.skipped = 0
+
+    def _all_ranks_agree(self, flag, device):
+        if not self.distributed:
+            return flag
+        t = torch.tensor(float(flag), device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.PRODUCT)
+        return bool(t.item() > 0)
+
+    def __call__(self, data):
+        self.model.train()
+        self.optimizer.zero_grad(set_to_none=True)
+        with torch.autocast(self.device_type, dtype=self.amp_dtype or torch.bfloat16,
+                            enabled=self.amp_dtype is not None):
+            pred = self.fwd_model(data)
+            losses, _ = self.model.loss(pred, {**pred, **data})
+            loss = torch.mean(losses["total"])
+        do_backward = self._all_ranks_agree(loss.requires_grad, loss.device)
+        if do_backward:
+            loss.backward()
+            if self.clip_grad is not None:
+                gn = torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.clip_grad)
+                if not torch.isfinite(gn):
+                    self.skipped += 1
+                    return {k: v.detach() for k, v in losses.items() if torch.is_tensor(v)}
+            self.optimizer.step()
+        else:
+            self.skipped += 1
+        return {k: v.detach() for k, v in losses.items() if torch.is_tensor(v)}
+
+
+def reduce_losses(losses, dst=0):
+    """Mean over samples, then mean over ranks on ``dst`` (logging path, train.py:525-531)."""
+    out = {}
+    for k in sorted(losses):
+        v = losses[k].float().mean()
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            v = v.clone()
+            dist.reduce(v, dst=dst, op=dist.ReduceOp.SUM)
+            v = v / dist.get_world_size()
+        out[k] = float(v.item())
+    return out
