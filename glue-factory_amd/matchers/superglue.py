@@ -1,0 +1,249 @@
+"""SuperGlue matcher on the MI355X hot path (drop-in for gluefactory_nonfree.superglue).
+
+Same plugin surface as the reference (gluefactory_nonfree/superglue.py:221-355): ``BaseModel``
+subclass, same ``default_conf`` keys / ``required_data_keys`` and the same ``state_dict``
+names and shapes (Conv1d weights stay ``(out, in, 1)``, BatchNorm running statistics included).
+
+What runs where
+  * Conv1d(k=1) layers are GEMMs over channels-last activations ``[2B, N, C]`` (both images
+    stacked; hipBLASLt through torch);
+  * attention (superglue.py:112-135): the MFMA flash kernels of csrc/attention.hip.  The
+    reference puts the head index FASTEST in the channel dimension (``view(b, dim, h, n)``);
+    the projection weight rows (and the merge weight columns) are gathered once so the kernels
+    see ``[.., head, channel]`` with contiguous channels — no activation shuffles;
+  * BatchNorm (+ReLU) stays stock torch (``nn.BatchNorm1d`` / SyncBatchNorm-convertible), with
+    one call per image exactly like the reference (batch statistics per image set);
+  * couplings ``[[scores/sqrt(d), a],[a, a]]`` are written in one pass by ``gf_assign_write``
+    from MFMA tiles (no ``sim`` tensor, no torch.cat), then the log-domain Sinkhorn iterations
+    and their hand-derived reverse sweep run in csrc/sinkhorn.hip (superglue.py:186-214);
+  * ``loss`` returns ``(losses, {})`` — the reference returns a bare dict, which breaks
+    ``TwoViewPipeline.loss``'s tuple unpack; the values match the dict's.
+"""
+from pathlib import Path
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .. import ops
+from ..base_model import BaseModel
+
+
+def MLP(channels, do_bn=True):
+    layers = []
+    n = len(channels)
+    for i in range(1, n):
+        layers.append(nn.Conv1d(channels[i - 1], channels[i], kernel_size=1, bias=True))
+        if i < n - 1:
+            if do_bn:
+                layers.append(nn.BatchNorm1d(channels[i]))
+            layers.append(nn.ReLU())
+    return nn.Sequential(*layers)
+
+
+def _conv_cl(x, conv, rows=None, cols=None):
+    """Conv1d(k=1) on channels-last x [..., Cin]; optional gather of output rows / input columns."""
+    w = conv.weight.squeeze(-1)
+    b = conv.bias
+    if rows is not None:
+        w, b = w.index_select(0, rows), b.index_select(0, rows)
+    if cols is not None:
+        w = w.index_select(1, cols)
+    return F.linear(x, w.to(x.dtype), b.to(x.dtype))
+
+
+def _mlp_cl(seq, x, halves):
+    """Run an MLP Sequential (Conv1d / BatchNorm1d / ReLU) on channels-last x [B',N,C].
+    BatchNorm is applied per image set (``halves`` = 2 when two images are stacked on the batch
+    axis), reproducing the reference's one-call-per-image statistics and running-stat updates."""
+    for layer in seq:
+        if isinstance(layer, nn.Conv1d):
+            x = _conv_cl(x, layer)
+        elif isinstance(layer, nn.modules.batchnorm._BatchNorm):
+            b, n, c = x.shape
+            parts = x.float().reshape(halves, (b // halves) * n, c)
+            x = torch.stack([layer(parts[i]) for i in range(halves)]).reshape(b, n, c).to(x.dtype)
+        else:
+            x = layer(x)
+    return x
+
+
+def normalize_keypoints(kpts, size=None, shape=None):
+    """Centre and divide by 0.7 * max(size) (superglue.py:82-93), fp32."""
+    kpts = kpts.float()
+    if size is None:
+        assert shape is not None
+        _, _, h, w = shape
+        size = kpts.new_tensor([[w, h]])
+    size = size.float().to(kpts)
+    return (kpts - size[:, None] / 2) / (size.max(1).values * 0.7)[:, None, None]
+
+
+class KeypointEncoder(nn.Module):
+    def __init__(self, feature_dim, layers, use_scores=True):
+        super().__init__()
+        self.use_scores = use_scores
+        self.encoder = MLP([3 if use_scores else 2] + list(layers) + [feature_dim])
+        nn.init.constant_(self.encoder[-1].bias, 0.0)
+
+    def forward(self, kpts, scores, halves=1):
+        x = torch.cat([kpts, scores[..., None]], -1) if self.use_scores else kpts
+        return _mlp_cl(self.encoder, x.float(), halves)
+
+
+class MultiHeadedAttention(nn.Module):
+    def __init__(self, h, d_model):
+        super().__init__()
+        assert d_model % h == 0
+        self.dim, self.h = d_model // h, h
+        self.merge = nn.Conv1d(d_model, d_model, kernel_size=1)
+        self.proj = nn.ModuleList([nn.Conv1d(d_model, d_model, kernel_size=1) for _ in range(3)])
+        # reference channel c = channel_in_head * h + head  ->  kernel order head * dim + channel
+        perm = (torch.arange(self.dim)[None, :] * h + torch.arange(h)[:, None]).reshape(-1)
+        self.register_buffer("_perm", perm, persistent=False)
+
+    def fused_projection(self, x):
+        w = torch.cat([p.weight.squeeze(-1).index_select(0, self._perm) for p in self.proj], 0)
+        b = torch.cat([p.bias.index_select(0, self._perm) for p in self.proj], 0)
+        qkv = F.linear(x, w.to(x.dtype), b.to(x.dtype))
+        return qkv.view(x.shape[0], x.shape[1], 3, self.h, self.dim)
+
+
+class AttentionalPropagation(nn.Module):
+    def __init__(self, num_dim, num_heads):
+        super().__init__()
+        self.attn = MultiHeadedAttention(num_heads, num_dim)
+        self.mlp = MLP([num_dim * 2, num_dim * 2, num_dim])
+        nn.init.constant_(self.mlp[-1].bias, 0.0)
+
+    def forward(self, x, cross, halves):
+        """x [B',N,C] (stacked images when halves == 2); returns the residual delta."""
+        b, n, d = x.shape
+        o = ops.attention_qkv(self.attn.fused_projection(x), cross=cross)
+        msg = _conv_cl(o.view(b, n, d), self.attn.merge, cols=self.attn._perm)
+        return _mlp_cl(self.mlp, torch.cat([x, msg], -1), halves)
+
+    def forward_pair(self, x0, x1, cross):
+        """Different keypoint counts: one projection per image, generic attention op."""
+        outs = []
+        p0, p1 = self.attn.fused_projection(x0), self.attn.fused_projection(x1)
+        for x, pq, ps in ((x0, p0, p1 if cross else p0), (x1, p1, p0 if cross else p1)):
+            o = ops.attention(pq[:, :, 0], ps[:, :, 1], ps[:, :, 2])
+            msg = _conv_cl(o.reshape(x.shape), self.attn.merge, cols=self.attn._perm)
+            outs.append(_mlp_cl(self.mlp, torch.cat([x, msg], -1), 1))
+        return outs
+
+
+class AttentionalGNN(nn.Module):
+    def __init__(self, feature_dim, layer_names):
+        super().__init__()
+        self.layers = nn.ModuleList([AttentionalPropagation(feature_dim, 4) for _ in layer_names])
+        self.names = list(layer_names)
+
+
+class SuperGlue(BaseModel):
+    default_conf = {
+        "descriptor_dim": 256,
+        "weights": None,           # path to a state_dict (the reference default "outdoor" needs network)
+        "keypoint_encoder": [32, 64, 128, 256],
+        "GNN_layers": ["self", "cross"] * 9,
+        "num_sinkhorn_iterations": 50,
+        "filter_threshold": 0.2,
+        "use_scores": True,
+        "mp": False,
+        "loss": {"nll_balancing": 0.5},
+    }
+    required_data_keys = ["view0", "view1", "keypoints0", "keypoints1", "descriptors0", "descriptors1",
+                          "keypoint_scores0", "keypoint_scores1"]
+
+    def _init(self, conf):
+        if conf.descriptor_dim != 256:
+            raise NotImplementedError("the HIP attention kernels are built for 4 heads of 64 channels")
+        self.kenc = KeypointEncoder(conf.descriptor_dim, conf.keypoint_encoder, conf.use_scores)
+        self.gnn = AttentionalGNN(conf.descriptor_dim, conf.GNN_layers)
+        self.final_proj = nn.Conv1d(conf.descriptor_dim, conf.descriptor_dim, kernel_size=1, bias=True)
+        self.register_parameter("bin_score", nn.Parameter(torch.tensor(1.0)))
+        if conf.weights:
+            path = Path(conf.weights)
+            if not path.exists():
+                raise FileNotFoundError(f"SuperGlue weights '{conf.weights}' not found locally "
+                                        "(pretrained downloads need network access)")
+            self.load_state_dict(torch.load(str(path), map_location="cpu"))
+
+    def _forward(self, data):
+        kpts0, kpts1 = data["keypoints0"], data["keypoints1"]
+        if kpts0.shape[1] == 0 or kpts1.shape[1] == 0:
+            s0, s1 = kpts0.shape[:-1], kpts1.shape[:-1]
+            return {"matches0": kpts0.new_full(s0, -1, dtype=torch.int),
+                    "matches1": kpts1.new_full(s1, -1, dtype=torch.int),
+                    "matching_scores0": kpts0.new_zeros(s0), "matching_scores1": kpts1.new_zeros(s1)}
+        if not kpts0.is_cuda:
+            raise RuntimeError("glue_factory_amd.SuperGlue runs on the MI355X HIP path only (no CPU fallback)")
+        T = torch.bfloat16 if (self.conf.mp or torch.is_autocast_enabled()) else torch.float32
+        with torch.autocast(device_type="cuda", enabled=False):
+            return self._forward_impl(data, T)
+
+    def _forward_impl(self, data, T):
+        conf = self.conf
+        view0, view1 = data["view0"], data["view1"]
+        kpts0 = normalize_keypoints(data["keypoints0"], size=view0.get("image_size"),
+                                    shape=view0["image"].shape if "image" in view0 else None)
+        kpts1 = normalize_keypoints(data["keypoints1"], size=view1.get("image_size"),
+                                    shape=view1["image"].shape if "image" in view1 else None)
+        b, m = kpts0.shape[:2]
+        n = kpts1.shape[1]
+        sc0, sc1 = data["keypoint_scores0"].float(), data["keypoint_scores1"].float()
+        d = conf.descriptor_dim
+        if m == n:
+            enc = self.kenc(torch.cat([kpts0, kpts1], 0), torch.cat([sc0, sc1], 0), halves=2)
+            x = (torch.cat([data["descriptors0"], data["descriptors1"]], 0).float() + enc).to(T)
+            for layer, name in zip(self.gnn.layers, self.gnn.names):
+                if name not in ("self", "cross"):
+                    raise ValueError(name)
+                x = x + layer(x, cross=(name == "cross"), halves=2)
+            md = _conv_cl(x, self.final_proj)
+            md0, md1 = md[:b], md[b:]
+        else:
+            x0 = (data["descriptors0"].float() + self.kenc(kpts0, sc0)).to(T)
+            x1 = (data["descriptors1"].float() + self.kenc(kpts1, sc1)).to(T)
+            for layer, name in zip(self.gnn.layers, self.gnn.names):
+                if name not in ("self", "cross"):
+                    raise ValueError(name)
+                d0, d1 = layer.forward_pair(x0, x1, cross=(name == "cross"))
+                x0, x1 = x0 + d0, x1 + d1
+            md0, md1 = _conv_cl(x0, self.final_proj), _conv_cl(x1, self.final_proj)
+
+        alpha = self.bin_score.float()
+        # couplings Z = [[md0.md1^T / sqrt(d), a], [a, a]] in one MFMA pass (superglue.py:200-204)
+        zero_m, zero_n = md0.new_zeros((b, m), dtype=torch.float32), md0.new_zeros((b, n), dtype=torch.float32)
+        Z = ops.assign_write(md0.contiguous(), md1.contiguous(), zero_m, zero_n, alpha.expand(b, m),
+                             alpha.expand(b, n), alpha=d ** -0.5, corner=alpha)
+        scores = ops.sinkhorn(Z, conf.num_sinkhorn_iterations)
+
+        with torch.no_grad():
+            core = scores[:, :-1, :-1]
+            max0, a0 = core.max(2)
+            a1 = core.max(1).indices
+            m0, m1, ms0, ms1 = ops.filter_matches(max0, a0, a1, conf.filter_threshold)
+        return {"sinkhorn_cost": Z[:, :-1, :-1], "log_assignment": scores, "matches0": m0, "matches1": m1,
+                "matching_scores0": ms0, "matching_scores1": ms1}
+
+    def loss(self, pred, data):
+        la = pred["log_assignment"]
+        bi, ii, ji = data["gt_assignment"].nonzero(as_tuple=True)
+        bsz = la.shape[0]
+        neg0 = (data["gt_matches0"] == -1).float()
+        neg1 = (data["gt_matches1"] == -1).float()
+        num_pos = torch.zeros(bsz, device=la.device).index_add_(0, bi, torch.ones_like(bi, dtype=torch.float32))
+        num_pos = num_pos.clamp(min=1.0)
+        num_neg = (neg0.sum(1) + neg1.sum(1)).clamp(min=1.0)
+        nll_pos = -torch.zeros(bsz, device=la.device).index_add_(0, bi, la[bi, ii, ji]) / num_pos
+        nll_neg = -((la[:, :-1, -1] * neg0).sum(1) + (la[:, -1, :-1] * neg1).sum(1)) / num_neg
+        bal = self.conf.loss.nll_balancing
+        nll = bal * nll_pos + (1 - bal) * nll_neg
+        losses = {"total": nll, "assignment_nll": nll, "nll_pos": nll_pos, "nll_neg": nll_neg,
+                  "num_matchable": num_pos, "num_unmatchable": num_neg, "bin_score": self.bin_score[None]}
+        return losses, {}
+
+
+__main_model__ = SuperGlue

@@ -313,7 +313,10 @@ class _AssignWrite(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, a, b, rowbias, colbias, bin_col, bin_row, alpha, corner):
+        # corner: python float, or a 0-d / [B] tensor (differentiable, e.g. SuperGlue's bin_score)
         _chk(a, b, rowbias, colbias, bin_col, bin_row)
+        corner_t = corner if torch.is_tensor(corner) else None
+        corner = 0.0 if corner_t is not None else corner
         a, b = _mat3(a), _mat3(b)
         B, M, D = a.shape
         N = b.shape[1]
@@ -322,6 +325,9 @@ class _AssignWrite(torch.autograd.Function):
         _lib.check(_lib.load().gf_assign_write(_p(a), _p(b), _p(rb), _p(cb), _p(bc), _p(br),
                                                float(alpha), float(corner), _p(out), B, M, N, D,
                                                _dt(a), _stream()), "gf_assign_write")
+        if corner_t is not None:
+            out[:, -1, -1] = corner_t.detach().float()
+        ctx.corner_shape = None if corner_t is None else corner_t.shape
         ctx.save_for_backward(a, b)
         ctx.alpha = alpha
         ctx.dts = (rowbias.dtype, colbias.dtype, bin_col.dtype, bin_row.dtype)
@@ -337,8 +343,11 @@ class _AssignWrite(torch.autograd.Function):
         da = torch.bmm(g, b)
         db = torch.bmm(g.transpose(1, 2), a)
         d = ctx.dts
+        gcorner = None
+        if ctx.corner_shape is not None:
+            gcorner = G[:, -1, -1].sum() if len(ctx.corner_shape) == 0 else G[:, -1, -1].reshape(ctx.corner_shape)
         return (da, db, core.sum(2).to(d[0]), core.sum(1).to(d[1]), G[:, :-1, -1].to(d[2]),
-                G[:, -1, :-1].to(d[3]), None, None)
+                G[:, -1, :-1].to(d[3]), None, gcorner)
 
 
 def assign_write(a, b, rowbias, colbias, bin_col, bin_row, alpha=2.0, corner=0.0):
@@ -359,3 +368,94 @@ def filter_matches(max0, arg0, arg1, th):
     _lib.check(_lib.load().gf_filter_matches(_p(max0), _p(arg0), _p(arg1), float(th), _p(m0), _p(m1),
                                              _p(s0), _p(s1), B, M, N, _stream()), "gf_filter_matches")
     return m0, m1, s0, s1
+
+
+# ------------------------------------------------------------------------------ generic fused-qkv attention
+class _AttentionQKV(torch.autograd.Function):
+    """Attention on a fused projection qkv [B',N,3,H,D] (no rotary; SuperGlue / GlueStick GNN).
+
+    cross=False: every image attends to itself.  cross=True: B' = 2B stacked images, image b
+    attends to the keys/values of image (b + B) mod 2B.  Every q/k/v slot is consumed by exactly
+    one call, so the backward writes dq/dk/dv straight into one dqkv buffer."""
+
+    @staticmethod
+    def forward(ctx, qkv, cross):
+        B2, N, _, H, D = qkv.shape
+        o = torch.empty((B2, N, H, D), dtype=qkv.dtype, device=qkv.device)
+        lse = torch.empty((B2, H, N), dtype=torch.float32, device=qkv.device)
+        q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+        if not cross:
+            attn_fwd_raw(q, k, v, D ** -0.5, out=o, lse=lse)
+        else:
+            B = B2 // 2
+            attn_fwd_raw(q[:B], k[B:], v[B:], D ** -0.5, out=o[:B], lse=lse[:B])
+            attn_fwd_raw(q[B:], k[:B], v[:B], D ** -0.5, out=o[B:], lse=lse[B:])
+        ctx.save_for_backward(qkv, o, lse)
+        ctx.cross = cross
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qkv, o, lse = ctx.saved_tensors
+        B2, N, _, H, D = qkv.shape
+        if not do.is_contiguous():
+            do = do.contiguous()
+        d = torch.empty_like(qkv)
+        q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+        dq, dk, dv = d[:, :, 0], d[:, :, 1], d[:, :, 2]
+        if not ctx.cross:
+            attn_bwd_raw(q, k, v, o, do, lse, dq, dk, dv, D ** -0.5)
+        else:
+            B = B2 // 2
+            attn_bwd_raw(q[:B], k[B:], v[B:], o[:B], do[:B], lse[:B], dq[:B], dk[B:], dv[B:], D ** -0.5)
+            attn_bwd_raw(q[B:], k[:B], v[:B], o[B:], do[B:], lse[B:], dq[B:], dk[:B], dv[:B], D ** -0.5)
+        return d, None
+
+
+def attention_qkv(qkv, cross=False):
+    return _AttentionQKV.apply(qkv, cross)
+
+
+# ------------------------------------------------------------------------------ Sinkhorn optimal transport
+class _Sinkhorn(torch.autograd.Function):
+    """out = Z + u + v - norm after `iters` log-domain Sinkhorn iterations on the couplings
+    Z [B,M+1,N+1] (fp32).  Only the u/v iterates are kept for the backward."""
+
+    @staticmethod
+    def forward(ctx, Z, iters):
+        _chk(Z)
+        assert Z.dtype == torch.float32 and Z.dim() == 3
+        Z = Z.contiguous()
+        B, R, C = Z.shape
+        M, N = R - 1, C - 1
+        L = _lib.load()
+        nbytes = L.gf_sinkhorn_ws_bytes(B, M, N, iters)
+        if nbytes < 0:
+            _lib.check(int(nbytes), "gf_sinkhorn_ws_bytes")
+        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=Z.device)
+        out = torch.empty_like(Z)
+        uh = torch.empty((max(iters, 1), B, R), dtype=torch.float32, device=Z.device)
+        vh = torch.empty((max(iters, 1), B, C), dtype=torch.float32, device=Z.device)
+        _lib.check(L.gf_sinkhorn_fwd(_p(Z), _p(out), _p(uh), _p(vh), _p(ws), B, M, N, iters, _stream()),
+                   "gf_sinkhorn_fwd")
+        ctx.save_for_backward(Z, uh, vh)
+        ctx.iters = iters
+        return out
+
+    @staticmethod
+    def backward(ctx, G):
+        Z, uh, vh = ctx.saved_tensors
+        B, R, C = Z.shape
+        M, N = R - 1, C - 1
+        G = G.float().contiguous()
+        L = _lib.load()
+        ws = torch.empty(int(L.gf_sinkhorn_ws_bytes(B, M, N, ctx.iters)), dtype=torch.uint8, device=Z.device)
+        gZ = torch.empty_like(Z)
+        gr, gc = G.sum(2).contiguous(), G.sum(1).contiguous()
+        _lib.check(L.gf_sinkhorn_bwd(_p(Z), _p(G), _p(gr), _p(gc), _p(uh), _p(vh), _p(gZ), _p(ws),
+                                     B, M, N, ctx.iters, _stream()), "gf_sinkhorn_bwd")
+        return gZ, None
+
+
+def sinkhorn(Z, iters):
+    return _Sinkhorn.apply(Z, iters)

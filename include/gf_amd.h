@@ -114,6 +114,21 @@ int gf_filter_matches(const float* max0, const int64_t* arg0, const int64_t* arg
                       int64_t* m0, int64_t* m1, float* s0, float* s1,
                       int B, int M, int N, void* stream);
 
+/* ---- log-domain Sinkhorn optimal transport (gluefactory_nonfree/superglue.py:186-214) --------
+ * Z [B, M+1, N+1] fp32 couplings (scores augmented with the bin score), iterated `iters`
+ * times: u = log_mu - LSE_j(Z + v), v = log_nu - LSE_i(Z + u) with the marginals of
+ * superglue.py:206-209.  Stores every iterate in u_hist [iters, B, M+1], v_hist [iters, B, N+1]
+ * (all the backward needs) and writes out = Z + u + v - norm ([B, M+1, N+1], norm = -log(M+N)).
+ * ws: device workspace of gf_sinkhorn_ws_bytes(B, M, N, iters) bytes (same buffer size for both calls). */
+int64_t gf_sinkhorn_ws_bytes(int B, int M, int N, int iters);
+int gf_sinkhorn_fwd(const float* Z, float* out, float* u_hist, float* v_hist, void* ws,
+                    int B, int M, int N, int iters, void* stream);
+/* Backward: gout [B,M+1,N+1] and its row / column sums gsum_row [B,M+1], gsum_col [B,N+1]
+ * -> gZ [B,M+1,N+1] (the caller reduces the bin row/column/corner of gZ to d bin_score). */
+int gf_sinkhorn_bwd(const float* Z, const float* gout, const float* gsum_row, const float* gsum_col,
+                    const float* u_hist, const float* v_hist, float* gZ, void* ws,
+                    int B, int M, int N, int iters, void* stream);
+
 /* ---- fused elementwise ops of the transformer block ---------------------------------------
  * Rotary embedding applied in place to the q and k thirds of a fused [B,N,3,H,D] projection
  * (lightglue.py:42-49,159-160): cs [B,N,D] holds cos in the even and sin in the odd slot of

@@ -85,6 +85,53 @@ def gen_lightglue(name, batch, n0, n1, n_layers, dim, heads, seed, size, store_p
           "matches", (pred["matches0"] > -1).sum(1).tolist())
 
 
+def gen_superglue(name, batch, n0, n1, gnn, iters, seed):
+    """Reference SuperGlue (weights=None, seeded state_dict shared with the oracle): eval and
+    train-mode forward, loss values and gradient norms; plus a bare log_optimal_transport case."""
+    from gluefactory_nonfree.superglue import SuperGlue, log_optimal_transport
+    from oracle import superglue_oracle as sgo
+
+    params = sgo.init_params(256, gnn_layers=len(gnn), seed=seed)
+    data = make_pairs(batch, n0, n1, dim=256, size=(640, 480), seed=seed + 1)
+    data["view0"]["image"] = torch.zeros(batch, 1, 480, 640)
+    data["view1"]["image"] = torch.zeros(batch, 1, 480, 640)
+    model = SuperGlue({"weights": None, "GNN_layers": gnn, "num_sinkhorn_iterations": iters})
+    res = model.load_state_dict(params, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    out = {}
+    model.eval()
+    with torch.no_grad():
+        pe = model(data)
+    out.update(_np({k: pe[k] for k in ("log_assignment", "matches0", "matches1", "matching_scores0")}, "eval."))
+    model.train()
+    pred = model(data)
+    losses = model.loss(pred, {**pred, **data})      # the reference returns a bare dict here
+    losses["total"].mean().backward()
+    out.update(_np({k: pred[k] for k in ("log_assignment", "matches0", "sinkhorn_cost")}, "train."))
+    out.update(_np({k: v for k, v in losses.items() if torch.is_tensor(v)}, "loss."))
+    for k, prm in model.named_parameters():
+        out["gradnorm." + k] = np.array([float(prm.grad.double().norm())])
+        if prm.grad.numel() <= 512:
+            out["grad." + k] = prm.grad.numpy()
+    out["param_checksum"] = np.array([float(sum(v.double().abs().sum() for v in params.values()))])
+    out.update(_np({k: v for k, v in data.items() if torch.is_tensor(v)}, "data."))
+    out["data.image_size0"] = data["view0"]["image_size"].numpy()
+    out["data.image_size1"] = data["view1"]["image_size"].numpy()
+    out["meta"] = np.array([batch, n0, n1, len(gnn), iters, seed])
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+    print(name, "loss", losses["total"].tolist(), "matches", (pred["matches0"] > -1).sum(1).tolist())
+    # bare optimal transport, with gradients w.r.t. scores and alpha
+    g = torch.Generator().manual_seed(seed)
+    scores = (torch.randn(2, 37, 45, generator=g) * 2).requires_grad_(True)
+    alpha = torch.tensor(0.8, requires_grad=True)
+    Z = log_optimal_transport(scores, alpha, 25)
+    G = torch.randn(Z.shape, generator=g)
+    (Z * G).sum().backward()
+    np.savez_compressed(os.path.join(GOLD, "superglue_ot.npz"), scores=scores.detach().numpy(),
+                        alpha=alpha.detach().numpy(), iters=np.array(25), out=Z.detach().numpy(),
+                        G=G.numpy(), gscores=scores.grad.numpy(), galpha=alpha.grad.numpy())
+
+
 def gen_gt(name, batch, n0, n1, seed):
     from gluefactory.geometry.gt_generation import gt_matches_from_homography
 
@@ -104,6 +151,7 @@ def main():
     gen_lightglue("lightglue_d256", batch=1, n0=72, n1=64, n_layers=2, dim=256, heads=4,
                   seed=23, size=(1024, 1024), store_params=False)
     gen_gt("gt_homography", batch=2, n0=96, n1=80, seed=5)
+    gen_superglue("superglue_d256", batch=2, n0=60, n1=52, gnn=["self", "cross"] * 2, iters=20, seed=31)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,120 @@
+"""Sinkhorn kernels and the SuperGlue plugin module vs the reference-generated golden vectors
+and the CPU oracle (fp32: 1e-4)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def test_sinkhorn_fwd_bwd_vs_reference_golden():
+    from glue_factory_amd import ops
+    z = load_golden("superglue_ot")
+    scores = torch.from_numpy(z["scores"]).cuda().requires_grad_(True)
+    alpha = torch.from_numpy(z["alpha"]).cuda().requires_grad_(True)
+    b, m, n = scores.shape
+    Z = torch.cat([torch.cat([scores, alpha.expand(b, m, 1)], -1),
+                   torch.cat([alpha.expand(b, 1, n), alpha.expand(b, 1, 1)], -1)], 1)
+    out = ops.sinkhorn(Z, int(z["iters"]))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), z["out"], rtol=1e-4, atol=1e-4)
+    (out * torch.from_numpy(z["G"]).cuda()).sum().backward()
+    sc = np.abs(z["gscores"]).max()
+    np.testing.assert_allclose(scores.grad.cpu().numpy() / sc, z["gscores"] / sc, rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(float(alpha.grad), float(z["galpha"]), rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("B,M,N,T", [(3, 130, 97, 7), (1, 1, 5, 3), (2, 300, 300, 0), (2, 2100, 2050, 2)])
+def test_sinkhorn_shapes_vs_oracle(B, M, N, T):
+    from glue_factory_amd import ops
+    from oracle import sinkhorn_oracle as so
+    g = torch.Generator().manual_seed(M + N + T)
+    scores = torch.randn(B, M, N, generator=g) * 3
+    alpha = torch.tensor(1.0)
+    Zc = so.couplings(scores.double(), alpha.double()).requires_grad_(True)
+    lmu, lnu, norm = so.marginals(M, N, Zc)
+    ref, _, _ = so.sinkhorn(Zc, lmu, lnu, T)
+    ref = ref - norm
+    G = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    (ref * G).sum().backward()
+    Zd = Zc.detach().float().cuda().requires_grad_(True)
+    out = ops.sinkhorn(Zd, T)
+    torch.testing.assert_close(out.detach().cpu().double(), ref.detach(), rtol=1e-4, atol=2e-4)
+    (out * G.float().cuda()).sum().backward()
+    sc = Zc.grad.abs().max().item()
+    torch.testing.assert_close(Zd.grad.cpu().double() / sc, Zc.grad / sc, rtol=1e-3, atol=5e-4)
+    # a transport plan: rows of exp(out) (without the bin row) sum to 1 after column-last iterations
+    if T > 0:
+        col = (out.detach()[:, :, :-1] ).exp().sum(1)
+        torch.testing.assert_close(col, torch.ones_like(col), rtol=1e-3, atol=1e-3)
+
+
+def _sg_data(z, device):
+    t = lambda k: torch.from_numpy(z["data." + k]).to(device)  # noqa: E731
+    d = {k: t(k) for k in ("keypoints0", "keypoints1", "descriptors0", "descriptors1", "keypoint_scores0",
+                           "keypoint_scores1", "gt_assignment", "gt_matches0", "gt_matches1")}
+    d["view0"] = {"image_size": t("image_size0")}
+    d["view1"] = {"image_size": t("image_size1")}
+    return d
+
+
+def test_superglue_module_vs_reference_golden():
+    from glue_factory_amd.base_model import get_model
+    from oracle import superglue_oracle as sgo
+    z = load_golden("superglue_d256")
+    nl, iters, seed = int(z["meta"][3]), int(z["meta"][4]), int(z["meta"][5])
+    params = sgo.init_params(256, gnn_layers=nl, seed=seed)
+    SG = get_model("glue_factory_amd.matchers.superglue")
+    model = SG({"GNN_layers": ["self", "cross"] * (nl // 2), "num_sinkhorn_iterations": iters})
+    res = model.load_state_dict(params, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    model = model.cuda()
+    data = _sg_data(z, "cuda")
+    model.eval()
+    with torch.no_grad():
+        pe = model(data)
+    np.testing.assert_allclose(pe["log_assignment"].cpu().numpy(), z["eval.log_assignment"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_array_equal(pe["matches0"].cpu().numpy(), z["eval.matches0"])
+    np.testing.assert_allclose(pe["matching_scores0"].cpu().numpy(), z["eval.matching_scores0"], rtol=1e-3, atol=1e-6)
+    model.train()
+    pred = model(data)
+    losses, metrics = model.loss(pred, {**pred, **data})
+    assert metrics == {}
+    losses["total"].mean().backward()
+    np.testing.assert_allclose(pred["log_assignment"].detach().cpu().numpy(), z["train.log_assignment"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(pred["sinkhorn_cost"].detach().cpu().numpy(), z["train.sinkhorn_cost"], rtol=1e-4, atol=1e-4)
+    for k in [k[5:] for k in z if k.startswith("loss.")]:
+        np.testing.assert_allclose(losses[k].detach().cpu().numpy(), z["loss." + k], rtol=1e-4, atol=1e-4, err_msg=k)
+    for k, p in model.named_parameters():
+        assert p.grad is not None, k
+        ref = float(z["gradnorm." + k][0])
+        assert abs(float(p.grad.double().norm()) - ref) <= 3e-3 * ref + 1e-6, (k, float(p.grad.norm()), ref)
+        if "grad." + k in z:
+            sc = max(np.abs(z["grad." + k]).max(), 1e-6)
+            np.testing.assert_allclose(p.grad.cpu().numpy() / sc, z["grad." + k] / sc, rtol=2e-3, atol=2e-3, err_msg=k)
+    # BatchNorm running statistics were updated like the reference's (two calls per layer)
+    assert int(model.kenc.encoder[1].num_batches_tracked) == 2
+
+
+def test_superglue_unequal_counts_and_bf16():
+    from glue_factory_amd.matchers.superglue import SuperGlue
+    from glue_factory_amd.synthetic import make_pairs, to_device
+    from oracle import superglue_oracle as sgo
+    names = ["self", "cross"]
+    params = sgo.init_params(256, gnn_layers=2, seed=4)
+    data = make_pairs(2, 90, 70, dim=256, size=(640, 480), seed=9)
+    odata = dict(data, image_size0=data["view0"]["image_size"], image_size1=data["view1"]["image_size"])
+    with torch.no_grad():
+        ref = sgo.forward(params, odata, names, 10, training=False)
+    model = SuperGlue({"GNN_layers": names, "num_sinkhorn_iterations": 10}).cuda().eval()
+    model.load_state_dict(params)
+    cdata = to_device(data, "cuda")
+    with torch.no_grad():
+        pred = model(cdata)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            pb = model(cdata)
+    torch.testing.assert_close(pred["log_assignment"].cpu(), ref["log_assignment"], rtol=1e-4, atol=1e-4)
+    err = (pb["log_assignment"].cpu() - ref["log_assignment"]).abs().max().item()
+    print("superglue bf16 max|dlog_assignment| =", err)
+    assert err < 0.5

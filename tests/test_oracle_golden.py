@@ -74,3 +74,50 @@ def test_fp64_oracle_close_to_fp32_reference():
     with torch.no_grad():
         pred = lgo.forward(p64, data, L, H, training=False)
     np.testing.assert_allclose(pred["log_assignment"].numpy(), z["eval.log_assignment"], **TOL)
+
+
+# ----------------------------------------------------------------------------- SuperGlue / OT
+def _sg_data(z):
+    t = lambda k: torch.from_numpy(z["data." + k])  # noqa: E731
+    return {k: t(k) for k in ("keypoints0", "keypoints1", "descriptors0", "descriptors1",
+                              "keypoint_scores0", "keypoint_scores1", "gt_assignment", "gt_matches0",
+                              "gt_matches1", "image_size0", "image_size1")}
+
+
+def test_optimal_transport_forward_and_analytic_backward():
+    from oracle import sinkhorn_oracle as so
+    z = load_golden("superglue_ot")
+    scores, alpha, iters = torch.from_numpy(z["scores"]), torch.from_numpy(z["alpha"]), int(z["iters"])
+    out = so.log_optimal_transport(scores, alpha, iters)
+    np.testing.assert_allclose(out.numpy(), z["out"], rtol=1e-4, atol=1e-4)
+    # hand-derived reverse sweep (what csrc/sinkhorn.hip implements) vs the reference's autograd
+    b, m, n = scores.shape
+    Z = so.couplings(scores.double(), alpha.double())
+    lmu, lnu, _ = so.marginals(m, n, Z)
+    _, uh, vh = so.sinkhorn(Z, lmu, lnu, iters)
+    gZ = so.backward_recurrence(Z, torch.from_numpy(z["G"]).double(), uh, vh, lmu, lnu)
+    np.testing.assert_allclose(gZ[:, :m, :n].numpy(), z["gscores"], rtol=1e-3, atol=1e-4)
+    galpha = gZ[:, m, :].sum() + gZ[:, :m, n].sum()
+    np.testing.assert_allclose(float(galpha), float(z["galpha"]), rtol=1e-3, atol=1e-3)
+
+
+def test_superglue_oracle_matches_reference():
+    from oracle import superglue_oracle as sgo
+    z = load_golden("superglue_d256")
+    nl, iters, seed = int(z["meta"][3]), int(z["meta"][4]), int(z["meta"][5])
+    p = sgo.init_params(256, gnn_layers=nl, seed=seed)
+    chk = float(sum(v.double().abs().sum() for v in p.values()))
+    assert abs(chk - float(z["param_checksum"][0])) < 1e-6 * chk
+    names = ["self", "cross"] * (nl // 2)
+    data = _sg_data(z)
+    with torch.no_grad():
+        pe = sgo.forward(p, data, names, iters, training=False)
+    np.testing.assert_allclose(pe["log_assignment"].numpy(), z["eval.log_assignment"], **TOL)
+    np.testing.assert_array_equal(pe["matches0"].numpy(), z["eval.matches0"])
+    pred, losses, grads = sgo.train_step_grads(p, data, names, iters)
+    np.testing.assert_allclose(pred["log_assignment"].detach().numpy(), z["train.log_assignment"], **TOL)
+    for k in [k[5:] for k in z if k.startswith("loss.")]:
+        np.testing.assert_allclose(losses[k].detach().numpy(), z["loss." + k], **TOL, err_msg=k)
+    for k, g in grads.items():
+        ref = float(z["gradnorm." + k][0])
+        assert abs(float(g.double().norm()) - ref) <= 2e-3 * ref + 1e-6, k
