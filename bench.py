@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--roofline-only", action="store_true", help="only time the attention kernels")
     return ap.parse_args()
 
 
@@ -139,6 +140,11 @@ def cpu_baseline(n, layers):
 
 def main():
     args = parse()
+    if args.roofline_only:
+        torch.cuda.set_device(0)
+        print(json.dumps(roofline_attention(args.batch, args.kpts,
+                                            torch.bfloat16 if args.dtype == "bf16" else torch.float32)))
+        return
     from glue_factory_amd import lib
     from glue_factory_amd.matchers.lightglue import LightGlue
     from glue_factory_amd.synthetic import make_pairs, to_device

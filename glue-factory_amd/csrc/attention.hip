@@ -128,111 +128,257 @@ __device__ __forceinline__ void store_row(T* rowptr, const f32x16 (&acc)[HD / 32
 // ===========================================================================================
 // forward
 // ===========================================================================================
-template <typename T, int HD>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
-    using L = Lay<T, HD>;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    T* Ks = reinterpret_cast<T*>(smem);
-    T* Vt = Ks + L::ROWMAJOR;
+// One wave owns 64 query rows (two 32-row blocks): every K / V^T fragment read from LDS feeds two
+// MFMAs.  K/V tiles are double-buffered: the next tile's global loads are issued before the
+// compute of the current one and land in LDS after it (one barrier per tile).  The running max is
+// only raised (and O / l rescaled) when it grows by more than RESCALE_THR (0 in fp32 mode).
+template <typename T> struct RescaleThr { static constexpr float value = 0.f; };
+template <> struct RescaleThr<bf16_t> { static constexpr float value = 4.f; };   // P <= 2^4, log2 units
 
-    const int nqb = (p.Nq + 127) / 128;
+template <typename T, int HD> struct StageRegs {
+    static constexpr int NK = 64 * Lay<T, HD>::CPR / 256;   // row-major chunks per thread
+    static constexpr int NV = 32 * Lay<T, HD>::CPR / 256;   // row pairs x chunks per thread
+    u32x4 k[NK];
+    u32x4 v0[NV], v1[NV];
+};
+
+template <typename T, int HD>
+__device__ __forceinline__ void stage_load(StageRegs<T, HD>& rg, const T* kp, int64_t kld, const T* vp,
+                                           int64_t vld, int row0, int nmax) {
+    using L = Lay<T, HD>;
+#pragma unroll
+    for (int i = 0; i < StageRegs<T, HD>::NK; ++i) {
+        int c = threadIdx.x + 256 * i;
+        int r = c / L::CPR, cc = c % L::CPR;
+        int gr = min(row0 + r, nmax - 1);
+        rg.k[i] = *reinterpret_cast<const u32x4*>(kp + (int64_t)gr * kld + cc * L::VEC);
+    }
+#pragma unroll
+    for (int i = 0; i < StageRegs<T, HD>::NV; ++i) {
+        int it = threadIdx.x + 256 * i;
+        int p = it & 31, cc = it >> 5;
+        int r0 = min(row0 + 2 * p, nmax - 1), r1 = min(row0 + 2 * p + 1, nmax - 1);
+        rg.v0[i] = *reinterpret_cast<const u32x4*>(vp + (int64_t)r0 * vld + cc * L::VEC);
+        rg.v1[i] = *reinterpret_cast<const u32x4*>(vp + (int64_t)r1 * vld + cc * L::VEC);
+    }
+}
+
+template <typename T, int HD>
+__device__ __forceinline__ void stage_store(const StageRegs<T, HD>& rg, T* Ks, T* Vt) {
+    using L = Lay<T, HD>;
+    typedef typename Pair<T>::type pair_t;
+#pragma unroll
+    for (int i = 0; i < StageRegs<T, HD>::NK; ++i) {
+        int c = threadIdx.x + 256 * i;
+        int r = c / L::CPR, cc = c % L::CPR;
+        *reinterpret_cast<u32x4*>(Ks + r * L::LDR + cc * L::VEC) = rg.k[i];
+    }
+#pragma unroll
+    for (int i = 0; i < StageRegs<T, HD>::NV; ++i) {
+        int it = threadIdx.x + 256 * i;
+        int p = it & 31, cc = it >> 5;
+        union { u32x4 u; T e[L::VEC]; } a, b;
+        a.u = rg.v0[i];
+        b.u = rg.v1[i];
+#pragma unroll
+        for (int e = 0; e < L::VEC; ++e) {
+            pair_t pr = {a.e[e], b.e[e]};
+            *reinterpret_cast<pair_t*>(Vt + (cc * L::VEC + e) * L::LDT + 2 * p) = pr;
+        }
+    }
+}
+
+template <typename T, int HD>
+__global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_fwd_kernel(AttnParams p) {
+    using L = Lay<T, HD>;
+    constexpr int BUF = L::ROWMAJOR + L::TRANSP;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* lds = reinterpret_cast<T*>(smem);
+
+    const int nqb = (p.Nq + 255) / 256;
     const int total = nqb * p.H * p.B;
     int lb = xcd_remap(blockIdx.x, total);
     const int qb = lb % nqb, h = (lb / nqb) % p.H, b = lb / (nqb * p.H);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int qrow = qb * 128 + wave * 32 + l31;
-    const int qld = min(qrow, p.Nq - 1);
+    const int qrow0 = qb * 256 + wave * 64 + l31;
 
     const T* qp = reinterpret_cast<const T*>(p.q) + b * p.sqb + h * p.sqh;
     const T* kp = reinterpret_cast<const T*>(p.k) + b * p.skb + h * p.skh;
     const T* vp = reinterpret_cast<const T*>(p.v) + b * p.svb + h * p.svh;
 
-    Frag<T> qf[HD / 16];
-    load_row_frags<T, HD>(qf, qp + (int64_t)qld * p.sqn, hi);
+    Frag<T> qf[2][HD / 16];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+        load_row_frags<T, HD>(qf[j], qp + (int64_t)min(qrow0 + 32 * j, p.Nq - 1) * p.sqn, hi);
 
-    f32x16 o[HD / 32];
+    f32x16 o[2][HD / 32];
 #pragma unroll
-    for (int db = 0; db < HD / 32; ++db)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
-    float m = GF_NEG_BIG, lsum = 0.f;
-    const float c = p.scale * GF_LOG2E;
-
-    for (int kv0 = 0; kv0 < p.Nk; kv0 += 64) {
-        __syncthreads();
-        stage_rowmajor<T, HD>(Ks, kp, p.skn, kv0, p.Nk);
-        stage_tile<T, HD, false, true>(nullptr, Vt, vp, p.svn, kv0, p.Nk);
-        __syncthreads();
-
-        f32x16 s[2];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
-            mma_rows<T, HD>(s[kb], Ks, kb * 32, qf, l31, hi);
-        }
-        // scale into log2 units, mask keys beyond Nk, tile max
-        float mx = GF_NEG_BIG;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int key = kv0 + kb * 32 + crow(r, hi);
-                float x = (key < p.Nk) ? s[kb][r] * c : -INFINITY;
-                s[kb][r] = x;
-                mx = fmaxf(mx, x);
-            }
-        mx = fmaxf(mx, xhalf(mx));
-        const float mnew = fmaxf(m, mx);
-        const float alpha = fast_exp2(m - mnew);
-        m = mnew;
-        float ps = 0.f;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float e = fast_exp2(s[kb][r] - mnew);
-                s[kb][r] = e;
-                ps += e;
-            }
-        lsum = lsum * alpha + ps;
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int db = 0; db < HD / 32; ++db)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+            for (int r = 0; r < 16; ++r) o[j][db][r] = 0.f;
+    float m[2] = {GF_NEG_BIG, GF_NEG_BIG}, lsum[2] = {0.f, 0.f};
+    const float c = p.scale * GF_LOG2E;
+
+    StageRegs<T, HD> rg;
+    stage_load<T, HD>(rg, kp, p.skn, vp, p.svn, 0, p.Nk);
+    stage_store<T, HD>(rg, lds, lds + L::ROWMAJOR);
+    __syncthreads();
+
+    const int nt = (p.Nk + 63) / 64;
+    for (int t = 0; t < nt; ++t) {
+        const int kv0 = t * 64;
+        const T* Ks = lds + (t & 1) * BUF;
+        const T* Vt = Ks + L::ROWMAJOR;
+        if (t + 1 < nt) stage_load<T, HD>(rg, kp, p.skn, vp, p.svn, kv0 + 64, p.Nk);
+
+        f32x16 s[2][2];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) mma_transposed<T, HD>(o, Vt, kb * 32, s[kb], l31, hi);
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[j][kb][r] = 0.f;
+            const T* base = Ks + (kb * 32 + l31) * L::LDR + 8 * hi;
+#pragma unroll
+            for (int ks = 0; ks < HD / 16; ++ks) {
+                Frag<T> kf = ld_frag8(base + 16 * ks);
+                mma32(s[0][kb], kf, qf[0][ks]);
+                mma32(s[1][kb], kf, qf[1][ks]);
+            }
+        }
+        if (kv0 + 64 > p.Nk) {   // ragged last tile: keys past Nk never win the max and get P = 0
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (kv0 + kb * 32 + crow(r, hi) >= p.Nk) s[j][kb][r] = -INFINITY;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[j][kb][r]);
+            mx = fmaxf(mx, xhalf(mx)) * c;
+            if (__any(mx > m[j] + RescaleThr<T>::value)) {
+                const float mnew = fmaxf(m[j], mx);
+                const float alpha = fast_exp2(m[j] - mnew);
+                m[j] = mnew;
+                lsum[j] *= alpha;
+#pragma unroll
+                for (int db = 0; db < HD / 32; ++db)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[j][db][r] *= alpha;
+            }
+            float ps = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float e = fast_exp2(fmaf(s[j][kb][r], c, -m[j]));
+                    s[j][kb][r] = e;
+                    ps += e;
+                }
+            lsum[j] += ps;
+        }
+        // O^T[d][q] += V^T[d][key] P[key][q]; each V^T fragment feeds both query blocks
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                Frag<T> p0 = acc_to_frag<T>(s[0][kb], tt), p1 = acc_to_frag<T>(s[1][kb], tt);
+#pragma unroll
+                for (int db = 0; db < HD / 32; ++db) {
+                    const T* vb = Vt + (db * 32 + l31) * L::LDT + kb * 32 + 16 * tt + 4 * hi;
+                    Frag<T> vf = ld_frag4x2(vb, vb + 8);
+                    mma32(o[0][db], vf, p0);
+                    mma32(o[1][db], vf, p1);
+                }
+            }
+        if (t + 1 < nt) {
+            T* nb = lds + ((t + 1) & 1) * BUF;
+            stage_store<T, HD>(rg, nb, nb + L::ROWMAJOR);
+        }
+        __syncthreads();
     }
-    lsum += xhalf(lsum);
-    if (qrow < p.Nq) {
-        T* op = reinterpret_cast<T*>(p.o) + b * p.sob + h * p.soh + (int64_t)qrow * p.son;
-        store_row<T, HD>(op, o, 1.f / lsum, hi);
-        if (hi == 0) p.lse[((int64_t)b * p.H + h) * p.Nq + qrow] = (m + fast_log2(lsum)) * GF_LN2;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int qrow = qrow0 + 32 * j;
+        const float l = lsum[j] + xhalf(lsum[j]);
+        if (qrow < p.Nq) {
+            T* op = reinterpret_cast<T*>(p.o) + b * p.sob + h * p.soh + (int64_t)qrow * p.son;
+            store_row<T, HD>(op, o[j], 1.f / l, hi);
+            if (hi == 0) p.lse[((int64_t)b * p.H + h) * p.Nq + qrow] = (m[j] + fast_log2(l)) * GF_LN2;
+        }
     }
 }
 
 // ===========================================================================================
-// backward, part 1: dQ (and delta = rowsum(dO * O))
+// backward, part 1: dQ (and delta = rowsum(dO * O)); wave = 64 query rows, K/V tiles double-buffered
 // ===========================================================================================
+template <typename T, int HD> struct PairRegs {
+    static constexpr int N = 32 * Lay<T, HD>::CPR / 256;   // (row pair, chunk) items per thread
+    u32x4 a[N], b[N];
+};
 template <typename T, int HD>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
+__device__ __forceinline__ void pair_load(PairRegs<T, HD>& rg, const T* g, int64_t ld, int row0, int nmax) {
     using L = Lay<T, HD>;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    T* Ks = reinterpret_cast<T*>(smem);
-    T* Vs = Ks + L::ROWMAJOR;
-    T* Kt = Vs + L::ROWMAJOR;
+#pragma unroll
+    for (int i = 0; i < PairRegs<T, HD>::N; ++i) {
+        int it = threadIdx.x + 256 * i;
+        int p = it & 31, cc = it >> 5;
+        int r0 = min(row0 + 2 * p, nmax - 1), r1 = min(row0 + 2 * p + 1, nmax - 1);
+        rg.a[i] = *reinterpret_cast<const u32x4*>(g + (int64_t)r0 * ld + cc * L::VEC);
+        rg.b[i] = *reinterpret_cast<const u32x4*>(g + (int64_t)r1 * ld + cc * L::VEC);
+    }
+}
+template <typename T, int HD, bool ROWM, bool TRAN>
+__device__ __forceinline__ void pair_store(const PairRegs<T, HD>& rg, T* ldsR, T* ldsT) {
+    using L = Lay<T, HD>;
+    typedef typename Pair<T>::type pair_t;
+#pragma unroll
+    for (int i = 0; i < PairRegs<T, HD>::N; ++i) {
+        int it = threadIdx.x + 256 * i;
+        int p = it & 31, cc = it >> 5;
+        if (ROWM) {
+            *reinterpret_cast<u32x4*>(ldsR + (2 * p) * L::LDR + cc * L::VEC) = rg.a[i];
+            *reinterpret_cast<u32x4*>(ldsR + (2 * p + 1) * L::LDR + cc * L::VEC) = rg.b[i];
+        }
+        if (TRAN) {
+            union { u32x4 u; T e[L::VEC]; } x, y;
+            x.u = rg.a[i];
+            y.u = rg.b[i];
+#pragma unroll
+            for (int e = 0; e < L::VEC; ++e) {
+                pair_t pr = {x.e[e], y.e[e]};
+                *reinterpret_cast<pair_t*>(ldsT + (cc * L::VEC + e) * L::LDT + 2 * p) = pr;
+            }
+        }
+    }
+}
 
-    const int nqb = (p.Nq + 127) / 128;
+template <typename T, int HD>
+__global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dq_kernel(AttnParams p) {
+    using L = Lay<T, HD>;
+    constexpr int BUF = 2 * L::ROWMAJOR + L::TRANSP;   // K row-major | V row-major | K^T
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* lds = reinterpret_cast<T*>(smem);
+
+    const int nqb = (p.Nq + 255) / 256;
     const int total = nqb * p.H * p.B;
     int lb = xcd_remap(blockIdx.x, total);
     const int qb = lb % nqb, h = (lb / nqb) % p.H, b = lb / (nqb * p.H);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int qrow = qb * 128 + wave * 32 + l31;
-    const int qld = min(qrow, p.Nq - 1);
+    const int qrow0 = qb * 256 + wave * 64 + l31;
 
     const T* qp = reinterpret_cast<const T*>(p.q) + b * p.sqb + h * p.sqh;
     const T* kp = reinterpret_cast<const T*>(p.k) + b * p.skb + h * p.skh;
@@ -240,70 +386,118 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
     const T* op = reinterpret_cast<const T*>(p.o) + b * p.sob + h * p.soh;
     const T* dop = reinterpret_cast<const T*>(p.dout) + b * p.sdob + h * p.sdoh;
 
-    Frag<T> qf[HD / 16], dof[HD / 16];
-    load_row_frags<T, HD>(qf, qp + (int64_t)qld * p.sqn, hi);
-    load_row_frags<T, HD>(dof, dop + (int64_t)qld * p.sdon, hi);
-    float delta = 0.f;
-    {
+    Frag<T> qf[2][HD / 16], dof[2][HD / 16];
+    float delta[2], lse2[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int qld = min(qrow0 + 32 * j, p.Nq - 1);
+        load_row_frags<T, HD>(qf[j], qp + (int64_t)qld * p.sqn, hi);
+        load_row_frags<T, HD>(dof[j], dop + (int64_t)qld * p.sdon, hi);
         Frag<T> of[HD / 16];
         load_row_frags<T, HD>(of, op + (int64_t)qld * p.son, hi);
+        float d = 0.f;
 #pragma unroll
         for (int s = 0; s < HD / 16; ++s)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) delta += to_f32(of[s].v[e]) * to_f32(dof[s].v[e]);
-        delta += xhalf(delta);
+            for (int e = 0; e < 8; ++e) d += to_f32(of[s].v[e]) * to_f32(dof[j][s].v[e]);
+        d += xhalf(d);
+        delta[j] = d;
+        const int64_t stat = ((int64_t)b * p.H + h) * p.Nq + qld;
+        if (qrow0 + 32 * j < p.Nq && hi == 0) p.delta[stat] = d;
+        lse2[j] = p.lse[stat] * GF_LOG2E;
     }
-    const int64_t stat = ((int64_t)b * p.H + h) * p.Nq + qld;
-    if (qrow < p.Nq && hi == 0) p.delta[stat] = delta;
-    const float lse2 = p.lse[stat] * GF_LOG2E;
     const float c = p.scale * GF_LOG2E;
 
-    f32x16 dq[HD / 32];
+    f32x16 dq[2][HD / 32];
 #pragma unroll
-    for (int db = 0; db < HD / 32; ++db)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dq[db][r] = 0.f;
+        for (int db = 0; db < HD / 32; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dq[j][db][r] = 0.f;
 
-    for (int kv0 = 0; kv0 < p.Nk; kv0 += 64) {
-        __syncthreads();
-        stage_tile<T, HD, true, true>(Ks, Kt, kp, p.skn, kv0, p.Nk);
-        stage_rowmajor<T, HD>(Vs, vp, p.svn, kv0, p.Nk);
-        __syncthreads();
+    PairRegs<T, HD> kr, vr;
+    pair_load<T, HD>(kr, kp, p.skn, 0, p.Nk);
+    pair_load<T, HD>(vr, vp, p.svn, 0, p.Nk);
+    pair_store<T, HD, true, true>(kr, lds, lds + 2 * L::ROWMAJOR);
+    pair_store<T, HD, true, false>(vr, lds + L::ROWMAJOR, nullptr);
+    __syncthreads();
+
+    const int nt = (p.Nk + 63) / 64;
+    for (int t = 0; t < nt; ++t) {
+        const int kv0 = t * 64;
+        const T* Ks = lds + (t & 1) * BUF;
+        const T* Vs = Ks + L::ROWMAJOR;
+        const T* Kt = Vs + L::ROWMAJOR;
+        if (t + 1 < nt) {
+            pair_load<T, HD>(kr, kp, p.skn, kv0 + 64, p.Nk);
+            pair_load<T, HD>(vr, vp, p.svn, kv0 + 64, p.Nk);
+        }
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-            f32x16 s, dp;
+            f32x16 s[2], dp[2];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-            mma_rows<T, HD>(s, Ks, kb * 32, qf, l31, hi);
-            mma_rows<T, HD>(dp, Vs, kb * 32, dof, l31, hi);
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int key = kv0 + kb * 32 + crow(r, hi);
-                float pr = (key < p.Nk) ? fast_exp2(s[r] * c - lse2) : 0.f;
-                s[r] = pr * (dp[r] - delta);
+                for (int r = 0; r < 16; ++r) { s[j][r] = 0.f; dp[j][r] = 0.f; }
+            const T* kbase = Ks + (kb * 32 + l31) * L::LDR + 8 * hi;
+            const T* vbase = Vs + (kb * 32 + l31) * L::LDR + 8 * hi;
+#pragma unroll
+            for (int ks = 0; ks < HD / 16; ++ks) {
+                Frag<T> kf = ld_frag8(kbase + 16 * ks);
+                mma32(s[0], kf, qf[0][ks]);
+                mma32(s[1], kf, qf[1][ks]);
+                Frag<T> vf = ld_frag8(vbase + 16 * ks);
+                mma32(dp[0], vf, dof[0][ks]);
+                mma32(dp[1], vf, dof[1][ks]);
             }
-            mma_transposed<T, HD>(dq, Kt, kb * 32, s, l31, hi);
+            const bool ragged = kv0 + 64 > p.Nk;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float pr = fast_exp2(fmaf(s[j][r], c, -lse2[j]));
+                    if (ragged && kv0 + kb * 32 + crow(r, hi) >= p.Nk) pr = 0.f;
+                    s[j][r] = pr * (dp[j][r] - delta[j]);
+                }
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                Frag<T> d0 = acc_to_frag<T>(s[0], tt), d1 = acc_to_frag<T>(s[1], tt);
+#pragma unroll
+                for (int db = 0; db < HD / 32; ++db) {
+                    const T* tb = Kt + (db * 32 + l31) * L::LDT + kb * 32 + 16 * tt + 4 * hi;
+                    Frag<T> kt = ld_frag4x2(tb, tb + 8);
+                    mma32(dq[0][db], kt, d0);
+                    mma32(dq[1][db], kt, d1);
+                }
+            }
         }
+        if (t + 1 < nt) {
+            T* nb = lds + ((t + 1) & 1) * BUF;
+            pair_store<T, HD, true, true>(kr, nb, nb + 2 * L::ROWMAJOR);
+            pair_store<T, HD, true, false>(vr, nb + L::ROWMAJOR, nullptr);
+        }
+        __syncthreads();
     }
-    if (qrow < p.Nq) {
-        T* dqp = reinterpret_cast<T*>(p.dq) + b * p.sdqb + h * p.sdqh + (int64_t)qrow * p.sdqn;
-        store_row<T, HD>(dqp, dq, p.scale, hi);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int qrow = qrow0 + 32 * j;
+        if (qrow < p.Nq) {
+            T* dqp = reinterpret_cast<T*>(p.dq) + b * p.sdqb + h * p.sdqh + (int64_t)qrow * p.sdqn;
+            store_row<T, HD>(dqp, dq[j], p.scale, hi);
+        }
     }
 }
 
 // ===========================================================================================
-// backward, part 2: dK, dV (one workgroup per 128 keys, streaming Q / dO tiles)
+// backward, part 2: dK, dV (one workgroup per 128 keys, Q / dO tiles double-buffered)
 // ===========================================================================================
 template <typename T, int HD>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams p) {
     using L = Lay<T, HD>;
+    constexpr int BUF = 2 * L::ROWMAJOR + 2 * L::TRANSP + 128 * (int)(sizeof(float) / sizeof(T));
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    T* Qs = reinterpret_cast<T*>(smem);
-    T* dOs = Qs + L::ROWMAJOR;
-    T* Qt = dOs + L::ROWMAJOR;
-    T* dOt = Qt + L::TRANSP;
-    float* lse_s = reinterpret_cast<float*>(dOt + L::TRANSP);
-    float* del_s = lse_s + 64;
+    T* lds = reinterpret_cast<T*>(smem);
 
     const int nkb = (p.Nk + 127) / 128;
     const int total = nkb * p.H * p.B;
@@ -333,17 +527,48 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dk[db][r] = 0.f; dv[db][r] = 0.f; }
 
-    for (int q0 = 0; q0 < p.Nq; q0 += 64) {
-        __syncthreads();
-        stage_tile<T, HD, true, true>(Qs, Qt, qp, p.sqn, q0, p.Nq);
-        stage_tile<T, HD, true, true>(dOs, dOt, dop, p.sdon, q0, p.Nq);
+    auto stats_of = [&](T* buf) { return reinterpret_cast<float*>(buf + 2 * L::ROWMAJOR + 2 * L::TRANSP); };
+    auto load_stats = [&](int q0, float& l, float& d) {
+        // rows past Nq: lse = +inf makes P exactly 0
         if (threadIdx.x < 64) {
             int qi = q0 + threadIdx.x;
-            // rows past Nq: lse = +inf makes P exactly 0
-            lse_s[threadIdx.x] = (qi < p.Nq) ? lsep[qi] * GF_LOG2E : INFINITY;
-            del_s[threadIdx.x] = (qi < p.Nq) ? delp[qi] : 0.f;
+            l = (qi < p.Nq) ? lsep[qi] * GF_LOG2E : INFINITY;
+            d = (qi < p.Nq) ? delp[qi] : 0.f;
         }
-        __syncthreads();
+    };
+    auto store_stats = [&](T* buf, float l, float d) {
+        if (threadIdx.x < 64) {
+            float* st = stats_of(buf);
+            st[threadIdx.x] = l;
+            st[64 + threadIdx.x] = d;
+        }
+    };
+
+    PairRegs<T, HD> qr, dor;
+    float ls = 0.f, dl = 0.f;
+    pair_load<T, HD>(qr, qp, p.sqn, 0, p.Nq);
+    pair_load<T, HD>(dor, dop, p.sdon, 0, p.Nq);
+    load_stats(0, ls, dl);
+    pair_store<T, HD, true, true>(qr, lds, lds + 2 * L::ROWMAJOR);
+    pair_store<T, HD, true, true>(dor, lds + L::ROWMAJOR, lds + 2 * L::ROWMAJOR + L::TRANSP);
+    store_stats(lds, ls, dl);
+    __syncthreads();
+
+    const int nt = (p.Nq + 63) / 64;
+    for (int t = 0; t < nt; ++t) {
+        const int q0 = t * 64;
+        T* cur = lds + (t & 1) * BUF;
+        const T* Qs = cur;
+        const T* dOs = Qs + L::ROWMAJOR;
+        const T* Qt = dOs + L::ROWMAJOR;
+        const T* dOt = Qt + L::TRANSP;
+        const float* lse_s = stats_of(cur);
+        const float* del_s = lse_s + 64;
+        if (t + 1 < nt) {
+            pair_load<T, HD>(qr, qp, p.sqn, q0 + 64, p.Nq);
+            pair_load<T, HD>(dor, dop, p.sdon, q0 + 64, p.Nq);
+            load_stats(q0 + 64, ls, dl);
+        }
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
             f32x16 s, dp;
@@ -359,7 +584,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     int r = 4 * g + e;
-                    float pr = fast_exp2(s[r] * c - l4[e]);
+                    float pr = fast_exp2(fmaf(s[r], c, -l4[e]));
                     s[r] = pr;
                     ds[r] = pr * (dp[r] - d4[e]);
                 }
@@ -367,6 +592,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
             mma_transposed<T, HD>(dv, dOt, qb * 32, s, l31, hi);
             mma_transposed<T, HD>(dk, Qt, qb * 32, ds, l31, hi);
         }
+        if (t + 1 < nt) {
+            T* nb = lds + ((t + 1) & 1) * BUF;
+            pair_store<T, HD, true, true>(qr, nb, nb + 2 * L::ROWMAJOR);
+            pair_store<T, HD, true, true>(dor, nb + L::ROWMAJOR, nb + 2 * L::ROWMAJOR + L::TRANSP);
+            store_stats(nb, ls, dl);
+        }
+        __syncthreads();
     }
     if (krow < p.Nk) {
         T* dkp = reinterpret_cast<T*>(p.dk) + b * p.sdkb + h * p.sdkh + (int64_t)krow * p.sdkn;
@@ -376,10 +608,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
     }
 }
 
-template <typename T, int HD> size_t fwd_lds() { return (Lay<T, HD>::ROWMAJOR + Lay<T, HD>::TRANSP) * sizeof(T); }
-template <typename T, int HD> size_t dq_lds() { return (2 * Lay<T, HD>::ROWMAJOR + Lay<T, HD>::TRANSP) * sizeof(T); }
+template <typename T, int HD> size_t fwd_lds() { return 2 * (Lay<T, HD>::ROWMAJOR + Lay<T, HD>::TRANSP) * sizeof(T); }
+template <typename T, int HD> size_t dq_lds() { return 2 * (2 * Lay<T, HD>::ROWMAJOR + Lay<T, HD>::TRANSP) * sizeof(T); }
 template <typename T, int HD> size_t dkv_lds() {
-    return (2 * Lay<T, HD>::ROWMAJOR + 2 * Lay<T, HD>::TRANSP) * sizeof(T) + 128 * sizeof(float);
+    return 2 * ((2 * Lay<T, HD>::ROWMAJOR + 2 * Lay<T, HD>::TRANSP) * sizeof(T) + 128 * sizeof(float));
 }
 
 template <typename K> int set_lds(K kern, size_t bytes) {
@@ -392,14 +624,14 @@ template <typename K> int set_lds(K kern, size_t bytes) {
 }
 
 template <typename T> int launch_fwd(const AttnParams& p, hipStream_t st) {
-    int total = ((p.Nq + 127) / 128) * p.H * p.B;
+    int total = ((p.Nq + 255) / 256) * p.H * p.B;
     size_t lds = fwd_lds<T, 64>();
     if (int e = set_lds(attn_fwd_kernel<T, 64>, lds)) return e;
     attn_fwd_kernel<T, 64><<<dim3(total), dim3(256), lds, st>>>(p);
     return (int)hipGetLastError();
 }
 template <typename T> int launch_bwd(const AttnParams& p, hipStream_t st) {
-    int total = ((p.Nq + 127) / 128) * p.H * p.B;
+    int total = ((p.Nq + 255) / 256) * p.H * p.B;
     size_t lds = dq_lds<T, 64>();
     if (int e = set_lds(attn_bwd_dq_kernel<T, 64>, lds)) return e;
     attn_bwd_dq_kernel<T, 64><<<dim3(total), dim3(256), lds, st>>>(p);
