@@ -23,11 +23,18 @@ sys.path.insert(0, ROOT)
 
 # Library GEMM selection: replay the hipBLASLt/rocBLAS solutions tuned once on gfx950 for this
 # workload's GEMM shapes (PyTorch TunableOp, tuning itself disabled -> no timing side effects).
+# TunableOp reads "<name><device ordinal>.csv", so each rank gets a private copy of the table.
 _TUNED = os.path.join(ROOT, "glue-factory_amd", "tunableop_gfx950.csv")
 if os.path.exists(_TUNED) and "PYTORCH_TUNABLEOP_ENABLED" not in os.environ:
+    import shutil
+    import tempfile
+    _ord = int(os.environ.get("LOCAL_RANK", "0"))
+    _dir = os.path.join(tempfile.gettempdir(), f"gf_amd_tunableop_{os.getuid()}")
+    os.makedirs(_dir, exist_ok=True)
+    shutil.copyfile(_TUNED, os.path.join(_dir, f"table{_ord}.csv"))
     os.environ["PYTORCH_TUNABLEOP_ENABLED"] = "1"
     os.environ["PYTORCH_TUNABLEOP_TUNING"] = "0"
-    os.environ["PYTORCH_TUNABLEOP_FILENAME"] = _TUNED
+    os.environ["PYTORCH_TUNABLEOP_FILENAME"] = os.path.join(_dir, "table.csv")
 
 import torch  # noqa: E402  (after the TunableOp environment is set)
 
