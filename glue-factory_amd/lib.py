@@ -30,13 +30,15 @@ SIGNATURES = {
     "gf_sinkhorn_ws_bytes": [_I, _I, _I, _I],
     "gf_sinkhorn_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "gf_sinkhorn_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "gf_linear_dw_ws_bytes": [_I, _I, _I],
+    "gf_linear_dw": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "gf_rotary_qk": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "gf_rotary_qk_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "gf_ln_gelu_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _F, _I, _P],
     "gf_ln_gelu_nblk": [_I],
     "gf_ln_gelu_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
 }
-_RESTYPE = {"gf_sinkhorn_ws_bytes": _c.c_int64}
+_RESTYPE = {"gf_sinkhorn_ws_bytes": _c.c_int64, "gf_linear_dw_ws_bytes": _c.c_int64}
 
 _lib = None
 

@@ -68,7 +68,9 @@ def _ffn_modules(dim):
 
 
 def _lin(x, layer):
-    return F.linear(x, layer.weight.to(x.dtype), None if layer.bias is None else layer.bias.to(x.dtype))
+    if layer.out_features % 8 or layer.in_features % 8:   # 256 -> 1 heads: plain GEMV
+        return F.linear(x, layer.weight.to(x.dtype), None if layer.bias is None else layer.bias.to(x.dtype))
+    return ops.linear(x, layer.weight, layer.bias)
 
 
 def _ffn(ffn, x, msg):
@@ -93,9 +95,9 @@ class SelfBlock(nn.Module):
 
     def forward(self, x, theta, cs):
         b, n, d = x.shape
-        w = self.Wqkv.weight.index_select(0, self._perm).to(x.dtype)
-        bias = self.Wqkv.bias.index_select(0, self._perm).to(x.dtype)
-        qkv = F.linear(x, w, bias).view(b, n, 3, self.heads, self.head_dim)
+        w = self.Wqkv.weight.index_select(0, self._perm)
+        bias = self.Wqkv.bias.index_select(0, self._perm)
+        qkv = ops.linear(x, w, bias).view(b, n, 3, self.heads, self.head_dim)
         ctx = ops.self_attention_rotary(qkv, theta, cs)           # [b,n,H,hd]
         msg = _lin(ctx.view(b, n, d), self.out_proj)
         return _ffn(self.ffn, x, msg)
@@ -111,9 +113,9 @@ class CrossBlock(nn.Module):
         self.ffn = _ffn_modules(dim)
 
     def _proj(self, x):
-        w = torch.cat([self.to_qk.weight, self.to_v.weight], 0).to(x.dtype)
-        bias = torch.cat([self.to_qk.bias, self.to_v.bias], 0).to(x.dtype)
-        return F.linear(x, w, bias).view(x.shape[0], x.shape[1], 2, self.heads, self.head_dim)
+        w = torch.cat([self.to_qk.weight, self.to_v.weight], 0)
+        bias = torch.cat([self.to_qk.bias, self.to_v.bias], 0)
+        return ops.linear(x, w, bias).view(x.shape[0], x.shape[1], 2, self.heads, self.head_dim)
 
     def forward_stacked(self, x):
         """x [2B,N,C]: image 0 in the first half of the batch, image 1 in the second."""
@@ -148,9 +150,8 @@ class MatchAssignment(nn.Module):
         """Everything the log assignment is made of, without the matrix:
         A_ij = 2 md0_i.md1_j - r_i - c_j + lz0_i + lz1_j,  A_i,n = bin0_i,  A_m,j = bin1_j."""
         s = self.dim ** -0.25
-        w = (self.final_proj.weight * s).to(d0.dtype)
-        bias = (self.final_proj.bias * s).to(d0.dtype)
-        md0, md1 = F.linear(d0, w, bias), F.linear(d1, w, bias)
+        w, bias = self.final_proj.weight * s, self.final_proj.bias * s
+        md0, md1 = ops.linear(d0, w, bias), ops.linear(d1, w, bias)
         z0 = _lin(d0, self.matchability).squeeze(-1).float()
         z1 = _lin(d1, self.matchability).squeeze(-1).float()
         r, c = ops.dual_lse(md0, md1)

@@ -200,6 +200,53 @@ def cross_attention_stacked(p):
     return _CrossAttentionStacked.apply(p)
 
 
+# ------------------------------------------------------------------------------ linear layer
+class _Linear(torch.autograd.Function):
+    """y = x W^T + b with the forward / input-gradient GEMMs on the library (hipBLASLt) and the
+    weight / bias gradient (a tiny-output, 1e5-deep reduction) on the split-M MFMA kernel
+    gf_linear_dw, which returns fp32 gradients for the fp32 master parameters directly."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        wt = w.to(x.dtype)
+        y = torch.nn.functional.linear(x, wt, None if b is None else b.to(x.dtype))
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        ctx.bdtype = None if b is None else b.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        nout, k = w.shape
+        dy2 = dy.reshape(-1, nout)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = (dy2 @ w.to(dy2.dtype)).view(x.shape)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            x2 = x.reshape(-1, k)
+            if not x2.is_contiguous():
+                x2 = x2.contiguous()
+            m = x2.shape[0]
+            L = _lib.load()
+            ws = torch.empty(int(L.gf_linear_dw_ws_bytes(m, nout, k)), dtype=torch.uint8, device=x.device)
+            dw32 = torch.empty((nout, k), dtype=torch.float32, device=x.device)
+            db32 = torch.empty((nout,), dtype=torch.float32, device=x.device) if ctx.has_bias else None
+            _lib.check(L.gf_linear_dw(_p(dy2), _p(x2), _p(dw32), _p(db32), _p(ws), m, nout, k, _dt(x2),
+                                      _stream()), "gf_linear_dw")
+            dw = dw32.to(w.dtype)
+            db = None if db32 is None else db32.to(ctx.bdtype)
+        return dx, dw, db
+
+
+def linear(x, w, b=None):
+    """w, b: fp32 master parameters (or differentiable functions of them); x in the compute dtype."""
+    _chk(x)
+    return _Linear.apply(x, w, b)
+
+
 # ------------------------------------------------------------------------------ LN + GELU
 class _LnGelu(torch.autograd.Function):
     @staticmethod

@@ -129,6 +129,15 @@ int gf_sinkhorn_bwd(const float* Z, const float* gout, const float* gsum_row, co
                     const float* u_hist, const float* v_hist, float* gZ, void* ws,
                     int B, int M, int N, int iters, void* stream);
 
+/* ---- weight / bias gradient of a linear layer (autograd of every nn.Linear on the path,
+ * lightglue.py:131-221, 271-290): dW[n][k] = sum_m dY[m][n] X[m][k], db[n] = sum_m dY[m][n]
+ * with dY [M,Nout], X [M,K] row-major in `dtype` and fp32 outputs dW [Nout,K], db [Nout]
+ * (db may be NULL).  Split-M MFMA kernel + deterministic slice reduction; ws must hold
+ * gf_linear_dw_ws_bytes(M, Nout, K) bytes.  Nout and K must be multiples of 8 (bf16) / 4 (f32). */
+int64_t gf_linear_dw_ws_bytes(int M, int Nout, int K);
+int gf_linear_dw(const void* dy, const void* x, float* dw, float* db, void* ws,
+                 int M, int Nout, int K, int dtype, void* stream);
+
 /* ---- fused elementwise ops of the transformer block ---------------------------------------
  * Rotary embedding applied in place to the q and k thirds of a fused [B,N,3,H,D] projection
  * (lightglue.py:42-49,159-160): cs [B,N,D] holds cos in the even and sin in the odd slot of

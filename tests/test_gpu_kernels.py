@@ -228,3 +228,25 @@ def test_rows_lse_colbias_and_large_logits():
 def test_ops_reject_cpu_tensors():
     with pytest.raises(RuntimeError):
         ops.attention(torch.zeros(1, 4, 1, 64), torch.zeros(1, 4, 1, 64), torch.zeros(1, 4, 1, 64))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,Nout,K", [(1000, 256, 256), (4096, 768, 256), (777, 512, 512), (64, 8, 8), (5000, 264, 136)])
+def test_linear_dw(dtype, M, Nout, K):
+    g = torch.Generator().manual_seed(M + Nout)
+    x = torch.randn(M, K, generator=g).to(DEV, dtype).requires_grad_(True)
+    w = (torch.randn(Nout, K, generator=g) / K ** 0.5).to(DEV).requires_grad_(True)
+    b = torch.randn(Nout, generator=g).to(DEV).requires_grad_(True)
+    dy = torch.randn(M, Nout, generator=g).to(DEV, dtype)
+    y = ops.linear(x, w, b)
+    (y * dy).sum().backward()
+    xr, wr, br = (t.detach().cpu().double().requires_grad_(True) for t in (x, w.to(dtype), b.to(dtype)))
+    yr = torch.nn.functional.linear(xr, wr, br)
+    (yr * dy.cpu().double()).sum().backward()
+    tol = _tols(dtype)
+    torch.testing.assert_close(y.detach().cpu().double(), yr.detach(), **tol)
+    for name, a, r in (("dx", x.grad, xr.grad), ("dw", w.grad, wr.grad), ("db", b.grad, br.grad)):
+        sc = r.abs().max().item()
+        torch.testing.assert_close(a.cpu().double() / sc, r / sc, msg=lambda m: f"{name}: {m}",
+                                   rtol=1e-4 if dtype == torch.float32 else 2e-2, atol=1e-4 if dtype == torch.float32 else 2e-2)
+    assert w.grad.dtype == torch.float32 and b.grad.dtype == torch.float32
