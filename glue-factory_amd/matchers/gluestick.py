@@ -1,0 +1,342 @@
+"""GlueStick point + line matcher on the MI355X hot path (drop-in for
+gluefactory.models.matchers.gluestick).
+
+Same plugin surface as the reference (gluefactory/models/matchers/gluestick.py:25-462): BaseModel
+subclass, same ``default_conf`` / ``required_data_keys`` and ``state_dict`` names (``kenc``,
+``lenc``, ``gnn.layers.i.update.*``, ``gnn.line_layers.k.mlp.*``, ``final_proj``,
+``final_line_proj``, ``inter_line_proj.*``, ``bin_score``, ``line_bin_score``).
+
+What runs where
+  * GNN layers: the SuperGlue building blocks of ``superglue.py`` (library GEMMs over stacked
+    channels-last activations, MFMA flash attention with the head-fastest channel order folded
+    into the weights, one BatchNorm call per image);
+  * point assignment (gluestick.py:772-783, bin-augmented averaged double softmax): the row /
+    column log-sum-exp come from ``gf_rows_lse`` tiles of md0 md1^T (the bin joins through a
+    logaddexp on the [B,N] vectors) and the (N+1)^2 matrix is written once by ``gf_assign_write``;
+  * line layers (gather of junction descriptors, endpoint MLP, mean scatter back; :589-691) and
+    the line head (:336-376, 2*Nl x 2*Nl scores, two endpoint pairings) work on <= 1024-row
+    tensors and stay on stock torch ops.
+``line_attention: True`` is not implemented (no shipped config uses it).
+"""
+from pathlib import Path
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .. import ops
+from ..base_model import BaseModel
+from ..metrics import matcher_metrics
+from .superglue import MLP, AttentionalPropagation, KeypointEncoder, _conv_cl, _mlp_cl
+
+ETH_EPS = 1e-8
+
+
+def normalize_keypoints(kpts, shape_or_size):
+    """Centre, divide by 0.7 * max(size) (gluestick.py:477-488)."""
+    kpts = kpts.float()
+    if isinstance(shape_or_size, (tuple, list, torch.Size)):
+        h, w = shape_or_size[-2:]
+        size = kpts.new_tensor([[w, h]])
+    else:
+        size = shape_or_size.float().to(kpts)
+    return (kpts - size[:, None] / 2) / (size.max(1, keepdim=True).values * 0.7)[:, None]
+
+
+class EndPtEncoder(nn.Module):
+    def __init__(self, feature_dim, layers):
+        super().__init__()
+        self.encoder = MLP([5] + list(layers) + [feature_dim], do_bn=True)
+        nn.init.constant_(self.encoder[-1].bias, 0.0)
+
+    def forward(self, endpoints, scores, halves=1):
+        """endpoints [B,Nl,2,2] -> [B, 2Nl, D] (xy, offset to the other endpoint, line score)."""
+        b, nl = endpoints.shape[:2]
+        off = endpoints[:, :, 1] - endpoints[:, :, 0]
+        off = torch.stack([off, -off], 2).reshape(b, 2 * nl, 2)
+        x = torch.cat([endpoints.reshape(b, 2 * nl, 2), off, scores.repeat(1, 2)[..., None]], -1)
+        return _mlp_cl(self.encoder, x.float(), halves)
+
+
+class GNNLayer(nn.Module):
+    def __init__(self, feature_dim, layer_type, skip_init=False):
+        super().__init__()
+        assert layer_type in ("cross", "self")
+        self.type = layer_type
+        self.update = AttentionalPropagation(feature_dim, 4)
+        if skip_init:
+            self.update.register_parameter("scaling", nn.Parameter(torch.tensor(0.0)))
+        else:
+            self.update.scaling = 1.0
+
+
+class LineLayer(nn.Module):
+    def __init__(self, feature_dim, line_attention=False):
+        super().__init__()
+        if line_attention:
+            raise NotImplementedError("line_attention=True is not part of the accelerated path")
+        self.dim = feature_dim
+        self.mlp = MLP([feature_dim * 3, feature_dim * 2, feature_dim], do_bn=True)
+
+    def forward(self, ldesc, line_enc, junc_idx, halves):
+        """ldesc [B',N,D], line_enc [B',2Nl,D], junc_idx [B',2Nl] -> ldesc + mean endpoint update."""
+        b, n, d = ldesc.shape
+        idx = junc_idx[..., None].expand(-1, -1, d)
+        ld = ldesc.gather(1, idx)
+        ld2 = ld.reshape(b, -1, 2, d).flip(2).reshape(b, -1, d)
+        upd = _mlp_cl(self.mlp, torch.cat([ld, ld2, line_enc.to(ld.dtype)], -1), halves)
+        agg = torch.zeros_like(ldesc).scatter_reduce(1, idx, upd, reduce="mean", include_self=False)
+        return ldesc + agg
+
+
+class AttentionalGNN(nn.Module):
+    def __init__(self, feature_dim, layer_types, inter_supervision=None, num_line_iterations=1,
+                 line_attention=False):
+        super().__init__()
+        self.inter_supervision = inter_supervision
+        self.num_line_iterations = num_line_iterations
+        self.layers = nn.ModuleList([GNNLayer(feature_dim, t) for t in layer_types])
+        self.line_layers = nn.ModuleList([LineLayer(feature_dim, line_attention)
+                                          for _ in range(len(layer_types) // 2)])
+
+
+def log_double_softmax_dense(scores, bin_score):
+    """gluestick.py:772-783 on a small dense matrix (line head), stock torch."""
+    b, m, n = scores.shape
+    beta = bin_score.to(scores).reshape(1, 1, 1)
+    r = torch.logsumexp(torch.cat([scores, beta.expand(b, m, 1)], 2), 2)
+    c = torch.logsumexp(torch.cat([scores, beta.expand(b, 1, n)], 1), 1)
+    out = scores.new_zeros(b, m + 1, n + 1)
+    out[:, :m, :n] = scores - 0.5 * (r[:, :, None] + c[:, None, :])
+    out[:, :m, n] = beta.reshape(1, 1) - r
+    out[:, m, :n] = beta.reshape(1, 1) - c
+    return out
+
+
+class GlueStick(BaseModel):
+    default_conf = {
+        "input_dim": 256,
+        "descriptor_dim": 256,
+        "weights": None,
+        "version": "v0.1_arxiv",
+        "keypoint_encoder": [32, 64, 128, 256],
+        "GNN_layers": ["self", "cross"] * 9,
+        "num_line_iterations": 1,
+        "line_attention": False,
+        "filter_threshold": 0.2,
+        "checkpointed": False,     # accepted; activations are kept, never recomputed
+        "skip_init": False,
+        "inter_supervision": None,
+        "mp": False,
+        "loss": {"nll_weight": 1.0, "nll_balancing": 0.5, "inter_supervision": [0.3, 0.6]},
+    }
+    required_data_keys = ["view0", "view1", "keypoints0", "keypoints1", "descriptors0", "descriptors1",
+                          "keypoint_scores0", "keypoint_scores1", "lines0", "lines1", "lines_junc_idx0",
+                          "lines_junc_idx1", "line_scores0", "line_scores1"]
+
+    def _init(self, conf):
+        if conf.descriptor_dim != 256:
+            raise NotImplementedError("the HIP attention kernels are built for 4 heads of 64 channels")
+        d = conf.descriptor_dim
+        if conf.input_dim != d:
+            self.input_proj = nn.Conv1d(conf.input_dim, d, kernel_size=1)
+            nn.init.constant_(self.input_proj.bias, 0.0)
+        self.kenc = KeypointEncoder(d, conf.keypoint_encoder)
+        self.lenc = EndPtEncoder(d, conf.keypoint_encoder)
+        inter = None if conf.inter_supervision is None else list(conf.inter_supervision)
+        self.gnn = AttentionalGNN(d, conf.GNN_layers, inter, conf.num_line_iterations, conf.line_attention)
+        self.final_proj = nn.Conv1d(d, d, kernel_size=1)
+        self.final_line_proj = nn.Conv1d(d, d, kernel_size=1)
+        for c in (self.final_proj, self.final_line_proj):
+            nn.init.constant_(c.bias, 0.0)
+            nn.init.orthogonal_(c.weight, gain=1)
+        self.layer2idx = {}
+        if inter is not None:
+            self.inter_line_proj = nn.ModuleList([nn.Conv1d(d, d, kernel_size=1) for _ in inter])
+            for i, layer in enumerate(inter):
+                nn.init.constant_(self.inter_line_proj[i].bias, 0.0)
+                nn.init.orthogonal_(self.inter_line_proj[i].weight, gain=1)
+                self.layer2idx[layer] = i
+        self.register_parameter("bin_score", nn.Parameter(torch.tensor(1.0)))
+        self.register_parameter("line_bin_score", nn.Parameter(torch.tensor(1.0)))
+        if conf.weights:
+            path = Path(conf.weights)
+            if not path.exists():
+                raise FileNotFoundError(f"GlueStick weights '{conf.weights}' not found locally")
+            sd = torch.load(str(path), map_location="cpu")
+            if "model" in sd:
+                sd = {k.replace("matcher.", "").replace("module.", ""): v for k, v in sd["model"].items()
+                      if "matcher." in k}
+            self.load_state_dict(sd, strict=False)
+
+    # ------------------------------------------------------------------ heads
+    def _filter(self, scores):
+        with torch.no_grad():
+            core = scores[:, :-1, :-1]
+            max0, a0 = core.max(2)
+            a1 = core.max(1).indices
+            return ops.filter_matches(max0, a0, a1, self.conf.filter_threshold)
+
+    def _point_head(self, d0, d1):
+        d = self.conf.descriptor_dim
+        s = d ** -0.25
+        w, b = self.final_proj.weight.squeeze(-1) * s, self.final_proj.bias * s
+        md0, md1 = ops.linear(d0, w, b), ops.linear(d1, w, b)       # S = md0 md1^T = scores / sqrt(d)
+        r_raw, c_raw = ops.dual_lse(md0, md1)
+        beta = self.bin_score.float()
+        r, c = torch.logaddexp(r_raw, beta), torch.logaddexp(c_raw, beta)
+        return ops.assign_write(md0, md1, -0.5 * r, -0.5 * c, beta - r, beta - c, alpha=1.0, corner=0.0)
+
+    def _line_head(self, ld0, ld1, idx0, idx1, proj):
+        d = self.conf.descriptor_dim
+        m0, m1 = _conv_cl(ld0, proj).float(), _conv_cl(ld1, proj).float()
+        s = torch.bmm(m0, m1.transpose(1, 2)) / d ** 0.5
+        s = s.gather(2, idx1[:, None, :].expand(-1, s.shape[1], -1))
+        s = s.gather(1, idx0[:, :, None].expand(-1, -1, s.shape[2]))
+        b = s.shape[0]
+        s = s.reshape(b, idx0.shape[1] // 2, 2, idx1.shape[1] // 2, 2)
+        raw = 0.5 * torch.maximum(s[:, :, 0, :, 0] + s[:, :, 1, :, 1], s[:, :, 0, :, 1] + s[:, :, 1, :, 0])
+        scores = log_double_softmax_dense(raw, self.line_bin_score.float())
+        return (scores, *self._filter(scores), raw)
+
+    # ------------------------------------------------------------------ forward
+    def _forward(self, data):
+        dev = data["keypoints0"].device
+        b = len(data["keypoints0"])
+        n0, n1 = data["keypoints0"].shape[1], data["keypoints1"].shape[1]
+        nl0, nl1 = data["lines0"].shape[1], data["lines1"].shape[1]
+        if n0 == 0 or n1 == 0:
+            z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=dev)  # noqa: E731
+            f = lambda *s: torch.full(s, -1, dtype=torch.int64, device=dev)          # noqa: E731
+            return {"log_assignment": z(b, n0, n1), "matches0": f(b, n0), "matches1": f(b, n1),
+                    "matching_scores0": z(b, n0), "matching_scores1": z(b, n1),
+                    "line_log_assignment": z(b, nl0, nl1), "line_matches0": f(b, nl0), "line_matches1": f(b, nl1),
+                    "line_matching_scores0": z(b, nl0), "line_matching_scores1": z(b, n1)}
+        if not data["keypoints0"].is_cuda:
+            raise RuntimeError("glue_factory_amd.GlueStick runs on the MI355X HIP path only (no CPU fallback)")
+        T = torch.bfloat16 if (self.conf.mp or torch.is_autocast_enabled()) else torch.float32
+        with torch.autocast(device_type="cuda", enabled=False):
+            return self._forward_impl(data, T)
+
+    def _forward_impl(self, data, T):
+        conf = self.conf
+        b = len(data["keypoints0"])
+        v0, v1 = data["view0"], data["view1"]
+        size0 = v0["image_size"] if "image_size" in v0 else v0["image"].shape
+        size1 = v1["image_size"] if "image_size" in v1 else v1["image"].shape
+        n0, n1 = data["keypoints0"].shape[1], data["keypoints1"].shape[1]
+        nl0, nl1 = data["lines0"].shape[1], data["lines1"].shape[1]
+        idx0, idx1 = data["lines_junc_idx0"].flatten(1, 2), data["lines_junc_idx1"].flatten(1, 2)
+        have_lines = nl0 > 0 and nl1 > 0
+        stacked = n0 == n1 and nl0 == nl1
+        halves = 2 if stacked else 1
+
+        def cat2(a, b_):
+            return [torch.cat([a, b_], 0)] if stacked else [a, b_]
+
+        kp = cat2(normalize_keypoints(data["keypoints0"], size0), normalize_keypoints(data["keypoints1"], size1))
+        sc = cat2(data["keypoint_scores0"].float(), data["keypoint_scores1"].float())
+        desc = cat2(data["descriptors0"].float(), data["descriptors1"].float())
+        if conf.input_dim != conf.descriptor_dim:
+            desc = [_conv_cl(x, self.input_proj) for x in desc]
+        xs = [(x + self.kenc(k, s, halves)).to(T) for x, k, s in zip(desc, kp, sc)]
+        jidx = cat2(idx0, idx1)
+        if have_lines:
+            ln = cat2(normalize_keypoints(data["lines0"].flatten(1, 2), size0).reshape(b, nl0, 2, 2),
+                      normalize_keypoints(data["lines1"].flatten(1, 2), size1).reshape(b, nl1, 2, 2))
+            lsc = cat2(data["line_scores0"].float(), data["line_scores1"].float())
+            lenc = [self.lenc(l_, s_, halves) for l_, s_ in zip(ln, lsc)]
+        inter_desc = {}
+        inter = self.gnn.inter_supervision
+        for i, layer in enumerate(self.gnn.layers):
+            cross = layer.type == "cross"
+            if stacked:
+                xs = [xs[0] + layer.update(xs[0], cross=cross, halves=2) * layer.update.scaling]
+            else:
+                d0, d1 = layer.update.forward_pair(xs[0], xs[1], cross=cross)
+                xs = [xs[0] + d0 * layer.update.scaling, xs[1] + d1 * layer.update.scaling]
+            if layer.type == "self" and have_lines:
+                for _ in range(self.gnn.num_line_iterations):
+                    xs = [self.gnn.line_layers[i // 2](x, le, ji, halves) for x, le, ji in zip(xs, lenc, jidx)]
+            if inter is not None and (i // 2) in inter and cross:
+                inter_desc[i // 2] = xs
+        split = (lambda t: (t[0][:b], t[0][b:])) if stacked else (lambda t: (t[0], t[1]))
+        d0, d1 = split(xs)
+
+        pred = {}
+        kp_scores = self._point_head(d0, d1)
+        m0, m1, ms0, ms1 = self._filter(kp_scores)
+        pred.update({"log_assignment": kp_scores, "matches0": m0, "matches1": m1,
+                     "matching_scores0": ms0, "matching_scores1": ms1})
+        if have_lines:
+            ls, lm0, lm1, lms0, lms1, raw = self._line_head(d0[:, :2 * nl0], d1[:, :2 * nl1], idx0, idx1,
+                                                            self.final_line_proj)
+            for layer_id in (inter or []):
+                e0, e1 = split(inter_desc[layer_id])
+                li, a0, a1, s0, s1, _ = self._line_head(e0[:, :2 * nl0], e1[:, :2 * nl1], idx0, idx1,
+                                                        self.inter_line_proj[self.layer2idx[layer_id]])
+                pred.update({f"line_{layer_id}_log_assignment": li, f"line_{layer_id}_matches0": a0,
+                             f"line_{layer_id}_matches1": a1, f"line_{layer_id}_matching_scores0": s0,
+                             f"line_{layer_id}_matching_scores1": s1})
+        else:
+            dev = d0.device
+            ls = torch.zeros(b, nl0, nl1, device=dev)
+            lm0 = torch.full((b, nl0), -1, device=dev, dtype=torch.int64)
+            lm1 = torch.full((b, nl1), -1, device=dev, dtype=torch.int64)
+            lms0, lms1 = torch.zeros(b, nl0, device=dev), torch.zeros(b, nl1, device=dev)
+            raw = torch.zeros(b, nl0, nl1, device=dev)
+        pred.update({"line_log_assignment": ls, "line_matches0": lm0, "line_matches1": lm1,
+                     "line_matching_scores0": lms0, "line_matching_scores1": lms1, "raw_line_scores": raw})
+        return pred
+
+    # ------------------------------------------------------------------ loss
+    def sub_loss(self, pred, data, losses, bin_score, prefix="", layer=-1):
+        suffix = "" if layer == -1 else f"{layer}_"
+        weight = 1.0 if layer == -1 else self.conf.loss.inter_supervision[self.layer2idx[layer]]
+        la = pred[prefix + suffix + "log_assignment"]
+        bi, ii, ji = data["gt_" + prefix + "assignment"].nonzero(as_tuple=True)
+        bsz = la.shape[0]
+        neg0 = (data["gt_" + prefix + "matches0"] == -1).float()
+        neg1 = (data["gt_" + prefix + "matches1"] == -1).float()
+        zeros = torch.zeros(bsz, device=la.device)
+        num_pos = zeros.index_add(0, bi, torch.ones_like(bi, dtype=torch.float32)).clamp(min=1.0)
+        num_neg = (neg0.sum(1) + neg1.sum(1)).clamp(min=1.0)
+        nll_pos = -zeros.index_add(0, bi, la[bi, ii, ji]) / num_pos
+        nll_neg = -((la[:, :-1, -1] * neg0).sum(1) + (la[:, -1, :-1] * neg1).sum(1)) / num_neg
+        bal = self.conf.loss.nll_balancing
+        nll = bal * nll_pos + (1 - bal) * nll_neg
+        losses[prefix + suffix + "assignment_nll"] = nll
+        if self.conf.loss.nll_weight > 0:
+            losses["total"] = losses["total"] + nll * self.conf.loss.nll_weight * weight
+        if suffix == "":
+            losses[prefix + "num_matchable"] = num_pos
+            losses[prefix + "num_unmatchable"] = num_neg
+            with torch.no_grad():
+                losses[prefix + "sinkhorn_norm"] = la.exp()[:, :-1].sum(2).mean(1)
+            losses[prefix + "bin_score"] = bin_score[None]
+        return losses
+
+    def loss(self, pred, data):
+        losses = {"total": 0}
+        if not (data["keypoints0"].shape[1] == 0 or data["keypoints1"].shape[1] == 0):
+            losses = self.sub_loss(pred, data, losses, self.bin_score, prefix="")
+        has_lines = ("lines0" in data and "lines1" in data and data["lines0"].shape[1] > 0
+                     and data["lines1"].shape[1] > 0)
+        if has_lines:
+            losses = self.sub_loss(pred, data, losses, self.line_bin_score, prefix="line_")
+        if self.conf.inter_supervision:
+            for layer in self.conf.inter_supervision:
+                losses = self.sub_loss(pred, data, losses, self.line_bin_score, prefix="line_", layer=layer)
+        metrics = {}
+        if not self.training:
+            if "matches0" in pred and pred["matches0"].shape[1] > 0 and pred["matches1"].shape[1] > 0:
+                metrics.update(matcher_metrics(pred, data, prefix=""))
+            if "line_matches0" in pred and has_lines:
+                metrics.update(matcher_metrics(pred, data, prefix="line_"))
+            if self.conf.inter_supervision:
+                for layer in self.conf.inter_supervision:
+                    metrics.update(matcher_metrics(pred, data, prefix=f"line_{layer}_", prefix_gt="line_"))
+        return losses, metrics
+
+
+__main_model__ = GlueStick

@@ -340,8 +340,12 @@ class LightGlue(nn.Module):
     def _nll(self, h, gt):
         """weight_loss of utils/losses.py:6-25 on the non-zero weights only."""
         bi, ii, ji = gt["pos"]
-        dot = (h["md0"][bi, ii].float() * h["md1"][bi, ji].float()).sum(-1)
-        a_pos = 2.0 * dot - h["r"][bi, ii] - h["c"][bi, ji] + h["lz0"][bi, ii] + h["lz1"][bi, ji]
+        m, n = h["md0"].shape[1], h["md1"].shape[1]
+        f0, f1 = bi * m + ii, bi * n + ji     # flat row ids: index_select's backward is a sort-free index_add
+        dot = (h["md0"].flatten(0, 1).index_select(0, f0).float()
+               * h["md1"].flatten(0, 1).index_select(0, f1).float()).sum(-1)
+        a_pos = (2.0 * dot - h["r"].flatten().index_select(0, f0) - h["c"].flatten().index_select(0, f1)
+                 + h["lz0"].flatten().index_select(0, f0) + h["lz1"].flatten().index_select(0, f1))
         nll_pos = -torch.zeros_like(gt["num_pos"]).index_add_(0, bi, a_pos) / gt["num_pos"]
         nll_neg = -((h["bin0"] * gt["neg0"]).sum(-1) + (h["bin1"] * gt["neg1"]).sum(-1)) / (gt["n0"] + gt["n1"])
         bal = self.conf.loss.nll_balancing

@@ -49,7 +49,9 @@ def _conv_cl(x, conv, rows=None, cols=None):
         w, b = w.index_select(0, rows), b.index_select(0, rows)
     if cols is not None:
         w = w.index_select(1, cols)
-    return F.linear(x, w.to(x.dtype), b.to(x.dtype))
+    if w.shape[0] % 8 or w.shape[1] % 8:
+        return F.linear(x, w.to(x.dtype), b.to(x.dtype))
+    return ops.linear(x, w, b)
 
 
 def _mlp_cl(seq, x, halves):
@@ -105,7 +107,7 @@ class MultiHeadedAttention(nn.Module):
     def fused_projection(self, x):
         w = torch.cat([p.weight.squeeze(-1).index_select(0, self._perm) for p in self.proj], 0)
         b = torch.cat([p.bias.index_select(0, self._perm) for p in self.proj], 0)
-        qkv = F.linear(x, w.to(x.dtype), b.to(x.dtype))
+        qkv = ops.linear(x, w, b)
         return qkv.view(x.shape[0], x.shape[1], 3, self.h, self.dim)
 
 

@@ -132,6 +132,44 @@ def gen_superglue(name, batch, n0, n1, gnn, iters, seed):
                         G=G.numpy(), gscores=scores.grad.numpy(), galpha=alpha.grad.numpy())
 
 
+def gen_gluestick(name, batch, n_kpts, n_lines, gnn, inter, seed):
+    """Reference GlueStick (weights=None) on a synthetic point+line batch: eval + train forward,
+    every loss entry and all gradient norms."""
+    from gluefactory.models.matchers.gluestick import GlueStick
+    from glue_factory_amd.synthetic import make_point_line_pairs
+    from oracle import gluestick_oracle as gso
+
+    params = gso.init_params(256, gnn_layers=len(gnn), inter=inter, seed=seed)
+    data = make_point_line_pairs(batch, n_kpts, n_lines, dim=256, size=(640, 480), seed=seed + 1)
+    model = GlueStick({"weights": None, "GNN_layers": gnn, "inter_supervision": inter})
+    res = model.load_state_dict(params, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    out = {}
+    keys = ("log_assignment", "matches0", "matching_scores0", "line_log_assignment", "line_matches0",
+            "raw_line_scores")
+    model.eval()
+    with torch.no_grad():
+        pe = model(data)
+    out.update(_np({k: pe[k] for k in keys}, "eval."))
+    model.train()
+    pred = model(data)
+    losses, _ = model.loss(pred, {**pred, **data})
+    losses["total"].mean().backward()
+    out.update(_np({k: pred[k] for k in keys}, "train."))
+    for layer in inter or []:
+        out[f"train.line_{layer}_log_assignment"] = pred[f"line_{layer}_log_assignment"].detach().numpy()
+    out.update(_np({k: v for k, v in losses.items() if torch.is_tensor(v)}, "loss."))
+    for k, prm in model.named_parameters():
+        out["gradnorm." + k] = np.array([float(prm.grad.double().norm())])
+    out["param_checksum"] = np.array([float(sum(v.double().abs().sum() for v in params.values()))])
+    out.update(_np({k: v for k, v in data.items() if torch.is_tensor(v)}, "data."))
+    out["data.image_size0"] = data["view0"]["image_size"].numpy()
+    out["data.image_size1"] = data["view1"]["image_size"].numpy()
+    out["meta"] = np.array([batch, n_kpts, n_lines, len(gnn), seed] + list(inter or []))
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+    print(name, "loss", losses["total"].tolist(), "line matches", (pred["line_matches0"] > -1).sum(1).tolist())
+
+
 def gen_gt(name, batch, n0, n1, seed):
     from gluefactory.geometry.gt_generation import gt_matches_from_homography
 
@@ -151,6 +189,7 @@ def main():
     gen_lightglue("lightglue_d256", batch=1, n0=72, n1=64, n_layers=2, dim=256, heads=4,
                   seed=23, size=(1024, 1024), store_params=False)
     gen_gt("gt_homography", batch=2, n0=96, n1=80, seed=5)
+    gen_gluestick("gluestick_d256", batch=2, n_kpts=40, n_lines=12, gnn=["self", "cross"] * 2, inter=[0], seed=41)
     gen_superglue("superglue_d256", batch=2, n0=60, n1=52, gnn=["self", "cross"] * 2, iters=20, seed=31)
 
 

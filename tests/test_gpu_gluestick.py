@@ -1,0 +1,81 @@
+"""GlueStick plugin module (points + lines) vs the reference-generated golden vectors (fp32: 1e-4)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _data(z, device):
+    d = {k[5:]: torch.from_numpy(z[k]).to(device) for k in z if k.startswith("data.")}
+    d["view0"] = {"image_size": d.pop("image_size0")}
+    d["view1"] = {"image_size": d.pop("image_size1")}
+    return d
+
+
+def test_gluestick_module_vs_reference_golden():
+    from glue_factory_amd.base_model import get_model
+    from oracle import gluestick_oracle as gso
+    z = load_golden("gluestick_d256")
+    nl, seed = int(z["meta"][3]), int(z["meta"][4])
+    inter = [int(v) for v in z["meta"][5:]]
+    params = gso.init_params(256, gnn_layers=nl, inter=inter, seed=seed)
+    GS = get_model("glue_factory_amd.matchers.gluestick")
+    model = GS({"GNN_layers": ["self", "cross"] * (nl // 2), "inter_supervision": inter})
+    res = model.load_state_dict(params, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    model = model.cuda()
+    data = _data(z, "cuda")
+    model.eval()
+    with torch.no_grad():
+        pe = model(data)
+        _, metrics = model.loss(pe, {**pe, **data})
+    assert {"match_recall", "line_match_precision", f"line_{inter[0]}_accuracy"} <= set(metrics)
+    for k in ("log_assignment", "line_log_assignment", "raw_line_scores"):
+        np.testing.assert_allclose(pe[k].cpu().numpy(), z["eval." + k], rtol=1e-4, atol=1e-4, err_msg=k)
+    np.testing.assert_array_equal(pe["matches0"].cpu().numpy(), z["eval.matches0"])
+    np.testing.assert_array_equal(pe["line_matches0"].cpu().numpy(), z["eval.line_matches0"])
+    model.train()
+    pred = model(data)
+    losses, _ = model.loss(pred, {**pred, **data})
+    losses["total"].mean().backward()
+    for k in ("log_assignment", "line_log_assignment", f"line_{inter[0]}_log_assignment"):
+        np.testing.assert_allclose(pred[k].detach().cpu().numpy(), z["train." + k], rtol=1e-4, atol=1e-4, err_msg=k)
+    for k in [k[5:] for k in z if k.startswith("loss.")]:
+        np.testing.assert_allclose(losses[k].detach().cpu().numpy(), z["loss." + k], rtol=1e-4, atol=1e-4, err_msg=k)
+    for k, p in model.named_parameters():
+        assert p.grad is not None, k
+        ref = float(z["gradnorm." + k][0])
+        assert abs(float(p.grad.double().norm()) - ref) <= 5e-3 * ref + 1e-5, (k, float(p.grad.norm()), ref)
+
+
+def test_gluestick_unequal_counts_and_bf16():
+    from glue_factory_amd.matchers.gluestick import GlueStick
+    from glue_factory_amd.synthetic import make_point_line_pairs, to_device
+    from oracle import gluestick_oracle as gso
+    names = ["self", "cross"]
+    params = gso.init_params(256, gnn_layers=2, seed=6)
+    data = make_point_line_pairs(2, 70, 20, dim=256, size=(640, 480), seed=8)
+    # drop a few keypoints / lines from image 1 so the counts differ
+    for k in ("keypoints1", "descriptors1", "keypoint_scores1"):
+        data[k] = data[k][:, :-5]
+    for k in ("lines1", "lines_junc_idx1", "line_scores1"):
+        data[k] = data[k][:, :-3]
+    data["lines_junc_idx1"] = data["lines_junc_idx1"].clamp(max=2 * 17 - 1)
+    odata = dict(data, image_size0=data["view0"]["image_size"], image_size1=data["view1"]["image_size"])
+    with torch.no_grad():
+        ref = gso.forward(params, odata, names, training=False)
+    model = GlueStick({"GNN_layers": names}).cuda().eval()
+    model.load_state_dict(params)
+    cdata = to_device(data, "cuda")
+    with torch.no_grad():
+        pred = model(cdata)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            pb = model(cdata)
+    torch.testing.assert_close(pred["log_assignment"].cpu(), ref["log_assignment"], rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(pred["line_log_assignment"].cpu(), ref["line_log_assignment"], rtol=1e-4, atol=1e-4)
+    err = (pb["log_assignment"].cpu() - ref["log_assignment"]).abs().max().item()
+    print("gluestick bf16 max|dlog_assignment| =", err)
+    assert err < 0.5

@@ -121,3 +121,35 @@ def test_superglue_oracle_matches_reference():
     for k, g in grads.items():
         ref = float(z["gradnorm." + k][0])
         assert abs(float(g.double().norm()) - ref) <= 2e-3 * ref + 1e-6, k
+
+
+# ----------------------------------------------------------------------------- GlueStick
+def _gs_data(z):
+    keys = [k[5:] for k in z if k.startswith("data.")]
+    return {k: torch.from_numpy(z["data." + k]) for k in keys}
+
+
+def test_gluestick_oracle_matches_reference():
+    from oracle import gluestick_oracle as gso
+    z = load_golden("gluestick_d256")
+    nl, seed = int(z["meta"][3]), int(z["meta"][4])
+    inter = [int(v) for v in z["meta"][5:]]
+    p = gso.init_params(256, gnn_layers=nl, inter=inter, seed=seed)
+    chk = float(sum(v.double().abs().sum() for v in p.values()))
+    assert abs(chk - float(z["param_checksum"][0])) < 1e-6 * chk
+    names = ["self", "cross"] * (nl // 2)
+    data = _gs_data(z)
+    with torch.no_grad():
+        pe = gso.forward(p, data, names, training=False, inter=inter)
+    for k in ("log_assignment", "line_log_assignment", "raw_line_scores"):
+        np.testing.assert_allclose(pe[k].numpy(), z["eval." + k], **TOL, err_msg=k)
+    np.testing.assert_array_equal(pe["matches0"].numpy(), z["eval.matches0"])
+    np.testing.assert_array_equal(pe["line_matches0"].numpy(), z["eval.line_matches0"])
+    pred, losses, grads = gso.train_step_grads(p, data, names, inter=inter)
+    for k in ("log_assignment", "line_log_assignment", f"line_{inter[0]}_log_assignment"):
+        np.testing.assert_allclose(pred[k].detach().numpy(), z["train." + k], **TOL, err_msg=k)
+    for k in [k[5:] for k in z if k.startswith("loss.")]:
+        np.testing.assert_allclose(losses[k].detach().numpy(), z["loss." + k], **TOL, err_msg=k)
+    for k, g in grads.items():
+        ref = float(z["gradnorm." + k][0])
+        assert abs(float(g.double().norm()) - ref) <= 3e-3 * ref + 1e-5, (k, float(g.norm()), ref)
