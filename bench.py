@@ -60,6 +60,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--roofline-only", action="store_true", help="only time the attention kernels")
+    ap.add_argument("--time-extractor", action="store_true",
+                    help="also time the frozen SuperPoint forward (stock torch) on 2*batch 1024x1024 images")
     return ap.parse_args()
 
 
@@ -211,6 +213,14 @@ def main():
                                 / world / (MFMA_BF16_PEAK_TFLOPS * 1e12), 4),
         "final_loss": round(float(loss.item()), 4),
     }
+    if rank == 0 and args.time_extractor:
+        from glue_factory_amd.extractors.superpoint_open import SuperPoint
+        sp = SuperPoint({"max_num_keypoints": args.kpts, "force_num_keypoints": True, "detection_threshold": 0.0,
+                         "nms_radius": 3}).cuda().eval()
+        img = torch.rand(2 * args.batch, 1, 1024, 1024, device="cuda")
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            t_sp = time_kernel(lambda: sp({"image": img}), iters=3, warm=1)
+        out["extractor_ms"] = round(t_sp * 1e3, 2)
     if rank == 0:
         if not args.no_roofline:
             out["roofline"] = roofline_attention(args.batch, args.kpts,

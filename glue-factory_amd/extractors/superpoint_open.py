@@ -1,0 +1,151 @@
+"""SuperPoint (open re-implementation) extractor — stock PyTorch-ROCm convolutions by design.
+
+north_star keeps the VGG backbone and the detector / descriptor heads on stock PyTorch conv
+(MIOpen); this module mirrors the interface, defaults and ``state_dict`` layout of
+gluefactory/models/extractors/superpoint_open.py:78-216 so checkpoints interchange:
+``{"image"} -> {"keypoints" (+0.5), "keypoint_scores", "descriptors" [B,N,256]}``.
+
+Differences in HOW (not what): the per-image python loop over ``torch.where`` / ``topk``
+(superpoint_open.py:154-176) is a single batched top-k over the flattened score map, so the
+forward has no host synchronisation; images with fewer than ``max_num_keypoints`` detections are
+padded like the reference's ``pad_and_stack(mode="random_c")`` (uniform inside the detected
+keypoints' bounding box, score 0).  ``weights=None`` gives a seeded random initialisation
+(pretrained files cannot be downloaded on this target); a local path is loaded as usual.
+"""
+from collections import OrderedDict
+from pathlib import Path
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..base_model import BaseModel
+
+
+def sample_descriptors(keypoints, descriptors, s=8):
+    """Bilinear sampling of the dense descriptor map at keypoint locations, then L2 norm."""
+    b, c, h, w = descriptors.shape
+    kp = (keypoints + 0.5) / (keypoints.new_tensor([w, h]) * s) * 2 - 1
+    d = F.grid_sample(descriptors, kp.view(b, 1, -1, 2), mode="bilinear", align_corners=False)
+    return F.normalize(d.reshape(b, c, -1), p=2, dim=1)
+
+
+def batched_nms(scores, nms_radius):
+    assert nms_radius >= 0
+
+    def max_pool(x):
+        return F.max_pool2d(x, kernel_size=nms_radius * 2 + 1, stride=1, padding=nms_radius)
+
+    zeros = torch.zeros_like(scores)
+    max_mask = scores == max_pool(scores)
+    for _ in range(2):
+        supp_mask = max_pool(max_mask.float()) > 0
+        supp_scores = torch.where(supp_mask, zeros, scores)
+        new_max_mask = supp_scores == max_pool(supp_scores)
+        max_mask = max_mask | (new_max_mask & (~supp_mask))
+    return torch.where(max_mask, scores, zeros)
+
+
+class VGGBlock(nn.Sequential):
+    def __init__(self, c_in, c_out, kernel_size, relu=True):
+        super().__init__(OrderedDict([
+            ("conv", nn.Conv2d(c_in, c_out, kernel_size=kernel_size, stride=1, padding=(kernel_size - 1) // 2)),
+            ("activation", nn.ReLU(inplace=True) if relu else nn.Identity()),
+            ("bn", nn.BatchNorm2d(c_out, eps=0.001)),
+        ]))
+
+
+class SuperPoint(BaseModel):
+    default_conf = {
+        "descriptor_dim": 256,
+        "nms_radius": 4,
+        "max_num_keypoints": None,
+        "force_num_keypoints": False,
+        "detection_threshold": 0.005,
+        "remove_borders": 4,
+        "channels": [64, 64, 128, 128, 256],
+        "dense_outputs": None,
+        "weights": None,
+    }
+    required_data_keys = ["image"]
+
+    def _init(self, conf):
+        self.stride = 2 ** (len(conf.channels) - 2)
+        channels = [1, *conf.channels[:-1]]
+        backbone = []
+        for i, c in enumerate(channels[1:], 1):
+            layers = [VGGBlock(channels[i - 1], c, 3), VGGBlock(c, c, 3)]
+            if i < len(channels) - 1:
+                layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+            backbone.append(nn.Sequential(*layers))
+        self.backbone = nn.Sequential(*backbone)
+        c = conf.channels[-1]
+        self.detector = nn.Sequential(VGGBlock(channels[-1], c, 3), VGGBlock(c, self.stride ** 2 + 1, 1, relu=False))
+        self.descriptor = nn.Sequential(VGGBlock(channels[-1], c, 3), VGGBlock(c, conf.descriptor_dim, 1, relu=False))
+        if conf.weights is not None:
+            path = Path(conf.weights)
+            if not path.exists():
+                raise FileNotFoundError(f"SuperPoint weights '{conf.weights}' not found locally")
+            self.load_state_dict(torch.load(str(path), map_location="cpu"))
+
+    def _forward(self, data):
+        conf = self.conf
+        image = data["image"]
+        if image.shape[1] == 3:
+            image = (image * image.new_tensor([0.299, 0.587, 0.114]).view(1, 3, 1, 1)).sum(1, keepdim=True)
+        features = self.backbone(image)
+        dense = F.normalize(self.descriptor(features).float(), p=2, dim=1)
+        scores = F.softmax(self.detector(features).float(), 1)[:, :-1]
+        b, _, h, w = scores.shape
+        s = self.stride
+        scores = scores.permute(0, 2, 3, 1).reshape(b, h, w, s, s).permute(0, 1, 3, 2, 4).reshape(b, h * s, w * s)
+        scores = batched_nms(scores, conf.nms_radius)
+        if conf.remove_borders:
+            pad = conf.remove_borders
+            scores[:, :pad] = -1
+            scores[:, :, :pad] = -1
+            scores[:, -pad:] = -1
+            scores[:, :, -pad:] = -1
+        H, W = scores.shape[1:]
+        k = conf.max_num_keypoints
+        if k is None:
+            if b != 1:
+                raise ValueError("max_num_keypoints is required for batched extraction")
+            idx = torch.where(scores[0] > conf.detection_threshold)
+            keypoints = torch.stack(idx[::-1], -1).float()[None]
+            kscores = scores[0][idx][None]
+        else:
+            flat = scores.reshape(b, -1)
+            kscores, ind = torch.topk(flat, min(k, flat.shape[1]), dim=1, sorted=True)
+            keypoints = torch.stack([ind % W, ind // W], -1).float()
+            valid = kscores > conf.detection_threshold
+            if conf.force_num_keypoints:
+                # pad like pad_and_stack(mode="random_c"): uniform in the detections' bounding box
+                big = torch.full_like(keypoints, float("inf"))
+                lo = torch.where(valid[..., None], keypoints, big).amin(1, keepdim=True)
+                hi = torch.where(valid[..., None], keypoints, -big).amax(1, keepdim=True)
+                bound = float(min(image.shape[-2:]))
+                lo = torch.where(torch.isfinite(lo), lo, torch.zeros_like(lo))
+                hi = torch.where(torch.isfinite(hi), hi, torch.full_like(hi, bound))
+                rnd = lo + torch.rand_like(keypoints) * (hi - lo)
+                keypoints = torch.where(valid[..., None], keypoints, rnd)
+                kscores = torch.where(valid, kscores, torch.zeros_like(kscores))
+                if keypoints.shape[1] < k:
+                    extra = k - keypoints.shape[1]
+                    keypoints = torch.cat([keypoints, lo + torch.rand(b, extra, 2, device=lo.device) * (hi - lo)], 1)
+                    kscores = torch.cat([kscores, kscores.new_zeros(b, extra)], 1)
+            elif b == 1:
+                keypoints, kscores = keypoints[:, valid[0]], kscores[:, valid[0]]
+            elif not bool(valid.all()):
+                raise ValueError("images yield different keypoint counts: set force_num_keypoints")
+        desc = sample_descriptors(keypoints, dense, s)
+        pred = {"keypoints": keypoints + 0.5, "keypoint_scores": kscores, "descriptors": desc.transpose(-1, -2)}
+        if conf.dense_outputs:
+            pred["dense_descriptors"] = dense
+        return pred
+
+    def loss(self, pred, data):
+        raise NotImplementedError
+
+
+__main_model__ = SuperPoint

@@ -170,6 +170,32 @@ def gen_gluestick(name, batch, n_kpts, n_lines, gnn, inter, seed):
     print(name, "loss", losses["total"].tolist(), "line matches", (pred["line_matches0"] > -1).sum(1).tolist())
 
 
+def gen_superpoint(name, seed):
+    """Reference superpoint_open on seeded random weights (shared through a temp state_dict file)
+    and seeded images; eval-mode and train-mode (batch-statistics BatchNorm) outputs."""
+    import tempfile
+    from gluefactory.models.extractors.superpoint_open import SuperPoint as RefSP
+    from glue_factory_amd.extractors.superpoint_open import SuperPoint
+
+    conf = {"max_num_keypoints": 100, "force_num_keypoints": True, "detection_threshold": 0.0, "nms_radius": 3}
+    torch.manual_seed(seed)
+    ours = SuperPoint(conf)
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "sp.pth")
+        torch.save(ours.state_dict(), path)
+        ref = RefSP({**conf, "weights": path})
+    g = torch.Generator().manual_seed(seed + 1)
+    image = torch.rand(2, 3, 120, 160, generator=g)
+    out = {"image": image.numpy(), "seed": np.array(seed)}
+    for mode in ("eval", "train"):
+        getattr(ref, mode)()
+        with torch.no_grad():
+            pr = ref({"image": image})
+        out.update(_np(pr, mode + "."))
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+    print(name, "keypoints", tuple(pr["keypoints"].shape))
+
+
 def gen_gt(name, batch, n0, n1, seed):
     from gluefactory.geometry.gt_generation import gt_matches_from_homography
 
@@ -189,6 +215,7 @@ def main():
     gen_lightglue("lightglue_d256", batch=1, n0=72, n1=64, n_layers=2, dim=256, heads=4,
                   seed=23, size=(1024, 1024), store_params=False)
     gen_gt("gt_homography", batch=2, n0=96, n1=80, seed=5)
+    gen_superpoint("superpoint_open", seed=51)
     gen_gluestick("gluestick_d256", batch=2, n_kpts=40, n_lines=12, gnn=["self", "cross"] * 2, inter=[0], seed=41)
     gen_superglue("superglue_d256", batch=2, n0=60, n1=52, gnn=["self", "cross"] * 2, iters=20, seed=31)
 
