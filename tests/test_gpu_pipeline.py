@@ -24,8 +24,8 @@ def _batch(b=2, h=240, w=320, seed=0):
     g = torch.Generator().manual_seed(seed)
     img = torch.rand(b, 3, h, w, generator=g)
     size = torch.tensor([[w, h]], dtype=torch.float32).repeat(b, 1)
-    return {"view0": {"image": img, "image_size": size}, "view1": {"image": img.roll(3, -1), "image_size": size},
-            "H_0to1": torch.tensor([[1.0, 0, 3], [0, 1, 0], [0, 0, 1]])[None].repeat(b, 1, 1)}
+    return {"view0": {"image": img, "image_size": size}, "view1": {"image": img.roll(8, -1), "image_size": size},   # one 8-px SuperPoint cell: shift-equivariant
+            "H_0to1": torch.tensor([[1.0, 0, 8], [0, 1, 0], [0, 0, 1]])[None].repeat(b, 1, 1)}
 
 
 def test_pipeline_train_step_and_overfit():
