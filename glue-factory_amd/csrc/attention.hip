@@ -32,12 +32,17 @@ template <typename T, int HD> struct Lay {
     static constexpr int VEC = 16 / sizeof(T);   // elements per 16-byte chunk
     static constexpr int CPR = HD / VEC;         // chunks per row
     static constexpr int LDR = HD + VEC;         // row-major LDS stride (+16 B: conflict-free b128)
-    static constexpr int LDT = 64 + 4;           // transposed LDS stride (64 rows of the tile + pad)
+    static constexpr int LDT = 64 + 8;           // transposed LDS stride (64 rows of the tile + 16 B pad)
     static constexpr int ROWMAJOR = 64 * LDR;    // elements
     static constexpr int TRANSP = HD * LDT;      // elements
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// Position of tile row r inside a transposed LDS row: bits 2 and 3 of r are swapped so that the 8
+// rows a lane needs for one k-step of the second MFMA — {16t + 4hi + e, 16t + 8 + 4hi + e}, e<4, the
+// C-layout rows of accumulator registers 8t..8t+7 — are 8 CONSECUTIVE elements (one 16-byte read).
+__device__ __forceinline__ int tpos(int r) { return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1); }
 
 // ---- global -> LDS staging of a 64-row tile (rows clamped to the last valid row) ----------
 template <typename T, int HD>
@@ -74,7 +79,7 @@ __device__ __forceinline__ void stage_tile(T* ldsR, T* ldsT, const T* g, int64_t
 #pragma unroll
             for (int e = 0; e < L::VEC; ++e) {
                 pair_t pr = {v0.e[e], v1.e[e]};
-                *reinterpret_cast<pair_t*>(ldsT + (cc * L::VEC + e) * L::LDT + 2 * p) = pr;
+                *reinterpret_cast<pair_t*>(ldsT + (cc * L::VEC + e) * L::LDT + tpos(2 * p)) = pr;
             }
         }
     }
@@ -108,8 +113,8 @@ __device__ __forceinline__ void mma_transposed(f32x16 (&acc)[HD / 32], const T* 
         Frag<T> pf = acc_to_frag<T>(p, t);
 #pragma unroll
         for (int db = 0; db < HD / 32; ++db) {
-            const T* base = ldsT + (db * 32 + l31) * L::LDT + i0 + 16 * t + 4 * hi;
-            mma32(acc[db], ld_frag4x2(base, base + 8), pf);
+            const T* base = ldsT + (db * 32 + l31) * L::LDT + i0 + 16 * t + 8 * hi;
+            mma32(acc[db], ld_frag8(base), pf);
         }
     }
 }
@@ -183,7 +188,7 @@ __device__ __forceinline__ void stage_store(const StageRegs<T, HD>& rg, T* Ks, T
 #pragma unroll
         for (int e = 0; e < L::VEC; ++e) {
             pair_t pr = {a.e[e], b.e[e]};
-            *reinterpret_cast<pair_t*>(Vt + (cc * L::VEC + e) * L::LDT + 2 * p) = pr;
+            *reinterpret_cast<pair_t*>(Vt + (cc * L::VEC + e) * L::LDT + tpos(2 * p)) = pr;
         }
     }
 }
@@ -296,8 +301,8 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_fwd_kernel(A
                 Frag<T> p0 = acc_to_frag<T>(s[0][kb], tt), p1 = acc_to_frag<T>(s[1][kb], tt);
 #pragma unroll
                 for (int db = 0; db < HD / 32; ++db) {
-                    const T* vb = Vt + (db * 32 + l31) * L::LDT + kb * 32 + 16 * tt + 4 * hi;
-                    Frag<T> vf = ld_frag4x2(vb, vb + 8);
+                    const T* vb = Vt + (db * 32 + l31) * L::LDT + kb * 32 + 16 * tt + 8 * hi;
+                    Frag<T> vf = ld_frag8(vb);
                     mma32(o[0][db], vf, p0);
                     mma32(o[1][db], vf, p1);
                 }
@@ -358,7 +363,7 @@ __device__ __forceinline__ void pair_store(const PairRegs<T, HD>& rg, T* ldsR, T
 #pragma unroll
             for (int e = 0; e < L::VEC; ++e) {
                 pair_t pr = {x.e[e], y.e[e]};
-                *reinterpret_cast<pair_t*>(ldsT + (cc * L::VEC + e) * L::LDT + 2 * p) = pr;
+                *reinterpret_cast<pair_t*>(ldsT + (cc * L::VEC + e) * L::LDT + tpos(2 * p)) = pr;
             }
         }
     }
@@ -465,8 +470,8 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dq_kerne
                 Frag<T> d0 = acc_to_frag<T>(s[0], tt), d1 = acc_to_frag<T>(s[1], tt);
 #pragma unroll
                 for (int db = 0; db < HD / 32; ++db) {
-                    const T* tb = Kt + (db * 32 + l31) * L::LDT + kb * 32 + 16 * tt + 4 * hi;
-                    Frag<T> kt = ld_frag4x2(tb, tb + 8);
+                    const T* tb = Kt + (db * 32 + l31) * L::LDT + kb * 32 + 16 * tt + 8 * hi;
+                    Frag<T> kt = ld_frag8(tb);
                     mma32(dq[0][db], kt, d0);
                     mma32(dq[1][db], kt, d1);
                 }
