@@ -60,6 +60,11 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--roofline-only", action="store_true", help="only time the attention kernels")
+    ap.add_argument("--micro", action="store_true", help="print per-kernel micro timings and exit")
+    ap.add_argument("--model", default="lightglue", choices=["lightglue", "superglue", "gluestick"],
+                    help="lightglue = the headline configs[1]; superglue / gluestick = configs[3] / [4] (extra lines)")
+    ap.add_argument("--lines", type=int, default=512, help="gluestick: line segments per image")
+    ap.add_argument("--sinkhorn-iters", type=int, default=100)
     ap.add_argument("--time-extractor", action="store_true",
                     help="also time the frozen SuperPoint forward (stock torch) on 2*batch 1024x1024 images")
     return ap.parse_args()
@@ -106,6 +111,46 @@ def roofline_attention(batch, n, dtype):
     }
 
 
+def micro_bench(batch, n, dtype):
+    """Per-kernel timings at the step's own shapes (tuning aid; not part of the JSON contract)."""
+    from glue_factory_amd import ops
+    from glue_factory_amd import lib as L_
+    M = 2 * batch * n
+    dev = "cuda"
+    out = {}
+    g = torch.Generator(device=dev).manual_seed(0)
+    lib = L_.load()
+    for nout, k in ((768, 256), (256, 256), (512, 512), (256, 512), (512, 256)):
+        dy = torch.randn(M, nout, device=dev, dtype=dtype, generator=g)
+        x = torch.randn(M, k, device=dev, dtype=dtype, generator=g)
+        ws = torch.empty(int(lib.gf_linear_dw_ws_bytes(M, nout, k)), dtype=torch.uint8, device=dev)
+        dw = torch.empty(nout, k, device=dev)
+        db = torch.empty(nout, device=dev)
+        t = time_kernel(lambda: lib.gf_linear_dw(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr(),
+                                                 ws.data_ptr(), M, nout, k, 1 if dtype == torch.bfloat16 else 0,
+                                                 torch.cuda.current_stream().cuda_stream))
+        out[f"linear_dw_{nout}x{k}_us"] = round(t * 1e6, 1)
+        out[f"linear_dw_{nout}x{k}_TF"] = round(2.0 * M * nout * k / t / 1e12, 1)
+    x = torch.randn(M, 512, device=dev, dtype=dtype, generator=g)
+    gam, bet = torch.ones(512, device=dev), torch.zeros(512, device=dev)
+    xr = x.clone().requires_grad_(True)
+    y = ops.ln_gelu(xr, gam, bet)
+    out["ln_gelu_fwd_us"] = round(time_kernel(lambda: ops.ln_gelu(x, gam, bet)) * 1e6, 1)
+    dy = torch.randn_like(y)
+    out["ln_gelu_fwd+bwd_us"] = round(time_kernel(lambda: ops.ln_gelu(xr, gam, bet).backward(dy)) * 1e6, 1)
+    a = torch.randn(batch, n, 256, device=dev, dtype=dtype, generator=g) * 0.5
+    b = torch.randn(batch, n, 256, device=dev, dtype=dtype, generator=g) * 0.5
+    out["rows_lse_us"] = round(time_kernel(lambda: ops.rows_lse(a, b)) * 1e6, 1)
+    cb = torch.zeros(batch, n, device=dev)
+    out["rows_argmax_us"] = round(time_kernel(lambda: ops.rows_argmax(a, b, cb, 2.0)) * 1e6, 1)
+    ar, br = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    r, c = ops.dual_lse(ar, br)
+    gr, gc = torch.randn_like(r), torch.randn_like(c)
+    out["dual_lse_fwd+bwd_us"] = round(time_kernel(
+        lambda: torch.autograd.backward(ops.dual_lse(ar, br), (gr, gc))) * 1e6, 1)
+    return out
+
+
 def cpu_baseline(n, layers):
     """CPU oracle (port of the reference algorithm, oracle/lightglue_oracle.py) on the host cores:
     full train step (forward + loss + backward) at B=1 pair, same N and L; pairs/s = 1/step.
@@ -149,6 +194,10 @@ def cpu_baseline(n, layers):
 
 def main():
     args = parse()
+    if args.micro:
+        torch.cuda.set_device(0)
+        print(json.dumps(micro_bench(args.batch, args.kpts, torch.bfloat16 if args.dtype == "bf16" else torch.float32)))
+        return
     if args.roofline_only:
         torch.cuda.set_device(0)
         print(json.dumps(roofline_attention(args.batch, args.kpts,
@@ -167,11 +216,22 @@ def main():
     lib.load()
 
     torch.manual_seed(0)
-    model = LightGlue({"n_layers": args.layers, "filter_threshold": 0.1}).cuda().train()
+    if args.model == "lightglue":
+        model = LightGlue({"n_layers": args.layers, "filter_threshold": 0.1}).cuda().train()
+        cpu_data = make_pairs(args.batch, args.kpts, dim=DIM, seed=100 + rank)
+    elif args.model == "superglue":
+        from glue_factory_amd.matchers.superglue import SuperGlue
+        model = SuperGlue({"num_sinkhorn_iterations": args.sinkhorn_iters}).cuda().train()
+        cpu_data = make_pairs(args.batch, args.kpts, dim=DIM, seed=100 + rank)
+    else:
+        from glue_factory_amd.matchers.gluestick import GlueStick
+        from glue_factory_amd.synthetic import make_point_line_pairs
+        model = GlueStick({}).cuda().train()
+        cpu_data = make_point_line_pairs(args.batch, args.kpts, args.lines, dim=DIM, seed=100 + rank)
     opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)
     stepper = TrainStep(model, opt, amp_dtype=torch.bfloat16 if args.dtype == "bf16" else None,
                         device_ids=[local])
-    data = to_device(make_pairs(args.batch, args.kpts, dim=DIM, seed=100 + rank), "cuda")
+    data = to_device(cpu_data, "cuda")
 
     def step():
         return stepper(data)["total"].mean()
@@ -198,6 +258,19 @@ def main():
 
     pairs = args.batch * world * args.steps
     value = pairs / dt
+    if args.model != "lightglue":      # extra (non-headline) configurations: short report
+        if rank == 0:
+            print(json.dumps({"metric": f"image-pairs/sec (train step) {args.model}", "value": round(value, 2),
+                              "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "ms_per_step": round(dt / args.steps * 1e3, 3), "dtype": args.dtype, "data": "synthetic",
+                              "config": {"workload": f"{args.model} matcher train step, {args.batch} pairs/GPU, "
+                                                     f"N={args.kpts}" + (f" + {args.lines} lines" if args.model == "gluestick" else "")
+                                                     + (f", {args.sinkhorn_iters} Sinkhorn iterations" if args.model == "superglue" else "")},
+                              "final_loss": round(float(loss.item()), 4)}), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     out = {
         "metric": "image-pairs/sec (train step) SP+LightGlue N=2048 d=256 L=9",
         "value": round(value, 2), "unit": "image-pairs/s", "n_gpus": world,
