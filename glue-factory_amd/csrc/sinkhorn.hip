@@ -41,31 +41,54 @@ struct Geo {
 __device__ __forceinline__ float lmu(const Geo& g, int i) { return i < g.M ? g.norm : g.lmu_last; }
 __device__ __forceinline__ float lnu(const Geo& g, int j) { return j < g.N ? g.norm : g.lnu_last; }
 
+// Cooperative, fully coalesced pull of `n` contiguous floats (the RB rows of one block are adjacent
+// in memory) into LDS with 16-byte loads/stores: the LDS image is shifted by (global offset mod 4)
+// floats so that global-aligned <=> LDS-aligned; 8 independent loads per thread are in flight
+// before the first LDS store (memory-level parallelism, one workgroup per CU).
+#define SK_THREADS 512
+__device__ __forceinline__ void pull_block(float* __restrict__ Zs, const float* __restrict__ g, int n, int shift) {
+    const int tid = threadIdx.x;
+    const int head = min(n, (4 - shift) & 3);            // scalars before the first aligned float4
+    if (tid < head) Zs[shift + tid] = g[tid];
+    const int nvec = (n - head) >> 2;
+    const f32x4* gv = reinterpret_cast<const f32x4*>(g + head);
+    f32x4* lv = reinterpret_cast<f32x4*>(Zs + shift + head);
+    int i = tid;
+    for (; i + 7 * SK_THREADS < nvec; i += 8 * SK_THREADS) {
+        f32x4 t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = gv[i + k * SK_THREADS];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) lv[i + k * SK_THREADS] = t[k];
+    }
+    for (; i < nvec; i += SK_THREADS) lv[i] = gv[i];
+    const int tail0 = head + (nvec << 2);
+    if (tid < n - tail0) Zs[shift + tail0 + tid] = g[tail0 + tid];
+}
+
 // ---- forward: rows -> u, column partials -----------------------------------------------------
 // grid (nblk, Bc); v == nullptr means v = 0 (first iteration)
-__global__ __launch_bounds__(256) void sk_rows_fwd(const float* __restrict__ Z, const float* __restrict__ v,
-                                                   float* __restrict__ u, float* __restrict__ u_hist,
-                                                   float* __restrict__ pm, float* __restrict__ ps, Geo g) {
+__global__ __launch_bounds__(SK_THREADS) void sk_rows_fwd(const float* __restrict__ Z, const float* __restrict__ v,
+                                                          float* __restrict__ u, float* __restrict__ u_hist,
+                                                          float* __restrict__ pm, float* __restrict__ ps, Geo g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* Zs = reinterpret_cast<float*>(smem);          // [RB][C]
-    float* vs = Zs + (size_t)g.RB * g.C;                 // [C]
+    float* Zraw = reinterpret_cast<float*>(smem);        // [4 + RB*C]
+    float* vs = Zraw + 4 + (size_t)g.RB * g.C;           // [C]
     float* us = vs + g.C;                                // [RB]
     const int blk = blockIdx.x, b = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float* Zb = Z + (size_t)b * g.R * g.C;
-    for (int j = threadIdx.x; j < g.C; j += 256) vs[j] = v ? v[(size_t)b * g.C + j] : 0.f;
-    __syncthreads();
     const int nrows = min(g.RB, g.R - blk * g.RB);
-    for (int r = wave; r < nrows; r += 4) {
+    const size_t e0 = ((size_t)b * g.R + (size_t)blk * g.RB) * g.C;
+    const int shift = (int)((reinterpret_cast<uintptr_t>(Z + e0) >> 2) & 3);   // float offset inside a 16-byte line
+    pull_block(Zraw, Z + e0, nrows * g.C, shift);
+    float* Zs = Zraw + shift;
+    for (int j = threadIdx.x; j < g.C; j += SK_THREADS) vs[j] = v ? v[(size_t)b * g.C + j] : 0.f;
+    __syncthreads();
+    for (int r = wave; r < nrows; r += SK_THREADS / 64) {
         const int gi = blk * g.RB + r;
-        const float* zr = Zb + (size_t)gi * g.C;
-        float* zs = Zs + (size_t)r * g.C;
+        const float* zs = Zs + (size_t)r * g.C;
         float mx = -INFINITY;
-        for (int j = lane; j < g.C; j += 64) {
-            float z = zr[j];
-            zs[j] = z;
-            mx = fmaxf(mx, z + vs[j]);
-        }
+        for (int j = lane; j < g.C; j += 64) mx = fmaxf(mx, zs[j] + vs[j]);
         mx = wave_max(mx);
         float s = 0.f;
         for (int j = lane; j < g.C; j += 64) s += __expf(zs[j] + vs[j] - mx);
@@ -80,7 +103,7 @@ __global__ __launch_bounds__(256) void sk_rows_fwd(const float* __restrict__ Z, 
     __syncthreads();
     float* pmb = pm + ((size_t)b * g.nblk + blk) * g.C;
     float* psb = ps + ((size_t)b * g.nblk + blk) * g.C;
-    for (int j = threadIdx.x; j < g.C; j += 256) {
+    for (int j = threadIdx.x; j < g.C; j += SK_THREADS) {
         float mx = -INFINITY;
         for (int r = 0; r < nrows; ++r) mx = fmaxf(mx, Zs[(size_t)r * g.C + j] + us[r]);
         float s = 0.f;
@@ -90,20 +113,34 @@ __global__ __launch_bounds__(256) void sk_rows_fwd(const float* __restrict__ Z, 
     }
 }
 
-// grid (ceil(C/256), Bc)
-__global__ void sk_cols_fwd(const float* __restrict__ pm, const float* __restrict__ ps, float* __restrict__ v,
-                            float* __restrict__ v_hist, Geo g) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
-    if (j >= g.C) return;
-    const float* pmb = pm + (size_t)b * g.nblk * g.C + j;
-    const float* psb = ps + (size_t)b * g.nblk * g.C + j;
-    float mx = -INFINITY;
-    for (int k = 0; k < g.nblk; ++k) mx = fmaxf(mx, pmb[(size_t)k * g.C]);
-    float s = 0.f;
-    for (int k = 0; k < g.nblk; ++k) s += psb[(size_t)k * g.C] * __expf(pmb[(size_t)k * g.C] - mx);
-    const float vn = lnu(g, j) - (mx + __logf(s));
-    v[(size_t)b * g.C + j] = vn;
-    v_hist[(size_t)b * g.C + j] = vn;
+// grid (ceil(C/64), Bc), 256 threads = 64 columns x 4 block-groups, combined through LDS
+__global__ __launch_bounds__(256) void sk_cols_fwd(const float* __restrict__ pm, const float* __restrict__ ps,
+                                                   float* __restrict__ v, float* __restrict__ v_hist, Geo g) {
+    __shared__ float sm[4][64], ss[4][64];
+    const int cx = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + cx, b = blockIdx.y;
+    const int jc = min(j, g.C - 1);
+    const float* pmb = pm + (size_t)b * g.nblk * g.C + jc;
+    const float* psb = ps + (size_t)b * g.nblk * g.C + jc;
+    float mx = -INFINITY, s = 0.f;
+    for (int k = grp; k < g.nblk; k += 4) {
+        const float m2 = pmb[(size_t)k * g.C], s2 = psb[(size_t)k * g.C];
+        const float mn = fmaxf(mx, m2);
+        s = s * __expf(mx - mn) + s2 * __expf(m2 - mn);
+        mx = mn;
+    }
+    sm[grp][cx] = mx;
+    ss[grp][cx] = s;
+    __syncthreads();
+    if (grp == 0 && j < g.C) {
+        float M = fmaxf(fmaxf(sm[0][cx], sm[1][cx]), fmaxf(sm[2][cx], sm[3][cx]));
+        float S = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) S += (sm[k][cx] == -INFINITY) ? 0.f : ss[k][cx] * __expf(sm[k][cx] - M);
+        const float vn = lnu(g, j) - (M + __logf(S));
+        v[(size_t)b * g.C + j] = vn;
+        v_hist[(size_t)b * g.C + j] = vn;
+    }
 }
 
 // out = Z + u + v - norm ; grid (ceil(C/256), R, Bc)
@@ -119,38 +156,36 @@ __global__ void sk_final_fwd(const float* __restrict__ Z, const float* __restric
 // ---- backward: one reverse iteration -----------------------------------------------------------
 // ubar_i = base_i - sum_j exp(Z_ij + u_i + (vk_j - lnu_j)) vbar_j ; column partials of
 // sum_i exp(Z_ij + (u_i - lmu_i) + vprev_j) ubar_i
-__global__ __launch_bounds__(256) void sk_rows_bwd(const float* __restrict__ Z, const float* __restrict__ uk,
-                                                   const float* __restrict__ vk, const float* __restrict__ vprev,
-                                                   const float* __restrict__ vbar, const float* __restrict__ base,
-                                                   float* __restrict__ ubar_out, float* __restrict__ psum, Geo g) {
+__global__ __launch_bounds__(SK_THREADS) void sk_rows_bwd(const float* __restrict__ Z, const float* __restrict__ uk,
+                                                          const float* __restrict__ vk, const float* __restrict__ vprev,
+                                                          const float* __restrict__ vbar, const float* __restrict__ base,
+                                                          float* __restrict__ ubar_out, float* __restrict__ psum, Geo g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* Zs = reinterpret_cast<float*>(smem);
-    float* as = Zs + (size_t)g.RB * g.C;     // vk - lnu
-    float* bs = as + g.C;                    // vbar
-    float* ps_ = bs + g.C;                   // vprev
-    float* us = ps_ + g.C;                   // [RB] u - lmu
-    float* ubs = us + g.RB;                  // [RB] ubar
+    float* Zraw = reinterpret_cast<float*>(smem);
+    float* as = Zraw + 4 + (size_t)g.RB * g.C;     // vk - lnu
+    float* bs = as + g.C;                          // vbar
+    float* ps_ = bs + g.C;                         // vprev
+    float* us = ps_ + g.C;                         // [RB] u - lmu
+    float* ubs = us + g.RB;                        // [RB] ubar
     const int blk = blockIdx.x, b = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float* Zb = Z + (size_t)b * g.R * g.C;
-    for (int j = threadIdx.x; j < g.C; j += 256) {
+    const int nrows = min(g.RB, g.R - blk * g.RB);
+    const size_t e0 = ((size_t)b * g.R + (size_t)blk * g.RB) * g.C;
+    const int shift = (int)((reinterpret_cast<uintptr_t>(Z + e0) >> 2) & 3);   // float offset inside a 16-byte line
+    pull_block(Zraw, Z + e0, nrows * g.C, shift);
+    float* Zs = Zraw + shift;
+    for (int j = threadIdx.x; j < g.C; j += SK_THREADS) {
         as[j] = vk[(size_t)b * g.C + j] - lnu(g, j);
         bs[j] = vbar[(size_t)b * g.C + j];
         ps_[j] = vprev ? vprev[(size_t)b * g.C + j] : 0.f;
     }
     __syncthreads();
-    const int nrows = min(g.RB, g.R - blk * g.RB);
-    for (int r = wave; r < nrows; r += 4) {
+    for (int r = wave; r < nrows; r += SK_THREADS / 64) {
         const int gi = blk * g.RB + r;
-        const float* zr = Zb + (size_t)gi * g.C;
-        float* zs = Zs + (size_t)r * g.C;
+        const float* zs = Zs + (size_t)r * g.C;
         const float ui = uk[(size_t)b * g.R + gi];
         float acc = 0.f;
-        for (int j = lane; j < g.C; j += 64) {
-            float z = zr[j];
-            zs[j] = z;
-            acc += __expf(z + ui + as[j]) * bs[j];
-        }
+        for (int j = lane; j < g.C; j += 64) acc += __expf(zs[j] + ui + as[j]) * bs[j];
         acc = wave_sum(acc);
         const float ub = (base ? base[(size_t)b * g.R + gi] : 0.f) - acc;
         if (lane == 0) {
@@ -161,7 +196,7 @@ __global__ __launch_bounds__(256) void sk_rows_bwd(const float* __restrict__ Z, 
     }
     __syncthreads();
     float* pb = psum + ((size_t)b * g.nblk + blk) * g.C;
-    for (int j = threadIdx.x; j < g.C; j += 256) {
+    for (int j = threadIdx.x; j < g.C; j += SK_THREADS) {
         float acc = 0.f;
         const float vp = ps_[j];
         for (int r = 0; r < nrows; ++r) acc += __expf(Zs[(size_t)r * g.C + j] + us[r] + vp) * ubs[r];
@@ -169,13 +204,17 @@ __global__ __launch_bounds__(256) void sk_rows_bwd(const float* __restrict__ Z, 
     }
 }
 
-__global__ void sk_cols_bwd(const float* __restrict__ psum, float* __restrict__ vbar_out, Geo g) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
-    if (j >= g.C) return;
-    const float* pb = psum + (size_t)b * g.nblk * g.C + j;
+__global__ __launch_bounds__(256) void sk_cols_bwd(const float* __restrict__ psum, float* __restrict__ vbar_out, Geo g) {
+    __shared__ float ss[4][64];
+    const int cx = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + cx, b = blockIdx.y;
+    const int jc = min(j, g.C - 1);
+    const float* pb = psum + (size_t)b * g.nblk * g.C + jc;
     float s = 0.f;
-    for (int k = 0; k < g.nblk; ++k) s += pb[(size_t)k * g.C];
-    vbar_out[(size_t)b * g.C + j] = -s;
+    for (int k = grp; k < g.nblk; k += 4) s += pb[(size_t)k * g.C];
+    ss[grp][cx] = s;
+    __syncthreads();
+    if (grp == 0 && j < g.C) vbar_out[(size_t)b * g.C + j] = -(ss[0][cx] + ss[1][cx] + ss[2][cx] + ss[3][cx]);
 }
 
 // dZ = G - sum_k [...] ; thread = 1 column x 8 rows ; grid (ceil(C/256), ceil(R/8), Bc)
@@ -225,7 +264,7 @@ Geo make_geo(int B, int M, int N) {
     Geo g;
     g.B = B; g.M = M; g.N = N; g.R = M + 1; g.C = N + 1;
     // rows per block: bounded by LDS (RB rows + 4 column vectors), at most 16
-    size_t rb = (LDS_BUDGET - 4 * (size_t)g.C * 4 - 256) / ((size_t)g.C * 4);
+    size_t rb = (LDS_BUDGET - 4 * (size_t)g.C * 4 - 512) / ((size_t)g.C * 4);
     g.RB = (int)(rb > 16 ? 16 : rb);
     g.nblk = g.RB > 0 ? (g.R + g.RB - 1) / g.RB : 0;
     g.norm = -logf((float)(M + N));
@@ -242,7 +281,7 @@ int batch_chunk(const Geo& g) {
 }
 
 size_t rows_lds(const Geo& g, bool bwd) {
-    return ((size_t)g.RB * g.C + (bwd ? 3 : 1) * (size_t)g.C + 2 * (size_t)g.RB) * 4 + 64;
+    return ((size_t)g.RB * g.C + 4 + (bwd ? 3 : 1) * (size_t)g.C + 2 * (size_t)g.RB) * 4 + 64;
 }
 
 }  // namespace
@@ -276,11 +315,11 @@ extern "C" int gf_sinkhorn_fwd(const float* Z, float* out, float* u_hist, float*
     for (int b0 = 0; b0 < B; b0 += ch) {
         const int bc = (B - b0) < ch ? (B - b0) : ch;
         for (int it = 0; it < iters; ++it) {
-            sk_rows_fwd<<<dim3(g.nblk, bc), 256, lds, st>>>(
+            sk_rows_fwd<<<dim3(g.nblk, bc), SK_THREADS, lds, st>>>(
                 Z + b0 * zs, it == 0 ? nullptr : vcur + (size_t)b0 * g.C, ucur + (size_t)b0 * g.R,
                 u_hist + ((size_t)it * B + b0) * g.R, pm + (size_t)b0 * g.nblk * g.C,
                 ps + (size_t)b0 * g.nblk * g.C, g);
-            sk_cols_fwd<<<dim3((g.C + 255) / 256, bc), 256, 0, st>>>(
+            sk_cols_fwd<<<dim3((g.C + 63) / 64, bc), 256, 0, st>>>(
                 pm + (size_t)b0 * g.nblk * g.C, ps + (size_t)b0 * g.nblk * g.C, vcur + (size_t)b0 * g.C,
                 v_hist + ((size_t)it * B + b0) * g.C, g);
         }
@@ -321,11 +360,11 @@ extern "C" int gf_sinkhorn_bwd(const float* Z, const float* gout, const float* g
             const float* uk = u_hist + ((size_t)(k - 1) * B + b0) * g.R;
             const float* vk = v_hist + ((size_t)(k - 1) * B + b0) * g.C;
             const float* vp = k >= 2 ? v_hist + ((size_t)(k - 2) * B + b0) * g.C : nullptr;
-            sk_rows_bwd<<<dim3(g.nblk, bc), 256, lds, st>>>(
+            sk_rows_bwd<<<dim3(g.nblk, bc), SK_THREADS, lds, st>>>(
                 Z + b0 * zs, uk, vk, vp, vbar_hist + ((size_t)k * B + b0) * g.C,
                 k == iters ? gsum_row + (size_t)b0 * g.R : nullptr,
                 ubar_hist + ((size_t)(k - 1) * B + b0) * g.R, psum + (size_t)b0 * g.nblk * g.C, g);
-            sk_cols_bwd<<<dim3((g.C + 255) / 256, bc), 256, 0, st>>>(
+            sk_cols_bwd<<<dim3((g.C + 63) / 64, bc), 256, 0, st>>>(
                 psum + (size_t)b0 * g.nblk * g.C, vbar_hist + ((size_t)(k - 1) * B + b0) * g.C, g);
         }
         sk_final_bwd<<<dim3((g.C + 255) / 256, (g.R + 7) / 8, bc), 256, 0, st>>>(
