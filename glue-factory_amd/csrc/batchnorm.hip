@@ -1,0 +1,183 @@
+// BatchNorm1d(+ReLU) over channels-last activations [M = B*N, C], batch statistics in training.
+//
+// Replaces the BatchNorm1d+ReLU pairs of the SuperGlue / GlueStick MLPs (reference:
+// gluefactory_nonfree/superglue.py:70-79, gluefactory/models/matchers/gluestick.py:465-474),
+// which torch serves with channels-last reduction kernels at ~0.2 TB/s for these shapes.
+// HBM-bound design: one column-sum pass (per-thread 16-byte column chunk, rows strided over the
+// workgroup, LDS combine, per-block partials -> host-side tiny sum / all-reduce for SyncBN) and
+// one fused normalise+affine+ReLU pass; the backward mirrors it (sum dz, sum dz*xhat, then dx).
+// T in / T out, fp32 statistics.
+#include "gf_common.h"
+#include "gf_amd.h"
+
+namespace {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+int bn_blocks(int M) {
+    int nb = (M + 255) / 256;
+    return nb < 1 ? 1 : (nb > 512 ? 512 : nb);
+}
+
+// MODE 0: part[blk][0][c] = sum x, part[blk][1][c] = sum x^2
+// MODE 1: dz = dy * (relu ? z > 0 : 1); part[0] = sum dz, part[1] = sum dz * xhat
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void bn_colsum_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float* __restrict__ part, int M, int C, int relu) {
+    constexpr int VEC = 16 / sizeof(T);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = reinterpret_cast<float*>(smem);      // [256][2*VEC]
+    const int cpr = C / VEC;                          // chunks per row
+    const int cc = threadIdx.x % cpr, rl = threadIdx.x / cpr;
+    const int rows_per_iter = 256 / cpr;              // row lanes (threads beyond cpr*rows_per_iter idle)
+    float a0[VEC], a1[VEC], mu[VEC], rs[VEC], ga[VEC], be[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        a0[e] = 0.f; a1[e] = 0.f;
+        if (MODE == 1) {
+            int c = cc * VEC + e;
+            mu[e] = mean[c]; rs[e] = rstd[c]; ga[e] = gamma[c]; be[e] = beta[c];
+        }
+    }
+    if (rl < rows_per_iter) {
+        for (int64_t r = (int64_t)blockIdx.x * rows_per_iter + rl; r < M; r += (int64_t)gridDim.x * rows_per_iter) {
+            union { u32x4 u; T e[VEC]; } v, d;
+            v.u = *reinterpret_cast<const u32x4*>(x + r * C + cc * VEC);
+            if (MODE == 1) d.u = *reinterpret_cast<const u32x4*>(dy + r * C + cc * VEC);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                float xv = to_f32(v.e[e]);
+                if (MODE == 0) {
+                    a0[e] += xv;
+                    a1[e] += xv * xv;
+                } else {
+                    float xh = (xv - mu[e]) * rs[e];
+                    float z = xh * ga[e] + be[e];
+                    float dz = (relu && z <= 0.f) ? 0.f : to_f32(d.e[e]);
+                    a0[e] += dz;
+                    a1[e] += dz * xh;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        red[threadIdx.x * 2 * VEC + e] = a0[e];
+        red[threadIdx.x * 2 * VEC + VEC + e] = a1[e];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const int ccx = c / VEC, e = c % VEC;
+        float s0 = 0.f, s1 = 0.f;
+        for (int l = 0; l < rows_per_iter; ++l) {
+            const int t = l * cpr + ccx;
+            s0 += red[t * 2 * VEC + e];
+            s1 += red[t * 2 * VEC + VEC + e];
+        }
+        part[((int64_t)blockIdx.x * 2 + 0) * C + c] = s0;
+        part[((int64_t)blockIdx.x * 2 + 1) * C + c] = s1;
+    }
+}
+
+// MODE 0 (forward):  y = act(xhat * gamma + beta)
+// MODE 1 (backward): dx = gamma * rstd * (dz - m1 - xhat * m2), dz = dy * (z > 0), m1/m2 per-channel means
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ m1, const float* __restrict__ m2,
+                                                       T* __restrict__ out, int64_t M, int C, int relu) {
+    constexpr int VEC = 16 / sizeof(T);
+    const int cpr = C / VEC;
+    const int64_t total = M * cpr;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int cc = (int)(i % cpr);
+        union { u32x4 u; T e[VEC]; } v, d, o;
+        v.u = *reinterpret_cast<const u32x4*>(x + i * VEC);
+        if (MODE == 1) d.u = *reinterpret_cast<const u32x4*>(dy + i * VEC);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const int c = cc * VEC + e;
+            const float xh = (to_f32(v.e[e]) - mean[c]) * rstd[c];
+            const float z = xh * gamma[c] + beta[c];
+            if (MODE == 0) {
+                o.e[e] = from_f32<T>((relu && z <= 0.f) ? 0.f : z);
+            } else {
+                const float dz = (relu && z <= 0.f) ? 0.f : to_f32(d.e[e]);
+                o.e[e] = from_f32<T>(gamma[c] * rstd[c] * (dz - m1[c] - xh * m2[c]));
+            }
+        }
+        *reinterpret_cast<u32x4*>(out + i * VEC) = o.u;
+    }
+}
+
+template <typename T>
+int bn_check(int C) {
+    constexpr int VEC = 16 / sizeof(T);
+    return (C % VEC == 0 && C / VEC <= 256) ? 0 : GF_ERR_UNSUPPORTED;
+}
+
+template <typename T, int MODE>
+int launch_colsum(const void* x, const void* dy, const float* mean, const float* rstd, const float* gamma,
+                  const float* beta, float* part, int M, int C, int relu, hipStream_t st) {
+    if (int e = bn_check<T>(C)) return e;
+    constexpr int VEC = 16 / sizeof(T);
+    size_t lds = 256 * 2 * VEC * sizeof(float);
+    bn_colsum_kernel<T, MODE><<<bn_blocks(M), 256, lds, st>>>(reinterpret_cast<const T*>(x), reinterpret_cast<const T*>(dy),
+                                                              mean, rstd, gamma, beta, part, M, C, relu);
+    return (int)hipGetLastError();
+}
+template <typename T, int MODE>
+int launch_apply(const void* x, const void* dy, const float* mean, const float* rstd, const float* gamma,
+                 const float* beta, const float* m1, const float* m2, void* out, int M, int C, int relu, hipStream_t st) {
+    if (int e = bn_check<T>(C)) return e;
+    constexpr int VEC = 16 / sizeof(T);
+    int64_t total = (int64_t)M * (C / VEC);
+    int nb = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    bn_apply_kernel<T, MODE><<<nb, 256, 0, st>>>(reinterpret_cast<const T*>(x), reinterpret_cast<const T*>(dy), mean, rstd,
+                                                 gamma, beta, m1, m2, reinterpret_cast<T*>(out), M, C, relu);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" int gf_bn_nblk(int M) { return bn_blocks(M); }
+
+extern "C" int gf_bn_stats(const void* x, float* part, int M, int C, int dtype, void* stream) {
+    if (M <= 0 || C <= 0) return GF_ERR_SHAPE;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == GF_F32) return launch_colsum<float, 0>(x, nullptr, nullptr, nullptr, nullptr, nullptr, part, M, C, 0, st);
+    if (dtype == GF_BF16) return launch_colsum<bf16_t, 0>(x, nullptr, nullptr, nullptr, nullptr, nullptr, part, M, C, 0, st);
+    return GF_ERR_DTYPE;
+}
+
+extern "C" int gf_bn_act_fwd(const void* x, const float* mean, const float* rstd, const float* gamma,
+                             const float* beta, void* y, int M, int C, int relu, int dtype, void* stream) {
+    if (M <= 0 || C <= 0) return GF_ERR_SHAPE;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == GF_F32) return launch_apply<float, 0>(x, nullptr, mean, rstd, gamma, beta, nullptr, nullptr, y, M, C, relu, st);
+    if (dtype == GF_BF16) return launch_apply<bf16_t, 0>(x, nullptr, mean, rstd, gamma, beta, nullptr, nullptr, y, M, C, relu, st);
+    return GF_ERR_DTYPE;
+}
+
+extern "C" int gf_bn_bwd_stats(const void* x, const void* dy, const float* mean, const float* rstd,
+                               const float* gamma, const float* beta, float* part, int M, int C, int relu,
+                               int dtype, void* stream) {
+    if (M <= 0 || C <= 0) return GF_ERR_SHAPE;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == GF_F32) return launch_colsum<float, 1>(x, dy, mean, rstd, gamma, beta, part, M, C, relu, st);
+    if (dtype == GF_BF16) return launch_colsum<bf16_t, 1>(x, dy, mean, rstd, gamma, beta, part, M, C, relu, st);
+    return GF_ERR_DTYPE;
+}
+
+extern "C" int gf_bn_bwd_dx(const void* x, const void* dy, const float* mean, const float* rstd,
+                            const float* gamma, const float* beta, const float* m1, const float* m2,
+                            void* dx, int M, int C, int relu, int dtype, void* stream) {
+    if (M <= 0 || C <= 0) return GF_ERR_SHAPE;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == GF_F32) return launch_apply<float, 1>(x, dy, mean, rstd, gamma, beta, m1, m2, dx, M, C, relu, st);
+    if (dtype == GF_BF16) return launch_apply<bf16_t, 1>(x, dy, mean, rstd, gamma, beta, m1, m2, dx, M, C, relu, st);
+    return GF_ERR_DTYPE;
+}

@@ -32,6 +32,11 @@ SIGNATURES = {
     "gf_sinkhorn_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "gf_linear_dw_ws_bytes": [_I, _I, _I],
     "gf_linear_dw": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "gf_bn_nblk": [_I],
+    "gf_bn_stats": [_P, _P, _I, _I, _I, _P],
+    "gf_bn_act_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "gf_bn_bwd_stats": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "gf_bn_bwd_dx": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "gf_rotary_qk": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "gf_rotary_qk_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "gf_ln_gelu_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _F, _I, _P],

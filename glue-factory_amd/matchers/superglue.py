@@ -56,17 +56,29 @@ def _conv_cl(x, conv, rows=None, cols=None):
 
 def _mlp_cl(seq, x, halves):
     """Run an MLP Sequential (Conv1d / BatchNorm1d / ReLU) on channels-last x [B',N,C].
-    BatchNorm is applied per image set (``halves`` = 2 when two images are stacked on the batch
-    axis), reproducing the reference's one-call-per-image statistics and running-stat updates."""
-    for layer in seq:
+    BatchNorm (+ the ReLU that follows it) is one fused HIP pass pair, applied per image set
+    (``halves`` = 2 when two images are stacked on the batch axis), reproducing the reference's
+    one-call-per-image statistics and running-stat updates."""
+    layers = list(seq)
+    i = 0
+    while i < len(layers):
+        layer = layers[i]
         if isinstance(layer, nn.Conv1d):
             x = _conv_cl(x, layer)
         elif isinstance(layer, nn.modules.batchnorm._BatchNorm):
+            relu = i + 1 < len(layers) and isinstance(layers[i + 1], nn.ReLU)
             b, n, c = x.shape
-            parts = x.float().reshape(halves, (b // halves) * n, c)
-            x = torch.stack([layer(parts[i]) for i in range(halves)]).reshape(b, n, c).to(x.dtype)
+            if c % 8:
+                parts = x.float().reshape(halves, (b // halves) * n, c)
+                y = torch.stack([layer(parts[k]) for k in range(halves)]).reshape(b, n, c).to(x.dtype)
+                x = torch.relu(y) if relu else y
+            else:
+                parts = x.reshape(halves, (b // halves) * n, c)
+                x = torch.stack([ops.batch_norm_act(parts[k], layer, relu) for k in range(halves)]).reshape(b, n, c)
+            i += int(relu)
         else:
             x = layer(x)
+        i += 1
     return x
 
 

@@ -506,3 +506,91 @@ class _Sinkhorn(torch.autograd.Function):
 
 def sinkhorn(Z, iters):
     return _Sinkhorn.apply(Z, iters)
+
+
+# ------------------------------------------------------------------------------ BatchNorm1d (+ReLU)
+class _BatchNormAct(torch.autograd.Function):
+    """act(BatchNorm(x)) on channels-last x [M,C]; batch statistics in training (optionally summed
+    across ranks = SyncBatchNorm), given statistics in eval.  Returns (y, mean, biased var, count);
+    only y is differentiable."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, mean_in, rstd_in, eps, training, relu, sync):
+        _chk(x)
+        M, C = x.shape
+        L = _lib.load()
+        g32, b32 = gamma.float().contiguous(), beta.float().contiguous()
+        if training:
+            part = torch.empty((L.gf_bn_nblk(M), 2, C), dtype=torch.float32, device=x.device)
+            _lib.check(L.gf_bn_stats(_p(x), _p(part), M, C, _dt(x), _stream()), "gf_bn_stats")
+            s = part.sum(0)
+            n_t = s.new_tensor(float(M))
+            if sync:
+                import torch.distributed as dist
+                packed = torch.cat([s.flatten(), n_t[None]])
+                dist.all_reduce(packed)
+                s, n_t = packed[:-1].view(2, C), packed[-1]
+            mean = (s[0] / n_t).contiguous()
+            var = (s[1] / n_t - mean * mean).clamp(min=0.0)
+            rstd = torch.rsqrt(var + eps).contiguous()
+        else:
+            mean, rstd = mean_in.float().contiguous(), rstd_in.float().contiguous()
+            var, n_t = mean.new_zeros(C), mean.new_tensor(float(M))
+        y = torch.empty_like(x)
+        _lib.check(L.gf_bn_act_fwd(_p(x), _p(mean), _p(rstd), _p(g32), _p(b32), _p(y), M, C, int(relu), _dt(x),
+                                   _stream()), "gf_bn_act_fwd")
+        ctx.save_for_backward(x, mean, rstd, g32, b32, n_t)
+        ctx.cfg = (training, relu, sync, gamma.dtype, beta.dtype)
+        ctx.mark_non_differentiable(mean, var, n_t)
+        return y, mean, var, n_t
+
+    @staticmethod
+    def backward(ctx, dy, _gm, _gv, _gn):
+        x, mean, rstd, g32, b32, n_t = ctx.saved_tensors
+        training, relu, sync, gdt, bdt = ctx.cfg
+        M, C = x.shape
+        if not dy.is_contiguous():
+            dy = dy.contiguous()
+        L = _lib.load()
+        part = torch.empty((L.gf_bn_nblk(M), 2, C), dtype=torch.float32, device=x.device)
+        _lib.check(L.gf_bn_bwd_stats(_p(x), _p(dy), _p(mean), _p(rstd), _p(g32), _p(b32), _p(part), M, C,
+                                     int(relu), _dt(x), _stream()), "gf_bn_bwd_stats")
+        s = part.sum(0)
+        dbeta, dgamma = s[0].clone(), s[1].clone()          # local sums: DDP averages parameter grads
+        if training:
+            if sync:
+                import torch.distributed as dist
+                s = s.contiguous()
+                dist.all_reduce(s)
+            m1, m2 = (s[0] / n_t).contiguous(), (s[1] / n_t).contiguous()
+        else:
+            m1 = m2 = torch.zeros(C, dtype=torch.float32, device=x.device)
+        dx = torch.empty_like(x)
+        _lib.check(L.gf_bn_bwd_dx(_p(x), _p(dy), _p(mean), _p(rstd), _p(g32), _p(b32), _p(m1), _p(m2), _p(dx),
+                                  M, C, int(relu), _dt(x), _stream()), "gf_bn_bwd_dx")
+        return dx, dgamma.to(gdt), dbeta.to(bdt), None, None, None, None, None, None
+
+
+def batch_norm_act(x, bn, relu=True):
+    """x [M,C] channels-last through ``bn`` (an nn.BatchNorm1d / SyncBatchNorm that owns the affine
+    parameters and running statistics), then ReLU when ``relu``.  Training mode uses batch statistics
+    (summed across ranks when ``bn`` was converted to SyncBatchNorm) and updates the running
+    statistics like torch (momentum, unbiased variance, num_batches_tracked); eval uses them."""
+    assert x.dim() == 2
+    if not x.is_contiguous():
+        x = x.contiguous()
+    if bn.training or not bn.track_running_stats:
+        import torch.distributed as dist
+        sync = (isinstance(bn, torch.nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized()
+                and dist.get_world_size() > 1)
+        y, mean, var, n_t = _BatchNormAct.apply(x, bn.weight, bn.bias, None, None, bn.eps, True, relu, sync)
+        if bn.training and bn.track_running_stats:
+            with torch.no_grad():
+                bn.num_batches_tracked += 1
+                mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+                unbiased = var * (n_t / (n_t - 1).clamp(min=1.0))
+                bn.running_mean.mul_(1 - mom).add_(mean.to(bn.running_mean.dtype), alpha=mom)
+                bn.running_var.mul_(1 - mom).add_(unbiased.to(bn.running_var.dtype), alpha=mom)
+        return y
+    rstd = torch.rsqrt(bn.running_var.float() + bn.eps)
+    return _BatchNormAct.apply(x, bn.weight, bn.bias, bn.running_mean, rstd, bn.eps, False, relu, False)[0]

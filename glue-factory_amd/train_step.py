@@ -65,6 +65,10 @@ class TrainStep:
         self.fwd_model = model
         if self.distributed:
             from torch.nn.parallel import DistributedDataParallel as DDP
+            # train.py:338: BatchNorm layers (SuperGlue / GlueStick MLPs) use global-batch statistics;
+            # ops.batch_norm_act all-reduces its sums when it sees a SyncBatchNorm module.
+            if any(isinstance(m, torch.nn.modules.batchnorm._BatchNorm) for m in model.modules()):
+                self.model = model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
             # ~47 MB of fp32 gradients for LightGlue: 16 MB buckets let the all-reduce of the
             # assignment/confidence heads (first gradients of the backward) start while the
             # transformer backward is still running; loss() is called on the bare module (as the

@@ -138,6 +138,25 @@ int64_t gf_linear_dw_ws_bytes(int M, int Nout, int K);
 int gf_linear_dw(const void* dy, const void* x, float* dw, float* db, void* ws,
                  int M, int Nout, int K, int dtype, void* stream);
 
+/* ---- BatchNorm1d (+ReLU) over channels-last activations [M, C] (training: batch statistics) ------
+ * Replaces the Conv1d -> BatchNorm1d -> ReLU tails of superglue.py:70-79 / gluestick.py:465-474.
+ * gf_bn_stats:     part [gf_bn_nblk(M)][2][C] = per-block (sum x, sum x^2); the caller reduces the
+ *                  blocks (and all-reduces across ranks for SyncBatchNorm) and derives mean / rstd.
+ * gf_bn_act_fwd:   y = act((x - mean) * rstd * gamma + beta), act = ReLU if relu else identity.
+ * gf_bn_bwd_stats: part = per-block (sum dz, sum dz * xhat), dz = dy * (z > 0 or 1).
+ * gf_bn_bwd_dx:    dx = gamma * rstd * (dz - m1 - xhat * m2) with m1 = sum dz / n, m2 = sum dz*xhat / n
+ *                  (eval mode: pass zeros for m1/m2).  C must be a multiple of 8 (bf16) / 4 (f32). */
+int gf_bn_nblk(int M);
+int gf_bn_stats(const void* x, float* part, int M, int C, int dtype, void* stream);
+int gf_bn_act_fwd(const void* x, const float* mean, const float* rstd, const float* gamma,
+                  const float* beta, void* y, int M, int C, int relu, int dtype, void* stream);
+int gf_bn_bwd_stats(const void* x, const void* dy, const float* mean, const float* rstd,
+                    const float* gamma, const float* beta, float* part, int M, int C, int relu,
+                    int dtype, void* stream);
+int gf_bn_bwd_dx(const void* x, const void* dy, const float* mean, const float* rstd,
+                 const float* gamma, const float* beta, const float* m1, const float* m2,
+                 void* dx, int M, int C, int relu, int dtype, void* stream);
+
 /* ---- fused elementwise ops of the transformer block ---------------------------------------
  * Rotary embedding applied in place to the q and k thirds of a fused [B,N,3,H,D] projection
  * (lightglue.py:42-49,159-160): cs [B,N,D] holds cos in the even and sin in the odd slot of

@@ -250,3 +250,38 @@ def test_linear_dw(dtype, M, Nout, K):
         torch.testing.assert_close(a.cpu().double() / sc, r / sc, msg=lambda m: f"{name}: {m}",
                                    rtol=1e-4 if dtype == torch.float32 else 2e-2, atol=1e-4 if dtype == torch.float32 else 2e-2)
     assert w.grad.dtype == torch.float32 and b.grad.dtype == torch.float32
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,C,relu", [(1000, 512, True), (333, 32, True), (4096, 256, False)])
+def test_batch_norm_act(dtype, M, C, relu):
+    g = torch.Generator().manual_seed(M + C)
+    x = (torch.randn(M, C, generator=g) * 1.5 + 0.2).to(DEV, dtype)
+    dy = torch.randn(M, C, generator=g).to(DEV, dtype)
+    bn = torch.nn.BatchNorm1d(C).to(DEV)
+    with torch.no_grad():
+        bn.weight.copy_(1 + 0.2 * torch.randn(C, generator=g))
+        bn.bias.copy_(0.2 * torch.randn(C, generator=g))
+    ref = torch.nn.BatchNorm1d(C).double()
+    ref.load_state_dict({k: v.cpu().double() if v.is_floating_point() else v.cpu() for k, v in bn.state_dict().items()})
+    act = torch.relu if relu else (lambda t: t)
+    for mode in ("train", "eval"):
+        getattr(bn, mode)()
+        getattr(ref, mode)()
+        xs = x.clone().requires_grad_(True)
+        y = ops.batch_norm_act(xs, bn, relu)
+        (y * dy).sum().backward()
+        xr = x.detach().cpu().double().requires_grad_(True)
+        yr = act(ref(xr))
+        (yr * dy.cpu().double()).sum().backward()
+        tol = _tols(dtype)
+        torch.testing.assert_close(y.detach().cpu().double(), yr.detach(), **tol)
+        sc = xr.grad.abs().max().item()
+        torch.testing.assert_close(xs.grad.cpu().double() / sc, xr.grad / sc, **tol)
+        for a, b in ((bn.weight.grad, ref.weight.grad), (bn.bias.grad, ref.bias.grad)):
+            sc = b.abs().max().item()
+            torch.testing.assert_close(a.cpu().double() / sc, b / sc, **tol)
+        bn.zero_grad(); ref.zero_grad()
+    torch.testing.assert_close(bn.running_mean.cpu().double(), ref.running_mean, rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(bn.running_var.cpu().double(), ref.running_var, rtol=1e-3, atol=1e-3)
+    assert int(bn.num_batches_tracked) == 1
