@@ -43,6 +43,10 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // rows a lane needs for one k-step of the second MFMA — {16t + 4hi + e, 16t + 8 + 4hi + e}, e<4, the
 // C-layout rows of accumulator registers 8t..8t+7 — are 8 CONSECUTIVE elements (one 16-byte read).
 __device__ __forceinline__ int tpos(int r) { return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1); }
+// Transposed tiles are additionally XOR-swizzled in 8-element (16-byte) blocks by the low bits of
+// (row d >> 3): with the coalesced staging order (consecutive lanes = consecutive 16-byte chunks of one
+// source row) the 8 lanes of a chunk group would otherwise hit one LDS bank; reads stay 16-byte.
+__device__ __forceinline__ int tswz(int d, int pos) { return pos ^ (((d >> 3) & 7) << 3); }
 
 // ---- global -> LDS staging of a 64-row tile (rows clamped to the last valid row) ----------
 template <typename T, int HD>
@@ -59,31 +63,6 @@ __device__ __forceinline__ void stage_rowmajor(T* lds, const T* g, int64_t ld, i
 template <typename T> struct Pair;
 template <> struct Pair<bf16_t> { typedef bf16x2 type; };
 template <> struct Pair<float> { typedef f32x2 type; };
-
-// rows (2p, 2p+1) x chunk cc: optional row-major copy + transposed copy ldsT[d][row]
-template <typename T, int HD, bool ROWM, bool TRAN>
-__device__ __forceinline__ void stage_tile(T* ldsR, T* ldsT, const T* g, int64_t ld, int row0, int nmax) {
-    using L = Lay<T, HD>;
-    typedef typename Pair<T>::type pair_t;
-    for (int it = threadIdx.x; it < 32 * L::CPR; it += 256) {
-        int p = it & 31, cc = it >> 5;
-        int r0 = min(row0 + 2 * p, nmax - 1), r1 = min(row0 + 2 * p + 1, nmax - 1);
-        union { u32x4 u; T e[L::VEC]; } v0, v1;
-        v0.u = *reinterpret_cast<const u32x4*>(g + (int64_t)r0 * ld + cc * L::VEC);
-        v1.u = *reinterpret_cast<const u32x4*>(g + (int64_t)r1 * ld + cc * L::VEC);
-        if (ROWM) {
-            *reinterpret_cast<u32x4*>(ldsR + (2 * p) * L::LDR + cc * L::VEC) = v0.u;
-            *reinterpret_cast<u32x4*>(ldsR + (2 * p + 1) * L::LDR + cc * L::VEC) = v1.u;
-        }
-        if (TRAN) {
-#pragma unroll
-            for (int e = 0; e < L::VEC; ++e) {
-                pair_t pr = {v0.e[e], v1.e[e]};
-                *reinterpret_cast<pair_t*>(ldsT + (cc * L::VEC + e) * L::LDT + tpos(2 * p)) = pr;
-            }
-        }
-    }
-}
 
 // B-operand style fragments of one row held in registers: row[16 s + 8 hi + e], s = 0..HD/16-1
 template <typename T, int HD>
@@ -113,8 +92,8 @@ __device__ __forceinline__ void mma_transposed(f32x16 (&acc)[HD / 32], const T* 
         Frag<T> pf = acc_to_frag<T>(p, t);
 #pragma unroll
         for (int db = 0; db < HD / 32; ++db) {
-            const T* base = ldsT + (db * 32 + l31) * L::LDT + i0 + 16 * t + 8 * hi;
-            mma32(acc[db], ld_frag8(base), pf);
+            const int d = db * 32 + l31;
+            mma32(acc[db], ld_frag8(ldsT + d * L::LDT + tswz(d, i0 + 16 * t + 8 * hi)), pf);
         }
     }
 }
@@ -161,7 +140,7 @@ __device__ __forceinline__ void stage_load(StageRegs<T, HD>& rg, const T* kp, in
 #pragma unroll
     for (int i = 0; i < StageRegs<T, HD>::NV; ++i) {
         int it = threadIdx.x + 256 * i;
-        int p = it & 31, cc = it >> 5;
+        int cc = it % L::CPR, p = it / L::CPR;
         int r0 = min(row0 + 2 * p, nmax - 1), r1 = min(row0 + 2 * p + 1, nmax - 1);
         rg.v0[i] = *reinterpret_cast<const u32x4*>(vp + (int64_t)r0 * vld + cc * L::VEC);
         rg.v1[i] = *reinterpret_cast<const u32x4*>(vp + (int64_t)r1 * vld + cc * L::VEC);
@@ -181,14 +160,15 @@ __device__ __forceinline__ void stage_store(const StageRegs<T, HD>& rg, T* Ks, T
 #pragma unroll
     for (int i = 0; i < StageRegs<T, HD>::NV; ++i) {
         int it = threadIdx.x + 256 * i;
-        int p = it & 31, cc = it >> 5;
+        int cc = it % L::CPR, p = it / L::CPR;
         union { u32x4 u; T e[L::VEC]; } a, b;
         a.u = rg.v0[i];
         b.u = rg.v1[i];
 #pragma unroll
         for (int e = 0; e < L::VEC; ++e) {
             pair_t pr = {a.e[e], b.e[e]};
-            *reinterpret_cast<pair_t*>(Vt + (cc * L::VEC + e) * L::LDT + tpos(2 * p)) = pr;
+            const int d = cc * L::VEC + e;
+            *reinterpret_cast<pair_t*>(Vt + d * L::LDT + tswz(d, tpos(2 * p))) = pr;
         }
     }
 }
@@ -301,8 +281,8 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_fwd_kernel(A
                 Frag<T> p0 = acc_to_frag<T>(s[0][kb], tt), p1 = acc_to_frag<T>(s[1][kb], tt);
 #pragma unroll
                 for (int db = 0; db < HD / 32; ++db) {
-                    const T* vb = Vt + (db * 32 + l31) * L::LDT + kb * 32 + 16 * tt + 8 * hi;
-                    Frag<T> vf = ld_frag8(vb);
+                    const int d = db * 32 + l31;
+                    Frag<T> vf = ld_frag8(Vt + d * L::LDT + tswz(d, kb * 32 + 16 * tt + 8 * hi));
                     mma32(o[0][db], vf, p0);
                     mma32(o[1][db], vf, p1);
                 }
@@ -338,7 +318,7 @@ __device__ __forceinline__ void pair_load(PairRegs<T, HD>& rg, const T* g, int64
 #pragma unroll
     for (int i = 0; i < PairRegs<T, HD>::N; ++i) {
         int it = threadIdx.x + 256 * i;
-        int p = it & 31, cc = it >> 5;
+        int cc = it % L::CPR, p = it / L::CPR;
         int r0 = min(row0 + 2 * p, nmax - 1), r1 = min(row0 + 2 * p + 1, nmax - 1);
         rg.a[i] = *reinterpret_cast<const u32x4*>(g + (int64_t)r0 * ld + cc * L::VEC);
         rg.b[i] = *reinterpret_cast<const u32x4*>(g + (int64_t)r1 * ld + cc * L::VEC);
@@ -351,7 +331,7 @@ __device__ __forceinline__ void pair_store(const PairRegs<T, HD>& rg, T* ldsR, T
 #pragma unroll
     for (int i = 0; i < PairRegs<T, HD>::N; ++i) {
         int it = threadIdx.x + 256 * i;
-        int p = it & 31, cc = it >> 5;
+        int cc = it % L::CPR, p = it / L::CPR;
         if (ROWM) {
             *reinterpret_cast<u32x4*>(ldsR + (2 * p) * L::LDR + cc * L::VEC) = rg.a[i];
             *reinterpret_cast<u32x4*>(ldsR + (2 * p + 1) * L::LDR + cc * L::VEC) = rg.b[i];
@@ -363,7 +343,8 @@ __device__ __forceinline__ void pair_store(const PairRegs<T, HD>& rg, T* ldsR, T
 #pragma unroll
             for (int e = 0; e < L::VEC; ++e) {
                 pair_t pr = {x.e[e], y.e[e]};
-                *reinterpret_cast<pair_t*>(ldsT + (cc * L::VEC + e) * L::LDT + tpos(2 * p)) = pr;
+                const int d = cc * L::VEC + e;
+                *reinterpret_cast<pair_t*>(ldsT + d * L::LDT + tswz(d, tpos(2 * p))) = pr;
             }
         }
     }
@@ -470,8 +451,8 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dq_kerne
                 Frag<T> d0 = acc_to_frag<T>(s[0], tt), d1 = acc_to_frag<T>(s[1], tt);
 #pragma unroll
                 for (int db = 0; db < HD / 32; ++db) {
-                    const T* tb = Kt + (db * 32 + l31) * L::LDT + kb * 32 + 16 * tt + 8 * hi;
-                    Frag<T> kt = ld_frag8(tb);
+                    const int d = db * 32 + l31;
+                    Frag<T> kt = ld_frag8(Kt + d * L::LDT + tswz(d, kb * 32 + 16 * tt + 8 * hi));
                     mma32(dq[0][db], kt, d0);
                     mma32(dq[1][db], kt, d1);
                 }

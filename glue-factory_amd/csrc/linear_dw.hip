@@ -27,6 +27,11 @@ template <> struct PairT<float> { typedef f32x2 type; };
 
 template <typename T> struct DwRegs { u32x4 a[DwLay<T>::ITEMS], b[DwLay<T>::ITEMS]; };
 
+// 8-element (16-byte) blocks of a transposed row are XOR-swizzled by the row's chunk index so that
+// the coalesced staging order (consecutive lanes = consecutive 16-byte chunks of one source row)
+// spreads its transposed 4-byte stores over the LDS banks; fragment reads stay 16-byte.
+__device__ __forceinline__ int dswz(int d, int pos) { return pos ^ (((d >> 3) & 7) << 3); }
+
 // rows [m0, m0+64) x cols [c0, c0+128) of a row-major [M, ld] matrix (zero beyond M / ncols)
 template <typename T>
 __device__ __forceinline__ void dw_load(DwRegs<T>& rg, const T* g, int64_t ld, int m0, int mend, int c0, int ncols) {
@@ -34,7 +39,7 @@ __device__ __forceinline__ void dw_load(DwRegs<T>& rg, const T* g, int64_t ld, i
 #pragma unroll
     for (int i = 0; i < L::ITEMS; ++i) {
         int it = threadIdx.x + 256 * i;
-        int p = it & 31, cc = it >> 5;
+        int cc = it % L::CPR, p = it / L::CPR;
         int r0 = m0 + 2 * p, r1 = r0 + 1, col = c0 + cc * L::VEC;
         u32x4 z = {0, 0, 0, 0};
         bool okc = col < ncols;
@@ -49,14 +54,15 @@ __device__ __forceinline__ void dw_store(const DwRegs<T>& rg, T* ldsT) {
 #pragma unroll
     for (int i = 0; i < L::ITEMS; ++i) {
         int it = threadIdx.x + 256 * i;
-        int p = it & 31, cc = it >> 5;
+        int cc = it % L::CPR, p = it / L::CPR;
         union { u32x4 u; T e[L::VEC]; } x, y;
         x.u = rg.a[i];
         y.u = rg.b[i];
 #pragma unroll
         for (int e = 0; e < L::VEC; ++e) {
             pair_t pr = {x.e[e], y.e[e]};
-            *reinterpret_cast<pair_t*>(ldsT + (cc * L::VEC + e) * L::LDT + 2 * p) = pr;
+            const int d = cc * L::VEC + e;
+            *reinterpret_cast<pair_t*>(ldsT + d * L::LDT + dswz(d, 2 * p)) = pr;
         }
     }
 }
@@ -124,8 +130,9 @@ __global__ __launch_bounds__(256, 2) void linear_dw_kernel(const T* __restrict__
             Frag<T> af[2], bf[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                af[i] = ld_frag8(At + (wn * 64 + i * 32 + l31) * L::LDT + 16 * s + 8 * hi);
-                bf[i] = ld_frag8(Bt + (wk * 64 + i * 32 + l31) * L::LDT + 16 * s + 8 * hi);
+                const int dn = wn * 64 + i * 32 + l31, dk = wk * 64 + i * 32 + l31;
+                af[i] = ld_frag8(At + dn * L::LDT + dswz(dn, 16 * s + 8 * hi));
+                bf[i] = ld_frag8(Bt + dk * L::LDT + dswz(dk, 16 * s + 8 * hi));
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -154,19 +161,22 @@ __global__ __launch_bounds__(256, 2) void linear_dw_kernel(const T* __restrict__
             }
         }
     if (tk == 0) {
-        // threads with equal chunk index cc are 32 consecutive lanes (p = it & 31): butterfly over p
+        // chunk cc = it % CPR is fixed per thread across chunks; its 32 row pairs p = it / CPR are spread
+        // over the whole workgroup -> combine through LDS (reused after the last barrier)
+        float* red = reinterpret_cast<float*>(smem);
+        __syncthreads();
 #pragma unroll
         for (int i = 0; i < L::ITEMS; ++i) {
             int it = threadIdx.x + 256 * i;
-            int cc = it >> 5;
 #pragma unroll
-            for (int e = 0; e < L::VEC; ++e) {
-                float v = bsum[i][e];
-#pragma unroll
-                for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off);
-                int col = tn * 128 + cc * L::VEC + e;
-                if ((it & 31) == 0 && col < Nout) bpart[(int64_t)slice * Nout + col] = v;
-            }
+            for (int e = 0; e < L::VEC; ++e) red[it * L::VEC + e] = bsum[i][e];
+        }
+        __syncthreads();
+        for (int col = threadIdx.x; col < 128; col += 256) {
+            const int cc = col / L::VEC, e = col % L::VEC;
+            float v = 0.f;
+            for (int p = 0; p < 32; ++p) v += red[(p * L::CPR + cc) * L::VEC + e];
+            if (tn * 128 + col < Nout) bpart[(int64_t)slice * Nout + tn * 128 + col] = v;
         }
     }
 }
