@@ -7,6 +7,7 @@
 // through LDS TRANSPOSED (token axis contiguous, so MFMA fragments are 16-byte reads),
 // double-buffered with register prefetch, accumulates in fp32, and writes its partial tile to
 // a workspace; a second kernel sums the slices (deterministic, no atomics) into fp32 dW / db.
+#include <cstdlib>
 #include "gf_common.h"
 #include "gf_amd.h"
 
@@ -75,10 +76,17 @@ __global__ __launch_bounds__(256, 2) void linear_dw_kernel(const T* __restrict__
     using L = DwLay<T>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* lds = reinterpret_cast<T*>(smem);           // 2 buffers x (A^T tile | B^T tile)
+    // XCD-aware order: block b runs on XCD b % 8; all output tiles of one M-slice are given to the
+    // same XCD back to back, so the dY / X row slabs they share are served by that XCD's L2 instead of
+    // being re-read from HBM once per tile (4x the traffic at 512x512).
     const int ntk = (K + 127) / 128;
-    const int tn = blockIdx.x / ntk, tk = blockIdx.x % ntk;
-    const int slice = blockIdx.y;
+    const int ntile = ((Nout + 127) / 128) * ntk;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int tile = j % ntile;
+    const int slice = (j / ntile) * 8 + xcd;
+    const int tn = tile / ntk, tk = tile % ntk;
     const int m_begin = slice * rows_per_slice, m_end = min(M, m_begin + rows_per_slice);
+    if (m_begin >= M) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const int wn = wave >> 1, wk = wave & 1;       // 2 x 2 waves, each 64 (n) x 64 (k)
@@ -181,18 +189,248 @@ __global__ __launch_bounds__(256, 2) void linear_dw_kernel(const T* __restrict__
     }
 }
 
-__global__ void linear_dw_reduce(const float* __restrict__ part, const float* __restrict__ bpart,
-                                 float* __restrict__ dw, float* __restrict__ db, int nslice, int64_t nw, int Nout) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// ---------------------------------------------------------------------------------------------
+// bf16 fast path: ROW-MAJOR LDS tiles (16-byte coalesced global loads -> conflict-free 16-byte LDS
+// stores, no transposing stores at all) read back through gfx950's transposing LDS load
+// ds_read_b64_tr_b16.  Semantics (probed on hardware, tools/probe/tr.hip): inside each group of 16
+// lanes, lane s supplies the address of 4 consecutive bf16; output lane i receives, for j = 0..3,
+// element (i & 3) of source lane (i >> 2) + 4 j.  With source lane s pointing at
+// tile[m0 + (s >> 2)][c0 + 4 (s & 3)], output lane i holds column c0 + i at rows m0 .. m0 + 3:
+// exactly the "4 consecutive tokens of my column" an MFMA fragment needs.
+// ---------------------------------------------------------------------------------------------
+constexpr int TR_LD = 128 + 32;                 // row stride (bf16): 320 B -> rows 16 banks apart (of 64)
+constexpr int TR_TILE = 64 * TR_LD;
+
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ u32x2 ds_read_tr16(const bf16_t* p) {
+    u32x2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"((unsigned)(size_t)p) : "memory");
+    return v;
+}
+
+struct TrRegs { u32x4 v[4]; unsigned ok; };     // 64 x 128 bf16 tile = 1024 chunks / 256 threads
+
+// Loads are UNCONDITIONAL (indices clamped into the matrix, validity kept as bits and applied when
+// the registers are stashed): predicated loads become exec-masked branches, which both serialise
+// issue and make the compiler fall back to s_waitcnt vmcnt(0), i.e. no prefetch across iterations.
+__device__ __forceinline__ void tr_load(TrRegs& rg, const bf16_t* g, int64_t ld, int m0, int mend, int c0, int ncols) {
+    rg.ok = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int it = threadIdx.x + 256 * i;
+        int cc = it & 15, r = it >> 4;
+        int row = m0 + r, col = c0 + cc * 8;
+        rg.ok |= (unsigned)(row < mend && col < ncols) << i;
+        rg.v[i] = *reinterpret_cast<const u32x4*>(g + (int64_t)min(row, mend - 1) * ld + min(col, ncols - 8));
+    }
+}
+__device__ __forceinline__ void tr_mask(TrRegs& rg) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned keep = (rg.ok >> i) & 1u ? 0xffffffffu : 0u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rg.v[i][e] &= keep;
+    }
+}
+__device__ __forceinline__ void tr_store(const TrRegs& rg, bf16_t* tile) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int it = threadIdx.x + 256 * i;
+        int cc = it & 15, r = it >> 4;
+        *reinterpret_cast<u32x4*>(tile + r * TR_LD + cc * 8) = rg.v[i];
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void linear_dw_tr_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                              float* __restrict__ part, float* __restrict__ bpart,
+                                                              int M, int Nout, int K, int rows_per_slice) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* lds = reinterpret_cast<bf16_t*>(smem);          // 2 buffers x (dY tile | X tile), row-major
+    // XCD-aware order: block b runs on XCD b % 8; all output tiles of one M-slice are given to the
+    // same XCD back to back, so the dY / X row slabs they share are served by that XCD's L2 instead of
+    // being re-read from HBM once per tile (4x the traffic at 512x512).
+    const int ntk = (K + 127) / 128;
+    const int ntile = ((Nout + 127) / 128) * ntk;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int tile = j % ntile;
+    const int slice = (j / ntile) * 8 + xcd;
+    const int tn = tile / ntk, tk = tile % ntk;
+    const int m_begin = slice * rows_per_slice, m_end = min(M, m_begin + rows_per_slice);
+    if (m_begin >= M) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wn = wave >> 1, wk = wave & 1;
+    // per-lane part of the transposing-read address: row (s >> 2) + 8 hi, column 16 (g & 1) + 4 (s & 3)
+    const int s16 = lane & 15, g1 = (lane >> 4) & 1;
+    const int lane_off = ((s16 >> 2) + 8 * hi) * TR_LD + 16 * g1 + 4 * (s16 & 3);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float bsum[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bsum[i][e] = 0.f;
+
+    // Global loads run TWO chunks ahead of the MFMAs (two register sets, statically indexed through an
+    // unroll-by-2), the LDS image one chunk ahead.
+    TrRegs ra0, rb0, ra1, rb1;
+    auto load = [&](TrRegs& a_, TrRegs& b_, int c) {
+        tr_load(a_, dy, Nout, m_begin + c * 64, m_end, tn * 128, Nout);
+        tr_load(b_, x, K, m_begin + c * 64, m_end, tk * 128, K);
+    };
+    auto stash = [&](TrRegs& a_, TrRegs& b_, int c) {
+        tr_mask(a_);
+        tr_mask(b_);
+        if (tk == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                union { u32x4 u; bf16_t e[8]; } t;
+                t.u = a_.v[i];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bsum[i][e] += (float)t.e[e];
+            }
+        }
+        bf16_t* nb = lds + (c & 1) * 2 * TR_TILE;
+        tr_store(a_, nb);
+        tr_store(b_, nb + TR_TILE);
+    };
+    // Fragment reads of k-step ks+1 are issued before the MFMAs of k-step ks (two register sets), so the
+    // LDS latency of the (compiler-invisible) transposing reads hides behind 4 MFMAs instead of stalling.
+    struct FragSet { u32x2 a[2][2], b[2][2]; };
+    auto issue = [&](FragSet& f, const bf16_t* At, const bf16_t* Bt, int ks) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const bf16_t* pa = At + (16 * ks) * TR_LD + wn * 64 + i * 32 + lane_off;
+            const bf16_t* pb = Bt + (16 * ks) * TR_LD + wk * 64 + i * 32 + lane_off;
+            f.a[i][0] = ds_read_tr16(pa);
+            f.a[i][1] = ds_read_tr16(pa + 4 * TR_LD);
+            f.b[i][0] = ds_read_tr16(pb);
+            f.b[i][1] = ds_read_tr16(pb + 4 * TR_LD);
+        }
+    };
+    auto wait_all = [&](FragSet& f) {
+        // asm loads are invisible to the compiler's waitcnt bookkeeping: tie every destination to the wait
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(f.a[0][0]), "+v"(f.a[0][1]), "+v"(f.a[1][0]), "+v"(f.a[1][1]),
+                       "+v"(f.b[0][0]), "+v"(f.b[0][1]), "+v"(f.b[1][0]), "+v"(f.b[1][1])
+                     :: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto mfmas = [&](const FragSet& f) {
+        Frag<bf16_t> af[2], bf[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            union { u32x2 u[2]; bf16x8 v; } ta, tb;
+            ta.u[0] = f.a[i][0]; ta.u[1] = f.a[i][1];
+            tb.u[0] = f.b[i][0]; tb.u[1] = f.b[i][1];
+            af[i].v = ta.v;
+            bf[i].v = tb.v;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) mma32(acc[i][j], af[i], bf[j]);
+    };
+    auto compute = [&](int c) {
+        const bf16_t* At = lds + (c & 1) * 2 * TR_TILE;
+        const bf16_t* Bt = At + TR_TILE;
+        FragSet f0, f1;
+        issue(f0, At, Bt, 0);
+        wait_all(f0);
+        issue(f1, At, Bt, 1);
+        mfmas(f0);
+        wait_all(f1);
+        issue(f0, At, Bt, 2);
+        mfmas(f1);
+        wait_all(f0);
+        issue(f1, At, Bt, 3);
+        mfmas(f0);
+        wait_all(f1);
+        mfmas(f1);
+    };
+    const int nchunk = (m_end - m_begin + 63) / 64;
+    if (nchunk > 0) {
+        load(ra0, rb0, 0);
+        if (nchunk > 1) load(ra1, rb1, 1);
+        stash(ra0, rb0, 0);
+    }
+    __syncthreads();
+    // top of iteration c: LDS[c&1] holds chunk c; register set (c+1)&1 holds chunk c+1 (maybe in flight)
+    for (int c = 0; c < nchunk; c += 2) {
+        if (c + 2 < nchunk) load(ra0, rb0, c + 2);
+        compute(c);
+        if (c + 1 < nchunk) stash(ra1, rb1, c + 1);
+        __syncthreads();
+        if (c + 1 < nchunk) {
+            if (c + 3 < nchunk) load(ra1, rb1, c + 3);
+            compute(c + 1);
+            if (c + 2 < nchunk) stash(ra0, rb0, c + 2);
+            __syncthreads();
+        }
+    }
+    float* pp = part + (int64_t)slice * Nout * K;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int kk = tk * 128 + wk * 64 + j * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int nn = tn * 128 + wn * 64 + i * 32 + crow(r, hi);
+                if (nn < Nout && kk < K) pp[(int64_t)nn * K + kk] = acc[i][j][r];
+            }
+        }
+    if (tk == 0) {
+        // column chunk cc = tid & 15 is fixed per thread; its rows are spread over the workgroup
+        float* red = reinterpret_cast<float*>(smem);
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            red[threadIdx.x * 8 + e] = bsum[0][e] + bsum[1][e] + bsum[2][e] + bsum[3][e];
+        __syncthreads();
+        for (int col = threadIdx.x; col < 128; col += 256) {
+            const int cc = col >> 3, e = col & 7;
+            float v = 0.f;
+            for (int r = 0; r < 16; ++r) v += red[(r * 16 + cc) * 8 + e];
+            if (tn * 128 + col < Nout) bpart[(int64_t)slice * Nout + tn * 128 + col] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void linear_dw_reduce(const float* __restrict__ part, const float* __restrict__ bpart,
+                                                        float* __restrict__ dw, float* __restrict__ db, int nslice,
+                                                        int64_t nw, int Nout) {
+    // nw = Nout*K is a multiple of 16: one float4 per thread, four independent partial chains
+    int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i < nw) {
-        float s = 0.f;
-        for (int k = 0; k < nslice; ++k) s += part[(int64_t)k * nw + i];
-        dw[i] = s;
-    } else if (db && i < nw + Nout) {
-        int n = (int)(i - nw);
-        float s = 0.f;
-        for (int k = 0; k < nslice; ++k) s += bpart[(int64_t)k * Nout + n];
-        db[n] = s;
+        f32x4 a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
+        int k = 0;
+        for (; k + 3 < nslice; k += 4) {
+            a0 += *reinterpret_cast<const f32x4*>(part + (int64_t)k * nw + i);
+            a1 += *reinterpret_cast<const f32x4*>(part + (int64_t)(k + 1) * nw + i);
+            a2 += *reinterpret_cast<const f32x4*>(part + (int64_t)(k + 2) * nw + i);
+            a3 += *reinterpret_cast<const f32x4*>(part + (int64_t)(k + 3) * nw + i);
+        }
+        for (; k < nslice; ++k) a0 += *reinterpret_cast<const f32x4*>(part + (int64_t)k * nw + i);
+        *reinterpret_cast<f32x4*>(dw + i) = (a0 + a1) + (a2 + a3);
+    } else if (db) {
+        int64_t n = (i - nw) / 4 * 4 + 0;   // threads past nw handle 4 bias columns each
+        for (int e = 0; e < 4; ++e) {
+            int64_t col = (i - nw) + e;
+            if (col < Nout) {
+                float s = 0.f;
+                for (int k2 = 0; k2 < nslice; ++k2) s += bpart[(int64_t)k2 * Nout + col];
+                db[col] = s;
+            }
+        }
+        (void)n;
     }
 }
 
@@ -200,7 +438,11 @@ struct DwPlan { int ntile, nslice, rows; };
 DwPlan plan(int M, int Nout, int K) {
     DwPlan p;
     p.ntile = ((Nout + 127) / 128) * ((K + 127) / 128);
-    int want = (640 + p.ntile - 1) / p.ntile;                 // ~2.5 workgroups per CU in total
+    // workgroups in flight: one per CU keeps the per-slice partial traffic low for small outputs; at 16+
+    // tiles two per CU pay off (measured on MI355X, M = 131072).  GF_DW_WG overrides (tuning knob).
+    static const int forced = getenv("GF_DW_WG") ? atoi(getenv("GF_DW_WG")) : 0;
+    const int total_wg = forced > 0 ? forced : (p.ntile >= 16 ? 512 : 256);
+    int want = (total_wg + p.ntile - 1) / p.ntile;
     int rows = (M + want - 1) / want;
     rows = ((rows + 63) / 64) * 64;
     if (rows < 256) rows = 256;
@@ -221,7 +463,7 @@ int launch_dw(const void* dy, const void* x, float* dw, float* db, void* ws, int
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
-    linear_dw_kernel<T><<<dim3(p.ntile, p.nslice), 256, lds, st>>>(
+    linear_dw_kernel<T><<<dim3(p.ntile * ((p.nslice + 7) / 8) * 8), 256, lds, st>>>(
         reinterpret_cast<const T*>(dy), reinterpret_cast<const T*>(x), part, bpart, M, Nout, K, p.rows);
     int64_t nw = (int64_t)Nout * K;
     int64_t tot = nw + (db ? Nout : 0);
@@ -237,6 +479,22 @@ extern "C" int64_t gf_linear_dw_ws_bytes(int M, int Nout, int K) {
     return ((int64_t)p.nslice * Nout * K + (int64_t)p.nslice * Nout) * 4 + 256;
 }
 
+int launch_dw_tr(const void* dy, const void* x, float* dw, float* db, void* ws, int M, int Nout, int K, hipStream_t st) {
+    DwPlan p = plan(M, Nout, K);
+    float* part = reinterpret_cast<float*>(ws);
+    float* bpart = part + (int64_t)p.nslice * Nout * K;
+    size_t lds = 4 * (size_t)TR_TILE * sizeof(bf16_t);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_dw_tr_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    linear_dw_tr_kernel<<<dim3(p.ntile * ((p.nslice + 7) / 8) * 8), 256, lds, st>>>(
+        reinterpret_cast<const bf16_t*>(dy), reinterpret_cast<const bf16_t*>(x), part, bpart, M, Nout, K, p.rows);
+    int64_t nw = (int64_t)Nout * K;
+    int64_t tot = (nw + (db ? Nout : 0) + 3) / 4;
+    linear_dw_reduce<<<dim3((unsigned)((tot + 255) / 256)), 256, 0, st>>>(part, bpart, dw, db, p.nslice, nw, Nout);
+    return (int)hipGetLastError();
+}
+
 extern "C" int gf_linear_dw(const void* dy, const void* x, float* dw, float* db, void* ws,
                             int M, int Nout, int K, int dtype, void* stream) {
     if (M <= 0 || Nout <= 0 || K <= 0) return GF_ERR_SHAPE;
@@ -244,6 +502,6 @@ extern "C" int gf_linear_dw(const void* dy, const void* x, float* dw, float* db,
     if (Nout % align || K % align) return GF_ERR_ALIGN;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (dtype == GF_F32) return launch_dw<float>(dy, x, dw, db, ws, M, Nout, K, st);
-    if (dtype == GF_BF16) return launch_dw<bf16_t>(dy, x, dw, db, ws, M, Nout, K, st);
+    if (dtype == GF_BF16) return launch_dw_tr(dy, x, dw, db, ws, M, Nout, K, st);
     return GF_ERR_DTYPE;
 }
