@@ -514,19 +514,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams p) {
         for (int r = 0; r < 16; ++r) { dk[db][r] = 0.f; dv[db][r] = 0.f; }
 
     auto stats_of = [&](T* buf) { return reinterpret_cast<float*>(buf + 2 * L::ROWMAJOR + 2 * L::TRANSP); };
+    // raw prefetch only: consuming the values here (scale / select) would force the wave to wait for the
+    // whole prefetch batch at the top of the iteration; they are finished in store_stats, after the MFMAs.
     auto load_stats = [&](int q0, float& l, float& d) {
-        // rows past Nq: lse = +inf makes P exactly 0
         if (threadIdx.x < 64) {
-            int qi = q0 + threadIdx.x;
-            l = (qi < p.Nq) ? lsep[qi] * GF_LOG2E : INFINITY;
-            d = (qi < p.Nq) ? delp[qi] : 0.f;
+            int qi = min(q0 + (int)threadIdx.x, p.Nq - 1);
+            l = lsep[qi];
+            d = delp[qi];
         }
     };
-    auto store_stats = [&](T* buf, float l, float d) {
+    auto store_stats = [&](T* buf, int q0, float l, float d) {
         if (threadIdx.x < 64) {
             float* st = stats_of(buf);
-            st[threadIdx.x] = l;
-            st[64 + threadIdx.x] = d;
+            const bool ok = q0 + (int)threadIdx.x < p.Nq;     // rows past Nq: lse = +inf makes P exactly 0
+            st[threadIdx.x] = ok ? l * GF_LOG2E : INFINITY;
+            st[64 + threadIdx.x] = ok ? d : 0.f;
         }
     };
 
@@ -537,7 +539,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams p) {
     load_stats(0, ls, dl);
     pair_store<T, HD, true, true>(qr, lds, lds + 2 * L::ROWMAJOR);
     pair_store<T, HD, true, true>(dor, lds + L::ROWMAJOR, lds + 2 * L::ROWMAJOR + L::TRANSP);
-    store_stats(lds, ls, dl);
+    store_stats(lds, 0, ls, dl);
     __syncthreads();
 
     const int nt = (p.Nq + 63) / 64;
@@ -582,7 +584,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams p) {
             T* nb = lds + ((t + 1) & 1) * BUF;
             pair_store<T, HD, true, true>(qr, nb, nb + 2 * L::ROWMAJOR);
             pair_store<T, HD, true, true>(dor, nb + L::ROWMAJOR, nb + 2 * L::ROWMAJOR + L::TRANSP);
-            store_stats(nb, ls, dl);
+            store_stats(nb, q0 + 64, ls, dl);
         }
         __syncthreads();
     }
