@@ -27,6 +27,53 @@ def warp_points(points, H, inverse=False, eps=1e-5):
 
 
 @torch.no_grad()
+def gt_matches_from_homography_fused(kp0, kp1, H, pos_th=3.0, neg_th=3.0, with_reward=False):
+    """Same labels through the HIP nearest-neighbour kernel (gf_gt_nn): no [B,M,N] fp32 tensor is
+    built; the dense boolean ``assignment`` the plugin contract asks for is a zero-fill + scatter.
+    ``reward`` (dense, unused by the matcher losses) is only produced on request (stock torch)."""
+    from . import lib as _lib
+    b, m = kp0.shape[:2]
+    n = kp1.shape[1]
+    kp0, kp1 = kp0.float().contiguous(), kp1.float().contiguous()
+    kp0_1 = warp_points(kp0, H.float(), inverse=False).contiguous()
+    kp1_0 = warp_points(kp1, H.float(), inverse=True).contiguous()
+    dev = kp0.device
+    L = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+
+    def nn(own, own_w, oth, oth_w):
+        no = own.shape[1]
+        arg = torch.empty((b, no), dtype=torch.int64, device=dev)
+        dmin = torch.empty((b, no), dtype=torch.float32, device=dev)
+        omin = torch.empty((b, no), dtype=torch.float32, device=dev)
+        _lib.check(L.gf_gt_nn(own.data_ptr(), own_w.data_ptr(), oth.data_ptr(), oth_w.data_ptr(), arg.data_ptr(),
+                              dmin.data_ptr(), omin.data_ptr(), b, no, oth.shape[1], st), "gf_gt_nn")
+        return arg, dmin, omin
+
+    min0, d0, own0 = nn(kp0, kp0_1, kp1, kp1_0)      # rows: dist0 = |H kp0 - kp1|^2 is the "own" distance
+    min1, d1, own1 = nn(kp1, kp1_0, kp0, kp0_1)      # columns: dist1 = |kp0 - H^-1 kp1|^2
+    ar0 = torch.arange(m, device=dev)[None]
+    ar1 = torch.arange(n, device=dev)[None]
+    pos0 = (min1.gather(1, min0) == ar0) & (d0 < pos_th ** 2)
+    pos1 = (min0.gather(1, min1) == ar1) & (d1 < pos_th ** 2)
+    positive = torch.zeros(b, m, n, dtype=torch.bool, device=dev)
+    positive.scatter_(2, min0[..., None], pos0[..., None])
+    m0 = torch.where(pos0, min0, torch.full_like(min0, IGNORE_FEATURE))
+    m1 = torch.where(pos1, min1, torch.full_like(min1, IGNORE_FEATURE))
+    m0 = torch.where(own0 > neg_th ** 2, torch.full_like(m0, UNMATCHED_FEATURE), m0)
+    m1 = torch.where(own1 > neg_th ** 2, torch.full_like(m1, UNMATCHED_FEATURE), m1)
+    out = {"assignment": positive, "matches0": m0, "matches1": m1,
+           "matching_scores0": (m0 > -1).float(), "matching_scores1": (m1 > -1).float(),
+           "proj_0to1": kp0_1, "proj_1to0": kp1_0}
+    if with_reward:
+        dist0 = ((kp0_1[:, :, None] - kp1[:, None]) ** 2).sum(-1)
+        dist1 = ((kp0[:, :, None] - kp1_0[:, None]) ** 2).sum(-1)
+        dist = torch.maximum(dist0, dist1)
+        out["reward"] = (dist < pos_th ** 2).float() - (dist > neg_th ** 2).float()
+    return out
+
+
+@torch.no_grad()
 def gt_matches_from_homography(kp0, kp1, H, pos_th=3.0, neg_th=3.0):
     b, m = kp0.shape[:2]
     n = kp1.shape[1]

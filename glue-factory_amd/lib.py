@@ -37,6 +37,7 @@ SIGNATURES = {
     "gf_bn_act_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "gf_bn_bwd_stats": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "gf_bn_bwd_dx": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "gf_gt_nn": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "gf_rotary_qk": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "gf_rotary_qk_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "gf_ln_gelu_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _F, _I, _P],

@@ -157,6 +157,16 @@ int gf_bn_bwd_dx(const void* x, const void* dy, const float* mean, const float* 
                  const float* gamma, const float* beta, const float* m1, const float* m2,
                  void* dx, int M, int C, int relu, int dtype, void* stream);
 
+/* ---- ground-truth nearest neighbours under a homography (gluefactory/geometry/gt_generation.py:120-150)
+ * For every point i of the "own" set [B,No,2] (own = its coordinates, own_warped = the same points
+ * warped into the other image) against the "other" set [B,Ns,2] (+ its warped copy):
+ *   d_own(i,j) = |own_warped_i - oth_j|^2,  d_oth(i,j) = |own_i - oth_warped_j|^2,  d = max(d_own, d_oth)
+ *   arg[b,i] = argmin_j d (lowest index on ties), dmin[b,i] = min_j d, own_min[b,i] = min_j d_own.
+ * Called as (kp0, H kp0, kp1, H^-1 kp1) and (kp1, H^-1 kp1, kp0, H kp0) it yields everything the
+ * labelling needs (mutual arg-mins, positive / negative thresholds) without any [B,M,N] tensor. */
+int gf_gt_nn(const float* own, const float* own_warped, const float* oth, const float* oth_warped,
+             int64_t* arg, float* dmin, float* own_min, int B, int No, int Ns, void* stream);
+
 /* ---- fused elementwise ops of the transformer block ---------------------------------------
  * Rotary embedding applied in place to the q and k thirds of a fused [B,N,3,H,D] projection
  * (lightglue.py:42-49,159-160): cs [B,N,D] holds cos in the even and sin in the odd slot of

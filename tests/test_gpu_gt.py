@@ -1,0 +1,37 @@
+"""Fused ground-truth nearest-neighbour kernel vs the reference's gt_matches_from_homography outputs
+(tests/golden/gt_homography.npz) and vs the torch restatement at the benchmark size."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def test_fused_gt_matches_reference_golden():
+    from glue_factory_amd.gt import gt_matches_from_homography_fused
+    z = load_golden("gt_homography")
+    kp0, kp1, H = (torch.from_numpy(z["data." + k]).cuda() for k in ("keypoints0", "keypoints1", "H_0to1"))
+    out = gt_matches_from_homography_fused(kp0, kp1, H, 3.0, 3.0, with_reward=True)
+    for k in ("assignment", "matches0", "matches1"):
+        np.testing.assert_array_equal(out[k].cpu().numpy(), z["gt." + k], err_msg=k)
+    for k in ("reward", "matching_scores0", "matching_scores1", "proj_0to1", "proj_1to0"):
+        np.testing.assert_allclose(out[k].cpu().numpy(), z["gt." + k], rtol=1e-5, atol=1e-4, err_msg=k)
+
+
+@pytest.mark.parametrize("b,m,n", [(3, 2048, 2048), (2, 700, 1025), (1, 1, 5)])
+def test_fused_gt_equals_torch_path(b, m, n):
+    from glue_factory_amd.gt import gt_matches_from_homography, gt_matches_from_homography_fused
+    from glue_factory_amd.synthetic import make_pairs
+    data = make_pairs(b, m, n, dim=8, size=(1024, 1024), seed=m + n, with_gt=False)
+    kp0, kp1, H = (data[k].cuda() for k in ("keypoints0", "keypoints1", "H_0to1"))
+    ref = gt_matches_from_homography(kp0, kp1, H, 3.0, 3.0)
+    out = gt_matches_from_homography_fused(kp0, kp1, H, 3.0, 3.0)
+    for k in ("assignment", "matches0", "matches1"):
+        assert torch.equal(out[k], ref[k]), k
+    assert "reward" not in out
+    # idempotence-style property at full size: every positive is mutual and inside the threshold
+    m0, m1 = out["matches0"], out["matches1"]
+    rows = (m0 >= 0).nonzero()
+    assert torch.equal(m1[rows[:, 0], m0[rows[:, 0], rows[:, 1]]], rows[:, 1])
