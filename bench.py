@@ -292,7 +292,7 @@ def main():
         # secondary scope (P): frozen SuperPoint forward on synthetic 1024x1024 images (stock
         # PyTorch-ROCm conv, by design) + homography ground truth + the same matcher train step.
         from glue_factory_amd.extractors.superpoint_open import SuperPoint
-        from glue_factory_amd.gt import gt_matches_from_homography
+        from glue_factory_amd.gt import gt_matches_from_homography_fused as gt_matches_from_homography
         sp = SuperPoint({"max_num_keypoints": args.kpts, "force_num_keypoints": True, "detection_threshold": 0.0,
                          "nms_radius": 3}).cuda().eval()
         g = torch.Generator(device="cuda").manual_seed(7)
@@ -321,7 +321,7 @@ def main():
         tp = (time.perf_counter() - t0) / 3
         out["pipeline"] = {"value": round(args.batch / tp, 2), "unit": "image-pairs/s", "ms_per_step": round(tp * 1e3, 2),
                            "scope": "frozen SuperPoint-open forward on 2x32 synthetic 1024x1024 images (stock torch/MIOpen) "
-                                    "+ homography GT (torch) + LightGlue train step"}
+                                    "+ homography GT (gf_gt_nn) + LightGlue train step"}
     if rank == 0:
         if not args.no_roofline:
             out["roofline"] = roofline_attention(args.batch, args.kpts,
