@@ -74,7 +74,7 @@ def _lin(x, layer):
 
 
 def _ffn(ffn, x, msg):
-    h = _lin(torch.cat([x, msg], -1), ffn[0])
+    h = ops.linear_cat(x, msg, ffn[0].weight, ffn[0].bias)
     h = ops.ln_gelu(h, ffn[1].weight, ffn[1].bias, ffn[1].eps)
     return x + _lin(h, ffn[3])
 

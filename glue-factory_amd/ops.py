@@ -247,6 +247,61 @@ def linear(x, w, b=None):
     return _Linear.apply(x, w, b)
 
 
+def _dw(dy2, x2, nout, k, with_bias):
+    L = _lib.load()
+    m = x2.shape[0]
+    ws = torch.empty(int(L.gf_linear_dw_ws_bytes(m, nout, k)), dtype=torch.uint8, device=x2.device)
+    dw32 = torch.empty((nout, k), dtype=torch.float32, device=x2.device)
+    db32 = torch.empty((nout,), dtype=torch.float32, device=x2.device) if with_bias else None
+    _lib.check(L.gf_linear_dw(_p(dy2), _p(x2), _p(dw32), _p(db32), _p(ws), m, nout, k, _dt(x2), _stream()),
+               "gf_linear_dw")
+    return dw32, db32
+
+
+class _LinearCat(torch.autograd.Function):
+    """y = [x1 | x2] W^T + b without building the concatenation: two accumulating GEMMs forward, two
+    input-gradient GEMMs and two gf_linear_dw calls backward (the FFN input cat[x, message] of
+    lightglue.py:163 / :219-220)."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, w, b):
+        k1 = x1.shape[-1]
+        wt = w.to(x1.dtype)
+        y = torch.nn.functional.linear(x1, wt[:, :k1], None if b is None else b.to(x1.dtype))
+        y.view(-1, y.shape[-1]).addmm_(x2.reshape(-1, x2.shape[-1]), wt[:, k1:].t())
+        ctx.save_for_backward(x1, x2, w)
+        ctx.bdtype = None if b is None else b.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x1, x2, w = ctx.saved_tensors
+        nout, k = w.shape
+        k1 = x1.shape[-1]
+        dy2 = dy.reshape(-1, nout)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        wt = w.to(dy2.dtype)
+        dx1 = (dy2 @ wt[:, :k1]).view(x1.shape) if ctx.needs_input_grad[0] else None
+        dx2 = (dy2 @ wt[:, k1:]).view(x2.shape) if ctx.needs_input_grad[1] else None
+        dw = db = None
+        if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
+            a = x1.reshape(-1, k1)
+            c = x2.reshape(-1, k - k1)
+            a = a if a.is_contiguous() else a.contiguous()
+            c = c if c.is_contiguous() else c.contiguous()
+            dwa, db32 = _dw(dy2, a, nout, k1, ctx.bdtype is not None)
+            dwb, _ = _dw(dy2, c, nout, k - k1, False)
+            dw = torch.cat([dwa, dwb], 1).to(w.dtype)
+            db = None if db32 is None else db32.to(ctx.bdtype)
+        return dx1, dx2, dw, db
+
+
+def linear_cat(x1, x2, w, b=None):
+    _chk(x1, x2)
+    return _LinearCat.apply(x1, x2, w, b)
+
+
 # ------------------------------------------------------------------------------ LN + GELU
 class _LnGelu(torch.autograd.Function):
     @staticmethod

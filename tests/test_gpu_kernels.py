@@ -285,3 +285,22 @@ def test_batch_norm_act(dtype, M, C, relu):
     torch.testing.assert_close(bn.running_mean.cpu().double(), ref.running_mean, rtol=1e-3, atol=1e-3)
     torch.testing.assert_close(bn.running_var.cpu().double(), ref.running_var, rtol=1e-3, atol=1e-3)
     assert int(bn.num_batches_tracked) == 1
+
+
+def test_linear_cat_equals_linear_of_cat():
+    g = torch.Generator().manual_seed(0)
+    x1 = torch.randn(3, 50, 256, generator=g).to(DEV).requires_grad_(True)
+    x2 = torch.randn(3, 50, 256, generator=g).to(DEV).requires_grad_(True)
+    w = (torch.randn(512, 512, generator=g) / 22).to(DEV).requires_grad_(True)
+    b = torch.randn(512, generator=g).to(DEV).requires_grad_(True)
+    dy = torch.randn(3, 50, 512, generator=g).to(DEV)
+    y = ops.linear_cat(x1, x2, w, b)
+    (y * dy).sum().backward()
+    got = [t.grad.clone() for t in (x1, x2, w, b)]
+    for t in (x1, x2, w, b):
+        t.grad = None
+    yr = torch.nn.functional.linear(torch.cat([x1, x2], -1), w, b)
+    (yr * dy).sum().backward()
+    torch.testing.assert_close(y, yr, rtol=1e-4, atol=1e-4)
+    for a, t in zip(got, (x1, x2, w, b)):
+        torch.testing.assert_close(a, t.grad, rtol=1e-4, atol=1e-3)
