@@ -159,6 +159,17 @@ class MatchAssignment(nn.Module):
                 "lz0": F.logsigmoid(z0), "lz1": F.logsigmoid(z1),
                 "bin0": F.logsigmoid(-z0), "bin1": F.logsigmoid(-z1)}
 
+    def stats_stacked(self, x, b):
+        """Same as ``stats`` on the batch-stacked descriptors x [2B,N,D] (image 0 first): one GEMM for both
+        images and gradients that stay stacked (no slice / zero-fill / add nodes in the autograd graph)."""
+        s = self.dim ** -0.25
+        md = ops.linear(x, self.final_proj.weight * s, self.final_proj.bias * s)
+        z = _lin(x, self.matchability).squeeze(-1).float()
+        r, c = ops.dual_lse_stacked(md)
+        lz, lnz = F.logsigmoid(z), F.logsigmoid(-z)
+        return {"md": md, "md0": md[:b], "md1": md[b:], "r": r, "c": c,
+                "lz0": lz[:b], "lz1": lz[b:], "bin0": lnz[:b], "bin1": lnz[b:]}
+
     @staticmethod
     def materialize(h):
         return ops.assign_write(h["md0"], h["md1"], h["lz0"] - h["r"], h["lz1"] - h["c"],
@@ -286,7 +297,7 @@ class LightGlue(nn.Module):
             desc0, desc1 = _lin(desc0, self.input_proj), _lin(desc1, self.input_proj)
 
         stacked = m == n
-        all0, all1 = [], []
+        all0, all1, layer_x = [], [], []
         if stacked:   # both images share every GEMM / kernel launch
             x = torch.cat([desc0, desc1], 0)
             theta, cs = self.posenc(torch.cat([kpts0, kpts1], 0))
@@ -294,8 +305,10 @@ class LightGlue(nn.Module):
                 x = layer.self_attn(x, theta, cs)
                 x = layer.cross_attn.forward_stacked(x)
                 if self.training or i == conf.n_layers - 1:
-                    all0.append(x[:b])
-                    all1.append(x[b:])
+                    layer_x.append(x)
+                    with torch.no_grad():      # public copies; gradients flow through the stacked list
+                        all0.append(x[:b])
+                        all1.append(x[b:])
             desc0, desc1 = x[:b], x[b:]
         else:
             th0, cs0 = self.posenc(kpts0)
@@ -308,14 +321,26 @@ class LightGlue(nn.Module):
                     all0.append(desc0)
                     all1.append(desc1)
 
-        head = self.log_assignment[conf.n_layers - 1].stats(desc0, desc1)
+        if stacked:
+            head = self.log_assignment[conf.n_layers - 1].stats_stacked(x, b)
+        else:
+            head = self.log_assignment[conf.n_layers - 1].stats(desc0, desc1)
         scores = MatchAssignment.materialize(head)
         am = MatchAssignment.argmaxes(head)
         m0, m1, ms0, ms1 = ops.filter_matches(am["max0"], am["arg0"], am["arg1"], conf.filter_threshold)
+        if stacked and self.training:
+            # ref_descriptors are detached copies in this mode: the loss differentiates through the private
+            # stacked list below (identical values), which keeps every gradient batch-stacked.
+            rd0, rd1 = torch.stack(all0, 1), torch.stack(all1, 1)
+            extra = {"_layer_desc": layer_x}
+        else:
+            rd0, rd1 = torch.stack(all0, 1), torch.stack(all1, 1)
+            extra = {}
         return {
+            **extra,
             "matches0": m0, "matches1": m1,
             "matching_scores0": ms0, "matching_scores1": ms1,
-            "ref_descriptors0": torch.stack(all0, 1), "ref_descriptors1": torch.stack(all1, 1),
+            "ref_descriptors0": rd0, "ref_descriptors1": rd1,
             "log_assignment": scores,
             "prune0": torch.ones_like(ms0) * conf.n_layers,
             "prune1": torch.ones_like(ms1) * conf.n_layers,
@@ -342,8 +367,13 @@ class LightGlue(nn.Module):
         bi, ii, ji = gt["pos"]
         m, n = h["md0"].shape[1], h["md1"].shape[1]
         f0, f1 = bi * m + ii, bi * n + ji     # flat row ids: index_select's backward is a sort-free index_add
-        dot = (h["md0"].flatten(0, 1).index_select(0, f0).float()
-               * h["md1"].flatten(0, 1).index_select(0, f1).float()).sum(-1)
+        if "md" in h:                         # stacked: one gather / one scatter-add for both images
+            rows = h["md"].flatten(0, 1).index_select(0, torch.cat([f0, f1 + h["md0"].shape[0] * m]))
+            p_ = f0.shape[0]
+            dot = (rows[:p_].float() * rows[p_:].float()).sum(-1)
+        else:
+            dot = (h["md0"].flatten(0, 1).index_select(0, f0).float()
+                   * h["md1"].flatten(0, 1).index_select(0, f1).float()).sum(-1)
         a_pos = (2.0 * dot - h["r"].flatten().index_select(0, f0) - h["c"].flatten().index_select(0, f1)
                  + h["lz0"].flatten().index_select(0, f0) + h["lz1"].flatten().index_select(0, f1))
         nll_pos = -torch.zeros_like(gt["num_pos"]).index_add_(0, bi, a_pos) / gt["num_pos"]
@@ -362,8 +392,17 @@ class LightGlue(nn.Module):
         L = rd0.shape[1]
         gt = self._gt_sparse(data)
 
+        layer_x = pred.get("_layer_desc")
+
         def head(i):
+            if layer_x is not None:
+                return self.log_assignment[i].stats_stacked(layer_x[i], rd0.shape[0])
             return self.log_assignment[i].stats(rd0[:, i], rd1[:, i])
+
+        def conf_inputs(i):
+            if layer_x is not None:
+                return layer_x[i][:rd0.shape[0]], layer_x[i][rd0.shape[0]:]
+            return rd0[:, i], rd1[:, i]
 
         nll, stats = self._nll(head(L - 1), gt)
         losses = {"total": nll, "last": nll.clone().detach(), **stats}
@@ -388,8 +427,9 @@ class LightGlue(nn.Module):
             am = MatchAssignment.argmaxes(h)
             tc = self.token_confidence[i]
             bce = F.binary_cross_entropy_with_logits
-            conf_i = (bce(tc.logits(rd0[:, i]), (am["full0"] == fin0).float(), reduction="none").mean(-1)
-                      + bce(tc.logits(rd1[:, i]), (am["full1"] == fin1).float(), reduction="none").mean(-1)) / 2.0
+            c0, c1 = conf_inputs(i)
+            conf_i = (bce(tc.logits(c0), (am["full0"] == fin0).float(), reduction="none").mean(-1)
+                      + bce(tc.logits(c1), (am["full1"] == fin1).float(), reduction="none").mean(-1)) / 2.0
             losses["confidence"] = losses["confidence"] + conf_i / (L - 1)
         losses["total"] = losses["total"] / sum_weights
         if self.training:

@@ -54,13 +54,17 @@ def _conv_cl(x, conv, rows=None, cols=None):
     return ops.linear(x, w, b)
 
 
-def _mlp_cl(seq, x, halves):
+def _mlp_cl(seq, x, halves, x2=None):
     """Run an MLP Sequential (Conv1d / BatchNorm1d / ReLU) on channels-last x [B',N,C].
     BatchNorm (+ the ReLU that follows it) is one fused HIP pass pair, applied per image set
     (``halves`` = 2 when two images are stacked on the batch axis), reproducing the reference's
     one-call-per-image statistics and running-stat updates."""
     layers = list(seq)
     i = 0
+    if x2 is not None:      # first conv on cat[x, x2] without building the concatenation
+        first = layers[0]
+        x = ops.linear_cat(x, x2, first.weight.squeeze(-1), first.bias)
+        i = 1
     while i < len(layers):
         layer = layers[i]
         if isinstance(layer, nn.Conv1d):
@@ -135,7 +139,7 @@ class AttentionalPropagation(nn.Module):
         b, n, d = x.shape
         o = ops.attention_qkv(self.attn.fused_projection(x), cross=cross)
         msg = _conv_cl(o.view(b, n, d), self.attn.merge, cols=self.attn._perm)
-        return _mlp_cl(self.mlp, torch.cat([x, msg], -1), halves)
+        return _mlp_cl(self.mlp, x, halves, x2=msg)
 
     def forward_pair(self, x0, x1, cross):
         """Different keypoint counts: one projection per image, generic attention op."""
@@ -144,7 +148,7 @@ class AttentionalPropagation(nn.Module):
         for x, pq, ps in ((x0, p0, p1 if cross else p0), (x1, p1, p0 if cross else p1)):
             o = ops.attention(pq[:, :, 0], ps[:, :, 1], ps[:, :, 2])
             msg = _conv_cl(o.reshape(x.shape), self.attn.merge, cols=self.attn._perm)
-            outs.append(_mlp_cl(self.mlp, torch.cat([x, msg], -1), 1))
+            outs.append(_mlp_cl(self.mlp, x, 1, x2=msg))
         return outs
 
 

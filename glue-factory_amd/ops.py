@@ -210,21 +210,22 @@ class _Linear(torch.autograd.Function):
     def forward(ctx, x, w, b):
         wt = w.to(x.dtype)
         y = torch.nn.functional.linear(x, wt, None if b is None else b.to(x.dtype))
-        ctx.save_for_backward(x, w)
+        ctx.save_for_backward(x, wt)
+        ctx.wdtype = w.dtype
         ctx.has_bias = b is not None
         ctx.bdtype = None if b is None else b.dtype
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w = ctx.saved_tensors
-        nout, k = w.shape
+        x, wt = ctx.saved_tensors
+        nout, k = wt.shape
         dy2 = dy.reshape(-1, nout)
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = (dy2 @ w.to(dy2.dtype)).view(x.shape)
+            dx = (dy2 @ wt).view(x.shape)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             x2 = x.reshape(-1, k)
             if not x2.is_contiguous():
@@ -236,7 +237,7 @@ class _Linear(torch.autograd.Function):
             db32 = torch.empty((nout,), dtype=torch.float32, device=x.device) if ctx.has_bias else None
             _lib.check(L.gf_linear_dw(_p(dy2), _p(x2), _p(dw32), _p(db32), _p(ws), m, nout, k, _dt(x2),
                                       _stream()), "gf_linear_dw")
-            dw = dw32.to(w.dtype)
+            dw = dw32.to(ctx.wdtype)
             db = None if db32 is None else db32.to(ctx.bdtype)
         return dx, dw, db
 
@@ -269,19 +270,19 @@ class _LinearCat(torch.autograd.Function):
         wt = w.to(x1.dtype)
         y = torch.nn.functional.linear(x1, wt[:, :k1], None if b is None else b.to(x1.dtype))
         y.view(-1, y.shape[-1]).addmm_(x2.reshape(-1, x2.shape[-1]), wt[:, k1:].t())
-        ctx.save_for_backward(x1, x2, w)
+        ctx.save_for_backward(x1, x2, wt)
+        ctx.wdtype = w.dtype
         ctx.bdtype = None if b is None else b.dtype
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x1, x2, w = ctx.saved_tensors
-        nout, k = w.shape
+        x1, x2, wt = ctx.saved_tensors
+        nout, k = wt.shape
         k1 = x1.shape[-1]
         dy2 = dy.reshape(-1, nout)
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
-        wt = w.to(dy2.dtype)
         dx1 = (dy2 @ wt[:, :k1]).view(x1.shape) if ctx.needs_input_grad[0] else None
         dx2 = (dy2 @ wt[:, k1:]).view(x2.shape) if ctx.needs_input_grad[1] else None
         dw = db = None
@@ -292,7 +293,7 @@ class _LinearCat(torch.autograd.Function):
             c = c if c.is_contiguous() else c.contiguous()
             dwa, db32 = _dw(dy2, a, nout, k1, ctx.bdtype is not None)
             dwb, _ = _dw(dy2, c, nout, k - k1, False)
-            dw = torch.cat([dwa, dwb], 1).to(w.dtype)
+            dw = torch.cat([dwa, dwb], 1).to(ctx.wdtype)
             db = None if db32 is None else db32.to(ctx.bdtype)
         return dx1, dx2, dw, db
 
@@ -408,6 +409,41 @@ class _DualLSE(torch.autograd.Function):
 
 def dual_lse(a, b):
     return _DualLSE.apply(a, b)
+
+
+class _DualLSEStacked(torch.autograd.Function):
+    """dual_lse on a batch-stacked md [2B,N,D] (image 0 = first half): the gradient comes back as ONE
+    stacked tensor (the two GEMMs write into its halves), so autograd needs no slice/zero-fill/add."""
+
+    @staticmethod
+    def forward(ctx, md):
+        B = md.shape[0] // 2
+        a, b = md[:B], md[B:]
+        r = rows_lse(a, b)
+        c = rows_lse(b, a)
+        ctx.save_for_backward(md, r, c)
+        return r, c
+
+    @staticmethod
+    def backward(ctx, gr, gc):
+        md, r, c = ctx.saved_tensors
+        B2, N, D = md.shape
+        B = B2 // 2
+        a, b = md[:B], md[B:]
+        gr = torch.zeros_like(r) if gr is None else gr.float().contiguous()
+        gc = torch.zeros_like(c) if gc is None else gc.float().contiguous()
+        dS = torch.empty((B, N, N), dtype=md.dtype, device=md.device)
+        _lib.check(_lib.load().gf_dual_softmax_bwd(_p(a), _p(b), _p(r), _p(c), _p(gr), _p(gc), None, 0,
+                                                   0.0, _p(dS), B, N, N, D, _dt(md), _stream()),
+                   "gf_dual_softmax_bwd")
+        d = torch.empty_like(md)
+        torch.bmm(dS, b, out=d[:B])
+        torch.bmm(dS.transpose(1, 2), a, out=d[B:])
+        return d
+
+
+def dual_lse_stacked(md):
+    return _DualLSEStacked.apply(md)
 
 
 class _AssignWrite(torch.autograd.Function):
