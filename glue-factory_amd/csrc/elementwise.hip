@@ -131,22 +131,27 @@ __global__ __launch_bounds__(256) void ln_gelu_fwd_kernel(const T* x, const floa
     for (int row = blockIdx.x * 4 + wave; row < R; row += gridDim.x * 4) {
         float v[NCH][VEC];
         load_row<T, NCH>(v, x + (int64_t)row * C, C, lane);
-        float s = 0.f;
-#pragma unroll
-        for (int ch = 0; ch < NCH; ++ch)
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) s += v[ch][e];
-        const float mu = wave_sum(s) / C;
-        float q = 0.f;
+        // shifted single pass: sums of d = x - x0 and d^2 (x0 = the row's first element keeps the
+        // cancellation of E[d^2] - E[d]^2 harmless); the two butterflies are independent and interleave
+        const float x0 = __shfl(v[0][0], 0);
+        float s = 0.f, q = 0.f;
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
                 int col = (ch * 64 + lane) * VEC + e;
-                float d = col < C ? v[ch][e] - mu : 0.f;
+                float d = col < C ? v[ch][e] - x0 : 0.f;
+                s += d;
                 q += d * d;
             }
-        const float rs = rsqrtf(wave_sum(q) / C + eps);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            s += __shfl_xor(s, off);
+            q += __shfl_xor(q, off);
+        }
+        const float md = s / C;
+        const float mu = x0 + md;
+        const float rs = rsqrtf(fmaxf(q / C - md * md, 0.f) + eps);
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
