@@ -241,9 +241,6 @@ class LightGlue(nn.Module):
             [min(max(0.8 + 0.1 * math.exp(-4.0 * i / n), 0.0), 1.0) for i in range(n)]))
         if conf.weights is not None:
             self._load_weights(conf.weights)
-        if conf.depth_confidence > 0 or conf.width_confidence > 0:
-            warnings.warn("adaptive depth/width (eval-only early stop and point pruning) is not "
-                          "part of the training hot path and is ignored", stacklevel=2)
 
     def _load_weights(self, weights):
         path = Path(weights)
@@ -296,6 +293,11 @@ class LightGlue(nn.Module):
         if not isinstance(self.input_proj, nn.Identity):
             desc0, desc1 = _lin(desc0, self.input_proj), _lin(desc1, self.input_proj)
 
+        do_early_stop = conf.depth_confidence > 0 and not self.training
+        do_point_pruning = conf.width_confidence > 0 and not self.training
+        if do_early_stop or do_point_pruning:
+            return self._forward_adaptive(kpts0, kpts1, desc0, desc1, do_early_stop, do_point_pruning)
+
         stacked = m == n
         all0, all1, layer_x = [], [], []
         if stacked:   # both images share every GEMM / kernel launch
@@ -347,6 +349,76 @@ class LightGlue(nn.Module):
             # private: final-layer arg-maxes incl. dustbins, reused by loss() for the confidence targets
             "_final_argmax0": am["full0"], "_final_argmax1": am["full1"],
         }
+
+    # ------------------------------------------------------------------ eval-only adaptive depth / width
+    def _forward_adaptive(self, kpts0, kpts1, desc0, desc1, do_early_stop, do_point_pruning):
+        """Inference-time early stopping (token confidences) and point pruning (matchability), batch size 1
+        (lightglue.py:461-529, 545-570).  Stock index_select compaction between layers; every layer still
+        runs on the HIP kernels with the shrinking keypoint counts."""
+        conf = self.conf
+        b, m = kpts0.shape[:2]
+        n = kpts1.shape[1]
+        assert b == 1, "adaptive depth/width needs batch size 1 (as in the reference)"
+        dev = kpts0.device
+        th0, cs0 = self.posenc(kpts0)
+        th1, cs1 = self.posenc(kpts1)
+        ind0 = torch.arange(m, device=dev)[None]
+        ind1 = torch.arange(n, device=dev)[None]
+        prune0, prune1 = torch.ones_like(ind0), torch.ones_like(ind1)
+        last = conf.n_layers - 1
+        for i, layer in enumerate(self.transformers):
+            desc0 = layer.self_attn(desc0, th0, cs0)
+            desc1 = layer.self_attn(desc1, th1, cs1)
+            desc0, desc1 = layer.cross_attn(desc0, desc1)
+            last = i
+            if i == conf.n_layers - 1:
+                break
+            token0 = token1 = None
+            if do_early_stop:
+                token0, token1 = self.token_confidence[i](desc0, desc1)
+                confidences = torch.cat([token0, token1], -1)
+                ratio = 1.0 - (confidences < self.confidence_thresholds[i]).float().sum() / (m + n)
+                if ratio > conf.depth_confidence:
+                    break
+            if do_point_pruning:
+                def prune(desc, th, cs, ind, pr, token):
+                    keep = self.log_assignment[i].get_matchability(desc) > (1 - conf.width_confidence)
+                    if token is not None:       # low-confidence points are never pruned
+                        keep |= token <= self.confidence_thresholds[i]
+                    k = torch.where(keep)[1]
+                    ind = ind.index_select(1, k)
+                    pr[:, ind[0]] += 1
+                    return (desc.index_select(1, k).contiguous(), th.index_select(1, k).contiguous(),
+                            cs.index_select(1, k).contiguous(), ind)
+                desc0, th0, cs0, ind0 = prune(desc0, th0, cs0, ind0, prune0, token0)
+                desc1, th1, cs1, ind1 = prune(desc1, th1, cs1, ind1, prune1, token1)
+                if desc0.shape[1] == 0 or desc1.shape[1] == 0:
+                    break
+        if desc0.shape[1] == 0 or desc1.shape[1] == 0:
+            scores = desc0.new_zeros((b, desc0.shape[1] + 1, desc1.shape[1] + 1), dtype=torch.float32)
+            m0 = torch.full((b, desc0.shape[1]), -1, device=dev, dtype=torch.int64)
+            m1 = torch.full((b, desc1.shape[1]), -1, device=dev, dtype=torch.int64)
+            ms0, ms1 = scores.new_zeros((b, desc0.shape[1])), scores.new_zeros((b, desc1.shape[1]))
+        else:
+            head = self.log_assignment[last].stats(desc0, desc1)
+            scores = MatchAssignment.materialize(head)
+            am = MatchAssignment.argmaxes(head)
+            m0, m1, ms0, ms1 = ops.filter_matches(am["max0"], am["arg0"], am["arg1"], conf.filter_threshold)
+        if do_point_pruning:     # scatter back to the original keypoint indexing
+            m0_ = torch.full((b, m), -1, device=dev, dtype=m0.dtype)
+            m1_ = torch.full((b, n), -1, device=dev, dtype=m1.dtype)
+            m0_[:, ind0[0]] = torch.where(m0 == -1, -1, ind1.gather(1, m0.clamp(min=0)))
+            m1_[:, ind1[0]] = torch.where(m1 == -1, -1, ind0.gather(1, m1.clamp(min=0)))
+            ms0_, ms1_ = ms0.new_zeros((b, m)), ms1.new_zeros((b, n))
+            ms0_[:, ind0[0]] = ms0
+            ms1_[:, ind1[0]] = ms1
+            m0, m1, ms0, ms1 = m0_, m1_, ms0_, ms1_
+        else:
+            prune0 = torch.ones_like(ms0) * conf.n_layers
+            prune1 = torch.ones_like(ms1) * conf.n_layers
+        return {"matches0": m0, "matches1": m1, "matching_scores0": ms0, "matching_scores1": ms1,
+                "ref_descriptors0": desc0[:, None], "ref_descriptors1": desc1[:, None],
+                "log_assignment": scores, "prune0": prune0, "prune1": prune1, "stop_layer": last}
 
     # ------------------------------------------------------------------ loss
     @staticmethod

@@ -118,3 +118,38 @@ def test_train_step_bf16_close_to_oracle():
         a, b = p.grad.cpu().flatten().double(), grads_o[k].flatten().double()
         cos.append(torch.nn.functional.cosine_similarity(a, b, dim=0).item())
     assert min(cos) > 0.9, min(cos)
+
+
+def test_eval_adaptive_depth_and_width():
+    """Eval-only early stop / point pruning (b == 1): neutral settings reproduce the plain path; biased
+    token / matchability heads trigger the stop and prune points, whose matches come back as -1."""
+    from glue_factory_amd.synthetic import make_pairs
+    L = 3
+    params = lgo.init_params(L, 256, 4, seed=7)
+    data = _to_cuda(make_pairs(1, 160, 200, dim=256, size=(640, 480), seed=8))
+    plain = _model(params, L).eval()
+    with torch.no_grad():
+        ref = plain(data)
+    # random-weight confidences (~0.5) never reach the thresholds: nothing stops, nothing is pruned
+    neutral = _model(params, L, depth_confidence=0.95, width_confidence=0.99).eval()
+    with torch.no_grad():
+        out = neutral(data)
+    assert out["stop_layer"] == L - 1
+    torch.testing.assert_close(out["log_assignment"], ref["log_assignment"], rtol=1e-4, atol=1e-4)
+    assert torch.equal(out["matches0"], ref["matches0"]) and torch.equal(out["prune0"], torch.full_like(out["prune0"], L))
+    # confident tokens -> stop after the first layer
+    p2 = dict(params)
+    p2["token_confidence.0.token.0.bias"] = torch.tensor([8.0])
+    stop = _model(p2, L, depth_confidence=0.9).eval()
+    with torch.no_grad():
+        o2 = stop(data)
+    assert o2["stop_layer"] == 0 and o2["log_assignment"].shape == (1, 161, 201)
+    # pruning: keep a point only if sigmoid(matchability) > 0.5  (about half of them)
+    prune = _model(params, L, width_confidence=0.5).eval()
+    with torch.no_grad():
+        o3 = prune(data)
+    kept0 = (o3["prune0"] == L).sum().item()
+    assert 0 < kept0 < 160 and o3["matches0"].shape == (1, 160)
+    assert (o3["matches0"][o3["prune0"] < L] == -1).all()
+    valid = o3["matches0"] > -1
+    assert (o3["matches1"][0, o3["matches0"][valid]] == valid.nonzero()[:, 1]).all()
