@@ -38,6 +38,9 @@ SIGNATURES = {
     "gf_bn_bwd_stats": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "gf_bn_bwd_dx": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "gf_gt_nn": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "gf_rowdot_nblk": [_I],
+    "gf_rowdot_fwd": [_P, _P, _F, _P, _I, _I, _I, _P],
+    "gf_rowdot_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
     "gf_rotary_qk": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "gf_rotary_qk_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "gf_ln_gelu_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _F, _I, _P],

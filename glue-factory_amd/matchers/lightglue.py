@@ -68,7 +68,9 @@ def _ffn_modules(dim):
 
 
 def _lin(x, layer):
-    if layer.out_features % 8 or layer.in_features % 8:   # 256 -> 1 heads: plain GEMV
+    if layer.out_features == 1 and layer.in_features % 8 == 0:   # 256 -> 1 heads: streaming row-dot kernels
+        return ops.rowdot(x, layer.weight, layer.bias)[..., None]
+    if layer.out_features % 8 or layer.in_features % 8:
         return F.linear(x, layer.weight.to(x.dtype), None if layer.bias is None else layer.bias.to(x.dtype))
     return ops.linear(x, layer.weight, layer.bias)
 

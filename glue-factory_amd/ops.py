@@ -303,6 +303,48 @@ def linear_cat(x1, x2, w, b=None):
     return _LinearCat.apply(x1, x2, w, b)
 
 
+class _RowDot(torch.autograd.Function):
+    """z = x w^T + b for a single output channel (w [1,C], b [1]); returns fp32 [..]."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        C = x.shape[-1]
+        x2 = x.reshape(-1, C)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        M = x2.shape[0]
+        w32 = w.reshape(-1).float().contiguous()
+        z = torch.empty(M, dtype=torch.float32, device=x.device)
+        # the bias stays on the device (no .item() sync): added after the kernel
+        _lib.check(_lib.load().gf_rowdot_fwd(_p(x2), _p(w32), 0.0, _p(z), M, C, _dt(x2), _stream()), "gf_rowdot_fwd")
+        if b is not None:
+            z = z + b.float()
+        ctx.save_for_backward(x2, w32)
+        ctx.meta = (x.shape, w.shape, w.dtype, None if b is None else b.dtype)
+        return z.view(x.shape[:-1])
+
+    @staticmethod
+    def backward(ctx, dz):
+        x2, w32 = ctx.saved_tensors
+        xshape, wshape, wdt, bdt = ctx.meta
+        M, C = x2.shape
+        L = _lib.load()
+        dz = dz.reshape(-1).float().contiguous()
+        dx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
+        part = torch.empty((L.gf_rowdot_nblk(M), C + 1), dtype=torch.float32, device=x2.device)
+        _lib.check(L.gf_rowdot_bwd(_p(x2), _p(dz), _p(w32), _p(dx), _p(part), M, C, _dt(x2), _stream()),
+                   "gf_rowdot_bwd")
+        s = part.sum(0)
+        dw = s[:C].reshape(wshape).to(wdt)
+        db = None if bdt is None else s[C:].to(bdt)
+        return (None if dx is None else dx.view(xshape)), dw, db
+
+
+def rowdot(x, w, b=None):
+    _chk(x)
+    return _RowDot.apply(x, w, b)
+
+
 # ------------------------------------------------------------------------------ LN + GELU
 class _LnGelu(torch.autograd.Function):
     @staticmethod

@@ -167,6 +167,15 @@ int gf_bn_bwd_dx(const void* x, const void* dy, const float* mean, const float* 
 int gf_gt_nn(const float* own, const float* own_warped, const float* oth, const float* oth_warped,
              int64_t* arg, float* dmin, float* own_min, int B, int No, int Ns, void* stream);
 
+/* ---- single-output linear heads z[m] = x[m,:] . w + b (matchability / token-confidence logits,
+ * lightglue.py:71,275-276,285-286).  x [M,C] in `dtype`, w [C] fp32, z/dz [M] fp32.
+ * gf_rowdot_bwd writes dx = dz * w when dx != NULL (pass NULL for a detached input) and per-block
+ * partials part [gf_rowdot_nblk(M)][C+1] whose column sums are (dw[0..C), db). */
+int gf_rowdot_nblk(int M);
+int gf_rowdot_fwd(const void* x, const float* w, float bias, float* z, int M, int C, int dtype, void* stream);
+int gf_rowdot_bwd(const void* x, const float* dz, const float* w, void* dx, float* part,
+                  int M, int C, int dtype, void* stream);
+
 /* ---- fused elementwise ops of the transformer block ---------------------------------------
  * Rotary embedding applied in place to the q and k thirds of a fused [B,N,3,H,D] projection
  * (lightglue.py:42-49,159-160): cs [B,N,D] holds cos in the even and sin in the odd slot of

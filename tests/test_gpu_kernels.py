@@ -304,3 +304,23 @@ def test_linear_cat_equals_linear_of_cat():
     torch.testing.assert_close(y, yr, rtol=1e-4, atol=1e-4)
     for a, t in zip(got, (x1, x2, w, b)):
         torch.testing.assert_close(a, t.grad, rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,C", [(5000, 256), (33, 64)])
+def test_rowdot(dtype, M, C):
+    g = torch.Generator().manual_seed(M)
+    x = torch.randn(M, C, generator=g).to(DEV, dtype).requires_grad_(True)
+    w = (torch.randn(1, C, generator=g) / C ** 0.5).to(DEV).requires_grad_(True)
+    b = torch.randn(1, generator=g).to(DEV).requires_grad_(True)
+    dz = torch.randn(M, generator=g).to(DEV)
+    z = ops.rowdot(x, w, b)
+    (z * dz).sum().backward()
+    xr, wr, br = (t.detach().cpu().double().requires_grad_(True) for t in (x, w, b))
+    zr = torch.nn.functional.linear(xr, wr, br).squeeze(-1)
+    (zr * dz.cpu().double()).sum().backward()
+    tol = _tols(dtype)
+    torch.testing.assert_close(z.detach().cpu().double(), zr.detach(), **tol)
+    for a, r in ((x.grad, xr.grad), (w.grad, wr.grad), (b.grad, br.grad)):
+        sc = r.abs().max().item()
+        torch.testing.assert_close(a.cpu().double() / sc, r / sc, **tol)
