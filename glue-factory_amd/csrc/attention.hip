@@ -478,12 +478,19 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dq_kerne
 // ===========================================================================================
 // backward, part 2: dK, dV (one workgroup per 128 keys, Q / dO tiles double-buffered)
 // ===========================================================================================
+// Single LDS buffer, no register prefetch, <= 168 registers: three workgroups (12 waves) per CU hide
+// the LDS / HBM latency that two double-buffered workgroups could not (this kernel reads four staged
+// tiles per step and sat 53 % of its wave cycles in s_waitcnt at two waves per SIMD).
 template <typename T, int HD>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 1) void attn_bwd_dkv_kernel(AttnParams p) {
     using L = Lay<T, HD>;
-    constexpr int BUF = 2 * L::ROWMAJOR + 2 * L::TRANSP + 128 * (int)(sizeof(float) / sizeof(T));
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    T* lds = reinterpret_cast<T*>(smem);
+    T* Qs = reinterpret_cast<T*>(smem);
+    T* dOs = Qs + L::ROWMAJOR;
+    T* Qt = dOs + L::ROWMAJOR;
+    T* dOt = Qt + L::TRANSP;
+    float* lse_s = reinterpret_cast<float*>(dOt + L::TRANSP);
+    float* del_s = lse_s + 64;
 
     const int nkb = (p.Nk + 127) / 128;
     const int total = nkb * p.H * p.B;
@@ -513,50 +520,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dk[db][r] = 0.f; dv[db][r] = 0.f; }
 
-    auto stats_of = [&](T* buf) { return reinterpret_cast<float*>(buf + 2 * L::ROWMAJOR + 2 * L::TRANSP); };
-    // raw prefetch only: consuming the values here (scale / select) would force the wave to wait for the
-    // whole prefetch batch at the top of the iteration; they are finished in store_stats, after the MFMAs.
-    auto load_stats = [&](int q0, float& l, float& d) {
+    for (int q0 = 0; q0 < p.Nq; q0 += 64) {
+        __syncthreads();
+        {
+            PairRegs<T, HD> rg;
+            pair_load<T, HD>(rg, qp, p.sqn, q0, p.Nq);
+            pair_store<T, HD, true, true>(rg, Qs, Qt);
+            pair_load<T, HD>(rg, dop, p.sdon, q0, p.Nq);
+            pair_store<T, HD, true, true>(rg, dOs, dOt);
+        }
         if (threadIdx.x < 64) {
-            int qi = min(q0 + (int)threadIdx.x, p.Nq - 1);
-            l = lsep[qi];
-            d = delp[qi];
+            const int qi = q0 + threadIdx.x;
+            const bool ok = qi < p.Nq;                       // rows past Nq: lse = +inf makes P exactly 0
+            lse_s[threadIdx.x] = ok ? lsep[qi] * GF_LOG2E : INFINITY;
+            del_s[threadIdx.x] = ok ? delp[qi] : 0.f;
         }
-    };
-    auto store_stats = [&](T* buf, int q0, float l, float d) {
-        if (threadIdx.x < 64) {
-            float* st = stats_of(buf);
-            const bool ok = q0 + (int)threadIdx.x < p.Nq;     // rows past Nq: lse = +inf makes P exactly 0
-            st[threadIdx.x] = ok ? l * GF_LOG2E : INFINITY;
-            st[64 + threadIdx.x] = ok ? d : 0.f;
-        }
-    };
-
-    PairRegs<T, HD> qr, dor;
-    float ls = 0.f, dl = 0.f;
-    pair_load<T, HD>(qr, qp, p.sqn, 0, p.Nq);
-    pair_load<T, HD>(dor, dop, p.sdon, 0, p.Nq);
-    load_stats(0, ls, dl);
-    pair_store<T, HD, true, true>(qr, lds, lds + 2 * L::ROWMAJOR);
-    pair_store<T, HD, true, true>(dor, lds + L::ROWMAJOR, lds + 2 * L::ROWMAJOR + L::TRANSP);
-    store_stats(lds, 0, ls, dl);
-    __syncthreads();
-
-    const int nt = (p.Nq + 63) / 64;
-    for (int t = 0; t < nt; ++t) {
-        const int q0 = t * 64;
-        T* cur = lds + (t & 1) * BUF;
-        const T* Qs = cur;
-        const T* dOs = Qs + L::ROWMAJOR;
-        const T* Qt = dOs + L::ROWMAJOR;
-        const T* dOt = Qt + L::TRANSP;
-        const float* lse_s = stats_of(cur);
-        const float* del_s = lse_s + 64;
-        if (t + 1 < nt) {
-            pair_load<T, HD>(qr, qp, p.sqn, q0 + 64, p.Nq);
-            pair_load<T, HD>(dor, dop, p.sdon, q0 + 64, p.Nq);
-            load_stats(q0 + 64, ls, dl);
-        }
+        __syncthreads();
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
             f32x16 s, dp;
@@ -564,7 +543,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams p) {
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
             mma_rows<T, HD>(s, Qs, qb * 32, kf, l31, hi);     // S[q][key]
             mma_rows<T, HD>(dp, dOs, qb * 32, vf, l31, hi);   // dP[q][key]
-            f32x16 ds;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + qb * 32 + 8 * g + 4 * hi);
@@ -574,19 +552,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams p) {
                     int r = 4 * g + e;
                     float pr = fast_exp2(fmaf(s[r], c, -l4[e]));
                     s[r] = pr;
-                    ds[r] = pr * (dp[r] - d4[e]);
+                    dp[r] = pr * (dp[r] - d4[e]);             // dS overwrites dP
                 }
             }
             mma_transposed<T, HD>(dv, dOt, qb * 32, s, l31, hi);
-            mma_transposed<T, HD>(dk, Qt, qb * 32, ds, l31, hi);
+            mma_transposed<T, HD>(dk, Qt, qb * 32, dp, l31, hi);
         }
-        if (t + 1 < nt) {
-            T* nb = lds + ((t + 1) & 1) * BUF;
-            pair_store<T, HD, true, true>(qr, nb, nb + 2 * L::ROWMAJOR);
-            pair_store<T, HD, true, true>(dor, nb + L::ROWMAJOR, nb + 2 * L::ROWMAJOR + L::TRANSP);
-            store_stats(nb, q0 + 64, ls, dl);
-        }
-        __syncthreads();
     }
     if (krow < p.Nk) {
         T* dkp = reinterpret_cast<T*>(p.dk) + b * p.sdkb + h * p.sdkh + (int64_t)krow * p.sdkn;
@@ -599,7 +570,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnParams p) {
 template <typename T, int HD> size_t fwd_lds() { return 2 * (Lay<T, HD>::ROWMAJOR + Lay<T, HD>::TRANSP) * sizeof(T); }
 template <typename T, int HD> size_t dq_lds() { return 2 * (2 * Lay<T, HD>::ROWMAJOR + Lay<T, HD>::TRANSP) * sizeof(T); }
 template <typename T, int HD> size_t dkv_lds() {
-    return 2 * ((2 * Lay<T, HD>::ROWMAJOR + 2 * Lay<T, HD>::TRANSP) * sizeof(T) + 128 * sizeof(float));
+    return (2 * Lay<T, HD>::ROWMAJOR + 2 * Lay<T, HD>::TRANSP) * sizeof(T) + 128 * sizeof(float);
 }
 
 template <typename K> int set_lds(K kern, size_t bytes) {
