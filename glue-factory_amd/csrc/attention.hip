@@ -478,19 +478,12 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dq_kerne
 // ===========================================================================================
 // backward, part 2: dK, dV (one workgroup per 128 keys, Q / dO tiles double-buffered)
 // ===========================================================================================
-// Single LDS buffer, no register prefetch, <= 168 registers: three workgroups (12 waves) per CU hide
-// the LDS / HBM latency that two double-buffered workgroups could not (this kernel reads four staged
-// tiles per step and sat 53 % of its wave cycles in s_waitcnt at two waves per SIMD).
 template <typename T, int HD>
-__global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 1) void attn_bwd_dkv_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dkv_kernel(AttnParams p) {
     using L = Lay<T, HD>;
+    constexpr int BUF = 2 * L::ROWMAJOR + 2 * L::TRANSP + 128 * (int)(sizeof(float) / sizeof(T));
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    T* Qs = reinterpret_cast<T*>(smem);
-    T* dOs = Qs + L::ROWMAJOR;
-    T* Qt = dOs + L::ROWMAJOR;
-    T* dOt = Qt + L::TRANSP;
-    float* lse_s = reinterpret_cast<float*>(dOt + L::TRANSP);
-    float* del_s = lse_s + 64;
+    T* lds = reinterpret_cast<T*>(smem);
 
     const int nkb = (p.Nk + 127) / 128;
     const int total = nkb * p.H * p.B;
@@ -520,44 +513,117 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 1) void attn_bwd_dkv_kern
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dk[db][r] = 0.f; dv[db][r] = 0.f; }
 
-    for (int q0 = 0; q0 < p.Nq; q0 += 64) {
-        __syncthreads();
-        {
-            PairRegs<T, HD> rg;
-            pair_load<T, HD>(rg, qp, p.sqn, q0, p.Nq);
-            pair_store<T, HD, true, true>(rg, Qs, Qt);
-            pair_load<T, HD>(rg, dop, p.sdon, q0, p.Nq);
-            pair_store<T, HD, true, true>(rg, dOs, dOt);
-        }
+    auto stats_of = [&](T* buf) { return reinterpret_cast<float*>(buf + 2 * L::ROWMAJOR + 2 * L::TRANSP); };
+    // raw prefetch only: consuming the values here (scale / select) would force the wave to wait for the
+    // whole prefetch batch at the top of the iteration; they are finished in store_stats, after the MFMAs.
+    auto load_stats = [&](int q0, float& l, float& d) {
         if (threadIdx.x < 64) {
-            const int qi = q0 + threadIdx.x;
-            const bool ok = qi < p.Nq;                       // rows past Nq: lse = +inf makes P exactly 0
-            lse_s[threadIdx.x] = ok ? lsep[qi] * GF_LOG2E : INFINITY;
-            del_s[threadIdx.x] = ok ? delp[qi] : 0.f;
+            int qi = min(q0 + (int)threadIdx.x, p.Nq - 1);
+            l = lsep[qi];
+            d = delp[qi];
         }
-        __syncthreads();
+    };
+    auto store_stats = [&](T* buf, int q0, float l, float d) {
+        if (threadIdx.x < 64) {
+            float* st = stats_of(buf);
+            const bool ok = q0 + (int)threadIdx.x < p.Nq;     // rows past Nq: lse = +inf makes P exactly 0
+            st[threadIdx.x] = ok ? l * GF_LOG2E : INFINITY;
+            st[64 + threadIdx.x] = ok ? d : 0.f;
+        }
+    };
+
+    PairRegs<T, HD> qr, dor;
+    float ls = 0.f, dl = 0.f;
+    pair_load<T, HD>(qr, qp, p.sqn, 0, p.Nq);
+    pair_load<T, HD>(dor, dop, p.sdon, 0, p.Nq);
+    load_stats(0, ls, dl);
+    pair_store<T, HD, true, true>(qr, lds, lds + 2 * L::ROWMAJOR);
+    pair_store<T, HD, true, true>(dor, lds + L::ROWMAJOR, lds + 2 * L::ROWMAJOR + L::TRANSP);
+    store_stats(lds, 0, ls, dl);
+    __syncthreads();
+
+    const int nt = (p.Nq + 63) / 64;
+    for (int t = 0; t < nt; ++t) {
+        const int q0 = t * 64;
+        T* cur = lds + (t & 1) * BUF;
+        const T* Qs = cur;
+        const T* dOs = Qs + L::ROWMAJOR;
+        const T* Qt = dOs + L::ROWMAJOR;
+        const T* dOt = Qt + L::TRANSP;
+        const float* lse_s = stats_of(cur);
+        const float* del_s = lse_s + 64;
+        if (t + 1 < nt) {
+            pair_load<T, HD>(qr, qp, p.sqn, q0 + 64, p.Nq);
+            pair_load<T, HD>(dor, dop, p.sdon, q0 + 64, p.Nq);
+            load_stats(q0 + 64, ls, dl);
+        }
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
+            // every LDS fragment of a phase is requested before the phase's first MFMA, so the reads
+            // overlap instead of forming a read -> wait -> MFMA chain
+            Frag<T> qa[HD / 16], da[HD / 16];
+            {
+                const T* qb_ = Qs + (qb * 32 + l31) * L::LDR + 8 * hi;
+                const T* db_ = dOs + (qb * 32 + l31) * L::LDR + 8 * hi;
+#pragma unroll
+                for (int s_ = 0; s_ < HD / 16; ++s_) qa[s_] = ld_frag8(qb_ + 16 * s_);
+#pragma unroll
+                for (int s_ = 0; s_ < HD / 16; ++s_) da[s_] = ld_frag8(db_ + 16 * s_);
+            }
+            __builtin_amdgcn_sched_barrier(0);
             f32x16 s, dp;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-            mma_rows<T, HD>(s, Qs, qb * 32, kf, l31, hi);     // S[q][key]
-            mma_rows<T, HD>(dp, dOs, qb * 32, vf, l31, hi);   // dP[q][key]
+#pragma unroll
+            for (int s_ = 0; s_ < HD / 16; ++s_) mma32(s, qa[s_], kf[s_]);      // S[q][key]
+#pragma unroll
+            for (int s_ = 0; s_ < HD / 16; ++s_) mma32(dp, da[s_], vf[s_]);     // dP[q][key]
+            f32x4 l4[4], d4[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + qb * 32 + 8 * g + 4 * hi);
-                f32x4 d4 = *reinterpret_cast<const f32x4*>(del_s + qb * 32 + 8 * g + 4 * hi);
+                l4[g] = *reinterpret_cast<const f32x4*>(lse_s + qb * 32 + 8 * g + 4 * hi);
+                d4[g] = *reinterpret_cast<const f32x4*>(del_s + qb * 32 + 8 * g + 4 * hi);
+            }
+            Frag<T> dot[2][HD / 32], qt[2][HD / 32];
+#pragma unroll
+            for (int t_ = 0; t_ < 2; ++t_)
+#pragma unroll
+                for (int db = 0; db < HD / 32; ++db) {
+                    const int d = db * 32 + l31;
+                    const int off = d * L::LDT + tswz(d, qb * 32 + 16 * t_ + 8 * hi);
+                    dot[t_][db] = ld_frag8(dOt + off);
+                    qt[t_][db] = ld_frag8(Qt + off);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     int r = 4 * g + e;
-                    float pr = fast_exp2(fmaf(s[r], c, -l4[e]));
+                    float pr = fast_exp2(fmaf(s[r], c, -l4[g][e]));
                     s[r] = pr;
-                    dp[r] = pr * (dp[r] - d4[e]);             // dS overwrites dP
+                    dp[r] = pr * (dp[r] - d4[g][e]);             // dS overwrites dP
                 }
+#pragma unroll
+            for (int t_ = 0; t_ < 2; ++t_) {
+                Frag<T> pf = acc_to_frag<T>(s, t_);
+#pragma unroll
+                for (int db = 0; db < HD / 32; ++db) mma32(dv[db], dot[t_][db], pf);
             }
-            mma_transposed<T, HD>(dv, dOt, qb * 32, s, l31, hi);
-            mma_transposed<T, HD>(dk, Qt, qb * 32, dp, l31, hi);
+#pragma unroll
+            for (int t_ = 0; t_ < 2; ++t_) {
+                Frag<T> pf = acc_to_frag<T>(dp, t_);
+#pragma unroll
+                for (int db = 0; db < HD / 32; ++db) mma32(dk[db], qt[t_][db], pf);
+            }
         }
+        if (t + 1 < nt) {
+            T* nb = lds + ((t + 1) & 1) * BUF;
+            pair_store<T, HD, true, true>(qr, nb, nb + 2 * L::ROWMAJOR);
+            pair_store<T, HD, true, true>(dor, nb + L::ROWMAJOR, nb + 2 * L::ROWMAJOR + L::TRANSP);
+            store_stats(nb, q0 + 64, ls, dl);
+        }
+        __syncthreads();
     }
     if (krow < p.Nk) {
         T* dkp = reinterpret_cast<T*>(p.dk) + b * p.sdkb + h * p.sdkh + (int64_t)krow * p.sdkn;
@@ -567,10 +633,278 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 3 : 1) void attn_bwd_dkv_kern
     }
 }
 
+// ===========================================================================================
+// bf16 fast path: LDS-DMA staging + hardware-transposed LDS reads
+// ===========================================================================================
+// Tiles are 64 rows x 128 B, row-major and UNPADDED in LDS (a `global_load_lds_dwordx4` writes
+// 64 lanes x 16 B contiguously, so there is no room for padding): instead the 16-byte chunk index of
+// row r is XORed with fswz(r).  Conflict-free for both access patterns used below:
+//   * ds_read_b128 of one chunk per row, rows = the lanes of a 16-lane service group;
+//   * ds_read_b64_tr_b16 of a 4-row x 32-column block per 32 lanes (the operand of the second MFMA,
+//     read TRANSPOSED straight from the row-major tile: no transposed copy, no VALU transposition).
+// The DMA writes LDS asynchronously (tracked by vmcnt): a 3-stage ring keeps two tiles in flight and
+// needs ONE raw s_barrier per tile.  Every LDS read is inline asm with hand-placed s_waitcnt, since
+// the compiler would otherwise drain vmcnt (= the prefetch) in front of each read.
+constexpr int FT_TILE = 8192;              // bytes of one 64 x 64 bf16 tile
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+__device__ __forceinline__ int fswz(int row) {
+    const int x = (row >> 1) & 7;
+    return ((x & 1) << 2) | (x >> 1);
+}
+__device__ __forceinline__ void dma16(const void* g, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((glb_void*)g, (lds_void*)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ void dma4(const void* g, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((glb_void*)g, (lds_void*)lds_wave_base, 4, 0, 0);
+}
+template <int OFF> __device__ __forceinline__ u32x4 lds_rd128(unsigned a) {
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF) : "memory");
+    return v;
+}
+template <int OFF> __device__ __forceinline__ u32x2 lds_rdtr(unsigned a) {
+    u32x2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF) : "memory");
+    return v;
+}
+template <int N> __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// the asm reads are invisible to the compiler's waitcnt bookkeeping: a tie after the wait orders every use
+template <typename V> __device__ __forceinline__ void tie(V& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ bf16x8 as_frag(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
+__device__ __forceinline__ bf16x8 as_frag(u32x2 lo, u32x2 hi) {
+    u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ bf16x8 cvt_frag(const f32x16& c, int t) {
+    bf16x8 f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = (bf16_t)c[8 * t + e];
+    return f;
+}
+__device__ __forceinline__ void mma16(f32x16& acc, bf16x8 a, bf16x8 b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+}
+
+// dK / dV: one workgroup per 128 keys (32 per wave, K and V fragments in registers), Q / dO / lse / delta
+// tiles of 64 query rows streamed through the ring.  -lse/scale and -delta are the INITIAL VALUES of the
+// S and dP accumulators, so P = exp2(c * acc) and dS = P * acc need no subtraction.
+constexpr int DKV_STATS = 2 * FT_TILE;                 // per wave: 16 lse | 16 delta | duplicates (256 B)
+constexpr int DKV_STAGE = 2 * FT_TILE + 1024;
+constexpr int DKV_NSTAGE = 3;
+
+template <int QB, typename Mid>
+__device__ __forceinline__ void dkv_half_tile(f32x16 (&dk)[2], f32x16 (&dv)[2], const bf16x8 (&kf)[4],
+                                              const bf16x8 (&vf)[4], const unsigned (&aR)[4],
+                                              const unsigned (&aT)[4], unsigned aS, float c, float rscale,
+                                              int hi, int nvalid, Mid&& mid) {
+    f32x4 l4[4], d4[4];
+#define GF_ST(g) l4[g] = __builtin_bit_cast(f32x4, lds_rd128<(2 * QB + (g >> 1)) * 256 + 32 * (g & 1)>(aS)); \
+                 d4[g] = __builtin_bit_cast(f32x4, lds_rd128<(2 * QB + (g >> 1)) * 256 + 32 * (g & 1) + 64>(aS));
+    GF_ST(0) GF_ST(1) GF_ST(2) GF_ST(3)
+#undef GF_ST
+    u32x4 qa[4], da[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qa[s] = lds_rd128<QB * 4096>(aR[s]);
+    wait_lgkm<4>();
+    f32x16 sa, dp;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        tie(l4[g]);
+        tie(d4[g]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            sa[4 * g + e] = -l4[g][e] * rscale;
+            dp[4 * g + e] = -d4[g][e];
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) da[s] = lds_rd128<FT_TILE + QB * 4096>(aR[s]);
+    wait_lgkm<4>();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {                               // k-steps chained on ONE accumulator: switching
+        tie(qa[s]);                                             // accumulators between MFMAs measured 9 % slower
+        mma16(sa, as_frag(qa[s]), kf[s]);                       // S[q][key] - lse/scale
+    }
+    // transposed operands: [t][db] -> rows 16t + 4hi + {0..3} (lo) and + 8 (hi half), columns db*32 + l31
+    u32x2 dot[2][2][2], qt[2][2][2];
+#define GF_TR(dst, base, t, db) dst[t][db][0] = lds_rdtr<base + QB * 4096 + t * 2048>(aT[db]); \
+                                dst[t][db][1] = lds_rdtr<base + QB * 4096 + t * 2048 + 1024>(aT[2 + db]);
+    GF_TR(dot, FT_TILE, 0, 0) GF_TR(dot, FT_TILE, 0, 1) GF_TR(dot, FT_TILE, 1, 0) GF_TR(dot, FT_TILE, 1, 1)
+    wait_lgkm<8>();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        tie(da[s]);
+        mma16(dp, as_frag(da[s]), vf[s]);                       // dP[q][key] - delta
+    }
+    GF_TR(qt, 0, 0, 0) GF_TR(qt, 0, 0, 1) GF_TR(qt, 0, 1, 0) GF_TR(qt, 0, 1, 1)
+#undef GF_TR
+    mid();                                                      // DMA issue rides in the VALU gap
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float pr = fast_exp2(sa[r] * c);
+        sa[r] = pr;
+        dp[r] = pr * dp[r];                                     // dS overwrites dP
+    }
+    if (nvalid < 64) {                                          // ragged last tile: rows past Nq contribute 0
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (QB * 32 + crow(r, hi) >= nvalid) { sa[r] = 0.f; dp[r] = 0.f; }
+    }
+    wait_lgkm<8>();
+    {
+        const bf16x8 pf0 = cvt_frag(sa, 0), pf1 = cvt_frag(sa, 1);
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+            tie(dot[0][db][0]); tie(dot[0][db][1]); tie(dot[1][db][0]); tie(dot[1][db][1]);
+            mma16(dv[db], as_frag(dot[0][db][0], dot[0][db][1]), pf0);
+            mma16(dv[db], as_frag(dot[1][db][0], dot[1][db][1]), pf1);
+        }
+    }
+    wait_lgkm<0>();
+    {
+        const bf16x8 pf0 = cvt_frag(dp, 0), pf1 = cvt_frag(dp, 1);
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+            tie(qt[0][db][0]); tie(qt[0][db][1]); tie(qt[1][db][0]); tie(qt[1][db][1]);
+            mma16(dk[db], as_frag(qt[0][db][0], qt[0][db][1]), pf0);
+            mma16(dk[db], as_frag(qt[1][db][0], qt[1][db][1]), pf1);
+        }
+    }
+}
+
+template <int NW>   // waves per workgroup (32 keys each): the Q/dO stream is shared by all of them
+__global__ __launch_bounds__(64 * NW, 8 / NW) void attn_bwd_dkv_bf16_kernel(AttnParams p) {
+    constexpr int KPB = 32 * NW, PPW = 8 / NW;    // keys per block, 1-KiB DMA pieces per wave and matrix
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const unsigned lds0 = (unsigned)(size_t)smem;
+
+    const int nkb = (p.Nk + KPB - 1) / KPB;
+    const int total = nkb * p.H * p.B;
+    int lb = xcd_remap(blockIdx.x, total);
+    const int kb_ = lb % nkb, h = (lb / nkb) % p.H, b = lb / (nkb * p.H);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, hi = lane >> 5, s16 = lane & 15, half = (lane >> 4) & 1;
+    const int krow = kb_ * KPB + wave * 32 + l31;
+    const int kld = min(krow, p.Nk - 1);
+
+    const bf16_t* qp = reinterpret_cast<const bf16_t*>(p.q) + b * p.sqb + h * p.sqh;
+    const bf16_t* kp = reinterpret_cast<const bf16_t*>(p.k) + b * p.skb + h * p.skh;
+    const bf16_t* vp = reinterpret_cast<const bf16_t*>(p.v) + b * p.svb + h * p.svh;
+    const bf16_t* dop = reinterpret_cast<const bf16_t*>(p.dout) + b * p.sdob + h * p.sdoh;
+    const float* lsep = p.lse + ((int64_t)b * p.H + h) * p.Nq;
+    const float* delp = p.delta + ((int64_t)b * p.H + h) * p.Nq;
+
+    // ---- DMA descriptors: chunk (2 wave + i) * 64 + lane of a tile -> row, swizzled source column
+    int drow[PPW], dcol[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        drow[i] = (PPW * wave + i) * 8 + (lane >> 3);
+        dcol[i] = ((lane & 7) ^ fswz(drow[i])) * 8;
+    }
+    const float* statp = (lane & 16) ? delp : lsep;
+    const int srow = 16 * wave + s16;
+    const bool stat_wave = __builtin_amdgcn_readfirstlane(wave) < 4;
+    // part 0: Q pieces + stats, part 1: dO pieces (issued in the VALU gaps of the two half tiles)
+    const int64_t qstep = 64 * p.sqn, dostep = 64 * p.sdon;
+    const bf16_t* gq[PPW];
+    const bf16_t* gdo[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        gq[i] = qp + (int64_t)drow[i] * p.sqn + dcol[i];
+        gdo[i] = dop + (int64_t)drow[i] * p.sdon + dcol[i];
+    }
+    auto issue_part = [&](int part, int t, int stage) {
+        char* sb = smem + stage * DKV_STAGE;
+        const int q0 = t * 64;
+        if (q0 + 64 <= p.Nq) {
+#pragma unroll
+            for (int i = 0; i < PPW; ++i) {
+                if (part == 0) dma16(gq[i] + t * qstep, sb + (PPW * wave + i) * 1024);
+                else dma16(gdo[i] + t * dostep, sb + FT_TILE + (PPW * wave + i) * 1024);
+            }
+        } else {                                                // ragged last tile: rows clamped to Nq - 1
+#pragma unroll
+            for (int i = 0; i < PPW; ++i) {
+                const int64_t r = min(q0 + drow[i], p.Nq - 1);
+                if (part == 0) dma16(qp + r * p.sqn + dcol[i], sb + (PPW * wave + i) * 1024);
+                else dma16(dop + r * p.sdon + dcol[i], sb + FT_TILE + (PPW * wave + i) * 1024);
+            }
+        }
+        if (part == 0 && stat_wave) dma4(statp + min(q0 + srow, p.Nq - 1), sb + DKV_STATS + wave * 256);
+    };
+    auto issue_tile = [&](int t, int stage) { issue_part(0, t, stage); issue_part(1, t, stage); };
+
+    const int nt = (p.Nq + 63) / 64;
+    issue_tile(0, 0);
+    if (nt > 1) issue_tile(1, 1);
+
+    bf16x8 kf[4], vf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        kf[s] = *reinterpret_cast<const bf16x8*>(kp + (int64_t)kld * p.skn + 16 * s + 8 * hi);
+        vf[s] = *reinterpret_cast<const bf16x8*>(vp + (int64_t)kld * p.svn + 16 * s + 8 * hi);
+    }
+    const float c = p.scale * GF_LOG2E, rscale = 1.f / p.scale;
+
+    f32x16 dk[2], dv[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[db][r] = 0.f; dv[db][r] = 0.f; }
+
+    // ---- per-lane LDS read addresses (stage 0); see the layout note above
+    unsigned bR[4], bT[4];
+    {
+        const unsigned rb = l31 * 128 + 16 * (hi ^ fswz(l31));
+#pragma unroll
+        for (int s = 0; s < 4; ++s) bR[s] = lds0 + (rb ^ (32 * s));
+        const int bq = s16 >> 3;
+        const unsigned tb = (4 * hi + (s16 >> 2)) * 128 + 8 * (s16 & 1) +
+                            16 * ((2 * half + ((s16 & 3) >> 1)) ^ (4 * bq + hi));
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int db = 0; db < 2; ++db) bT[2 * u + db] = lds0 + (tb ^ (32 * u) ^ (64 * db));
+    }
+    const unsigned bS = lds0 + DKV_STATS + 16 * hi;
+
+    int stage = 0;
+    for (int t = 0; t < nt; ++t) {
+        if (t + 1 >= nt) wait_vm<0>();                            // tile t landed (this wave's share)
+        else if (stat_wave) wait_vm<2 * PPW + 1>();
+        else wait_vm<2 * PPW>();
+        __builtin_amdgcn_s_barrier();                             // ... everyone's; stage of tile t-1 is free
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned so = stage * DKV_STAGE;
+        unsigned aR[4], aT[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { aR[i] = bR[i] + so; aT[i] = bT[i] + so; }
+        const int nvalid = p.Nq - t * 64;
+        const int nstage = stage == 0 ? 2 : stage - 1;
+        const bool more = t + 2 < nt;
+        dkv_half_tile<0>(dk, dv, kf, vf, aR, aT, bS + so, c, rscale, hi, nvalid,
+                         [&] { if (more) issue_part(0, t + 2, nstage); });
+        dkv_half_tile<1>(dk, dv, kf, vf, aR, aT, bS + so, c, rscale, hi, nvalid,
+                         [&] { if (more) issue_part(1, t + 2, nstage); });
+        stage = stage == 2 ? 0 : stage + 1;
+    }
+    if (krow < p.Nk) {
+        bf16_t* dkp = reinterpret_cast<bf16_t*>(p.dk) + b * p.sdkb + h * p.sdkh + (int64_t)krow * p.sdkn;
+        bf16_t* dvp = reinterpret_cast<bf16_t*>(p.dv) + b * p.sdvb + h * p.sdvh + (int64_t)krow * p.sdvn;
+        store_row<bf16_t, 64>(dkp, dk, p.scale, hi);
+        store_row<bf16_t, 64>(dvp, dv, 1.f, hi);
+    }
+}
+
 template <typename T, int HD> size_t fwd_lds() { return 2 * (Lay<T, HD>::ROWMAJOR + Lay<T, HD>::TRANSP) * sizeof(T); }
 template <typename T, int HD> size_t dq_lds() { return 2 * (2 * Lay<T, HD>::ROWMAJOR + Lay<T, HD>::TRANSP) * sizeof(T); }
 template <typename T, int HD> size_t dkv_lds() {
-    return (2 * Lay<T, HD>::ROWMAJOR + 2 * Lay<T, HD>::TRANSP) * sizeof(T) + 128 * sizeof(float);
+    return 2 * ((2 * Lay<T, HD>::ROWMAJOR + 2 * Lay<T, HD>::TRANSP) * sizeof(T) + 128 * sizeof(float));
 }
 
 template <typename K> int set_lds(K kern, size_t bytes) {
@@ -593,9 +927,19 @@ template <typename T> int launch_bwd(const AttnParams& p, hipStream_t st) {
     int total = ((p.Nq + 255) / 256) * p.H * p.B;
     size_t lds = dq_lds<T, 64>();
     if (int e = set_lds(attn_bwd_dq_kernel<T, 64>, lds)) return e;
+#ifndef GF_PROBE_SKIP_DQ
     attn_bwd_dq_kernel<T, 64><<<dim3(total), dim3(256), lds, st>>>(p);
     if (int e = (int)hipGetLastError()) return e;
+#endif
     total = ((p.Nk + 127) / 128) * p.H * p.B;
+    if constexpr (sizeof(T) == 2) {
+        constexpr int NW = 4;                       // 8 waves sharing one Q/dO stream measured 7 % slower
+        total = ((p.Nk + 32 * NW - 1) / (32 * NW)) * p.H * p.B;
+        lds = DKV_NSTAGE * DKV_STAGE;
+        if (int e = set_lds(attn_bwd_dkv_bf16_kernel<NW>, lds)) return e;
+        attn_bwd_dkv_bf16_kernel<NW><<<dim3(total), dim3(64 * NW), lds, st>>>(p);
+        return (int)hipGetLastError();
+    }
     lds = dkv_lds<T, 64>();
     if (int e = set_lds(attn_bwd_dkv_kernel<T, 64>, lds)) return e;
     attn_bwd_dkv_kernel<T, 64><<<dim3(total), dim3(256), lds, st>>>(p);

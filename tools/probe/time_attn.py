@@ -1,0 +1,40 @@
+"""time gf_attn_fwd / gf_attn_bwd of probe builds: python tools/probe/time_attn.py libv_a.so libv_b.so ..."""
+import ctypes, sys, torch
+B2, H, N, D = 64, 4, 2048, 64
+P, I, F = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+S = ctypes.POINTER(ctypes.c_int64)
+def st(t): return (ctypes.c_int64 * 3)(t.stride(0), t.stride(1), t.stride(2))
+g = torch.Generator(device="cuda").manual_seed(0)
+qkv = torch.randn(B2, N, 3, H, D, device="cuda", dtype=torch.bfloat16, generator=g)
+do = torch.randn(B2, N, H, D, device="cuda", dtype=torch.bfloat16, generator=g)
+q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+o = torch.empty(B2, N, H, D, device="cuda", dtype=torch.bfloat16)
+lse = torch.empty(B2, H, N, device="cuda"); delta = torch.empty_like(lse)
+dqkv = torch.empty_like(qkv)
+stream = torch.cuda.current_stream().cuda_stream
+def timeit(fn, iters=20):
+    for _ in range(10): fn()
+    best = 1e9
+    for _ in range(4):
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(iters): fn()
+        b.record(); torch.cuda.synchronize()
+        best = min(best, a.elapsed_time(b) / iters)
+    return best
+for path in sys.argv[1:]:
+    lib = ctypes.CDLL(path)
+    lib.gf_attn_fwd.argtypes = [P, P, P, P, P, I, I, I, I, I, S, S, S, S, F, I, P]
+    lib.gf_attn_bwd.argtypes = [P] * 10 + [I] * 5 + [S] * 8 + [F, I, P]
+    def fwd():
+        rc = lib.gf_attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), B2, H, N, N, D,
+                             st(q), st(k), st(v), st(o), D ** -0.5, 1, stream)
+        assert rc == 0, rc
+    def bwd():
+        rc = lib.gf_attn_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(),
+                             delta.data_ptr(), dqkv[:, :, 0].data_ptr(), dqkv[:, :, 1].data_ptr(), dqkv[:, :, 2].data_ptr(),
+                             B2, H, N, N, D, st(q), st(k), st(v), st(o), st(do), st(q), st(k), st(v), D ** -0.5, 1, stream)
+        assert rc == 0, rc
+    fwd()
+    print(f"{path}: fwd {timeit(fwd)*1e3:.1f} us   bwd {timeit(bwd)*1e3:.1f} us", flush=True)
