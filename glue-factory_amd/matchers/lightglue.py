@@ -169,7 +169,7 @@ class MatchAssignment(nn.Module):
         z = _lin(x, self.matchability).squeeze(-1).float()
         r, c = ops.dual_lse_stacked(md)
         lz, lnz = F.logsigmoid(z), F.logsigmoid(-z)
-        return {"md": md, "md0": md[:b], "md1": md[b:], "r": r, "c": c,
+        return {"md": md, "z": z, "md0": md[:b], "md1": md[b:], "r": r, "c": c,
                 "lz0": lz[:b], "lz1": lz[b:], "bin0": lnz[:b], "bin1": lnz[b:]}
 
     @staticmethod
@@ -336,7 +336,7 @@ class LightGlue(nn.Module):
             # ref_descriptors are detached copies in this mode: the loss differentiates through the private
             # stacked list below (identical values), which keeps every gradient batch-stacked.
             rd0, rd1 = torch.stack(all0, 1), torch.stack(all1, 1)
-            extra = {"_layer_desc": layer_x}
+            extra = {"_layer_desc": layer_x, "_final_head": head}
         else:
             rd0, rd1 = torch.stack(all0, 1), torch.stack(all1, 1)
             extra = {}
@@ -461,12 +461,57 @@ class LightGlue(nn.Module):
         with torch.autocast(device_type="cuda", enabled=False):
             return self._loss(pred, data)
 
+    def _loss_fused(self, pred, data, gt):
+        """Training loss on the batch-stacked per-layer descriptors: one fused HIP node per layer
+        (ops.lg_layer_loss) and a handful of [L,B] tensor ops for the whole step."""
+        layer_x = pred["_layer_desc"]
+        L = len(layer_x)
+        b = pred["ref_descriptors0"].shape[0]
+        n = layer_x[0].shape[1]
+        fin0, fin1 = pred["_final_argmax0"], pred["_final_argmax1"]
+        accs = []
+        for i in range(L):
+            x = layer_x[i]
+            la = self.log_assignment[i]
+            fh = pred.get("_final_head") if i == L - 1 else None
+            if fh is not None:           # the forward pass already projected the last layer
+                md, z, rc = fh["md"], fh["z"], (fh["r"], fh["c"])
+            else:
+                s = la.dim ** -0.25
+                md = ops.linear(x, la.final_proj.weight * s, la.final_proj.bias * s)
+                z = _lin(x, la.matchability).squeeze(-1)
+                rc = None
+            t = self.token_confidence[i].logits(x) if i < L - 1 else None
+            accs.append(ops.lg_layer_loss(md, z, t, rc, gt["pos"], gt["neg0"], gt["neg1"], fin0, fin1))
+        acc = torch.stack(accs)                                       # [L, B, 4]
+        nll_pos = -acc[..., 0] / gt["num_pos"]
+        nll_neg = -acc[..., 1] / (gt["n0"] + gt["n1"])
+        bal = self.conf.loss.nll_balancing
+        nll = bal * nll_pos + (1 - bal) * nll_neg                     # [L, B]
+        gamma = self.conf.loss.gamma
+        w = [gamma ** (L - i - 1) if gamma > 0.0 else i + 1 for i in range(L - 1)] + [1.0]
+        w = torch.tensor(w, device=acc.device, dtype=torch.float32)
+        total = (nll * w[:, None]).sum(0) / w.sum()
+        losses = {"total": total, "last": nll[-1].detach(), "assignment_nll": nll[-1], "nll_pos": nll_pos[-1],
+                  "nll_neg": nll_neg[-1], "num_matchable": gt["num_pos"],
+                  "num_unmatchable": (gt["n0"] + gt["n1"]) / 2.0}
+        if L > 1:
+            losses["confidence"] = (acc[:-1, :, 2] + acc[:-1, :, 3]).sum(0) / (2.0 * n * (L - 1))
+        else:
+            losses["confidence"] = torch.zeros_like(total)
+        with torch.no_grad():
+            losses["row_norm"] = pred["log_assignment"].exp()[:, :-1].sum(2).mean(1)
+        losses["total"] = losses["total"] + losses["confidence"]
+        return losses, {}
+
     def _loss(self, pred, data):
         rd0, rd1 = pred["ref_descriptors0"], pred["ref_descriptors1"]
         L = rd0.shape[1]
         gt = self._gt_sparse(data)
 
         layer_x = pred.get("_layer_desc")
+        if layer_x is not None and self.training and "_final_argmax0" in pred:
+            return self._loss_fused(pred, data, gt)
 
         def head(i):
             if layer_x is not None:

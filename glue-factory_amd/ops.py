@@ -488,6 +488,81 @@ def dual_lse_stacked(md):
     return _DualLSEStacked.apply(md)
 
 
+class _LGLayerLoss(torch.autograd.Function):
+    """Partial sums acc [B,4] of one layer's deep-supervision loss (gf_lg_loss_fwd) from the batch-stacked
+    head inputs md [2B,N,D], z [2B,N] (matchability logits), t [2B,N] (token-confidence logits or None).
+    One node in the autograd graph: its backward writes d(md) (dense double-softmax part + sparse positives),
+    dz and dt directly."""
+
+    @staticmethod
+    def forward(ctx, md, z, t, rc, pos, neg0, neg1, fin0, fin1):
+        _chk(md, z, t)
+        lib = _lib.load()
+        md = _mat3(md)
+        B2, N, D = md.shape
+        B = B2 // 2
+        a, b = md[:B], md[B:]
+        z = z.float().contiguous()
+        if rc is None:
+            r, c = rows_lse(a, b), rows_lse(b, a)
+        else:
+            r, c = (x.detach().float().contiguous() for x in rc)
+        pb, pi, pj = (x.contiguous() for x in pos)
+        P = pb.shape[0]
+        neg0, neg1 = neg0.float().contiguous(), neg1.float().contiguous()
+        acc = torch.empty((B, 4), dtype=torch.float32, device=md.device)
+        tgt = v = arg = None
+        if t is not None:
+            t = t.float().contiguous()
+            cb = torch.empty((2, B, N), dtype=torch.float32, device=md.device)
+            _lib.check(lib.gf_lg_head_prep(_p(z[:B]), _p(z[B:]), _p(r), _p(c), _p(cb[0]), _p(cb[1]), B, N, N,
+                                           _stream()), "gf_lg_head_prep")
+            v0, a0 = rows_argmax(a, b, cb[0], 2.0)
+            v1, a1 = rows_argmax(b, a, cb[1], 2.0)
+            tgt = torch.empty((B2, N), dtype=torch.float32, device=md.device)
+            fin0, fin1 = fin0.contiguous(), fin1.contiguous()
+            extra = (_p(t[:B]), _p(t[B:]), _p(v0), _p(a0), _p(v1), _p(a1), _p(fin0), _p(fin1), _p(tgt[:B]), _p(tgt[B:]))
+        else:
+            extra = (None,) * 10
+        _lib.check(lib.gf_lg_loss_fwd(_p(a), _p(b), _p(z[:B]), _p(z[B:]), _p(r), _p(c), _p(pb), _p(pi), _p(pj), P,
+                                      _p(neg0), _p(neg1), *extra, _p(acc), B, N, N, D, _dt(md), _stream()),
+                   "gf_lg_loss_fwd")
+        ctx.save_for_backward(md, z, t, r, c, tgt, pb, pi, pj, neg0, neg1)
+        return acc
+
+    @staticmethod
+    def backward(ctx, gacc):
+        md, z, t, r, c, tgt, pb, pi, pj, neg0, neg1 = ctx.saved_tensors
+        lib = _lib.load()
+        B2, N, D = md.shape
+        B = B2 // 2
+        P = pb.shape[0]
+        a, b = md[:B], md[B:]
+        gacc = gacc.float().contiguous()
+        dz = torch.empty_like(z)
+        dt = None if t is None else torch.empty_like(t)
+        grc = torch.empty((2, B, N), dtype=torch.float32, device=md.device)
+        tp = (None,) * 4 if t is None else (_p(t[:B]), _p(t[B:]), _p(tgt[:B]), _p(tgt[B:]))
+        dtp = (None, None) if t is None else (_p(dt[:B]), _p(dt[B:]))
+        _lib.check(lib.gf_lg_loss_bwd_tokens(_p(z[:B]), _p(z[B:]), _p(neg0), _p(neg1), *tp, _p(pb), _p(pi), _p(pj), P,
+                                             _p(gacc), _p(dz[:B]), _p(dz[B:]), *dtp, _p(grc[0]), _p(grc[1]),
+                                             B, N, N, _stream()), "gf_lg_loss_bwd_tokens")
+        dS = torch.empty((B, N, N), dtype=md.dtype, device=md.device)
+        _lib.check(lib.gf_dual_softmax_bwd(_p(a), _p(b), _p(r), _p(c), _p(grc[0]), _p(grc[1]), None, 0, 0.0, _p(dS),
+                                           B, N, N, D, _dt(md), _stream()), "gf_dual_softmax_bwd")
+        d = torch.empty_like(md)
+        torch.bmm(dS, b, out=d[:B])
+        torch.bmm(dS.transpose(1, 2), a, out=d[B:])
+        _lib.check(lib.gf_lg_loss_bwd_rows(_p(a), _p(b), _p(pb), _p(pi), _p(pj), P, _p(gacc), _p(d[:B]), _p(d[B:]),
+                                           B, N, N, D, _dt(md), _stream()), "gf_lg_loss_bwd_rows")
+        return d, dz, dt, None, None, None, None, None, None
+
+
+def lg_layer_loss(md, z, t, rc, pos, neg0, neg1, fin0, fin1):
+    """acc [B,4] = (sum_pos A_ij, sum of weighted dustbin terms, sum bce image 0, sum bce image 1)."""
+    return _LGLayerLoss.apply(md, z, t, rc, pos, neg0, neg1, fin0, fin1)
+
+
 class _AssignWrite(torch.autograd.Function):
     """out[b,i,j] = alpha a_i.b_j + rowbias_i + colbias_j, plus dustbin column/row/corner."""
 

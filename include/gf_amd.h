@@ -176,6 +176,42 @@ int gf_rowdot_fwd(const void* x, const float* w, float bias, float* z, int M, in
 int gf_rowdot_bwd(const void* x, const float* dz, const float* w, void* dx, float* part,
                   int M, int C, int dtype, void* stream);
 
+/* ---- fused deep-supervision loss of one LightGlue layer (lightglue.py:598-657 `loss`,
+ * utils/losses.py:6-73 NLL with dustbins on the non-zero weights, lightglue.py:81-94 token confidence).
+ * Inputs are the head statistics, never the [B,M+1,N+1] matrix: md0 [B,M,D] / md1 [B,N,D] (final_proj
+ * outputs, scaled by D^-1/4), matchability logits z0 [B,M] / z1 [B,N], r [B,M] / c [B,N] (gf_rows_lse),
+ * positives as COO (pos_b, pos_i, pos_j)[P] (any order, duplicates allowed), dustbin weights neg0 / neg1.
+ *   A_ij = 2 md0_i.md1_j - r_i - c_j + logsig(z0_i) + logsig(z1_j),  A_i,N = logsig(-z0_i),  A_M,j = logsig(-z1_j)
+ * gf_lg_head_prep: cb0[b,j] = logsig(z1) - c, cb1[b,i] = logsig(z0) - r  (the colbias of gf_rows_argmax).
+ * gf_lg_loss_fwd: acc [B,4] = { sum_pos A_ij, sum_i neg0 A_i,N + sum_j neg1 A_M,j, sum_i bce(t0_i, tgt0_i),
+ *   sum_j bce(t1_j, tgt1_j) }.  With token logits t0 / t1 (NULL for the last layer): v0/a0, v1/a1 are the
+ *   gf_rows_argmax results with cb0 / cb1, fin0 / fin1 the final layer's arg-max incl. dustbin, and
+ *   tgt0 / tgt1 receive the 0/1 targets (layer arg-max incl. dustbin == final) for the backward.
+ * gf_lg_loss_bwd_tokens: from gacc = dL/dacc [B,4]: dz0, dz1, dt0, dt1 (dense) and gr = dL/dr, gc = dL/dc
+ *   restricted to the direct terms (the caller feeds them to gf_dual_softmax_bwd).
+ * gf_lg_loss_bwd_rows: dmd0[b,i,:] += 2 gacc[b,0] md1[b,j,:], dmd1[b,j,:] += 2 gacc[b,0] md0[b,i,:]
+ *   (atomic accumulation INTO dmd, after the dense part has been written). */
+int gf_lg_head_prep(const float* z0, const float* z1, const float* r, const float* c,
+                    float* cb0, float* cb1, int B, int M, int N, void* stream);
+int gf_lg_loss_fwd(const void* md0, const void* md1, const float* z0, const float* z1,
+                   const float* r, const float* c,
+                   const int64_t* pos_b, const int64_t* pos_i, const int64_t* pos_j, int64_t P,
+                   const float* neg0, const float* neg1,
+                   const float* t0, const float* t1,
+                   const float* v0, const int64_t* a0, const float* v1, const int64_t* a1,
+                   const int64_t* fin0, const int64_t* fin1,
+                   float* tgt0, float* tgt1, float* acc,
+                   int B, int M, int N, int D, int dtype, void* stream);
+int gf_lg_loss_bwd_tokens(const float* z0, const float* z1, const float* neg0, const float* neg1,
+                          const float* t0, const float* t1, const float* tgt0, const float* tgt1,
+                          const int64_t* pos_b, const int64_t* pos_i, const int64_t* pos_j, int64_t P,
+                          const float* gacc, float* dz0, float* dz1, float* dt0, float* dt1,
+                          float* gr, float* gc, int B, int M, int N, void* stream);
+int gf_lg_loss_bwd_rows(const void* md0, const void* md1,
+                        const int64_t* pos_b, const int64_t* pos_i, const int64_t* pos_j, int64_t P,
+                        const float* gacc, void* dmd0, void* dmd1,
+                        int B, int M, int N, int D, int dtype, void* stream);
+
 /* ---- fused elementwise ops of the transformer block ---------------------------------------
  * Rotary embedding applied in place to the q and k thirds of a fused [B,N,3,H,D] projection
  * (lightglue.py:42-49,159-160): cs [B,N,D] holds cos in the even and sin in the odd slot of
