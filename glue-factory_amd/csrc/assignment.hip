@@ -173,6 +173,91 @@ __global__ __launch_bounds__(256) void rows_argmax_kernel(HeadParams p) {
     }
 }
 
+// One pass over the streamed rows for BOTH statistics of a LightGlue head row:
+//   lse   = log sum_s exp(own . oth_s)                                     (WITH_LSE; -> f1)
+//   max / argmax over s of alpha * own . oth_s + logsigmoid(g0_s) - g1_s   (-> f0, i0)
+// (g0 = matchability logits of the streamed side, g1 = its normaliser from the previous pass.)
+template <typename T, int D, bool WITH_LSE>
+__global__ __launch_bounds__(256) void rows_lse_argmax_kernel(HeadParams p) {
+    GF_HEAD_PROLOGUE(T, D)
+    float m = GF_NEG_BIG, lsum = 0.f;
+    float best = -INFINITY;
+    int bidx = 0x7fffffff;
+    for (int s0 = 0; s0 < p.Ns; s0 += 64) {
+        __syncthreads();
+        stage_rows<T, D>(tile, othp, s0, p.Ns);
+        if (threadIdx.x < 64) {
+            const int si = s0 + threadIdx.x;
+            float bias = -INFINITY;
+            if (si < p.Ns) {
+                const float z = p.g0[(int64_t)b * p.Ns + si];
+                bias = fminf(z, 0.f) - log1pf(__expf(-fabsf(z))) - p.g1[(int64_t)b * p.Ns + si];
+            }
+            vec0[threadIdx.x] = bias;
+            vec1[threadIdx.x] = si < p.Ns ? 0.f : -INFINITY;      // rows past Ns never enter the lse
+        }
+        __syncthreads();
+        f32x16 s[2];
+        float mx = GF_NEG_BIG;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+            mma_tile<T, D>(s[kb], tile, kb * 32, of, l31, hi);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 b4 = *reinterpret_cast<const f32x4*>(vec0 + kb * 32 + 8 * g + 4 * hi);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float raw = s[kb][4 * g + e];
+                    const float x = p.alpha * raw + b4[e];
+                    const int idx = s0 + kb * 32 + 8 * g + 4 * hi + e;
+                    if (x > best || (x == best && idx < bidx)) { best = x; bidx = idx; }
+                    if (WITH_LSE) {
+                        const float y = raw * GF_LOG2E;
+                        s[kb][4 * g + e] = y;
+                        mx = fmaxf(mx, y);
+                    }
+                }
+            }
+        }
+        if (WITH_LSE) {
+            if (s0 + 64 > p.Ns) {                                 // ragged last tile
+                mx = GF_NEG_BIG;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 v4 = *reinterpret_cast<const f32x4*>(vec1 + kb * 32 + 8 * g + 4 * hi);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            s[kb][4 * g + e] += v4[e];
+                            mx = fmaxf(mx, s[kb][4 * g + e]);
+                        }
+                    }
+            }
+            mx = fmaxf(mx, xhalf(mx));
+            const float mnew = fmaxf(m, mx);
+            float ps = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ps += fast_exp2(s[kb][r] - mnew);
+            lsum = lsum * fast_exp2(m - mnew) + ps;
+            m = mnew;
+        }
+    }
+    float ob_ = xhalf(best);
+    int oi = __shfl_xor(bidx, 32);
+    if (ob_ > best || (ob_ == best && oi < bidx)) { best = ob_; bidx = oi; }
+    if (WITH_LSE) lsum += xhalf(lsum);
+    if (orow < p.No && hi == 0) {
+        p.f0[(int64_t)b * p.No + orow] = best;
+        p.i0[(int64_t)b * p.No + orow] = (bidx == 0x7fffffff) ? 0 : bidx;
+        if (WITH_LSE) p.f1[(int64_t)b * p.No + orow] = (m + fast_log2(lsum)) * GF_LN2;
+    }
+}
+
 // out[b, s, o] = alpha * oth_s . own_o + sbias_s + obias_o  (+ dustbin row / column / corner)
 // owner = column index of `out` ([B, Ns+1, No+1]); streamed = row index.
 template <typename T, int D>
@@ -295,7 +380,7 @@ template <typename K> int set_lds(K kern, size_t bytes) {
     return 0;
 }
 
-enum { K_LSE, K_ARGMAX, K_WRITE, K_BWD };
+enum { K_LSE, K_ARGMAX, K_WRITE, K_BWD, K_LSEARG, K_ZNARG };
 
 template <typename T, int D> int launch_td(int which, const HeadParams& p, hipStream_t st) {
     const int total = ((p.No + 127) / 128) * p.B;
@@ -310,9 +395,19 @@ template <typename T, int D> int launch_td(int which, const HeadParams& p, hipSt
         case K_LSE: GF_LAUNCH(rows_lse_kernel)
         case K_ARGMAX: GF_LAUNCH(rows_argmax_kernel)
         case K_WRITE: GF_LAUNCH(assign_write_kernel)
-        default: GF_LAUNCH(dual_softmax_bwd_kernel)
+        case K_BWD: GF_LAUNCH(dual_softmax_bwd_kernel)
+        default: break;
     }
 #undef GF_LAUNCH
+#define GF_LAUNCH2(flag)                                                              \
+    {                                                                                 \
+        if (int e = set_lds(rows_lse_argmax_kernel<T, D, flag>, lds)) return e;       \
+        rows_lse_argmax_kernel<T, D, flag><<<dim3(total), dim3(256), lds, st>>>(p);   \
+        return (int)hipGetLastError();                                                \
+    }
+    if (which == K_LSEARG) GF_LAUNCH2(true)
+    GF_LAUNCH2(false)
+#undef GF_LAUNCH2
 }
 
 template <typename T> int launch_t(int which, const HeadParams& p, int D, hipStream_t st) {
@@ -348,6 +443,16 @@ extern "C" int gf_rows_argmax(const void* a, const void* b, const float* colbias
     p.own = a; p.oth = b; p.B = B; p.No = M; p.Ns = N; p.sbias = colbias; p.alpha = alpha;
     p.f0 = rowmax; p.i0 = rowarg;
     return launch(K_ARGMAX, p, D, dtype, stream);
+}
+
+extern "C" int gf_rows_lse_argmax(const void* a, const void* b, const float* bias_z, const float* bias_n,
+                                  float alpha, float* lse, float* rowmax, int64_t* rowarg,
+                                  int B, int M, int N, int D, int dtype, void* stream) {
+    if (bias_z == nullptr || bias_n == nullptr || rowmax == nullptr || rowarg == nullptr) return GF_ERR_SHAPE;
+    HeadParams p = {};
+    p.own = a; p.oth = b; p.B = B; p.No = M; p.Ns = N; p.g0 = bias_z; p.g1 = bias_n; p.alpha = alpha;
+    p.f0 = rowmax; p.i0 = rowarg; p.f1 = lse;
+    return launch(lse ? K_LSEARG : K_ZNARG, p, D, dtype, stream);
 }
 
 extern "C" int gf_assign_write(const void* a, const void* b, const float* rowbias, const float* colbias,

@@ -23,17 +23,9 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// cb0[b,j] = logsigmoid(z1[b,j]) - c[b,j]   (column bias of the row arg-max over image-1 keypoints)
-// cb1[b,i] = logsigmoid(z0[b,i]) - r[b,i]
-__global__ __launch_bounds__(256) void head_prep_kernel(const float* __restrict__ z0, const float* __restrict__ z1,
-                                                        const float* __restrict__ r, const float* __restrict__ c,
-                                                        float* __restrict__ cb0, float* __restrict__ cb1,
-                                                        int64_t nm, int64_t nn) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < nm) cb1[i] = logsig(z0[i]) - r[i];
-    if (i < nn) cb0[i] = logsig(z1[i]) - c[i];
-}
-
+// one wave per chunk of POS_CHUNK consecutive positives; the per-image sums are kept in registers while
+// the batch index stays the same (COO lists from nonzero() are sorted by it) -> a few atomics per wave
+constexpr int POS_CHUNK = 16;
 template <typename T>
 __global__ __launch_bounds__(256) void loss_pos_fwd_kernel(const T* __restrict__ md0, const T* __restrict__ md1,
                                                            const float* __restrict__ z0, const float* __restrict__ z1,
@@ -42,21 +34,28 @@ __global__ __launch_bounds__(256) void loss_pos_fwd_kernel(const T* __restrict__
                                                            const int64_t* __restrict__ pj, int64_t P,
                                                            float* __restrict__ acc, int M, int N, int D) {
     const int lane = threadIdx.x & 63;
-    const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (p >= P) return;
-    const int64_t b = pb[p], i = pi[p], j = pj[p];
-    const T* a = md0 + (b * M + i) * D;
-    const T* q = md1 + (b * N + j) * D;
-    float dot = 0.f;
-    for (int d = lane * 4; d < D; d += 256) {
+    const int64_t p0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * POS_CHUNK;
+    int64_t cur = -1;
+    float run = 0.f;
+    for (int64_t p = p0; p < min(p0 + POS_CHUNK, P); ++p) {
+        const int64_t b = pb[p], i = pi[p], j = pj[p];
+        const T* a = md0 + (b * M + i) * D;
+        const T* q = md1 + (b * N + j) * D;
+        float dot = 0.f;
+        for (int d = lane * 4; d < D; d += 256) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) dot += to_f32(a[d + e]) * to_f32(q[d + e]);
-    }
-    dot = wave_sum(dot);
-    if (lane == 0) {
+            for (int e = 0; e < 4; ++e) dot += to_f32(a[d + e]) * to_f32(q[d + e]);
+        }
+        dot = wave_sum(dot);
         const float v = 2.f * dot - r[b * M + i] - c[b * N + j] + logsig(z0[b * M + i]) + logsig(z1[b * N + j]);
-        atomicAdd(acc + 4 * b, v);
+        if (b != cur) {
+            if (cur >= 0 && lane == 0) atomicAdd(acc + 4 * cur, run);
+            cur = b;
+            run = 0.f;
+        }
+        run += v;
     }
+    if (cur >= 0 && lane == 0) atomicAdd(acc + 4 * cur, run);
 }
 
 // one block per (image, batch element): dustbin NLL terms and token-confidence BCE of that image's tokens
@@ -180,15 +179,6 @@ __global__ __launch_bounds__(256) void loss_pos_bwd_rows_kernel(const T* __restr
 
 }  // namespace
 
-extern "C" int gf_lg_head_prep(const float* z0, const float* z1, const float* r, const float* c,
-                               float* cb0, float* cb1, int B, int M, int N, void* stream) {
-    if (B <= 0 || M <= 0 || N <= 0) return GF_ERR_SHAPE;
-    const int64_t nm = (int64_t)B * M, nn = (int64_t)B * N, mx = nm > nn ? nm : nn;
-    head_prep_kernel<<<dim3((unsigned)((mx + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
-        z0, z1, r, c, cb0, cb1, nm, nn);
-    return (int)hipGetLastError();
-}
-
 extern "C" int gf_lg_loss_fwd(const void* md0, const void* md1, const float* z0, const float* z1,
                               const float* r, const float* c,
                               const int64_t* pos_b, const int64_t* pos_i, const int64_t* pos_j, int64_t P,
@@ -205,7 +195,7 @@ extern "C" int gf_lg_loss_fwd(const void* md0, const void* md1, const float* z0,
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (hipError_t e = hipMemsetAsync(acc, 0, sizeof(float) * 4 * B, st)) return (int)e;
     if (P > 0) {
-        const dim3 grid((unsigned)((P + 3) / 4));
+        const dim3 grid((unsigned)((P + 4 * POS_CHUNK - 1) / (4 * POS_CHUNK)));
         if (dtype == GF_BF16)
             loss_pos_fwd_kernel<bf16_t><<<grid, dim3(256), 0, st>>>(
                 static_cast<const bf16_t*>(md0), static_cast<const bf16_t*>(md1), z0, z1, r, c, pos_b, pos_i, pos_j, P,

@@ -504,21 +504,29 @@ class _LGLayerLoss(torch.autograd.Function):
         a, b = md[:B], md[B:]
         z = z.float().contiguous()
         if rc is None:
-            r, c = rows_lse(a, b), rows_lse(b, a)
+            c = rows_lse(b, a)
+            r = None
         else:
             r, c = (x.detach().float().contiguous() for x in rc)
         pb, pi, pj = (x.contiguous() for x in pos)
         P = pb.shape[0]
         neg0, neg1 = neg0.float().contiguous(), neg1.float().contiguous()
         acc = torch.empty((B, 4), dtype=torch.float32, device=md.device)
-        tgt = v = arg = None
+        tgt = None
+        if t is not None or r is None:      # three passes: c, then (r, row arg-max), then column arg-max
+            st = torch.empty((5, B, N), dtype=torch.float32, device=md.device)
+            ar = torch.empty((2, B, N), dtype=torch.int64, device=md.device)
+            v0, v1, a0, a1 = st[0], st[1], ar[0], ar[1]
+            want_r = r is None
+            if want_r:
+                r = st[2]
+            _lib.check(lib.gf_rows_lse_argmax(_p(a), _p(b), _p(z[B:]), _p(c), 2.0, _p(r) if want_r else None,
+                                              _p(v0), _p(a0), B, N, N, D, _dt(md), _stream()), "gf_rows_lse_argmax")
+            if t is not None:
+                _lib.check(lib.gf_rows_lse_argmax(_p(b), _p(a), _p(z[:B]), _p(r), 2.0, None, _p(v1), _p(a1),
+                                                  B, N, N, D, _dt(md), _stream()), "gf_rows_lse_argmax")
         if t is not None:
             t = t.float().contiguous()
-            cb = torch.empty((2, B, N), dtype=torch.float32, device=md.device)
-            _lib.check(lib.gf_lg_head_prep(_p(z[:B]), _p(z[B:]), _p(r), _p(c), _p(cb[0]), _p(cb[1]), B, N, N,
-                                           _stream()), "gf_lg_head_prep")
-            v0, a0 = rows_argmax(a, b, cb[0], 2.0)
-            v1, a1 = rows_argmax(b, a, cb[1], 2.0)
             tgt = torch.empty((B2, N), dtype=torch.float32, device=md.device)
             fin0, fin1 = fin0.contiguous(), fin1.contiguous()
             extra = (_p(t[:B]), _p(t[B:]), _p(v0), _p(a0), _p(v1), _p(a1), _p(fin0), _p(fin1), _p(tgt[:B]), _p(tgt[B:]))

@@ -84,6 +84,16 @@ int gf_rows_argmax(const void* a, const void* b, const float* colbias, float alp
                    float* rowmax, int64_t* rowarg,
                    int B, int M, int N, int D, int dtype, void* stream);
 
+/* gf_rows_lse_argmax: ONE pass over b for both per-row statistics of a LightGlue head
+ * (lightglue.py:262-263 log_softmax normaliser + lightglue.py:295 / 81-94 row arg-max):
+ *   lse[b,i]              = log sum_j exp(S_ij)                      (skipped when lse == NULL)
+ *   rowmax / rowarg [b,i] = max / argmax_j alpha * S_ij + logsigmoid(bias_z[b,j]) - bias_n[b,j]
+ * Three passes give everything a layer's loss needs: c = gf_rows_lse(b, a);
+ * (r, max0, arg0) = gf_rows_lse_argmax(a, b, z1, c); (max1, arg1) = gf_rows_lse_argmax(b, a, z0, r, lse=NULL). */
+int gf_rows_lse_argmax(const void* a, const void* b, const float* bias_z, const float* bias_n,
+                       float alpha, float* lse, float* rowmax, int64_t* rowarg,
+                       int B, int M, int N, int D, int dtype, void* stream);
+
 /* gf_assign_write: materialise the log assignment (lightglue.py:256-268)
  *   out[b,i,j] = alpha*S_ij + rowbias[b,i] + colbias[b,j]      i<M, j<N
  *   out[b,i,N] = bin_col[b,i];  out[b,M,j] = bin_row[b,j];  out[b,M,N] = corner
@@ -182,17 +192,14 @@ int gf_rowdot_bwd(const void* x, const float* dz, const float* w, void* dx, floa
  * outputs, scaled by D^-1/4), matchability logits z0 [B,M] / z1 [B,N], r [B,M] / c [B,N] (gf_rows_lse),
  * positives as COO (pos_b, pos_i, pos_j)[P] (any order, duplicates allowed), dustbin weights neg0 / neg1.
  *   A_ij = 2 md0_i.md1_j - r_i - c_j + logsig(z0_i) + logsig(z1_j),  A_i,N = logsig(-z0_i),  A_M,j = logsig(-z1_j)
- * gf_lg_head_prep: cb0[b,j] = logsig(z1) - c, cb1[b,i] = logsig(z0) - r  (the colbias of gf_rows_argmax).
  * gf_lg_loss_fwd: acc [B,4] = { sum_pos A_ij, sum_i neg0 A_i,N + sum_j neg1 A_M,j, sum_i bce(t0_i, tgt0_i),
  *   sum_j bce(t1_j, tgt1_j) }.  With token logits t0 / t1 (NULL for the last layer): v0/a0, v1/a1 are the
- *   gf_rows_argmax results with cb0 / cb1, fin0 / fin1 the final layer's arg-max incl. dustbin, and
+ *   gf_rows_lse_argmax results, fin0 / fin1 the final layer's arg-max incl. dustbin, and
  *   tgt0 / tgt1 receive the 0/1 targets (layer arg-max incl. dustbin == final) for the backward.
  * gf_lg_loss_bwd_tokens: from gacc = dL/dacc [B,4]: dz0, dz1, dt0, dt1 (dense) and gr = dL/dr, gc = dL/dc
  *   restricted to the direct terms (the caller feeds them to gf_dual_softmax_bwd).
  * gf_lg_loss_bwd_rows: dmd0[b,i,:] += 2 gacc[b,0] md1[b,j,:], dmd1[b,j,:] += 2 gacc[b,0] md0[b,i,:]
  *   (atomic accumulation INTO dmd, after the dense part has been written). */
-int gf_lg_head_prep(const float* z0, const float* z1, const float* r, const float* c,
-                    float* cb0, float* cb1, int B, int M, int N, void* stream);
 int gf_lg_loss_fwd(const void* md0, const void* md1, const float* z0, const float* z1,
                    const float* r, const float* c,
                    const int64_t* pos_b, const int64_t* pos_i, const int64_t* pos_j, int64_t P,

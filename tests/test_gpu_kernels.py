@@ -324,3 +324,39 @@ def test_rowdot(dtype, M, C):
     for a, r in ((x.grad, xr.grad), (w.grad, wr.grad), (b.grad, br.grad)):
         sc = r.abs().max().item()
         torch.testing.assert_close(a.cpu().double() / sc, r / sc, **tol)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N", [(200, 200), (130, 77)])
+def test_rows_lse_argmax_fused(dtype, M, N):
+    """gf_rows_lse_argmax == (gf_rows_lse, arg-max of 2 S + logsigmoid(z) - n) of a torch fp32 reference."""
+    from glue_factory_amd import lib as L_
+    from glue_factory_amd.ops import _p, _dt, _stream
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    B, D = 3, 256
+    a = (torch.randn(B, M, D, device="cuda", generator=g) * 0.3).to(dtype)
+    b = (torch.randn(B, N, D, device="cuda", generator=g) * 0.3).to(dtype)
+    z = torch.randn(B, N, device="cuda", generator=g)
+    n = torch.randn(B, N, device="cuda", generator=g)
+    S = torch.einsum("bmd,bnd->bmn", a.float(), b.float())
+    ref_lse = torch.logsumexp(S, -1)
+    full = 2.0 * S + (torch.nn.functional.logsigmoid(z) - n)[:, None, :]
+    ref_max, ref_arg = full.max(-1)
+    lse = torch.empty(B, M, device="cuda")
+    vmax = torch.empty(B, M, device="cuda")
+    arg = torch.empty(B, M, dtype=torch.int64, device="cuda")
+    lib = L_.load()
+    for with_lse in (True, False):
+        lse.fill_(-7.0)
+        L_.check(lib.gf_rows_lse_argmax(_p(a), _p(b), _p(z), _p(n), 2.0, _p(lse) if with_lse else None, _p(vmax), _p(arg),
+                                        B, M, N, D, _dt(a), _stream()), "gf_rows_lse_argmax")
+        tol = 1e-4 if dtype == torch.float32 else 2e-2
+        torch.testing.assert_close(vmax, ref_max, rtol=tol, atol=tol)
+        picked = full.gather(-1, arg[..., None]).squeeze(-1)
+        torch.testing.assert_close(picked, ref_max, rtol=tol, atol=tol)      # ties / near-ties may pick a neighbour
+        if dtype == torch.float32:
+            assert (arg == ref_arg).float().mean() > 0.999
+        if with_lse:
+            torch.testing.assert_close(lse, ref_lse, rtol=tol, atol=tol)
+        else:
+            assert (lse == -7.0).all()
