@@ -269,6 +269,8 @@ class LightGlue(nn.Module):
             raise RuntimeError("glue_factory_amd.LightGlue runs on the MI355X HIP path only "
                                "(move the batch to the GPU; there is no CPU fallback)")
         T = self._compute_dtype()  # read the autocast state before switching it off
+        if T != torch.float32:
+            ops.precast(list(self.parameters()), T, key=id(self))   # one multi-tensor cast per step
         with torch.autocast(device_type="cuda", enabled=False):
             return self._forward(data, T)
 

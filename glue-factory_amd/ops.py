@@ -201,6 +201,46 @@ def cross_attention_stacked(p):
 
 
 # ------------------------------------------------------------------------------ linear layer
+# ---- per-step low-precision copies of the fp32 master parameters -------------------------------
+# Every linear casts its weight / bias to the compute dtype; done one by one that is two tiny kernels per
+# layer per step.  precast() converts a whole parameter list with one multi-tensor copy into a flat buffer
+# and _lp() serves the views while the parameter's version counter is unchanged (the optimiser bumps it).
+_LP_CACHE = {}        # id(param) -> (param._version, dtype, view)
+_LP_FLAT = {}         # (key, dtype) -> (flat buffer, [views], [params])
+
+
+def precast(params, dtype, key="default"):
+    params = [p_ for p_ in params if p_.dtype != dtype and p_.is_cuda]
+    if not params:
+        return
+    slot = _LP_FLAT.get((key, dtype))
+    if slot is None or len(slot[2]) != len(params) or any(a is not b for a, b in zip(slot[2], params)):
+        sizes = [(p_.numel() + 7) // 8 * 8 for p_ in params]        # 16-byte aligned bf16 views
+        flat = torch.empty(sum(sizes), dtype=dtype, device=params[0].device)
+        views, off = [], 0
+        for p_, sz in zip(params, sizes):
+            views.append(flat[off:off + p_.numel()].view(p_.shape))
+            off += sz
+        slot = (flat, views, params)
+        _LP_FLAT[(key, dtype)] = slot
+    elif all(_LP_CACHE.get(id(p_), (None,))[0] == p_._version for p_ in params):
+        return                       # nothing changed since the last cast (e.g. two forwards per step)
+    with torch.no_grad():
+        torch._foreach_copy_(slot[1], [p_.detach() for p_ in params])
+    for p_, v in zip(params, slot[1]):
+        _LP_CACHE[id(p_)] = (p_._version, dtype, v, p_)
+
+
+def _lp(t, dtype):
+    """t in `dtype`: the precast copy when it is current, else a fresh cast."""
+    if t is None or t.dtype == dtype:
+        return t
+    hit = _LP_CACHE.get(id(t))
+    if hit is not None and hit[3] is t and hit[0] == t._version and hit[1] == dtype:
+        return hit[2]
+    return t.to(dtype)
+
+
 class _Linear(torch.autograd.Function):
     """y = x W^T + b with the forward / input-gradient GEMMs on the library (hipBLASLt) and the
     weight / bias gradient (a tiny-output, 1e5-deep reduction) on the split-M MFMA kernel
@@ -208,8 +248,8 @@ class _Linear(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b):
-        wt = w.to(x.dtype)
-        y = torch.nn.functional.linear(x, wt, None if b is None else b.to(x.dtype))
+        wt = _lp(w, x.dtype)
+        y = torch.nn.functional.linear(x, wt, _lp(b, x.dtype))
         ctx.save_for_backward(x, wt)
         ctx.wdtype = w.dtype
         ctx.has_bias = b is not None
@@ -267,8 +307,8 @@ class _LinearCat(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x1, x2, w, b):
         k1 = x1.shape[-1]
-        wt = w.to(x1.dtype)
-        y = torch.nn.functional.linear(x1, wt[:, :k1], None if b is None else b.to(x1.dtype))
+        wt = _lp(w, x1.dtype)
+        y = torch.nn.functional.linear(x1, wt[:, :k1], _lp(b, x1.dtype))
         y.view(-1, y.shape[-1]).addmm_(x2.reshape(-1, x2.shape[-1]), wt[:, k1:].t())
         ctx.save_for_backward(x1, x2, wt)
         ctx.wdtype = w.dtype
