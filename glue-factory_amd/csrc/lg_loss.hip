@@ -39,6 +39,7 @@ __global__ __launch_bounds__(256) void loss_pos_fwd_kernel(const T* __restrict__
     float run = 0.f;
     for (int64_t p = p0; p < min(p0 + POS_CHUNK, P); ++p) {
         const int64_t b = pb[p], i = pi[p], j = pj[p];
+        if (j < 0) continue;                                   // fixed-length list: "row has no positive"
         const T* a = md0 + (b * M + i) * D;
         const T* q = md1 + (b * N + j) * D;
         float dot = 0.f;
@@ -141,6 +142,7 @@ __global__ __launch_bounds__(256) void loss_pos_bwd_scalar_kernel(const float* _
                                                                   float* __restrict__ gr, float* __restrict__ gc, int M, int N) {
     const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (p >= P) return;
+    if (pj[p] < 0) return;
     const int64_t b = pb[p], f0 = b * M + pi[p], f1 = b * N + pj[p];
     const float g = gacc[4 * b];
     atomicAdd(gr + f0, -g);
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(256) void loss_pos_bwd_rows_kernel(const T* __restr
                                                                 T* __restrict__ dmd1, int M, int N, int D) {
     const int lane = threadIdx.x & 63;
     const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (p >= P) return;
+    if (p >= P || pj[p] < 0) return;
     const int64_t b = pb[p], o0 = (b * M + pi[p]) * D, o1 = (b * N + pj[p]) * D;
     const float g2 = 2.f * gacc[4 * b];
     for (int d = lane * 2; d < D; d += 128) {

@@ -64,7 +64,10 @@ def gt_matches_from_homography_fused(kp0, kp1, H, pos_th=3.0, neg_th=3.0, with_r
     m1 = torch.where(own1 > neg_th ** 2, torch.full_like(m1, UNMATCHED_FEATURE), m1)
     out = {"assignment": positive, "matches0": m0, "matches1": m1,
            "matching_scores0": (m0 > -1).float(), "matching_scores1": (m1 > -1).float(),
-           "proj_0to1": kp0_1, "proj_1to0": kp1_0}
+           "proj_0to1": kp0_1, "proj_1to0": kp1_0,
+           # private extra: the (at most one) positive column of every row of `assignment`, -1 if none.
+           # Lets the sparse losses skip nonzero() on the dense matrix (a 134 MB scan + a host sync).
+           "assignment_col0": torch.where(pos0, min0, torch.full_like(min0, -1))}
     if with_reward:
         dist0 = ((kp0_1[:, :, None] - kp1[:, None]) ** 2).sum(-1)
         dist1 = ((kp0[:, :, None] - kp1_0[:, None]) ** 2).sum(-1)
@@ -107,6 +110,7 @@ def gt_matches_from_homography(kp0, kp1, H, pos_th=3.0, neg_th=3.0):
     m1 = torch.where(neg1, torch.full_like(m1, UNMATCHED_FEATURE), m1)
     return {
         "assignment": positive,
+        "assignment_col0": torch.where(pos0, min0, torch.full_like(min0, -1)),
         "reward": reward,
         "matches0": m0,
         "matches1": m1,

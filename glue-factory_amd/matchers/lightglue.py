@@ -426,15 +426,25 @@ class LightGlue(nn.Module):
 
     # ------------------------------------------------------------------ loss
     @staticmethod
-    def _gt_sparse(data):
+    def _gt_sparse(data, fixed=False):
         """COO positives and dustbin masks of the dense weight matrix of
-        utils/losses.py:62-73 (weights = gt_assignment, (gt_matches0==-1), (gt_matches1==-1))."""
-        pos = data["gt_assignment"].nonzero(as_tuple=True)     # (b, i, j), one sync per step
+        utils/losses.py:62-73 (weights = gt_assignment, (gt_matches0==-1), (gt_matches1==-1)).
+        fixed=True (fused loss only): when the ground-truth producer also supplied
+        ``gt_assignment_col0`` (the single positive column of each row, -1 if none) the list has the fixed
+        length B*M with -1 marking "no positive": no scan of the dense matrix and no host sync."""
         neg0 = (data["gt_matches0"] == -1).float()
         neg1 = (data["gt_matches1"] == -1).float()
-        bsz = data["gt_assignment"].shape[0]
-        num_pos = torch.zeros(bsz, device=neg0.device).index_add_(
-            0, pos[0], torch.ones_like(pos[0], dtype=torch.float32)).clamp(min=1.0)
+        bsz, m = neg0.shape
+        col0 = data.get("gt_assignment_col0") if fixed else None
+        if col0 is not None:
+            dev = neg0.device
+            pos = (torch.arange(bsz, device=dev).repeat_interleave(m),
+                   torch.arange(m, device=dev).repeat(bsz), col0.reshape(-1).long())
+            num_pos = (col0 >= 0).sum(-1).float().clamp(min=1.0)
+        else:
+            pos = data["gt_assignment"].nonzero(as_tuple=True)     # (b, i, j), one sync per step
+            num_pos = torch.zeros(bsz, device=neg0.device).index_add_(
+                0, pos[0], torch.ones_like(pos[0], dtype=torch.float32)).clamp(min=1.0)
         return {"pos": pos, "neg0": neg0, "neg1": neg1, "num_pos": num_pos,
                 "n0": neg0.sum(-1).clamp(min=1.0), "n1": neg1.sum(-1).clamp(min=1.0)}
 
@@ -509,11 +519,10 @@ class LightGlue(nn.Module):
     def _loss(self, pred, data):
         rd0, rd1 = pred["ref_descriptors0"], pred["ref_descriptors1"]
         L = rd0.shape[1]
-        gt = self._gt_sparse(data)
-
         layer_x = pred.get("_layer_desc")
         if layer_x is not None and self.training and "_final_argmax0" in pred:
-            return self._loss_fused(pred, data, gt)
+            return self._loss_fused(pred, data, self._gt_sparse(data, fixed=True))
+        gt = self._gt_sparse(data)
 
         def head(i):
             if layer_x is not None:

@@ -58,6 +58,7 @@ def make_pairs(batch, n0, n1=None, dim=256, size=(1024, 1024), seed=0, frac_matc
     if with_gt:
         gt = gt_matches_from_homography(kp0, kp1, H, pos_th=3.0, neg_th=3.0)
         data["gt_assignment"] = gt["assignment"]
+        data["gt_assignment_col0"] = gt["assignment_col0"]
         data["gt_matches0"] = gt["matches0"]
         data["gt_matches1"] = gt["matches1"]
     return data
@@ -129,6 +130,6 @@ def make_point_line_pairs(batch, n_kpts, n_lines, dim=256, size=(1024, 1024), se
                  "line_scores0": torch.rand(batch, n_lines, generator=g),
                  "line_scores1": torch.rand(batch, n_lines, generator=g)})
     gt = gt_matches_from_homography(data["keypoints0"], data["keypoints1"], H, pos_th=3.0, neg_th=3.0)
-    data.update({"gt_assignment": gt["assignment"], "gt_matches0": gt["matches0"], "gt_matches1": gt["matches1"],
+    data.update({"gt_assignment": gt["assignment"], "gt_assignment_col0": gt["assignment_col0"], "gt_matches0": gt["matches0"], "gt_matches1": gt["matches1"],
                  "gt_line_assignment": gt_la, "gt_line_matches0": gt_l0, "gt_line_matches1": gt_l1})
     return data

@@ -190,7 +190,8 @@ int gf_rowdot_bwd(const void* x, const float* dz, const float* w, void* dx, floa
  * utils/losses.py:6-73 NLL with dustbins on the non-zero weights, lightglue.py:81-94 token confidence).
  * Inputs are the head statistics, never the [B,M+1,N+1] matrix: md0 [B,M,D] / md1 [B,N,D] (final_proj
  * outputs, scaled by D^-1/4), matchability logits z0 [B,M] / z1 [B,N], r [B,M] / c [B,N] (gf_rows_lse),
- * positives as COO (pos_b, pos_i, pos_j)[P] (any order, duplicates allowed), dustbin weights neg0 / neg1.
+ * positives as COO (pos_b, pos_i, pos_j)[P] (any order, duplicates allowed; entries with pos_j < 0 are
+ * skipped, so a fixed-length "one slot per row" list needs no compaction), dustbin weights neg0 / neg1.
  *   A_ij = 2 md0_i.md1_j - r_i - c_j + logsig(z0_i) + logsig(z1_j),  A_i,N = logsig(-z0_i),  A_M,j = logsig(-z1_j)
  * gf_lg_loss_fwd: acc [B,4] = { sum_pos A_ij, sum_i neg0 A_i,N + sum_j neg1 A_M,j, sum_i bce(t0_i, tgt0_i),
  *   sum_j bce(t1_j, tgt1_j) }.  With token logits t0 / t1 (NULL for the last layer): v0/a0, v1/a1 are the

@@ -153,3 +153,29 @@ def test_eval_adaptive_depth_and_width():
     assert (o3["matches0"][o3["prune0"] < L] == -1).all()
     valid = o3["matches0"] > -1
     assert (o3["matches1"][0, o3["matches0"][valid]] == valid.nonzero()[:, 1]).all()
+
+
+def test_fixed_length_positives_equal_dense_nonzero():
+    """gt_assignment_col0 (no dense scan, no host sync) and nonzero(gt_assignment) give the same step."""
+    from glue_factory_amd.synthetic import make_pairs
+    L = 3
+    params = lgo.init_params(L, 256, 4, seed=11)
+    data = _to_cuda(make_pairs(3, 320, dim=256, size=(640, 480), seed=12))
+    assert "gt_assignment_col0" in data
+    col = data["gt_assignment_col0"]
+    dense = torch.zeros_like(data["gt_assignment"])
+    dense.scatter_(2, col.clamp(min=0)[..., None], (col >= 0)[..., None])
+    assert torch.equal(dense, data["gt_assignment"])
+    out = []
+    for drop in (False, True):
+        model = _model(params, L).train()
+        d = {k: v for k, v in data.items() if not (drop and k == "gt_assignment_col0")}
+        pred = model(d)
+        losses, _ = model.loss(pred, {**pred, **d})
+        losses["total"].mean().backward()
+        out.append((losses, {k: p.grad.clone() for k, p in model.named_parameters()}))
+    for k in out[0][0]:
+        torch.testing.assert_close(out[0][0][k], out[1][0][k], rtol=1e-5, atol=1e-6, msg=lambda m: f"{k}: {m}")
+    for k in out[0][1]:
+        sc = max(out[1][1][k].abs().max().item(), 1e-9)
+        torch.testing.assert_close(out[0][1][k] / sc, out[1][1][k] / sc, rtol=1e-4, atol=1e-5, msg=lambda m: f"{k}: {m}")
