@@ -138,6 +138,14 @@ def micro_bench(batch, n, dtype):
     out["ln_gelu_fwd_us"] = round(time_kernel(lambda: ops.ln_gelu(x, gam, bet)) * 1e6, 1)
     dy = torch.randn_like(y)
     out["ln_gelu_fwd+bwd_us"] = round(time_kernel(lambda: ops.ln_gelu(xr, gam, bet).backward(dy)) * 1e6, 1)
+    mean = torch.zeros(M, device=dev)
+    rstd = torch.ones(M, device=dev)
+    nblk = lib.gf_ln_gelu_nblk(M)
+    dxb, dgp, dbp = torch.empty_like(x), torch.empty(nblk, 512, device=dev), torch.empty(nblk, 512, device=dev)
+    out["ln_gelu_bwd_kernel_us"] = round(time_kernel(lambda: lib.gf_ln_gelu_bwd(
+        x.data_ptr(), gam.data_ptr(), bet.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dy.data_ptr(), dxb.data_ptr(),
+        dgp.data_ptr(), dbp.data_ptr(), M, 512, 1 if dtype == torch.bfloat16 else 0,
+        torch.cuda.current_stream().cuda_stream)) * 1e6, 1)
     a = torch.randn(batch, n, 256, device=dev, dtype=dtype, generator=g) * 0.5
     b = torch.randn(batch, n, 256, device=dev, dtype=dtype, generator=g) * 0.5
     out["rows_lse_us"] = round(time_kernel(lambda: ops.rows_lse(a, b)) * 1e6, 1)

@@ -61,7 +61,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 // reuses the same exp(-z^2/2) for the Gaussian density term.
 __device__ __forceinline__ void gelu_parts(float z, float& cdf, float& pdf) {
     const float x = fabsf(z) * 0.70710678118654752f;
-    const float t = __frcp_rn(1.f + 0.3275911f * x);
+    const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * x);   // v_rcp_f32 (1 ulp); __frcp_rn is a full IEEE divide
     const float e = __expf(-x * x);                       // = exp(-z^2 / 2)
     const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
     const float erf_abs = 1.f - poly * e;
@@ -82,13 +82,14 @@ __device__ __forceinline__ float gelu_grad(float z) {
 template <typename T> struct Chunk { static constexpr int VEC = 16 / sizeof(T); };
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-template <typename T, int NCH>
+// FULL: C == NCH * 64 * VEC, every lane's chunk is inside the row (no exec-masked branches)
+template <typename T, int NCH, bool FULL = false>
 __device__ __forceinline__ void load_row(float (&x)[NCH][16 / sizeof(T)], const T* row, int C, int lane) {
     constexpr int VEC = 16 / sizeof(T);
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
         int col = (ch * 64 + lane) * VEC;
-        if (col < C) {
+        if (FULL || col < C) {
             union { u32x4 u; T e[VEC]; } v;
             v.u = *reinterpret_cast<const u32x4*>(row + col);
 #pragma unroll
@@ -99,13 +100,13 @@ __device__ __forceinline__ void load_row(float (&x)[NCH][16 / sizeof(T)], const 
         }
     }
 }
-template <typename T, int NCH>
+template <typename T, int NCH, bool FULL = false>
 __device__ __forceinline__ void store_row(T* row, const float (&y)[NCH][16 / sizeof(T)], int C, int lane) {
     constexpr int VEC = 16 / sizeof(T);
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
         int col = (ch * 64 + lane) * VEC;
-        if (col < C) {
+        if (FULL || col < C) {
             union { u32x4 u; T e[VEC]; } v;
 #pragma unroll
             for (int e = 0; e < VEC; ++e) v.e[e] = from_f32<T>(y[ch][e]);
@@ -114,7 +115,7 @@ __device__ __forceinline__ void store_row(T* row, const float (&y)[NCH][16 / siz
     }
 }
 
-template <typename T, int NCH>
+template <typename T, int NCH, bool FULL>
 __global__ __launch_bounds__(256) void ln_gelu_fwd_kernel(const T* x, const float* gamma, const float* beta, T* y,
                                                           float* mean, float* rstd, int R, int C, float eps) {
     constexpr int VEC = 16 / sizeof(T);
@@ -125,43 +126,70 @@ __global__ __launch_bounds__(256) void ln_gelu_fwd_kernel(const T* x, const floa
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
             int col = (ch * 64 + lane) * VEC + e;
-            g[ch][e] = col < C ? gamma[col] : 0.f;
-            bt[ch][e] = col < C ? beta[col] : 0.f;
+            g[ch][e] = (FULL || col < C) ? gamma[col] : 0.f;
+            bt[ch][e] = (FULL || col < C) ? beta[col] : 0.f;
         }
-    for (int row = blockIdx.x * 4 + wave; row < R; row += gridDim.x * 4) {
-        float v[NCH][VEC];
-        load_row<T, NCH>(v, x + (int64_t)row * C, C, lane);
+    // RPI rows per wave and iteration, the next ones prefetched
+    constexpr int RPI = 1;       // 2 rows per iteration measured no faster
+    const int stride = gridDim.x * 4 * RPI;
+    const float inv_c = 1.f / C;
+    int row = (blockIdx.x * 4 + wave) * RPI;
+    float nxt[RPI][NCH][VEC];
+#pragma unroll
+    for (int r = 0; r < RPI; ++r)
+        if (row + r < R) load_row<T, NCH, FULL>(nxt[r], x + (int64_t)(row + r) * C, C, lane);
+    for (; row < R; row += stride) {
+        float v[RPI][NCH][VEC];
+#pragma unroll
+        for (int r = 0; r < RPI; ++r)
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) v[r][ch][e] = nxt[r][ch][e];
+#pragma unroll
+        for (int r = 0; r < RPI; ++r)
+            if (row + stride + r < R) load_row<T, NCH, FULL>(nxt[r], x + (int64_t)(row + stride + r) * C, C, lane);
         // shifted single pass: sums of d = x - x0 and d^2 (x0 = the row's first element keeps the
-        // cancellation of E[d^2] - E[d]^2 harmless); the two butterflies are independent and interleave
-        const float x0 = __shfl(v[0][0], 0);
-        float s = 0.f, q = 0.f;
+        // cancellation of E[d^2] - E[d]^2 harmless)
+        float x0[RPI], s[RPI], q[RPI];
 #pragma unroll
-        for (int ch = 0; ch < NCH; ++ch)
+        for (int r = 0; r < RPI; ++r) {
+            x0[r] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[r][0][0]), 0));
+            s[r] = 0.f;
+            q[r] = 0.f;
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                int col = (ch * 64 + lane) * VEC + e;
-                float d = col < C ? v[ch][e] - x0 : 0.f;
-                s += d;
-                q += d * d;
-            }
+            for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            s += __shfl_xor(s, off);
-            q += __shfl_xor(q, off);
+                for (int e = 0; e < VEC; ++e) {
+                    int col = (ch * 64 + lane) * VEC + e;
+                    float d = (FULL || col < C) ? v[r][ch][e] - x0[r] : 0.f;
+                    s[r] += d;
+                    q[r] += d * d;
+                }
         }
-        const float md = s / C;
-        const float mu = x0 + md;
-        const float rs = rsqrtf(fmaxf(q / C - md * md, 0.f) + eps);
 #pragma unroll
-        for (int ch = 0; ch < NCH; ++ch)
+        for (int r = 0; r < RPI; ++r) {
+            s[r] = wave_allsum(s[r]);
+            q[r] = wave_allsum(q[r]);
+        }
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) v[ch][e] = gelu_f((v[ch][e] - mu) * rs * g[ch][e] + bt[ch][e]);
-        store_row<T, NCH>(y + (int64_t)row * C, v, C, lane);
-        if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+        for (int r = 0; r < RPI; ++r) {
+            if (row + r >= R) break;
+            const float md = s[r] * inv_c;
+            const float mu = x0[r] + md;
+            const float rs = rsqrtf(fmaxf(q[r] * inv_c - md * md, 0.f) + eps);
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e)
+                    v[r][ch][e] = gelu_f((v[r][ch][e] - mu) * rs * g[ch][e] + bt[ch][e]);
+            store_row<T, NCH, FULL>(y + (int64_t)(row + r) * C, v[r], C, lane);
+            if (lane == 0) { mean[row + r] = mu; rstd[row + r] = rs; }
+        }
     }
 }
 
-template <typename T, int NCH>
+template <typename T, int NCH, bool FULL>
 __global__ __launch_bounds__(256) void ln_gelu_bwd_kernel(const T* x, const float* gamma, const float* beta,
                                                           const float* mean, const float* rstd, const T* dy, T* dx,
                                                           float* dgamma_part, float* dbeta_part, int R, int C) {
@@ -175,15 +203,29 @@ __global__ __launch_bounds__(256) void ln_gelu_bwd_kernel(const T* x, const floa
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
             int col = (ch * 64 + lane) * VEC + e;
-            g[ch][e] = col < C ? gamma[col] : 0.f;
-            bt[ch][e] = col < C ? beta[col] : 0.f;
+            g[ch][e] = (FULL || col < C) ? gamma[col] : 0.f;
+            bt[ch][e] = (FULL || col < C) ? beta[col] : 0.f;
             dg[ch][e] = 0.f;
             db[ch][e] = 0.f;
         }
-    for (int row = blockIdx.x * 4 + wave; row < R; row += gridDim.x * 4) {
+    const int stride = gridDim.x * 4;
+    const float inv_c = 1.f / C;
+    int row = blockIdx.x * 4 + wave;
+    float nv[NCH][VEC], nd[NCH][VEC];
+    if (row < R) {
+        load_row<T, NCH, FULL>(nv, x + (int64_t)row * C, C, lane);
+        load_row<T, NCH, FULL>(nd, dy + (int64_t)row * C, C, lane);
+    }
+    for (; row < R; row += stride) {
         float v[NCH][VEC], d[NCH][VEC];
-        load_row<T, NCH>(v, x + (int64_t)row * C, C, lane);
-        load_row<T, NCH>(d, dy + (int64_t)row * C, C, lane);
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { v[ch][e] = nv[ch][e]; d[ch][e] = nd[ch][e]; }
+        if (row + stride < R) {                                                                   // prefetch
+            load_row<T, NCH, FULL>(nv, x + (int64_t)(row + stride) * C, C, lane);
+            load_row<T, NCH, FULL>(nd, dy + (int64_t)(row + stride) * C, C, lane);
+        }
         const float mu = mean[row], rs = rstd[row];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -193,7 +235,7 @@ __global__ __launch_bounds__(256) void ln_gelu_bwd_kernel(const T* x, const floa
                 int col = (ch * 64 + lane) * VEC + e;
                 float xh = (v[ch][e] - mu) * rs;
                 float z = xh * g[ch][e] + bt[ch][e];
-                float dz = col < C ? d[ch][e] * gelu_grad(z) : 0.f;
+                float dz = (FULL || col < C) ? d[ch][e] * gelu_grad(z) : 0.f;
                 dg[ch][e] += dz * xh;
                 db[ch][e] += dz;
                 float dxh = dz * g[ch][e];
@@ -202,12 +244,12 @@ __global__ __launch_bounds__(256) void ln_gelu_bwd_kernel(const T* x, const floa
                 s1 += dxh;
                 s2 += dxh * xh;
             }
-        const float m1 = wave_sum(s1) / C, m2 = wave_sum(s2) / C;
+        const float m1 = wave_allsum(s1) * inv_c, m2 = wave_allsum(s2) * inv_c;
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
             for (int e = 0; e < VEC; ++e) d[ch][e] = rs * (d[ch][e] - m1 - v[ch][e] * m2);
-        store_row<T, NCH>(dx + (int64_t)row * C, d, C, lane);
+        store_row<T, NCH, FULL>(dx + (int64_t)row * C, d, C, lane);
     }
     // reduce the 4 waves' column partials through LDS, one partial row per block
     constexpr int W = NCH * 64 * VEC;
@@ -231,7 +273,7 @@ __global__ __launch_bounds__(256) void ln_gelu_bwd_kernel(const T* x, const floa
 
 int ln_blocks(int R) {
     int nb = (R + 3) / 4;
-    return nb < 1 ? 1 : (nb > 1024 ? 1024 : nb);
+    return nb < 1 ? 1 : (nb > 2048 ? 2048 : nb);
 }
 
 template <typename T> int ln_nch(int C) {
@@ -250,12 +292,17 @@ int ln_fwd_t(const void* x, const float* gamma, const float* beta, void* y, floa
     int nb = ln_blocks(R);
     const T* xp = reinterpret_cast<const T*>(x);
     T* yp = reinterpret_cast<T*>(y);
-    switch (ln_nch<T>(C)) {
-        case 1: ln_gelu_fwd_kernel<T, 1><<<nb, 256, 0, st>>>(xp, gamma, beta, yp, mean, rstd, R, C, eps); break;
-        case 2: ln_gelu_fwd_kernel<T, 2><<<nb, 256, 0, st>>>(xp, gamma, beta, yp, mean, rstd, R, C, eps); break;
-        case 4: ln_gelu_fwd_kernel<T, 4><<<nb, 256, 0, st>>>(xp, gamma, beta, yp, mean, rstd, R, C, eps); break;
+    constexpr int VEC = 16 / sizeof(T);
+    const int nch = ln_nch<T>(C);
+    const bool full = nch > 0 && C == nch * 64 * VEC;
+#define GF_LN_FWD(N_, F_) ln_gelu_fwd_kernel<T, N_, F_><<<nb, 256, 0, st>>>(xp, gamma, beta, yp, mean, rstd, R, C, eps)
+    switch (nch) {
+        case 1: if (full) GF_LN_FWD(1, true); else GF_LN_FWD(1, false); break;
+        case 2: if (full) GF_LN_FWD(2, true); else GF_LN_FWD(2, false); break;
+        case 4: if (full) GF_LN_FWD(4, true); else GF_LN_FWD(4, false); break;
         default: return GF_ERR_UNSUPPORTED;
     }
+#undef GF_LN_FWD
     return (int)hipGetLastError();
 }
 
@@ -270,11 +317,14 @@ int ln_bwd_t(const void* x, const float* gamma, const float* beta, const float* 
     int nch = ln_nch<T>(C);
     if (nch < 0) return GF_ERR_UNSUPPORTED;
     size_t lds = (size_t)8 * nch * 64 * VEC * sizeof(float);
+    const bool full = C == nch * 64 * VEC;
+#define GF_LN_BWD(N_, F_) ln_gelu_bwd_kernel<T, N_, F_><<<nb, 256, lds, st>>>(xp, gamma, beta, mean, rstd, dyp, dxp, dgp, dbp, R, C)
     switch (nch) {
-        case 1: ln_gelu_bwd_kernel<T, 1><<<nb, 256, lds, st>>>(xp, gamma, beta, mean, rstd, dyp, dxp, dgp, dbp, R, C); break;
-        case 2: ln_gelu_bwd_kernel<T, 2><<<nb, 256, lds, st>>>(xp, gamma, beta, mean, rstd, dyp, dxp, dgp, dbp, R, C); break;
-        default: ln_gelu_bwd_kernel<T, 4><<<nb, 256, lds, st>>>(xp, gamma, beta, mean, rstd, dyp, dxp, dgp, dbp, R, C); break;
+        case 1: if (full) GF_LN_BWD(1, true); else GF_LN_BWD(1, false); break;
+        case 2: if (full) GF_LN_BWD(2, true); else GF_LN_BWD(2, false); break;
+        default: if (full) GF_LN_BWD(4, true); else GF_LN_BWD(4, false); break;
     }
+#undef GF_LN_BWD
     return (int)hipGetLastError();
 }
 

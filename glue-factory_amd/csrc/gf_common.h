@@ -114,6 +114,24 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 __device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
 __device__ __forceinline__ float xhalf(float x) { return __shfl_xor(x, 32); }
 
+// Sum over the 64 lanes, result in every lane, without touching the LDS pipe: a __shfl_xor butterfly
+// lowers to six dependent ds_bpermute round trips; DPP moves run at VALU rate.  Steps: quad_perm
+// [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror leave the 16-lane row sum in every lane of
+// the row; the four row sums meet through v_readlane.
+__device__ __forceinline__ float row16_allsum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false));
+    return v;
+}
+__device__ __forceinline__ float wave_allsum(float v) {
+    v = row16_allsum(v);
+    const int b = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16)) +
+           __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+}
+
 // Logical block index such that consecutive logical blocks run on the same XCD (block b is
 // dispatched to XCD b % 8): each XCD walks one contiguous chunk of the logical range, so
 // blocks sharing K/V (or md1) panels hit the same private L2.  Bijective for any total.
