@@ -9,6 +9,30 @@
 
 namespace {
 
+typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void load8(float (&x)[8], const bf16_t* p) {
+    union { u32x4_ u; bf16_t e[8]; } v;
+    v.u = *reinterpret_cast<const u32x4_*>(p);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = (float)v.e[e];
+}
+__device__ __forceinline__ void load8(float (&x)[8], const float* p) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { x[e] = a[e]; x[4 + e] = b[e]; }
+}
+__device__ __forceinline__ void store8(bf16_t* p, const float (&x)[8]) {
+    union { u32x4_ u; bf16_t e[8]; } v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v.e[e] = (bf16_t)x[e];
+    *reinterpret_cast<u32x4_*>(p) = v.u;
+}
+__device__ __forceinline__ void store8(float* p, const float (&x)[8]) {
+    f32x4 a = {x[0], x[1], x[2], x[3]}, b = {x[4], x[5], x[6], x[7]};
+    *reinterpret_cast<f32x4*>(p) = a;
+    *reinterpret_cast<f32x4*>(p + 4) = b;
+}
+
 // ---------------------------------------------------------------------------- rotary
 // qkv: [B*N, 3, H, D]; lane -> (half = q|k, pair i); loop over heads.
 template <typename T, bool INVERSE, bool WITH_DTHETA>
@@ -45,6 +69,52 @@ __global__ __launch_bounds__(256) void rotary_kernel(T* qkv, const T* yrot, cons
                 } else {
                     atomicAdd(&dtheta[tok * npair + i], acc);
                 }
+            }
+        }
+    }
+}
+
+// Vector form for D % 8 == 0 and 2*H*D <= 512 (LightGlue: H=4, D=64 -> exactly one wave per token): the q|k
+// block of a token is 2*H*D contiguous elements; lane w owns elements [8w, 8w+8) = 4 rotation pairs of one
+// head (one 16-byte load/store in bf16), cos/sin come as 8 consecutive floats.  The angle gradient sums
+// over the 2H lanes that share the same channel chunk (lane bits >= log2(D/8)).
+template <typename T, bool INVERSE, bool WITH_DTHETA>
+__global__ __launch_bounds__(256) void rotary_vec_kernel(T* qkv, const T* yrot, const float* cs, float* dtheta,
+                                                         int64_t tokens, int H, int D) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int W = 2 * H * D / 8, cpd = D / 8;           // work items per token, chunks per head
+    const bool active = lane < W;
+    const int d0 = (lane % cpd) * 8;
+    for (int64_t tok = (int64_t)blockIdx.x * 4 + wave; tok < tokens; tok += (int64_t)gridDim.x * 4) {
+        float x[8], y[8], c[8];
+        T* base = qkv + tok * 3 * H * D + lane * 8;
+        if (active) {
+            load8(x, base);
+            if (WITH_DTHETA) load8(y, yrot + tok * 3 * H * D + lane * 8);
+            const f32x4 c0 = *reinterpret_cast<const f32x4*>(cs + tok * D + d0);
+            const f32x4 c1 = *reinterpret_cast<const f32x4*>(cs + tok * D + d0 + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { c[e] = c0[e]; c[4 + e] = c1[e]; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { x[e] = 0.f; y[e] = 0.f; c[e] = 0.f; }
+        }
+        float acc[4], o[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float co = c[2 * i], si = INVERSE ? -c[2 * i + 1] : c[2 * i + 1];
+            if (WITH_DTHETA) acc[i] = x[2 * i + 1] * y[2 * i] - x[2 * i] * y[2 * i + 1];   // x = upstream gradient
+            o[2 * i] = x[2 * i] * co - x[2 * i + 1] * si;
+            o[2 * i + 1] = x[2 * i + 1] * co + x[2 * i] * si;
+        }
+        if (active) store8(base, o);
+        if (WITH_DTHETA) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                for (int off = cpd; off < 64; off <<= 1) acc[i] += __shfl_xor(acc[i], off);
+            if (lane < cpd) {
+                f32x4 v = {acc[0], acc[1], acc[2], acc[3]};
+                *reinterpret_cast<f32x4*>(dtheta + tok * (D / 2) + lane * 4) = v;
             }
         }
     }
@@ -330,19 +400,29 @@ int ln_bwd_t(const void* x, const float* gamma, const float* beta, const float* 
 
 }  // namespace
 
+// vector kernel: D % 8 == 0, one work item per lane, power-of-two chunk count per head (dtheta butterfly)
+static bool rotary_vec_ok(int H, int D) {
+    const int cpd = D / 8;
+    return D % 8 == 0 && 2 * H * D / 8 <= 64 && (cpd & (cpd - 1)) == 0 && (64 % cpd) == 0;
+}
+
 extern "C" int gf_rotary_qk(void* qkv, const float* cs, int B, int N, int H, int D, int inverse,
                             int dtype, void* stream) {
     if (B <= 0 || N <= 0 || H <= 0 || D <= 0 || (D & 1)) return GF_ERR_SHAPE;
+    if (dtype != GF_F32 && dtype != GF_BF16) return GF_ERR_DTYPE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     int64_t tokens = (int64_t)B * N;
-    int nb = (int)((tokens + 3) / 4 > 4096 ? 4096 : (tokens + 3) / 4);
+    int nb = (int)((tokens + 3) / 4 > 8192 ? 8192 : (tokens + 3) / 4);
+    const bool vec = rotary_vec_ok(H, D);
+#define GF_ROT(K, T, INV) K<T, INV, false><<<nb, 256, 0, st>>>((T*)qkv, nullptr, cs, nullptr, tokens, H, D)
     if (dtype == GF_F32) {
-        if (inverse) rotary_kernel<float, true, false><<<nb, 256, 0, st>>>((float*)qkv, nullptr, cs, nullptr, tokens, H, D);
-        else rotary_kernel<float, false, false><<<nb, 256, 0, st>>>((float*)qkv, nullptr, cs, nullptr, tokens, H, D);
-    } else if (dtype == GF_BF16) {
-        if (inverse) rotary_kernel<bf16_t, true, false><<<nb, 256, 0, st>>>((bf16_t*)qkv, nullptr, cs, nullptr, tokens, H, D);
-        else rotary_kernel<bf16_t, false, false><<<nb, 256, 0, st>>>((bf16_t*)qkv, nullptr, cs, nullptr, tokens, H, D);
-    } else return GF_ERR_DTYPE;
+        if (vec) { if (inverse) GF_ROT(rotary_vec_kernel, float, true); else GF_ROT(rotary_vec_kernel, float, false); }
+        else { if (inverse) GF_ROT(rotary_kernel, float, true); else GF_ROT(rotary_kernel, float, false); }
+    } else {
+        if (vec) { if (inverse) GF_ROT(rotary_vec_kernel, bf16_t, true); else GF_ROT(rotary_vec_kernel, bf16_t, false); }
+        else { if (inverse) GF_ROT(rotary_kernel, bf16_t, true); else GF_ROT(rotary_kernel, bf16_t, false); }
+    }
+#undef GF_ROT
     return (int)hipGetLastError();
 }
 
@@ -350,14 +430,15 @@ extern "C" int gf_rotary_qk_bwd(void* dqkv, const void* qkv_rot, const float* cs
                                 int B, int N, int H, int D, int dtype, void* stream) {
     if (B <= 0 || N <= 0 || H <= 0 || D <= 0 || (D & 1)) return GF_ERR_SHAPE;
     if (D > 64) return GF_ERR_UNSUPPORTED;  // keeps the q/k pair reduction inside one wave pass
+    if (dtype != GF_F32 && dtype != GF_BF16) return GF_ERR_DTYPE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     int64_t tokens = (int64_t)B * N;
-    int nb = (int)((tokens + 3) / 4 > 4096 ? 4096 : (tokens + 3) / 4);
-    if (dtype == GF_F32)
-        rotary_kernel<float, true, true><<<nb, 256, 0, st>>>((float*)dqkv, (const float*)qkv_rot, cs, dtheta, tokens, H, D);
-    else if (dtype == GF_BF16)
-        rotary_kernel<bf16_t, true, true><<<nb, 256, 0, st>>>((bf16_t*)dqkv, (const bf16_t*)qkv_rot, cs, dtheta, tokens, H, D);
-    else return GF_ERR_DTYPE;
+    int nb = (int)((tokens + 3) / 4 > 8192 ? 8192 : (tokens + 3) / 4);
+    const bool vec = rotary_vec_ok(H, D);
+#define GF_ROTB(K, T) K<T, true, true><<<nb, 256, 0, st>>>((T*)dqkv, (const T*)qkv_rot, cs, dtheta, tokens, H, D)
+    if (dtype == GF_F32) { if (vec) GF_ROTB(rotary_vec_kernel, float); else GF_ROTB(rotary_kernel, float); }
+    else { if (vec) GF_ROTB(rotary_vec_kernel, bf16_t); else GF_ROTB(rotary_kernel, bf16_t); }
+#undef GF_ROTB
     return (int)hipGetLastError();
 }
 

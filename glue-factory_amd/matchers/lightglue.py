@@ -293,9 +293,17 @@ class LightGlue(nn.Module):
             kpts1 = cat_so(kpts1, data["scales1"].float(), data["oris1"].float())
         desc0, desc1 = data["descriptors0"], data["descriptors1"]
         assert desc0.shape[-1] == conf.input_dim and desc1.shape[-1] == conf.input_dim
-        desc0, desc1 = desc0.to(T).contiguous(), desc1.to(T).contiguous()
-        if not isinstance(self.input_proj, nn.Identity):
-            desc0, desc1 = _lin(desc0, self.input_proj), _lin(desc1, self.input_proj)
+        x_in = None
+        if (m == n and isinstance(self.input_proj, nn.Identity) and not (desc0.requires_grad or desc1.requires_grad)):
+            # cast straight into the batch-stacked residual stream (no separate casts + concatenation)
+            x_in = torch.empty((2 * b, m, conf.input_dim), dtype=T, device=desc0.device)
+            x_in[:b].copy_(desc0)
+            x_in[b:].copy_(desc1)
+            desc0, desc1 = x_in[:b], x_in[b:]
+        else:
+            desc0, desc1 = desc0.to(T).contiguous(), desc1.to(T).contiguous()
+            if not isinstance(self.input_proj, nn.Identity):
+                desc0, desc1 = _lin(desc0, self.input_proj), _lin(desc1, self.input_proj)
 
         do_early_stop = conf.depth_confidence > 0 and not self.training
         do_point_pruning = conf.width_confidence > 0 and not self.training
@@ -305,7 +313,7 @@ class LightGlue(nn.Module):
         stacked = m == n
         all0, all1, layer_x = [], [], []
         if stacked:   # both images share every GEMM / kernel launch
-            x = torch.cat([desc0, desc1], 0)
+            x = x_in if x_in is not None else torch.cat([desc0, desc1], 0)
             theta, cs = self.posenc(torch.cat([kpts0, kpts1], 0))
             for i, layer in enumerate(self.transformers):
                 x = layer.self_attn(x, theta, cs)
