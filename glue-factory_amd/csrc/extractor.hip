@@ -1,0 +1,214 @@
+// Memory-bound tails of the frozen SuperPoint extractor (the convolutions themselves stay on the stock
+// library, by design).  Reference: gluefactory/models/extractors/superpoint_open.py
+//   * VGGBlock = Conv2d -> ReLU -> BatchNorm2d(eval) [-> MaxPool2d(2,2)]  (:37-75, :98-111)
+//       one pass over the channels-last activation instead of bias-add, clamp, batch-norm and pool passes;
+//   * simple_nms (:19-34): five 2r+1 max-pools and a dozen elementwise passes over the [B,H,W] score map
+//       become one kernel working on an LDS tile with a 5r halo.
+#include "gf_common.h"
+#include "gf_amd.h"
+
+namespace {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct V16 { static constexpr int N = 16 / sizeof(T); };
+
+template <typename T> __device__ __forceinline__ void ld_vec(float (&x)[16 / sizeof(T)], const T* p) {
+    union { u32x4 u; T e[16 / sizeof(T)]; } v;
+    v.u = *reinterpret_cast<const u32x4*>(p);
+#pragma unroll
+    for (int e = 0; e < (int)(16 / sizeof(T)); ++e) x[e] = to_f32(v.e[e]);
+}
+template <typename T> __device__ __forceinline__ void st_vec(T* p, const float (&x)[16 / sizeof(T)]) {
+    union { u32x4 u; T e[16 / sizeof(T)]; } v;
+#pragma unroll
+    for (int e = 0; e < (int)(16 / sizeof(T)); ++e) v.e[e] = from_f32<T>(x[e]);
+    *reinterpret_cast<u32x4*>(p) = v.u;
+}
+
+// y[p, c] = act(x[p, c] + bias[c]) * scale[c] + shift[c]   (channels-last: c fastest; in place when y == x)
+template <typename T, bool RELU>
+__global__ __launch_bounds__(256) void bias_act_bn_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                          const float* __restrict__ bias, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, int64_t nvec, int C) {
+    constexpr int VEC = V16<T>::N;
+    const int cv = C / VEC;                                   // vectors per pixel
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+        const int c0 = (int)(i % cv) * VEC;
+        float v[VEC];
+        ld_vec<T>(v, x + i * VEC);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            float t = v[e] + bias[c0 + e];
+            if (RELU) t = fmaxf(t, 0.f);
+            v[e] = t * scale[c0 + e] + shift[c0 + e];
+        }
+        st_vec<T>(y + i * VEC, v);
+    }
+}
+
+// same followed by MaxPool2d(2, 2): x [B,H,W,C] -> y [B,H/2,W/2,C]
+template <typename T, bool RELU>
+__global__ __launch_bounds__(256) void bias_act_bn_pool_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                               const float* __restrict__ bias, const float* __restrict__ scale,
+                                                               const float* __restrict__ shift, int64_t nvec_out,
+                                                               int H, int W, int C) {
+    constexpr int VEC = V16<T>::N;
+    const int cv = C / VEC, Wo = W / 2, Ho = H / 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec_out; i += (int64_t)gridDim.x * 256) {
+        const int c0 = (int)(i % cv) * VEC;
+        int64_t p = i / cv;
+        const int xo = (int)(p % Wo);
+        p /= Wo;
+        const int yo = (int)(p % Ho);
+        const int64_t b = p / Ho;
+        const T* src = x + (((b * H + 2 * yo) * W + 2 * xo) * (int64_t)C + c0);
+        float best[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) best[e] = -INFINITY;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                float v[VEC];
+                ld_vec<T>(v, src + ((int64_t)dy * W + dx) * C);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    float t = v[e] + bias[c0 + e];
+                    if (RELU) t = fmaxf(t, 0.f);
+                    best[e] = fmaxf(best[e], t * scale[c0 + e] + shift[c0 + e]);
+                }
+            }
+        st_vec<T>(y + i * VEC, best);
+    }
+}
+
+// ---- fused simple_nms ----------------------------------------------------------------------------
+// out = where(M, s, 0) with  M0 = (s == P(s));  twice: supp = P(M) > 0, ss = where(supp, 0, s),
+// M |= (ss == P(ss)) & ~supp;  P = max over the (2r+1)^2 window clipped to the image.
+// A workgroup produces a TS x TS output tile from a (TS + 10r)^2 input tile held in LDS; every pooling is
+// separable (row pass into a scratch plane, column pass back).  Pixels outside the image are -inf for the
+// score pools and "no maximum" for the mask pools, which is what clipping the window means.
+constexpr int NMS_TS = 32;
+
+template <int R>
+__global__ __launch_bounds__(256) void nms_kernel(const float* __restrict__ s, float* __restrict__ out, int H, int W,
+                                                  int border) {
+    constexpr int HALO = 5 * R, TW = NMS_TS + 2 * HALO, NP = TW * TW;
+    extern __shared__ float smem[];
+    float* sc = smem;                 // scores, -inf outside the image
+    float* pa = sc + NP;              // plane handed to the pooling
+    float* pt = pa + NP;              // row-pass scratch
+    float* pp = pt + NP;              // pooled plane
+    unsigned char* mk = reinterpret_cast<unsigned char*>(pp + NP);   // current maxima
+    unsigned char* sp = mk + NP;                                       // suppressed
+    const int b = blockIdx.z, ty0 = blockIdx.y * NMS_TS - HALO, tx0 = blockIdx.x * NMS_TS - HALO;
+    const float* img = s + (int64_t)b * H * W;
+    for (int i = threadIdx.x; i < NP; i += 256) {
+        const int y = ty0 + i / TW, x = tx0 + i % TW;
+        const bool in = y >= 0 && y < H && x >= 0 && x < W;
+        sc[i] = in ? img[(int64_t)y * W + x] : -INFINITY;
+    }
+    __syncthreads();
+    auto pool = [&](const float* src) {                      // pp = separable (2R+1)^2 max of src
+        for (int i = threadIdx.x; i < NP; i += 256) {
+            const int y = i / TW, x = i % TW;
+            const int x0 = max(x - R, 0), x1 = min(x + R, TW - 1);
+            float m = -INFINITY;
+            for (int xx = x0; xx <= x1; ++xx) m = fmaxf(m, src[y * TW + xx]);
+            pt[i] = m;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < NP; i += 256) {
+            const int y = i / TW, x = i % TW;
+            const int y0 = max(y - R, 0), y1 = min(y + R, TW - 1);
+            float m = -INFINITY;
+            for (int yy = y0; yy <= y1; ++yy) m = fmaxf(m, pt[yy * TW + x]);
+            pp[i] = m;
+        }
+        __syncthreads();
+    };
+    pool(sc);
+    for (int i = threadIdx.x; i < NP; i += 256) mk[i] = sc[i] != -INFINITY && sc[i] == pp[i];
+    __syncthreads();
+    for (int it = 0; it < 2; ++it) {
+        for (int i = threadIdx.x; i < NP; i += 256) pa[i] = sc[i] == -INFINITY ? -INFINITY : (mk[i] ? 1.f : 0.f);
+        __syncthreads();
+        pool(pa);
+        for (int i = threadIdx.x; i < NP; i += 256) {
+            const bool su = pp[i] > 0.f;
+            sp[i] = su;
+            pa[i] = sc[i] == -INFINITY ? -INFINITY : (su ? 0.f : sc[i]);
+        }
+        __syncthreads();
+        pool(pa);
+        for (int i = threadIdx.x; i < NP; i += 256)
+            mk[i] = mk[i] | (pa[i] != -INFINITY && pa[i] == pp[i] && !sp[i]);
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < NMS_TS * NMS_TS; i += 256) {
+        const int ly = i / NMS_TS, lx = i % NMS_TS;
+        const int y = blockIdx.y * NMS_TS + ly, x = blockIdx.x * NMS_TS + lx;
+        if (y < H && x < W) {
+            const int j = (ly + HALO) * TW + lx + HALO;
+            float v = mk[j] ? sc[j] : 0.f;
+            if (border > 0 && (y < border || x < border || y >= H - border || x >= W - border)) v = -1.f;
+            out[(int64_t)b * H * W + (int64_t)y * W + x] = v;
+        }
+    }
+}
+
+template <int R> size_t nms_lds() {
+    constexpr int TW = NMS_TS + 10 * R;
+    return (size_t)TW * TW * (4 * sizeof(float) + 2) + 16;
+}
+
+template <int R> int nms_launch(const float* s, float* out, int B, int H, int W, int border, hipStream_t st) {
+    const size_t lds = nms_lds<R>();
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nms_kernel<R>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    dim3 grid((W + NMS_TS - 1) / NMS_TS, (H + NMS_TS - 1) / NMS_TS, B);
+    nms_kernel<R><<<grid, dim3(256), lds, st>>>(s, out, H, W, border);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" int gf_bias_act_bn_nhwc(const void* x, void* y, const float* bias, const float* scale, const float* shift,
+                                   int B, int H, int W, int C, int relu, int pool, int dtype, void* stream) {
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return GF_ERR_SHAPE;
+    if (dtype != GF_F32 && dtype != GF_BF16) return GF_ERR_DTYPE;
+    const int vec = dtype == GF_BF16 ? 8 : 4;
+    if (C % vec) return GF_ERR_ALIGN;
+    if (pool && ((H | W) & 1)) return GF_ERR_SHAPE;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int64_t npix = (int64_t)B * (pool ? (H / 2) * (int64_t)(W / 2) : (int64_t)H * W);
+    const int64_t nvec = npix * (C / vec);
+    const int64_t want = (nvec + 255) / 256;
+    const int nb = (int)(want > 16384 ? 16384 : want);
+#define GF_BAB(T, RELU)                                                                                              \
+    if (pool)                                                                                                        \
+        bias_act_bn_pool_kernel<T, RELU><<<nb, 256, 0, st>>>((const T*)x, (T*)y, bias, scale, shift, nvec, H, W, C); \
+    else                                                                                                             \
+        bias_act_bn_kernel<T, RELU><<<nb, 256, 0, st>>>((const T*)x, (T*)y, bias, scale, shift, nvec, C);
+    if (dtype == GF_BF16) { if (relu) { GF_BAB(bf16_t, true) } else { GF_BAB(bf16_t, false) } }
+    else { if (relu) { GF_BAB(float, true) } else { GF_BAB(float, false) } }
+#undef GF_BAB
+    return (int)hipGetLastError();
+}
+
+extern "C" int gf_nms_scores(const float* scores, float* out, int B, int H, int W, int radius, int border,
+                             void* stream) {
+    if (B <= 0 || H <= 0 || W <= 0 || border < 0) return GF_ERR_SHAPE;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    switch (radius) {
+        case 1: return nms_launch<1>(scores, out, B, H, W, border, st);
+        case 2: return nms_launch<2>(scores, out, B, H, W, border, st);
+        case 3: return nms_launch<3>(scores, out, B, H, W, border, st);
+        case 4: return nms_launch<4>(scores, out, B, H, W, border, st);
+        default: return GF_ERR_UNSUPPORTED;
+    }
+}

@@ -5,6 +5,11 @@ north_star keeps the VGG backbone and the detector / descriptor heads on stock P
 gluefactory/models/extractors/superpoint_open.py:78-216 so checkpoints interchange:
 ``{"image"} -> {"keypoints" (+0.5), "keypoint_scores", "descriptors" [B,N,256]}``.
 
+On a HIP device, in eval mode with frozen weights, the memory-bound tails run on two HIP kernels
+(csrc/extractor.hip): every VGGBlock's bias + ReLU + BatchNorm(eval) [+ 2x2 max-pool] is ONE pass over a
+channels-last activation (the convolution itself is the stock library call, bias-free), and simple_nms +
+border removal is one LDS-tiled kernel instead of five max-pools and a dozen elementwise passes.
+
 Differences in HOW (not what): the per-image python loop over ``torch.where`` / ``topk``
 (superpoint_open.py:154-176) is a single batched top-k over the flattened score map, so the
 forward has no host synchronisation; images with fewer than ``max_num_keypoints`` detections are
@@ -88,24 +93,102 @@ class SuperPoint(BaseModel):
                 raise FileNotFoundError(f"SuperPoint weights '{conf.weights}' not found locally")
             self.load_state_dict(torch.load(str(path), map_location="cpu"))
 
+    # ------------------------------------------------------------------ fused inference path (HIP)
+    def _use_fused(self, image):
+        if not image.is_cuda or self.training or not 1 <= self.conf.nms_radius <= 4:
+            return False
+        return not (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()))
+
+    def _fused_params(self, dtype):
+        """Per-block (channels-last weight in `dtype`, bias, BN scale, BN shift), rebuilt when a tensor changed."""
+        tensors = list(self.parameters()) + list(self.buffers())
+        key = (dtype, tuple(t._version for t in tensors), tuple(t.data_ptr() for t in tensors))
+        cache = getattr(self, "_fused_cache", None)
+        if cache is not None and cache[0] == key:
+            return cache[1]
+        out = {}
+        for name, blk in self.named_modules():
+            if isinstance(blk, VGGBlock):
+                bn = blk.bn
+                scale = (bn.weight.float() * torch.rsqrt(bn.running_var.float() + bn.eps)).contiguous()
+                shift = (bn.bias.float() - bn.running_mean.float() * scale).contiguous()
+                w = blk.conv.weight.detach().to(dtype).contiguous(memory_format=torch.channels_last)
+                out[name] = (w, blk.conv.bias.detach().float().contiguous(), scale, shift)
+        self._fused_cache = (key, out)
+        return out
+
+    def _fused_block(self, name, blk, x, params, pool=False):
+        """Conv2d (library, bias-free) + one HIP pass for bias, ReLU, BatchNorm(eval) and the optional pool."""
+        from .. import lib as _lib
+        w, bias, scale, shift = params[name]
+        c_out = w.shape[0]
+        vec = 8 if x.dtype == torch.bfloat16 else 4
+        if c_out % vec:                         # e.g. the 65-channel detector head: stock modules
+            y = blk(x)
+            return F.max_pool2d(y, 2, 2) if pool else y
+        with torch.autocast(device_type="cuda", enabled=False):
+            y = F.conv2d(x, w, None, 1, blk.conv.padding)
+        if not y.is_contiguous(memory_format=torch.channels_last):
+            y = y.contiguous(memory_format=torch.channels_last)
+        b, _, h, wd = y.shape
+        out = y if not pool else torch.empty((b, c_out, h // 2, wd // 2), dtype=y.dtype, device=y.device,
+                                             memory_format=torch.channels_last)
+        relu = isinstance(blk.activation, nn.ReLU)
+        _lib.check(_lib.load().gf_bias_act_bn_nhwc(
+            y.data_ptr(), out.data_ptr(), bias.data_ptr(), scale.data_ptr(), shift.data_ptr(), b, h, wd, c_out,
+            int(relu), int(pool), 1 if y.dtype == torch.bfloat16 else 0, torch.cuda.current_stream().cuda_stream),
+            "gf_bias_act_bn_nhwc")
+        return out
+
+    def _fused_features(self, image):
+        dtype = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else torch.float32
+        if dtype not in (torch.bfloat16, torch.float32):
+            dtype = torch.float32
+        params = self._fused_params(dtype)
+        x = image.to(dtype).contiguous(memory_format=torch.channels_last)
+        for si, stage in enumerate(self.backbone):
+            blocks = [m for m in stage if isinstance(m, VGGBlock)]
+            has_pool = any(isinstance(m, nn.MaxPool2d) for m in stage)
+            for bi, blk in enumerate(blocks):
+                x = self._fused_block(f"backbone.{si}.{bi}", blk, x, params, pool=has_pool and bi == len(blocks) - 1)
+        det = self._fused_block("detector.0", self.detector[0], x, params)
+        det = self._fused_block("detector.1", self.detector[1], det, params)
+        desc = self._fused_block("descriptor.0", self.descriptor[0], x, params)
+        desc = self._fused_block("descriptor.1", self.descriptor[1], desc, params)
+        return det, desc
+
     def _forward(self, data):
         conf = self.conf
         image = data["image"]
         if image.shape[1] == 3:
             image = (image * image.new_tensor([0.299, 0.587, 0.114]).view(1, 3, 1, 1)).sum(1, keepdim=True)
-        features = self.backbone(image)
-        dense = F.normalize(self.descriptor(features).float(), p=2, dim=1)
-        scores = F.softmax(self.detector(features).float(), 1)[:, :-1]
+        fused = self._use_fused(image)
+        if fused:
+            det, desc_map = self._fused_features(image)
+        else:
+            features = self.backbone(image)
+            det, desc_map = self.detector(features), self.descriptor(features)
+        dense = F.normalize(desc_map.float(), p=2, dim=1)
+        scores = F.softmax(det.float(), 1)[:, :-1]
         b, _, h, w = scores.shape
         s = self.stride
         scores = scores.permute(0, 2, 3, 1).reshape(b, h, w, s, s).permute(0, 1, 3, 2, 4).reshape(b, h * s, w * s)
-        scores = batched_nms(scores, conf.nms_radius)
-        if conf.remove_borders:
-            pad = conf.remove_borders
-            scores[:, :pad] = -1
-            scores[:, :, :pad] = -1
-            scores[:, -pad:] = -1
-            scores[:, :, -pad:] = -1
+        if fused:
+            from .. import lib as _lib
+            scores = scores.contiguous()
+            nms = torch.empty_like(scores)
+            _lib.check(_lib.load().gf_nms_scores(scores.data_ptr(), nms.data_ptr(), b, h * s, w * s, int(conf.nms_radius),
+                                                 int(conf.remove_borders or 0), torch.cuda.current_stream().cuda_stream),
+                       "gf_nms_scores")
+            scores = nms
+        else:
+            scores = batched_nms(scores, conf.nms_radius)
+            if conf.remove_borders:
+                pad = conf.remove_borders
+                scores[:, :pad] = -1
+                scores[:, :, :pad] = -1
+                scores[:, -pad:] = -1
+                scores[:, :, -pad:] = -1
         H, W = scores.shape[1:]
         k = conf.max_num_keypoints
         if k is None:

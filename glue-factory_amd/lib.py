@@ -38,6 +38,8 @@ SIGNATURES = {
     "gf_bn_bwd_stats": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "gf_bn_bwd_dx": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "gf_gt_nn": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "gf_bias_act_bn_nhwc": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "gf_nms_scores": [_P, _P, _I, _I, _I, _I, _I, _P],
     "gf_rowdot_nblk": [_I],
     "gf_rowdot_fwd": [_P, _P, _F, _P, _I, _I, _I, _P],
     "gf_rowdot_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _P],

@@ -177,6 +177,18 @@ int gf_bn_bwd_dx(const void* x, const void* dy, const float* mean, const float* 
 int gf_gt_nn(const float* own, const float* own_warped, const float* oth, const float* oth_warped,
              int64_t* arg, float* dmin, float* own_min, int B, int No, int Ns, void* stream);
 
+/* ---- frozen SuperPoint extractor tails (gluefactory/models/extractors/superpoint_open.py; the
+ * convolutions stay on the stock library).
+ * gf_bias_act_bn_nhwc: one pass for the VGGBlock tail Conv2d(no bias) -> +bias -> ReLU -> BatchNorm2d(eval)
+ *   (superpoint_open.py:37-75) on a channels-last activation x [B,H,W,C] (C fastest, C % (16/sizeof) == 0):
+ *   y = act(x + bias[c]) * scale[c] + shift[c], scale = gamma / sqrt(var + eps), shift = beta - mean * scale.
+ *   pool != 0 additionally applies MaxPool2d(2,2) (:98-105) and writes y [B,H/2,W/2,C]; otherwise y may alias x.
+ * gf_nms_scores: simple_nms (:19-34) with radius 1..4 on scores [B,H,W] fp32 -> out (0 where suppressed),
+ *   plus the border removal of :160-164 (out = -1 inside `border` pixels of the frame; 0 disables). */
+int gf_bias_act_bn_nhwc(const void* x, void* y, const float* bias, const float* scale, const float* shift,
+                        int B, int H, int W, int C, int relu, int pool, int dtype, void* stream);
+int gf_nms_scores(const float* scores, float* out, int B, int H, int W, int radius, int border, void* stream);
+
 /* ---- single-output linear heads z[m] = x[m,:] . w + b (matchability / token-confidence logits,
  * lightglue.py:71,275-276,285-286).  x [M,C] in `dtype`, w [C] fp32, z/dz [M] fp32.
  * gf_rowdot_bwd writes dx = dz * w when dx != NULL (pass NULL for a detached input) and per-block

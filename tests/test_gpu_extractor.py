@@ -1,0 +1,79 @@
+"""Fused tails of the frozen SuperPoint extractor (csrc/extractor.hip) against the stock-torch path and
+the reference-generated golden vectors."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("radius", [1, 3, 4])
+@pytest.mark.parametrize("shape", [(2, 97, 130), (1, 256, 256)])
+def test_nms_kernel_equals_max_pool_chain(radius, shape):
+    from glue_factory_amd import lib as L_
+    from glue_factory_amd.extractors.superpoint_open import batched_nms
+    g = torch.Generator(device="cuda").manual_seed(radius)
+    s = torch.rand(*shape, device="cuda", generator=g)
+    s[:, 10:30, 10:30] = 0.25                      # a plateau: ties everywhere inside it
+    s = (s * 64).round() / 64                      # and many exact ties elsewhere
+    ref = batched_nms(s, radius)
+    pad = 4
+    ref2 = ref.clone()
+    ref2[:, :pad] = -1; ref2[:, :, :pad] = -1; ref2[:, -pad:] = -1; ref2[:, :, -pad:] = -1
+    out = torch.empty_like(s)
+    lib = L_.load()
+    st = torch.cuda.current_stream().cuda_stream
+    L_.check(lib.gf_nms_scores(s.data_ptr(), out.data_ptr(), *shape, radius, 0, st), "gf_nms_scores")
+    assert torch.equal(out, ref)
+    L_.check(lib.gf_nms_scores(s.data_ptr(), out.data_ptr(), *shape, radius, pad, st), "gf_nms_scores")
+    assert torch.equal(out, ref2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("pool", [0, 1])
+def test_bias_act_bn_kernel(dtype, pool):
+    from glue_factory_amd import lib as L_
+    g = torch.Generator(device="cuda").manual_seed(3)
+    B, C, H, W = 2, 64, 20, 36
+    x = torch.randn(B, C, H, W, device="cuda", generator=g).to(dtype).contiguous(memory_format=torch.channels_last)
+    bias, scale, shift = (torch.randn(C, device="cuda", generator=g) for _ in range(3))
+    ref = torch.relu(x.float() + bias.view(1, C, 1, 1)) * scale.view(1, C, 1, 1) + shift.view(1, C, 1, 1)
+    if pool:
+        ref = torch.nn.functional.max_pool2d(ref, 2, 2)
+    y = torch.empty((B, C, H // 2, W // 2) if pool else (B, C, H, W), dtype=dtype, device="cuda",
+                    memory_format=torch.channels_last)
+    L_.check(L_.load().gf_bias_act_bn_nhwc(x.data_ptr(), y.data_ptr(), bias.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                           B, H, W, C, 1, pool, 1 if dtype == torch.bfloat16 else 0,
+                                           torch.cuda.current_stream().cuda_stream), "gf_bias_act_bn_nhwc")
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    torch.testing.assert_close(y.float(), ref, rtol=tol, atol=tol)
+
+
+def test_fused_extractor_matches_golden_and_stock_path():
+    from glue_factory_amd.extractors.superpoint_open import SuperPoint
+    z = load_golden("superpoint_open")
+    torch.manual_seed(int(z["seed"]))
+    model = SuperPoint({"max_num_keypoints": 100, "force_num_keypoints": True, "detection_threshold": 0.0,
+                        "nms_radius": 3}).cuda().eval()
+    image = torch.from_numpy(z["image"]).cuda()
+    with torch.no_grad():
+        assert model._use_fused(image)
+        pred = model({"image": image})
+    np.testing.assert_allclose(pred["keypoint_scores"].cpu().numpy(), z["eval.keypoint_scores"], rtol=1e-4, atol=1e-6)
+    for b in range(image.shape[0]):
+        ours = {tuple(k): i for i, k in enumerate(pred["keypoints"][b].cpu().tolist())}
+        ref = z["eval.keypoints"][b].tolist()
+        common = [(ours[tuple(k)], j) for j, k in enumerate(ref) if tuple(k) in ours]
+        assert len(common) >= 0.95 * len(ref)
+        io, ir = zip(*common)
+        np.testing.assert_allclose(pred["descriptors"][b][list(io)].cpu().numpy(),
+                                   z["eval.descriptors"][b][list(ir)], rtol=1e-3, atol=1e-4)
+    # the stock path (grad enabled on a trainable copy) gives the same detections
+    for p in model.parameters():
+        p.requires_grad_(True)
+    assert not model._use_fused(image)
+    stock = model({"image": image})
+    np.testing.assert_allclose(stock["keypoint_scores"].detach().cpu().numpy(), pred["keypoint_scores"].cpu().numpy(),
+                               rtol=1e-4, atol=1e-6)
