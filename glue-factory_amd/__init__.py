@@ -10,4 +10,10 @@ Imported as ``glue_factory_amd`` (see the shim next to this directory).  Sub-mod
   gt         ground-truth assignment from homographies
   synthetic  seeded synthetic keypoint-pair generator
 """
+import os as _os
+
+# Let the stock convolution library take channels-last activations as they are (the fused extractor path keeps
+# them NHWC end to end); PyTorch-ROCm reads this once, at its first convolution call.
+_os.environ.setdefault("PYTORCH_MIOPEN_SUGGEST_NHWC", "1")
+
 __version__ = "0.1.0"

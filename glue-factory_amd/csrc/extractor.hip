@@ -86,10 +86,39 @@ __global__ __launch_bounds__(256) void bias_act_bn_pool_kernel(const T* __restri
 // ---- fused simple_nms ----------------------------------------------------------------------------
 // out = where(M, s, 0) with  M0 = (s == P(s));  twice: supp = P(M) > 0, ss = where(supp, 0, s),
 // M |= (ss == P(ss)) & ~supp;  P = max over the (2r+1)^2 window clipped to the image.
-// A workgroup produces a TS x TS output tile from a (TS + 10r)^2 input tile held in LDS; every pooling is
-// separable (row pass into a scratch plane, column pass back).  Pixels outside the image are -inf for the
+// A workgroup produces a TS x TS output tile from a (TS + 10r)^2 input tile held in LDS (three float planes
+// and two byte masks: 151 KB at r = 4); every pooling is separable (row pass into a scratch plane, column
+// pass back) with register windows.  Pixels outside the image are -inf for the
 // score pools and "no maximum" for the mask pools, which is what clipping the window means.
-constexpr int NMS_TS = 32;
+constexpr int NMS_TS = 64, NMS_SEG = 8;
+
+// 1-D running maximum of radius R over `n` lines of length `len`: each work item produces NMS_SEG consecutive
+// outputs of one line from NMS_SEG + 2R inputs held in registers (1.75 LDS reads per output at R = 3
+// instead of 2R + 1).  ALONG_X: lines are rows (stride 1 inside a line), else columns (stride TW).
+template <int R, int TW, bool ALONG_X>
+__device__ __forceinline__ void max1d(const float* __restrict__ src, float* __restrict__ dst) {
+    constexpr int NSEG = (TW + NMS_SEG - 1) / NMS_SEG;
+    for (int it = threadIdx.x; it < NSEG * TW; it += 256) {
+        // consecutive work items walk the direction that is contiguous in LDS (conflict-free)
+        const int line = ALONG_X ? it / NSEG : it % TW;
+        const int seg = ALONG_X ? it % NSEG : it / TW;
+        const int p0 = seg * NMS_SEG;
+        float v[NMS_SEG + 2 * R];
+#pragma unroll
+        for (int k = 0; k < NMS_SEG + 2 * R; ++k) {
+            const int p = p0 - R + k;
+            v[k] = (p >= 0 && p < TW) ? src[ALONG_X ? line * TW + p : p * TW + line] : -INFINITY;
+        }
+#pragma unroll
+        for (int k = 0; k < NMS_SEG; ++k) {
+            float m = v[k];
+#pragma unroll
+            for (int j = 1; j <= 2 * R; ++j) m = fmaxf(m, v[k + j]);
+            const int p = p0 + k;
+            if (p < TW) dst[ALONG_X ? line * TW + p : p * TW + line] = m;
+        }
+    }
+}
 
 template <int R>
 __global__ __launch_bounds__(256) void nms_kernel(const float* __restrict__ s, float* __restrict__ out, int H, int W,
@@ -97,53 +126,52 @@ __global__ __launch_bounds__(256) void nms_kernel(const float* __restrict__ s, f
     constexpr int HALO = 5 * R, TW = NMS_TS + 2 * HALO, NP = TW * TW;
     extern __shared__ float smem[];
     float* sc = smem;                 // scores, -inf outside the image
-    float* pa = sc + NP;              // plane handed to the pooling
+    float* pa = sc + NP;              // plane being pooled (in: map, out: pooled map)
     float* pt = pa + NP;              // row-pass scratch
-    float* pp = pt + NP;              // pooled plane
-    unsigned char* mk = reinterpret_cast<unsigned char*>(pp + NP);   // current maxima
+    unsigned char* mk = reinterpret_cast<unsigned char*>(pt + NP);   // current maxima
     unsigned char* sp = mk + NP;                                       // suppressed
     const int b = blockIdx.z, ty0 = blockIdx.y * NMS_TS - HALO, tx0 = blockIdx.x * NMS_TS - HALO;
     const float* img = s + (int64_t)b * H * W;
     for (int i = threadIdx.x; i < NP; i += 256) {
         const int y = ty0 + i / TW, x = tx0 + i % TW;
         const bool in = y >= 0 && y < H && x >= 0 && x < W;
-        sc[i] = in ? img[(int64_t)y * W + x] : -INFINITY;
+        const float v = in ? img[(int64_t)y * W + x] : -INFINITY;
+        sc[i] = v;
+        pa[i] = v;
     }
     __syncthreads();
-    auto pool = [&](const float* src) {                      // pp = separable (2R+1)^2 max of src
-        for (int i = threadIdx.x; i < NP; i += 256) {
-            const int y = i / TW, x = i % TW;
-            const int x0 = max(x - R, 0), x1 = min(x + R, TW - 1);
-            float m = -INFINITY;
-            for (int xx = x0; xx <= x1; ++xx) m = fmaxf(m, src[y * TW + xx]);
-            pt[i] = m;
-        }
+    auto pool = [&]() {                                      // pa <- (2R+1)^2 max of pa
+        max1d<R, TW, true>(pa, pt);
         __syncthreads();
-        for (int i = threadIdx.x; i < NP; i += 256) {
-            const int y = i / TW, x = i % TW;
-            const int y0 = max(y - R, 0), y1 = min(y + R, TW - 1);
-            float m = -INFINITY;
-            for (int yy = y0; yy <= y1; ++yy) m = fmaxf(m, pt[yy * TW + x]);
-            pp[i] = m;
-        }
+        max1d<R, TW, false>(pt, pa);
         __syncthreads();
     };
-    pool(sc);
-    for (int i = threadIdx.x; i < NP; i += 256) mk[i] = sc[i] != -INFINITY && sc[i] == pp[i];
+    pool();
+    for (int i = threadIdx.x; i < NP; i += 256) {
+        const float v = sc[i];
+        const bool m = v != -INFINITY && v == pa[i];
+        mk[i] = m;
+        pa[i] = v == -INFINITY ? -INFINITY : (m ? 1.f : 0.f);
+    }
     __syncthreads();
     for (int it = 0; it < 2; ++it) {
-        for (int i = threadIdx.x; i < NP; i += 256) pa[i] = sc[i] == -INFINITY ? -INFINITY : (mk[i] ? 1.f : 0.f);
-        __syncthreads();
-        pool(pa);
+        pool();                                              // dilated maxima
         for (int i = threadIdx.x; i < NP; i += 256) {
-            const bool su = pp[i] > 0.f;
+            const bool su = pa[i] > 0.f;
             sp[i] = su;
-            pa[i] = sc[i] == -INFINITY ? -INFINITY : (su ? 0.f : sc[i]);
+            const float v = sc[i];
+            pa[i] = v == -INFINITY ? -INFINITY : (su ? 0.f : v);            // supp_scores
         }
         __syncthreads();
-        pool(pa);
-        for (int i = threadIdx.x; i < NP; i += 256)
-            mk[i] = mk[i] | (pa[i] != -INFINITY && pa[i] == pp[i] && !sp[i]);
+        pool();
+        for (int i = threadIdx.x; i < NP; i += 256) {
+            const float v = sc[i];
+            const bool su = sp[i];
+            const float ss = su ? 0.f : v;
+            const bool m = mk[i] | (v != -INFINITY && ss == pa[i] && !su);
+            mk[i] = m;
+            pa[i] = v == -INFINITY ? -INFINITY : (m ? 1.f : 0.f);
+        }
         __syncthreads();
     }
     for (int i = threadIdx.x; i < NMS_TS * NMS_TS; i += 256) {
@@ -160,7 +188,7 @@ __global__ __launch_bounds__(256) void nms_kernel(const float* __restrict__ s, f
 
 template <int R> size_t nms_lds() {
     constexpr int TW = NMS_TS + 10 * R;
-    return (size_t)TW * TW * (4 * sizeof(float) + 2) + 16;
+    return (size_t)TW * TW * (3 * sizeof(float) + 2) + 16;
 }
 
 template <int R> int nms_launch(const float* s, float* out, int B, int H, int W, int border, hipStream_t st) {

@@ -145,7 +145,12 @@ class SuperPoint(BaseModel):
         if dtype not in (torch.bfloat16, torch.float32):
             dtype = torch.float32
         params = self._fused_params(dtype)
-        x = image.to(dtype).contiguous(memory_format=torch.channels_last)
+        x = image.to(dtype).contiguous()
+        if x.shape[1] == 1:     # one channel: NCHW and NHWC are the same bytes; give it the NHWC strides so the
+            b_, _, h_, w_ = x.shape    # first convolution already answers channels-last
+            x = x.as_strided(x.shape, (h_ * w_, 1, w_, 1))
+        else:
+            x = x.contiguous(memory_format=torch.channels_last)
         for si, stage in enumerate(self.backbone):
             blocks = [m for m in stage if isinstance(m, VGGBlock)]
             has_pool = any(isinstance(m, nn.MaxPool2d) for m in stage)
