@@ -65,8 +65,8 @@ def parse():
                     help="lightglue = the headline configs[1]; superglue / gluestick = configs[3] / [4] (extra lines)")
     ap.add_argument("--lines", type=int, default=512, help="gluestick: line segments per image")
     ap.add_argument("--sinkhorn-iters", type=int, default=100)
-    ap.add_argument("--time-extractor", action="store_true",
-                    help="also time the frozen SuperPoint forward (stock torch) on 2*batch 1024x1024 images")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="skip the secondary pipeline-scope measurement (SuperPoint forward + GT + matcher step)")
     return ap.parse_args()
 
 
@@ -200,6 +200,53 @@ def cpu_baseline(n, layers):
                       f"({dt:.2f} s/step) of the torch-CPU oracle on {cores} of {avail} host threads"}
 
 
+def pipeline_scope(args, stepper):
+    """Secondary scope (P): frozen SuperPoint forward on synthetic 1024x1024 images (stock library
+    convolutions + the fused HIP tails) + homography ground truth + the same matcher train step."""
+    import torch
+    from glue_factory_amd.extractors.superpoint_open import SuperPoint
+    from glue_factory_amd.gt import gt_matches_from_homography_fused as gt_matches_from_homography
+    sp = SuperPoint({"max_num_keypoints": args.kpts, "force_num_keypoints": True, "detection_threshold": 0.0,
+                     "nms_radius": 3}).cuda().eval()
+    g = torch.Generator(device="cuda").manual_seed(7)
+    img0 = torch.rand(args.batch, 1, 1024, 1024, device="cuda", generator=g)
+    img1 = img0.roll(8, -1)
+    Hm = torch.tensor([[1.0, 0, 8], [0, 1, 0], [0, 0, 1]], device="cuda")[None].repeat(args.batch, 1, 1)
+    size = torch.tensor([[1024.0, 1024.0]], device="cuda").repeat(args.batch, 1)
+
+    def extract():
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=args.dtype == "bf16"):
+            return sp({"image": torch.cat([img0, img1], 0)})
+
+    def pipeline_step():
+        f = extract()
+        b = args.batch
+        d = {"keypoints0": f["keypoints"][:b], "keypoints1": f["keypoints"][b:],
+             "descriptors0": f["descriptors"][:b], "descriptors1": f["descriptors"][b:],
+             "view0": {"image_size": size}, "view1": {"image_size": size}}
+        gt = gt_matches_from_homography(d["keypoints0"], d["keypoints1"], Hm, 3.0, 3.0)
+        d.update({"gt_assignment": gt["assignment"], "gt_assignment_col0": gt["assignment_col0"],
+                  "gt_matches0": gt["matches0"], "gt_matches1": gt["matches1"]})
+        return stepper(d)["total"].mean()
+
+    def timed(fn, n=3):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+
+    pipeline_step()                      # library autotuning of the convolutions happens here
+    te = timed(extract)
+    tp = timed(pipeline_step)
+    return {"value": round(args.batch / tp, 2), "unit": "image-pairs/s", "ms_per_step": round(tp * 1e3, 2),
+            "extractor_ms": round(te * 1e3, 2),
+            "scope": "frozen SuperPoint-open forward on 2x32 synthetic 1024x1024 images (library convolutions + fused HIP "
+                     "bias/ReLU/BN/pool and NMS kernels) + homography GT (gf_gt_nn) + LightGlue train step"}
+
+
 def main():
     args = parse()
     if args.micro:
@@ -296,40 +343,13 @@ def main():
                                 / world / (MFMA_BF16_PEAK_TFLOPS * 1e12), 4),
         "final_loss": round(float(loss.item()), 4),
     }
-    if rank == 0 and args.time_extractor and world == 1:
+    if rank == 0 and not args.no_pipeline and world == 1 and args.model == "lightglue":
         # secondary scope (P): frozen SuperPoint forward on synthetic 1024x1024 images (stock
         # PyTorch-ROCm conv, by design) + homography ground truth + the same matcher train step.
-        from glue_factory_amd.extractors.superpoint_open import SuperPoint
-        from glue_factory_amd.gt import gt_matches_from_homography_fused as gt_matches_from_homography
-        sp = SuperPoint({"max_num_keypoints": args.kpts, "force_num_keypoints": True, "detection_threshold": 0.0,
-                         "nms_radius": 3}).cuda().eval()
-        g = torch.Generator(device="cuda").manual_seed(7)
-        img0 = torch.rand(args.batch, 1, 1024, 1024, device="cuda", generator=g)
-        img1 = img0.roll(8, -1)
-        Hm = torch.tensor([[1.0, 0, 8], [0, 1, 0], [0, 0, 1]], device="cuda")[None].repeat(args.batch, 1, 1)
-        size = torch.tensor([[1024.0, 1024.0]], device="cuda").repeat(args.batch, 1)
-
-        def pipeline_step():
-            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=args.dtype == "bf16"):
-                f = sp({"image": torch.cat([img0, img1], 0)})
-            b = args.batch
-            d = {"keypoints0": f["keypoints"][:b], "keypoints1": f["keypoints"][b:],
-                 "descriptors0": f["descriptors"][:b], "descriptors1": f["descriptors"][b:],
-                 "view0": {"image_size": size}, "view1": {"image_size": size}}
-            gt = gt_matches_from_homography(d["keypoints0"], d["keypoints1"], Hm, 3.0, 3.0)
-            d.update({"gt_assignment": gt["assignment"], "gt_matches0": gt["matches0"], "gt_matches1": gt["matches1"]})
-            return stepper(d)["total"].mean()
-
-        pipeline_step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(3):
-            pipeline_step()
-        torch.cuda.synchronize()
-        tp = (time.perf_counter() - t0) / 3
-        out["pipeline"] = {"value": round(args.batch / tp, 2), "unit": "image-pairs/s", "ms_per_step": round(tp * 1e3, 2),
-                           "scope": "frozen SuperPoint-open forward on 2x32 synthetic 1024x1024 images (stock torch/MIOpen) "
-                                    "+ homography GT (gf_gt_nn) + LightGlue train step"}
+        try:
+            out["pipeline"] = pipeline_scope(args, stepper)
+        except Exception as e:  # the secondary scope must never cost the headline line
+            out["pipeline"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         if not args.no_roofline:
             out["roofline"] = roofline_attention(args.batch, args.kpts,
