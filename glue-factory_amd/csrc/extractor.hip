@@ -203,6 +203,47 @@ template <int R> int nms_launch(const float* s, float* out, int B, int H, int W,
     return (int)hipGetLastError();
 }
 
+// ---- descriptor sampling -------------------------------------------------------------------------
+// sample_descriptors (superpoint_open.py:10-16) fused with the per-pixel L2 normalisation of the dense map
+// (:149): out[b,n,:] = normalize( sum_k w_k * normalize(map[b, y_k, x_k, :]) ) over the 4 bilinear corners
+// (align_corners=False, zero padding), x_pix = (kp_x + 0.5) / s - 0.5.  One wave per keypoint; the
+// channels-last map makes every corner one contiguous C-vector.
+template <typename T>
+__global__ __launch_bounds__(256) void sample_desc_kernel(const T* __restrict__ map, const float* __restrict__ kpts,
+                                                          float* __restrict__ out, int64_t total, int N, int h, int w,
+                                                          int C, float inv_s) {
+    const int lane = threadIdx.x & 63;
+    const int64_t k = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (k >= total) return;
+    const int64_t b = k / N;
+    const float px = (kpts[2 * k] + 0.5f) * inv_s - 0.5f, py = (kpts[2 * k + 1] + 0.5f) * inv_s - 0.5f;
+    const float fx = floorf(px), fy = floorf(py);
+    const int x0 = (int)fx, y0 = (int)fy;
+    const float wx = px - fx, wy = py - fy;
+    const int nch = C / 64;                       // channels per lane (C % 64 == 0, <= 8 per lane)
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int xx = x0 + (c & 1), yy = y0 + (c >> 1);
+        const float wgt = ((c & 1) ? wx : 1.f - wx) * ((c >> 1) ? wy : 1.f - wy);
+        if (xx < 0 || xx >= w || yy < 0 || yy >= h) continue;          // wave-uniform
+        const T* src = map + ((b * h + yy) * (int64_t)w + xx) * C + lane * nch;
+        float v[8], ss = 0.f;
+        for (int e = 0; e < nch; ++e) { v[e] = to_f32(src[e]); ss += v[e] * v[e]; }
+        ss = wave_allsum(ss);
+        const float sc = wgt / fmaxf(sqrtf(ss), 1e-12f);
+        for (int e = 0; e < nch; ++e) acc[e] += sc * v[e];
+    }
+    float ss = 0.f;
+    for (int e = 0; e < nch; ++e) ss += acc[e] * acc[e];
+    ss = wave_allsum(ss);
+    const float sc = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+    float* dst = out + k * C + lane * nch;
+    for (int e = 0; e < nch; ++e) dst[e] = acc[e] * sc;
+}
+
 }  // namespace
 
 extern "C" int gf_bias_act_bn_nhwc(const void* x, void* y, const float* bias, const float* scale, const float* shift,
@@ -239,4 +280,20 @@ extern "C" int gf_nms_scores(const float* scores, float* out, int B, int H, int 
         case 4: return nms_launch<4>(scores, out, B, H, W, border, st);
         default: return GF_ERR_UNSUPPORTED;
     }
+}
+
+extern "C" int gf_sample_descriptors(const void* map, const float* kpts, float* out, int B, int N, int h, int w, int C,
+                                     int stride, int dtype, void* stream) {
+    if (B <= 0 || N <= 0 || h <= 0 || w <= 0 || stride <= 0) return GF_ERR_SHAPE;
+    if (C <= 0 || C % 64 || C > 512) return GF_ERR_ALIGN;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int64_t total = (int64_t)B * N;
+    const dim3 grid((unsigned)((total + 3) / 4));
+    if (dtype == GF_BF16)
+        sample_desc_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)map, kpts, out, total, N, h, w, C, 1.f / stride);
+    else if (dtype == GF_F32)
+        sample_desc_kernel<float><<<grid, 256, 0, st>>>((const float*)map, kpts, out, total, N, h, w, C, 1.f / stride);
+    else
+        return GF_ERR_DTYPE;
+    return (int)hipGetLastError();
 }

@@ -173,7 +173,9 @@ class SuperPoint(BaseModel):
         else:
             features = self.backbone(image)
             det, desc_map = self.detector(features), self.descriptor(features)
-        dense = F.normalize(desc_map.float(), p=2, dim=1)
+        def dense():          # per-pixel normalised map; the fused sampler normalises the corners itself
+            return F.normalize(desc_map.float(), p=2, dim=1)
+
         scores = F.softmax(det.float(), 1)[:, :-1]
         b, _, h, w = scores.shape
         s = self.stride
@@ -226,10 +228,21 @@ class SuperPoint(BaseModel):
                 keypoints, kscores = keypoints[:, valid[0]], kscores[:, valid[0]]
             elif not bool(valid.all()):
                 raise ValueError("images yield different keypoint counts: set force_num_keypoints")
-        desc = sample_descriptors(keypoints, dense, s)
-        pred = {"keypoints": keypoints + 0.5, "keypoint_scores": kscores, "descriptors": desc.transpose(-1, -2)}
+        if fused and desc_map.shape[1] % 64 == 0 and desc_map.shape[1] <= 512:
+            from .. import lib as _lib
+            dm = desc_map if desc_map.is_contiguous(memory_format=torch.channels_last) else \
+                desc_map.contiguous(memory_format=torch.channels_last)
+            kp = keypoints.float().contiguous()
+            descriptors = torch.empty((b, kp.shape[1], dm.shape[1]), dtype=torch.float32, device=dm.device)
+            _lib.check(_lib.load().gf_sample_descriptors(
+                dm.data_ptr(), kp.data_ptr(), descriptors.data_ptr(), b, kp.shape[1], dm.shape[2], dm.shape[3],
+                dm.shape[1], s, 1 if dm.dtype == torch.bfloat16 else 0, torch.cuda.current_stream().cuda_stream),
+                "gf_sample_descriptors")
+        else:
+            descriptors = sample_descriptors(keypoints, dense(), s).transpose(-1, -2)
+        pred = {"keypoints": keypoints + 0.5, "keypoint_scores": kscores, "descriptors": descriptors}
         if conf.dense_outputs:
-            pred["dense_descriptors"] = dense
+            pred["dense_descriptors"] = dense()
         return pred
 
     def loss(self, pred, data):

@@ -40,6 +40,7 @@ SIGNATURES = {
     "gf_gt_nn": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "gf_bias_act_bn_nhwc": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "gf_nms_scores": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "gf_sample_descriptors": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "gf_rowdot_nblk": [_I],
     "gf_rowdot_fwd": [_P, _P, _F, _P, _I, _I, _I, _P],
     "gf_rowdot_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _P],

@@ -188,6 +188,12 @@ int gf_gt_nn(const float* own, const float* own_warped, const float* oth, const 
 int gf_bias_act_bn_nhwc(const void* x, void* y, const float* bias, const float* scale, const float* shift,
                         int B, int H, int W, int C, int relu, int pool, int dtype, void* stream);
 int gf_nms_scores(const float* scores, float* out, int B, int H, int W, int radius, int border, void* stream);
+/* gf_sample_descriptors: sample_descriptors (:10-16) fused with the dense map's L2 normalisation (:149):
+ *   out[b,n,:] = normalize(sum over the 4 bilinear corners of w_k * normalize(map[b,y_k,x_k,:])), zero padding,
+ *   x_pix = (kp_x + 0.5) / stride - 0.5.  map [B,h,w,C] channels-last in `dtype` (C % 64 == 0), kpts [B,N,2] fp32
+ *   pixel coordinates WITHOUT the +0.5 output offset, out [B,N,C] fp32. */
+int gf_sample_descriptors(const void* map, const float* kpts, float* out, int B, int N, int h, int w, int C,
+                          int stride, int dtype, void* stream);
 
 /* ---- single-output linear heads z[m] = x[m,:] . w + b (matchability / token-confidence logits,
  * lightglue.py:71,275-276,285-286).  x [M,C] in `dtype`, w [C] fp32, z/dz [M] fp32.

@@ -77,3 +77,20 @@ def test_fused_extractor_matches_golden_and_stock_path():
     stock = model({"image": image})
     np.testing.assert_allclose(stock["keypoint_scores"].detach().cpu().numpy(), pred["keypoint_scores"].cpu().numpy(),
                                rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_sample_descriptors_kernel(dtype):
+    from glue_factory_amd import lib as L_
+    from glue_factory_amd.extractors.superpoint_open import sample_descriptors
+    g = torch.Generator(device="cuda").manual_seed(5)
+    B, C, h, w, N, s = 2, 256, 17, 23, 300, 8
+    m = torch.randn(B, C, h, w, device="cuda", generator=g).to(dtype).contiguous(memory_format=torch.channels_last)
+    kp = torch.rand(B, N, 2, device="cuda", generator=g) * torch.tensor([w * s - 1.0, h * s - 1.0], device="cuda")
+    kp[:, :4] = torch.tensor([[0.0, 0.0], [w * s - 1.0, h * s - 1.0], [0.0, h * s - 1.0], [3.5, 3.5]], device="cuda")
+    ref = sample_descriptors(kp, torch.nn.functional.normalize(m.float(), p=2, dim=1), s).transpose(-1, -2)
+    out = torch.empty(B, N, C, device="cuda")
+    L_.check(L_.load().gf_sample_descriptors(m.data_ptr(), kp.contiguous().data_ptr(), out.data_ptr(), B, N, h, w, C, s,
+                                             1 if dtype == torch.bfloat16 else 0, torch.cuda.current_stream().cuda_stream),
+             "gf_sample_descriptors")
+    torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-6)
