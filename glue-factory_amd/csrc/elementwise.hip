@@ -121,11 +121,6 @@ __global__ __launch_bounds__(256) void rotary_vec_kernel(T* qkv, const T* yrot, 
 }
 
 // ---------------------------------------------------------------------------- LN + GELU
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    return v;
-}
 // Exact (erf) GELU with erf from Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far inside the 1e-4 parity
 // budget): ~12 VALU + one v_exp instead of libm erff's ~30-instruction polynomial ladder; the backward
 // reuses the same exp(-z^2/2) for the Gaussian density term.

@@ -22,7 +22,6 @@ Compute dtype: fp32 (exact-fp32 MFMA, parity mode) by default, bf16 with fp32 st
 ``conf.mp`` is set or the call happens under ``torch.autocast``.  There is no CPU path.
 """
 import math
-import warnings
 from pathlib import Path
 
 import torch
