@@ -404,33 +404,35 @@ __global__ __launch_bounds__(256, 2) void linear_dw_tr_kernel(const bf16_t* __re
     }
 }
 
+// Sum of the per-slice partials.  A workgroup covers 64 float4 columns with FOUR slice groups (one per wave,
+// slices k = g mod 4) that meet in LDS: a 256x256 output with 64 slices is 256 workgroups of 16-deep
+// chains instead of 64 workgroups of 64-deep ones (the kernel is latency-, not bandwidth-bound).
+// Blocks past the weight columns reduce the bias partials the same way.  Deterministic (no atomics).
 __global__ __launch_bounds__(256) void linear_dw_reduce(const float* __restrict__ part, const float* __restrict__ bpart,
                                                         float* __restrict__ dw, float* __restrict__ db, int nslice,
-                                                        int64_t nw, int Nout) {
-    // nw = Nout*K is a multiple of 16: one float4 per thread, four independent partial chains
-    int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (i < nw) {
-        f32x4 a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
-        int k = 0;
-        for (; k + 3 < nslice; k += 4) {
-            a0 += *reinterpret_cast<const f32x4*>(part + (int64_t)k * nw + i);
-            a1 += *reinterpret_cast<const f32x4*>(part + (int64_t)(k + 1) * nw + i);
-            a2 += *reinterpret_cast<const f32x4*>(part + (int64_t)(k + 2) * nw + i);
-            a3 += *reinterpret_cast<const f32x4*>(part + (int64_t)(k + 3) * nw + i);
+                                                        int64_t nw, int Nout, int nwb) {
+    __shared__ f32x4 red[3][64];
+    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const bool is_bias = (int)blockIdx.x >= nwb;
+    const int64_t ncol4 = is_bias ? Nout / 4 : nw / 4;
+    const int64_t j = (int64_t)(is_bias ? blockIdx.x - nwb : blockIdx.x) * 64 + c;
+    const float* src = is_bias ? bpart : part;
+    const int64_t stride = is_bias ? Nout : nw;
+    f32x4 a0 = {0, 0, 0, 0}, a1 = a0;
+    if (j < ncol4) {
+        int k = g;
+        for (; k + 4 < nslice; k += 8) {
+            a0 += *reinterpret_cast<const f32x4*>(src + (int64_t)k * stride + 4 * j);
+            a1 += *reinterpret_cast<const f32x4*>(src + (int64_t)(k + 4) * stride + 4 * j);
         }
-        for (; k < nslice; ++k) a0 += *reinterpret_cast<const f32x4*>(part + (int64_t)k * nw + i);
-        *reinterpret_cast<f32x4*>(dw + i) = (a0 + a1) + (a2 + a3);
-    } else if (db) {
-        int64_t n = (i - nw) / 4 * 4 + 0;   // threads past nw handle 4 bias columns each
-        for (int e = 0; e < 4; ++e) {
-            int64_t col = (i - nw) + e;
-            if (col < Nout) {
-                float s = 0.f;
-                for (int k2 = 0; k2 < nslice; ++k2) s += bpart[(int64_t)k2 * Nout + col];
-                db[col] = s;
-            }
-        }
-        (void)n;
+        if (k < nslice) a0 += *reinterpret_cast<const f32x4*>(src + (int64_t)k * stride + 4 * j);
+    }
+    a0 += a1;
+    if (g > 0) red[g - 1][c] = a0;
+    __syncthreads();
+    if (g == 0 && j < ncol4) {
+        a0 = (a0 + red[0][c]) + (red[1][c] + red[2][c]);
+        *reinterpret_cast<f32x4*>((is_bias ? db : dw) + 4 * j) = a0;
     }
 }
 
@@ -466,8 +468,8 @@ int launch_dw(const void* dy, const void* x, float* dw, float* db, void* ws, int
     linear_dw_kernel<T><<<dim3(p.ntile * ((p.nslice + 7) / 8) * 8), 256, lds, st>>>(
         reinterpret_cast<const T*>(dy), reinterpret_cast<const T*>(x), part, bpart, M, Nout, K, p.rows);
     int64_t nw = (int64_t)Nout * K;
-    int64_t tot = nw + (db ? Nout : 0);
-    linear_dw_reduce<<<dim3((unsigned)((tot + 255) / 256)), 256, 0, st>>>(part, bpart, dw, db, p.nslice, nw, Nout);
+    const int nwb = (int)((nw / 4 + 63) / 64), nbb = db ? (Nout / 4 + 63) / 64 : 0;
+    linear_dw_reduce<<<dim3(nwb + nbb), 256, 0, st>>>(part, bpart, dw, db, p.nslice, nw, Nout, nwb);
     return (int)hipGetLastError();
 }
 
@@ -490,8 +492,8 @@ int launch_dw_tr(const void* dy, const void* x, float* dw, float* db, void* ws, 
     linear_dw_tr_kernel<<<dim3(p.ntile * ((p.nslice + 7) / 8) * 8), 256, lds, st>>>(
         reinterpret_cast<const bf16_t*>(dy), reinterpret_cast<const bf16_t*>(x), part, bpart, M, Nout, K, p.rows);
     int64_t nw = (int64_t)Nout * K;
-    int64_t tot = (nw + (db ? Nout : 0) + 3) / 4;
-    linear_dw_reduce<<<dim3((unsigned)((tot + 255) / 256)), 256, 0, st>>>(part, bpart, dw, db, p.nslice, nw, Nout);
+    const int nwb = (int)((nw / 4 + 63) / 64), nbb = db ? (Nout / 4 + 63) / 64 : 0;
+    linear_dw_reduce<<<dim3(nwb + nbb), 256, 0, st>>>(part, bpart, dw, db, p.nslice, nw, Nout, nwb);
     return (int)hipGetLastError();
 }
 
