@@ -440,11 +440,15 @@ struct DwPlan { int ntile, nslice, rows; };
 DwPlan plan(int M, int Nout, int K) {
     DwPlan p;
     p.ntile = ((Nout + 127) / 128) * ((K + 127) / 128);
-    // workgroups in flight: one per CU keeps the per-slice partial traffic low for small outputs; at 16+
-    // tiles two per CU pay off (measured on MI355X, M = 131072).  GF_DW_WG overrides (tuning knob).
+    // One full round of two workgroups per CU (512 slots): slices = floor(512 / tiles), so no workgroup is
+    // left for a second, nearly empty round (12 tiles x 43 slices = 516 workgroups ran 27 % slower).
+    // Measured on MI355X at M = 131072 with the 4-group reduce.  GF_DW_WG overrides (tuning knob).
     static const int forced = getenv("GF_DW_WG") ? atoi(getenv("GF_DW_WG")) : 0;
-    const int total_wg = forced > 0 ? forced : (p.ntile >= 16 ? 512 : 256);
-    int want = (total_wg + p.ntile - 1) / p.ntile;
+    const int total_wg = forced > 0 ? forced : 512;
+    // slices are dealt to the 8 XCDs round-robin: keep (slices per XCD) x tiles within that XCD's 64 slots
+    int per_xcd = (total_wg / 8) / p.ntile;
+    if (per_xcd < 1) per_xcd = 1;
+    int want = 8 * per_xcd;
     int rows = (M + want - 1) / want;
     rows = ((rows + 63) / 64) * 64;
     if (rows < 256) rows = 256;
