@@ -119,3 +119,130 @@ def gt_matches_from_homography(kp0, kp1, H, pos_th=3.0, neg_th=3.0):
         "proj_0to1": kp0_1,
         "proj_1to0": kp1_0,
     }
+
+
+# ------------------------------------------------------------------------------------------------ depth + pose
+def _depth_projections(kp0, kp1, data, cc_th, kw):
+    from .geometry import project, sample_depth
+    camera0, camera1 = data["view0"]["camera"], data["view1"]["camera"]
+    T_0to1 = data["T_0to1"]
+    T_1to0 = data["T_1to0"] if "T_1to0" in data else T_0to1.inv()
+    depth0, depth1 = data["view0"].get("depth"), data["view1"].get("depth")
+    if "depth_keypoints0" in kw and "depth_keypoints1" in kw:
+        d0, valid0 = kw["depth_keypoints0"], kw["valid_depth_keypoints0"]
+        d1, valid1 = kw["depth_keypoints1"], kw["valid_depth_keypoints1"]
+    else:
+        assert depth0 is not None and depth1 is not None
+        d0, valid0 = sample_depth(kp0, depth0)
+        d1, valid1 = sample_depth(kp1, depth1)
+    kp0_1, visible0 = project(kp0, d0, depth1, camera0, camera1, T_0to1, valid0, ccth=cc_th)
+    kp1_0, visible1 = project(kp1, d1, depth0, camera1, camera0, T_1to0, valid1, ccth=cc_th)
+    return d0, d1, valid0, valid1, kp0_1, kp1_0, visible0, visible1
+
+
+@torch.no_grad()
+def gt_matches_from_pose_depth(kp0, kp1, data, pos_th=3, neg_th=5, epi_th=None, cc_th=None, **kw):
+    """Ground truth from depth maps and the relative pose (gluefactory/geometry/gt_generation.py:13-106): reproject
+    both ways through the sampled depth, positives = mutual nearest neighbours under max(d_0->1, d_1->0) among
+    co-visible points closer than pos_th, negatives = points with valid depth whose reprojection is farther
+    than neg_th from every keypoint (optionally extended by the epipolar test), everything else ignored (-2)."""
+    from .geometry import skew_symmetric, sym_epipolar_distance_all
+    b, m = kp0.shape[:2]
+    n = kp1.shape[1]
+    if m == 0 or n == 0:
+        return {"assignment": torch.zeros(b, m, n, dtype=torch.bool, device=kp0.device),
+                "matches0": -torch.ones(b, m, dtype=torch.long, device=kp0.device),
+                "matches1": -torch.ones(b, n, dtype=torch.long, device=kp0.device)}
+    d0, d1, valid0, valid1, kp0_1, kp1_0, visible0, visible1 = _depth_projections(kp0, kp1, data, cc_th, kw)
+    mask_visible = visible0.unsqueeze(-1) & visible1.unsqueeze(-2)
+    dist0 = torch.sum((kp0_1.unsqueeze(-2) - kp1.unsqueeze(-3)) ** 2, -1)
+    dist1 = torch.sum((kp0.unsqueeze(-2) - kp1_0.unsqueeze(-3)) ** 2, -1)
+    dist = torch.max(dist0, dist1)
+    inf = dist.new_tensor(float("inf"))
+    dist = torch.where(mask_visible, dist, inf)
+    min0 = dist.min(-1).indices
+    min1 = dist.min(-2).indices
+    ismin0 = torch.zeros(dist.shape, dtype=torch.bool, device=dist.device)
+    ismin1 = ismin0.clone()
+    ismin0.scatter_(-1, min0.unsqueeze(-1), value=1)
+    ismin1.scatter_(-2, min1.unsqueeze(-2), value=1)
+    positive = ismin0 & ismin1 & (dist < pos_th ** 2)
+    negative0 = (dist0.min(-1).values > neg_th ** 2) & valid0
+    negative1 = (dist1.min(-2).values > neg_th ** 2) & valid1
+    unmatched, ignore = min0.new_tensor(UNMATCHED_FEATURE), min0.new_tensor(IGNORE_FEATURE)
+    m0 = torch.where(positive.any(-1), min0, ignore)
+    m1 = torch.where(positive.any(-2), min1, ignore)
+    m0 = torch.where(negative0, unmatched, m0)
+    m1 = torch.where(negative1, unmatched, m1)
+    camera0, camera1, T_0to1 = data["view0"]["camera"], data["view1"]["camera"], data["T_0to1"]
+    Fm = (camera1.calibration_matrix().inverse().transpose(-1, -2) @ (skew_symmetric(T_0to1.t) @ T_0to1.R)
+          @ camera0.calibration_matrix().inverse())
+    epi_dist = sym_epipolar_distance_all(kp0, kp1, Fm)
+    if epi_th is not None:
+        mask_ignore = (m0.unsqueeze(-1) == ignore) & (m1.unsqueeze(-2) == ignore)
+        epi_dist = torch.where(mask_ignore, epi_dist, inf)
+        exclude0 = epi_dist.min(-1).values > neg_th
+        exclude1 = epi_dist.min(-2).values > neg_th
+        m0 = torch.where((~valid0) & exclude0, ignore.new_tensor(-1), m0)
+        m1 = torch.where((~valid1) & exclude1, ignore.new_tensor(-1), m1)
+    return {"assignment": positive,
+            "assignment_col0": torch.where(positive.any(-1), min0, torch.full_like(min0, -1)),
+            "reward": (dist < pos_th ** 2).float() - (epi_dist > neg_th).float(),
+            "matches0": m0, "matches1": m1,
+            "matching_scores0": (m0 > -1).float(), "matching_scores1": (m1 > -1).float(),
+            "depth_keypoints0": d0, "depth_keypoints1": d1,
+            "proj_0to1": kp0_1, "proj_1to0": kp1_0, "visible0": visible0, "visible1": visible1}
+
+
+@torch.no_grad()
+def gt_matches_from_pose_depth_fused(kp0, kp1, data, pos_th=3, neg_th=5, cc_th=None, **kw):
+    """Same labels without any [B,M,N] fp32 tensor (HIP nearest-neighbour kernel gf_gt_nn); for the
+    configuration the matchers train with (no epipolar extension, no dense ``reward``).  Points that are not
+    co-visible are moved far away for the mutual-NN search (their rows / columns would be +inf in the dense
+    form); the negative test runs on the true reprojections, exactly as in the dense form."""
+    from . import lib as _lib
+    b, m = kp0.shape[:2]
+    n = kp1.shape[1]
+    d0, d1, valid0, valid1, kp0_1, kp1_0, visible0, visible1 = _depth_projections(kp0, kp1, data, cc_th, kw)
+    dev = kp0.device
+    kp0f, kp1f = kp0.float().contiguous(), kp1.float().contiguous()
+    # reprojections of points without depth are NaN: they are invisible (moved away below) and never "valid"
+    p01 = torch.nan_to_num(kp0_1.float(), nan=0.0, posinf=0.0, neginf=0.0).contiguous()
+    p10 = torch.nan_to_num(kp1_0.float(), nan=0.0, posinf=0.0, neginf=0.0).contiguous()
+    L = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+
+    def nn(own, own_w, oth, oth_w):
+        no = own.shape[1]
+        arg = torch.empty((b, no), dtype=torch.int64, device=dev)
+        dmin = torch.empty((b, no), dtype=torch.float32, device=dev)
+        omin = torch.empty((b, no), dtype=torch.float32, device=dev)
+        _lib.check(L.gf_gt_nn(own.data_ptr(), own_w.data_ptr(), oth.data_ptr(), oth_w.data_ptr(), arg.data_ptr(),
+                              dmin.data_ptr(), omin.data_ptr(), b, no, oth.shape[1], st), "gf_gt_nn")
+        return arg, dmin, omin
+
+    # invisible points: reprojection AND position pushed out, so max(d0, d1) is huge against every partner
+    far = 1.0e8
+    off0 = torch.where(visible0[..., None], torch.zeros_like(kp0f), torch.full_like(kp0f, far))
+    off1 = torch.where(visible1[..., None], torch.zeros_like(kp1f), torch.full_like(kp1f, -far))
+    a0, a0w = (kp0f + off0).contiguous(), (p01 + off0).contiguous()
+    a1, a1w = (kp1f + off1).contiguous(), (p10 + off1).contiguous()
+    min0, dd0, _ = nn(a0, a0w, a1, a1w)
+    min1, dd1, _ = nn(a1, a1w, a0, a0w)
+    _, _, own0 = nn(kp0f, p01, kp1f, p10)          # true reprojections: min_j |kp0_1 - kp1|^2
+    _, _, own1 = nn(kp1f, p10, kp0f, p01)
+    ar0 = torch.arange(m, device=dev)[None]
+    ar1 = torch.arange(n, device=dev)[None]
+    pos0 = (min1.gather(1, min0) == ar0) & (dd0 < pos_th ** 2) & visible0 & visible1.gather(1, min0)
+    pos1 = (min0.gather(1, min1) == ar1) & (dd1 < pos_th ** 2) & visible1 & visible0.gather(1, min1)
+    positive = torch.zeros(b, m, n, dtype=torch.bool, device=dev)
+    positive.scatter_(2, min0[..., None], pos0[..., None])
+    m0 = torch.where(pos0, min0, torch.full_like(min0, IGNORE_FEATURE))
+    m1 = torch.where(pos1, min1, torch.full_like(min1, IGNORE_FEATURE))
+    m0 = torch.where((own0 > neg_th ** 2) & valid0, torch.full_like(m0, UNMATCHED_FEATURE), m0)
+    m1 = torch.where((own1 > neg_th ** 2) & valid1, torch.full_like(m1, UNMATCHED_FEATURE), m1)
+    return {"assignment": positive, "assignment_col0": torch.where(pos0, min0, torch.full_like(min0, -1)),
+            "matches0": m0, "matches1": m1,
+            "matching_scores0": (m0 > -1).float(), "matching_scores1": (m1 > -1).float(),
+            "depth_keypoints0": d0, "depth_keypoints1": d1,
+            "proj_0to1": kp0_1, "proj_1to0": kp1_0, "visible0": visible0, "visible1": visible1}

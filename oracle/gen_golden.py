@@ -208,6 +208,61 @@ def gen_gt(name, batch, n0, n1, seed):
     print(name, "positives", ref["assignment"].sum((1, 2)).tolist())
 
 
+def depth_scene(batch, n0, n1, seed, hw=(96, 128)):
+    """Seeded synthetic two-view scene: smooth positive depth maps with holes, pinhole cameras, a small relative
+    pose; kp1 = reprojections of a subset of kp0 (+ noise) followed by uniform points.  Plain tensors only."""
+    g = torch.Generator().manual_seed(seed)
+    h, w = hw
+    ys, xs = torch.meshgrid(torch.arange(h).float(), torch.arange(w).float(), indexing="ij")
+    depth = []
+    for v in range(2):
+        d = 4.0 + 0.6 * torch.sin(xs / 17.0 + v) + 0.4 * torch.cos(ys / 11.0 - v) + 0.05 * torch.rand(batch, h, w, generator=g)
+        d[:, 20:30, 40:60] = 0.0                       # a hole (invalid depth)
+        d[torch.rand(batch, h, w, generator=g) < 0.03] = 0.0
+        depth.append(d)
+    f = 100.0
+    cam = torch.tensor([w, h, f, f, w / 2.0, h / 2.0]).repeat(batch, 1)
+    ang = 0.05 * (torch.rand(batch, 3, generator=g) - 0.5)
+    K = torch.zeros(batch, 3, 3)
+    K[:, 0, 1], K[:, 0, 2], K[:, 1, 2] = -ang[:, 2], ang[:, 1], -ang[:, 0]
+    K = K - K.transpose(1, 2)
+    R = torch.linalg.matrix_exp(K)
+    t = 0.3 * (torch.rand(batch, 3, generator=g) - 0.5)
+    kp0 = torch.rand(batch, n0, 2, generator=g) * torch.tensor([w - 1.0, h - 1.0])
+    return {"depth0": depth[0], "depth1": depth[1], "camera0": cam, "camera1": cam.clone(), "R": R, "t": t,
+            "keypoints0": kp0, "n1": n1, "seed": seed}
+
+
+def gen_gt_depth(name, batch, n0, n1, seed):
+    from gluefactory.geometry.depth import project, sample_depth
+    from gluefactory.geometry.gt_generation import gt_matches_from_pose_depth
+    from gluefactory.geometry.wrappers import Camera, Pose
+
+    sc = depth_scene(batch, n0, n1, seed)
+    cam0, cam1 = Camera(sc["camera0"]), Camera(sc["camera1"])
+    T = Pose.from_Rt(sc["R"], sc["t"])
+    kp0 = sc["keypoints0"]
+    d0, v0 = sample_depth(kp0, sc["depth0"])
+    proj, vis = project(kp0, d0, sc["depth1"], cam0, cam1, T, v0)
+    g = torch.Generator().manual_seed(seed + 1)
+    nm = (2 * n1) // 3
+    kp1 = torch.rand(batch, n1, 2, generator=g) * torch.tensor([127.0, 95.0])
+    src = torch.nan_to_num(proj[:, :nm], nan=5.0) + 0.7 * torch.randn(batch, nm, 2, generator=g)
+    kp1[:, :nm] = torch.where(vis[:, :nm, None], src, kp1[:, :nm])
+    kp1 = kp1[:, torch.randperm(n1, generator=g)]
+    data = {"view0": {"camera": cam0, "depth": sc["depth0"]}, "view1": {"camera": cam1, "depth": sc["depth1"]},
+            "T_0to1": T}
+    out = {"data.depth0": sc["depth0"].numpy(), "data.depth1": sc["depth1"].numpy(), "data.camera0": sc["camera0"].numpy(),
+           "data.camera1": sc["camera1"].numpy(), "data.R": sc["R"].numpy(), "data.t": sc["t"].numpy(),
+           "data.keypoints0": kp0.numpy(), "data.keypoints1": kp1.numpy()}
+    for tag, kwargs in (("plain", {}), ("cc", {"cc_th": 4.0}), ("epi", {"epi_th": 1.0, "cc_th": 4.0})):
+        ref = gt_matches_from_pose_depth(kp0, kp1, data, pos_th=3.0, neg_th=5.0, **kwargs)
+        out.update(_np(ref, f"{tag}."))
+        print(name, tag, "positives", ref["assignment"].sum((1, 2)).tolist(),
+              "unmatched0", (ref["matches0"] == -1).sum(1).tolist(), "ignored0", (ref["matches0"] == -2).sum(1).tolist())
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     gen_lightglue("lightglue_small", batch=2, n0=40, n1=48, n_layers=2, dim=64, heads=4,
@@ -215,6 +270,7 @@ def main():
     gen_lightglue("lightglue_d256", batch=1, n0=72, n1=64, n_layers=2, dim=256, heads=4,
                   seed=23, size=(1024, 1024), store_params=False)
     gen_gt("gt_homography", batch=2, n0=96, n1=80, seed=5)
+    gen_gt_depth("gt_depth", batch=2, n0=120, n1=100, seed=61)
     gen_superpoint("superpoint_open", seed=51)
     gen_gluestick("gluestick_d256", batch=2, n_kpts=40, n_lines=12, gnn=["self", "cross"] * 2, inter=[0], seed=41)
     gen_superglue("superglue_d256", batch=2, n0=60, n1=52, gnn=["self", "cross"] * 2, iters=20, seed=31)

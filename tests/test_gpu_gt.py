@@ -35,3 +35,24 @@ def test_fused_gt_equals_torch_path(b, m, n):
     m0, m1 = out["matches0"], out["matches1"]
     rows = (m0 >= 0).nonzero()
     assert torch.equal(m1[rows[:, 0], m0[rows[:, 0], rows[:, 1]]], rows[:, 1])
+
+
+@pytest.mark.parametrize("cc_th", [None, 4.0])
+def test_fused_depth_gt_equals_dense_form(cc_th):
+    """gt_matches_from_pose_depth_fused (gf_gt_nn, no [B,M,N] fp32 tensor) vs the dense torch form and the
+    reference-generated vectors."""
+    import numpy as np
+    from conftest import load_golden
+    from test_gt_golden import _depth_data
+    from glue_factory_amd.gt import gt_matches_from_pose_depth, gt_matches_from_pose_depth_fused
+    z = load_golden("gt_depth")
+    kp0, kp1, data = _depth_data(z, "cuda")
+    kw = {} if cc_th is None else {"cc_th": cc_th}
+    dense = gt_matches_from_pose_depth(kp0, kp1, data, pos_th=3.0, neg_th=5.0, **kw)
+    fused = gt_matches_from_pose_depth_fused(kp0, kp1, data, pos_th=3.0, neg_th=5.0, **kw)
+    for k in ("assignment", "assignment_col0", "matches0", "matches1", "visible0", "visible1"):
+        assert torch.equal(fused[k], dense[k]), k
+    tag = "plain" if cc_th is None else "cc"
+    np.testing.assert_array_equal(fused["matches0"].cpu().numpy(), z[f"{tag}.matches0"])
+    np.testing.assert_array_equal(fused["matches1"].cpu().numpy(), z[f"{tag}.matches1"])
+    np.testing.assert_array_equal(fused["assignment"].cpu().numpy(), z[f"{tag}.assignment"])

@@ -26,3 +26,41 @@ def test_gt_from_homography_matches_reference():
 def test_gt_empty_inputs():
     out = gt_matches_from_homography(torch.zeros(2, 0, 2), torch.zeros(2, 5, 2), torch.eye(3)[None].repeat(2, 1, 1))
     assert out["assignment"].shape == (2, 0, 5) and out["matches1"].tolist() == [[-1] * 5] * 2
+
+
+def _depth_data(z, device="cpu"):
+    from glue_factory_amd.geometry import Camera, Pose
+    t = lambda k: torch.from_numpy(z[k]).to(device)
+    data = {"view0": {"camera": Camera(t("data.camera0")), "depth": t("data.depth0")},
+            "view1": {"camera": Camera(t("data.camera1")), "depth": t("data.depth1")},
+            "T_0to1": Pose.from_Rt(t("data.R"), t("data.t"))}
+    return t("data.keypoints0"), t("data.keypoints1"), data
+
+
+def test_gt_from_pose_depth_matches_reference():
+    """gt_matches_from_pose_depth (+ our pinhole Camera / Pose) vs vectors produced by the reference's
+    gt_generation.py:13-106 with its own wrappers: plain, cycle-consistency and epipolar-extended variants."""
+    from glue_factory_amd.gt import gt_matches_from_pose_depth
+    z = load_golden("gt_depth")
+    kp0, kp1, data = _depth_data(z)
+    for tag, kw in (("plain", {}), ("cc", {"cc_th": 4.0}), ("epi", {"epi_th": 1.0, "cc_th": 4.0})):
+        out = gt_matches_from_pose_depth(kp0, kp1, data, pos_th=3.0, neg_th=5.0, **kw)
+        for k in ("assignment", "matches0", "matches1", "visible0", "visible1"):
+            np.testing.assert_array_equal(out[k].numpy(), z[f"{tag}.{k}"], err_msg=f"{tag}.{k}")
+        for k in ("reward", "matching_scores0", "depth_keypoints0", "depth_keypoints1", "proj_0to1", "proj_1to0"):
+            np.testing.assert_allclose(out[k].numpy(), z[f"{tag}.{k}"], rtol=1e-4, atol=1e-4, err_msg=f"{tag}.{k}",
+                                       equal_nan=True)
+        col = out["assignment_col0"]
+        dense = torch.zeros_like(out["assignment"])
+        dense.scatter_(2, col.clamp(min=0)[..., None], (col >= 0)[..., None])
+        assert torch.equal(dense, out["assignment"])
+
+
+def test_depth_matcher_plugin_surface():
+    from glue_factory_amd.base_model import get_model
+    z = load_golden("gt_depth")
+    kp0, kp1, data = _depth_data(z)
+    m = get_model("matchers.depth_matcher")({"th_consistency": 4.0})
+    pred = m({**data, "keypoints0": kp0, "keypoints1": kp1})
+    np.testing.assert_array_equal(pred["matches0"].numpy(), z["cc.matches0"])
+    np.testing.assert_array_equal(pred["assignment"].numpy(), z["cc.assignment"])
