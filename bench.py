@@ -102,7 +102,7 @@ def roofline_attention(batch, n, dtype):
     f_bwd = 2.5 * f_fwd
     ach = f_bwd / t_bwd / 1e12
     return {
-        "bound": "mfma", "kernel": "gf_attn_bwd (attn_bwd_dq_kernel + attn_bwd_dkv_kernel)",
+        "bound": "mfma", "kernel": "gf_attn_bwd (attn_bwd_dq_kernel + attn_bwd_dkv_bf16_kernel)",
         "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
         "launch_ms": round(t_bwd * 1e3, 4),
