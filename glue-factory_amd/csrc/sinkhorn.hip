@@ -18,6 +18,7 @@
 //   dZ_ij = G_ij - sum_k [ exp(Z_ij+u^k_i+v^k_j-log_nu_j) vbar^k_j + exp(Z_ij+u^k_i-log_mu_i+v^{k-1}_j) ubar^k_i ]
 // i.e. T passes of the same one-read shape plus one final pass; every exponent is <= 0 up to
 // rounding (Q, R are sub-stochastic), so no max-shift is needed in the reverse sweep.
+#include <cstdlib>
 #include "gf_common.h"
 #include "gf_amd.h"
 
@@ -265,7 +266,8 @@ Geo make_geo(int B, int M, int N) {
     g.B = B; g.M = M; g.N = N; g.R = M + 1; g.C = N + 1;
     // rows per block: bounded by LDS (RB rows + 4 column vectors), at most 16
     size_t rb = (LDS_BUDGET - 4 * (size_t)g.C * 4 - 512) / ((size_t)g.C * 4);
-    g.RB = (int)(rb > 16 ? 16 : rb);
+    static const int cap = getenv("GF_SK_RB") ? atoi(getenv("GF_SK_RB")) : 16;   // tuning knob
+    g.RB = (int)(rb > (size_t)cap ? (size_t)cap : rb);
     g.nblk = g.RB > 0 ? (g.R + g.RB - 1) / g.RB : 0;
     g.norm = -logf((float)(M + N));
     g.lmu_last = logf((float)N) + g.norm;
