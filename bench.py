@@ -293,7 +293,7 @@ def main():
 
     def barrier():
         if dist is not None:
-            dist.barrier()
+            dist.barrier(device_ids=[local])
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):

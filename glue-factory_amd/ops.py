@@ -4,6 +4,8 @@ PyTorch is plumbing here (device memory, streams, autograd graph); every op belo
 C ABI of include/gf_amd.h through ctypes with raw device pointers and the current HIP stream.
 There is no CPU or eager fallback: a non-CUDA tensor or a missing library raises.
 """
+import weakref
+
 import torch
 
 from . import lib as _lib
@@ -228,7 +230,7 @@ def precast(params, dtype, key="default"):
     with torch.no_grad():
         torch._foreach_copy_(slot[1], [p_.detach() for p_ in params])
     for p_, v in zip(params, slot[1]):
-        _LP_CACHE[id(p_)] = (p_._version, dtype, v, p_)
+        _LP_CACHE[id(p_)] = (p_._version, dtype, v, weakref.ref(p_))
 
 
 def _lp(t, dtype):
@@ -236,7 +238,7 @@ def _lp(t, dtype):
     if t is None or t.dtype == dtype:
         return t
     hit = _LP_CACHE.get(id(t))
-    if hit is not None and hit[3] is t and hit[0] == t._version and hit[1] == dtype:
+    if hit is not None and hit[3]() is t and hit[0] == t._version and hit[1] == dtype:
         return hit[2]
     return t.to(dtype)
 

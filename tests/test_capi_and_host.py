@@ -101,3 +101,35 @@ def test_lightglue_conf_state_dict_and_no_cpu_fallback():
         m(data)
     with pytest.raises(NotImplementedError):
         LightGlue({"descriptor_dim": 128, "num_heads": 4})
+
+
+def test_fixed_length_positive_list_equals_nonzero():
+    """LightGlue._gt_sparse: the fixed-length list built from gt_assignment_col0 carries the same positives
+    and counts as nonzero() on the dense matrix (host logic, CPU)."""
+    import torch
+    from glue_factory_amd.matchers.lightglue import LightGlue
+    from glue_factory_amd.synthetic import make_pairs
+    data = make_pairs(3, 50, 60, dim=8, size=(640, 480), seed=4)
+    dense = LightGlue._gt_sparse(data)
+    fixed = LightGlue._gt_sparse(data, fixed=True)
+    assert fixed["pos"][2].shape[0] == 3 * 50
+    keep = fixed["pos"][2] >= 0
+    got = torch.stack([t[keep] for t in fixed["pos"]], 1)
+    ref = torch.stack(dense["pos"], 1)
+    assert torch.equal(got, ref)                       # same (b, i, j) triples in the same (sorted) order
+    for k in ("num_pos", "n0", "n1", "neg0", "neg1"):
+        assert torch.equal(fixed[k], dense[k]), k
+    data.pop("gt_assignment_col0")
+    again = LightGlue._gt_sparse(data, fixed=True)     # producer without the key: dense path
+    assert torch.equal(torch.stack(again["pos"], 1), ref)
+
+
+def test_precast_cache_follows_parameter_versions():
+    import torch
+    from glue_factory_amd import ops
+    if not torch.cuda.is_available():
+        # CPU tensors are never cached (the product path is HIP-only): _lp is a plain cast
+        w = torch.nn.Parameter(torch.randn(4, 4))
+        ops.precast([w], torch.bfloat16, key="t")
+        assert ops._lp(w, torch.bfloat16).dtype == torch.bfloat16
+        assert id(w) not in ops._LP_CACHE
