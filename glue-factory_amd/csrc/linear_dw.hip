@@ -8,6 +8,7 @@
 // double-buffered with register prefetch, accumulates in fp32, and writes its partial tile to
 // a workspace; a second kernel sums the slices (deterministic, no atomics) into fp32 dW / db.
 #include <cstdlib>
+#include <type_traits>
 #include "gf_common.h"
 #include "gf_amd.h"
 
@@ -404,6 +405,174 @@ __global__ __launch_bounds__(256, 2) void linear_dw_tr_kernel(const bf16_t* __re
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// bf16, Nout % 128 == 0 and K % 128 == 0: LDS-DMA staging.  The register-staged kernel above spends more
+// LDS-pipe time on its staging stores (8 ds_write_b128 per thread and chunk: ~415 cycles per workgroup-chunk
+// at 79 B/clk) than on the transposing reads the MFMAs need (256 cycles), and the LDS pipe is what bounds it.
+// Here `global_load_lds_dwordx4` writes the tiles (32 tokens x 128 channels of dY and of X per stage,
+// unpadded rows, 16-byte chunks XOR-swizzled by (row & 3) << 2 so the 4-row transposing reads hit distinct
+// bank groups) into a 4-stage ring, counted vmcnt, one raw barrier per chunk; the bias gradient is a third
+// MFMA against a fragment of ones.
+// ---------------------------------------------------------------------------------------------
+constexpr int DM_ROWS = 32, DM_TILE = DM_ROWS * 256, DM_STAGE = 2 * DM_TILE, DM_NSTAGE = 4;
+typedef __attribute__((address_space(3))) void dm_lds_void;
+typedef const __attribute__((address_space(1))) void dm_glb_void;
+
+template <int OFF> __device__ __forceinline__ u32x2 dm_rdtr(unsigned a) {
+    u32x2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF) : "memory");
+    return v;
+}
+template <int N> __device__ __forceinline__ void dm_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <typename V> __device__ __forceinline__ void dm_tie(V& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ bf16x8 dm_frag(u32x2 lo, u32x2 hi) {
+    u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int SO, bool BIAS>
+__device__ __forceinline__ void dm_chunk(f32x16 (&acc)[2][2], f32x16 (&bacc)[2], unsigned aA, unsigned aB) {
+    // 32 tokens = 2 k-steps: [ks][i][half] for the dY^T (A) and X^T (B) fragments; i toggles address bit 6
+    u32x2 fa[2][2][2], fb[2][2][2];
+#define GF_RD(ks) \
+    fa[ks][0][0] = dm_rdtr<SO + ks * 4096>(aA);            fa[ks][0][1] = dm_rdtr<SO + ks * 4096 + 1024>(aA); \
+    fa[ks][1][0] = dm_rdtr<SO + ks * 4096>(aA ^ 64u);      fa[ks][1][1] = dm_rdtr<SO + ks * 4096 + 1024>(aA ^ 64u); \
+    fb[ks][0][0] = dm_rdtr<SO + DM_TILE + ks * 4096>(aB);  fb[ks][0][1] = dm_rdtr<SO + DM_TILE + ks * 4096 + 1024>(aB); \
+    fb[ks][1][0] = dm_rdtr<SO + DM_TILE + ks * 4096>(aB ^ 64u); fb[ks][1][1] = dm_rdtr<SO + DM_TILE + ks * 4096 + 1024>(aB ^ 64u);
+    GF_RD(0)
+    GF_RD(1)
+#undef GF_RD
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        if (ks == 0) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { dm_tie(fa[ks][i][0]); dm_tie(fa[ks][i][1]); dm_tie(fb[ks][i][0]); dm_tie(fb[ks][i][1]); }
+        const bf16x8 a0 = dm_frag(fa[ks][0][0], fa[ks][0][1]), a1 = dm_frag(fa[ks][1][0], fa[ks][1][1]);
+        const bf16x8 b0 = dm_frag(fb[ks][0][0], fb[ks][0][1]), b1 = dm_frag(fb[ks][1][0], fb[ks][1][1]);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+        if (BIAS) {
+            bacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, ones, bacc[0], 0, 0, 0);
+            bacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, ones, bacc[1], 0, 0, 0);
+        }
+    }
+}
+
+template <bool BIAS>
+__device__ __forceinline__ void dm_body(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, float* __restrict__ pp,
+                                        float* __restrict__ bp, int M, int Nout, int K, int m_begin, int m_end, int tn,
+                                        int tk) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const unsigned lds0 = (unsigned)(size_t)smem;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, hi = lane >> 5, s16 = lane & 15, g1 = (lane >> 4) & 1;
+    const int wn = wave >> 1, wk = wave & 1;
+
+    // ---- DMA descriptors: pieces 2*wave, 2*wave+1 of each tile; a piece = 4 rows x 256 B
+    const int prow = lane >> 4, pphys = lane & 15;
+    const int plog = pphys ^ ((prow & 3) << 2);
+    const bf16_t* gA = dy + (int64_t)tn * 128 + plog * 8;
+    const bf16_t* gB = x + (int64_t)tk * 128 + plog * 8;
+    auto issue = [&](int c, int stage) {
+        char* sb = smem + stage * DM_STAGE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int piece = 2 * wave + i;
+            const int64_t row = min(m_begin + c * DM_ROWS + 4 * piece + prow, M - 1);
+            __builtin_amdgcn_global_load_lds((dm_glb_void*)(gA + row * Nout), (dm_lds_void*)(sb + piece * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((dm_glb_void*)(gB + row * K), (dm_lds_void*)(sb + DM_TILE + piece * 1024), 16, 0, 0);
+        }
+    };
+    const int nchunk = (m_end - m_begin + DM_ROWS - 1) / DM_ROWS;
+#pragma unroll
+    for (int c = 0; c < DM_NSTAGE - 1; ++c)
+        if (c < nchunk) issue(c, c);
+
+    f32x16 acc[2][2], bacc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bacc[i][r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    }
+    // per-lane transposing-read addresses (stage 0, k-step 0, first half): row 8 hi + (s16 >> 2), 8-byte piece
+    // (s16 & 1) of logical 16-byte chunk 8 w + 2 g1 + ((s16 & 3) >> 1), XOR-swizzled by (row & 3) << 2
+    const int rr = (s16 >> 2) & 3;
+    auto rd_addr = [&](int w) {
+        const int chunk = (8 * w + 2 * g1 + ((s16 & 3) >> 1)) ^ (rr << 2);
+        return lds0 + (unsigned)((8 * hi + (s16 >> 2)) * 256 + chunk * 16 + (s16 & 1) * 8);
+    };
+    const unsigned aA = rd_addr(wn), aB = rd_addr(wk);
+
+    auto step = [&](int c, auto stage_c) {
+        constexpr int ST = decltype(stage_c)::value;
+        if (c + 1 >= nchunk) dm_wait_vm<0>();                     // chunk c landed (this wave's pieces)
+        else if (c + 2 >= nchunk) dm_wait_vm<4>();
+        else dm_wait_vm<8>();
+        __builtin_amdgcn_s_barrier();                             // ... everyone's; the stage of chunk c-1 is free
+        __builtin_amdgcn_sched_barrier(0);
+        if (c + DM_NSTAGE - 1 < nchunk) issue(c + DM_NSTAGE - 1, (ST + DM_NSTAGE - 1) % DM_NSTAGE);
+        const int valid = m_end - (m_begin + c * DM_ROWS);
+        if (valid < DM_ROWS) {                                    // ragged last chunk: rows past m_end count as 0
+            for (int i = threadIdx.x; i < 2 * DM_ROWS * 16; i += 256) {
+                const int row = (i >> 4) & (DM_ROWS - 1);
+                if (row >= valid) *reinterpret_cast<u32x4*>(smem + ST * DM_STAGE + (i >> 9) * DM_TILE + row * 256 + (i & 15) * 16) = u32x4{0, 0, 0, 0};
+            }
+            __syncthreads();
+        }
+        dm_chunk<ST * DM_STAGE, BIAS>(acc, bacc, aA, aB);
+    };
+    for (int c = 0; c < nchunk; c += DM_NSTAGE) {
+        step(c, std::integral_constant<int, 0>{});
+        if (c + 1 < nchunk) step(c + 1, std::integral_constant<int, 1>{});
+        if (c + 2 < nchunk) step(c + 2, std::integral_constant<int, 2>{});
+        if (c + 3 < nchunk) step(c + 3, std::integral_constant<int, 3>{});
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int kk = tk * 128 + wk * 64 + j * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int nn = tn * 128 + wn * 64 + i * 32 + crow(r, hi);
+                pp[(int64_t)nn * K + kk] = acc[i][j][r];
+            }
+        }
+    if (BIAS && wk == 0 && l31 == 0) {          // every column of the ones-product holds the row sums
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bp[tn * 128 + wn * 64 + i * 32 + crow(r, hi)] = bacc[i][r];
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void linear_dw_dma_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                               float* __restrict__ part, float* __restrict__ bpart,
+                                                               int M, int Nout, int K, int rows_per_slice) {
+    const int ntk = K / 128;
+    const int ntile = (Nout / 128) * ntk;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int tile = j % ntile;
+    const int slice = (j / ntile) * 8 + xcd;
+    const int tn = tile / ntk, tk = tile % ntk;
+    const int m_begin = slice * rows_per_slice, m_end = min(M, m_begin + rows_per_slice);
+    if (m_begin >= M) return;
+    float* pp = part + (int64_t)slice * Nout * K;
+    float* bp = bpart + (int64_t)slice * Nout;
+    if (tk == 0) dm_body<true>(dy, x, pp, bp, M, Nout, K, m_begin, m_end, tn, tk);
+    else dm_body<false>(dy, x, pp, bp, M, Nout, K, m_begin, m_end, tn, tk);
+}
+
 // Sum of the per-slice partials.  A workgroup covers 64 float4 columns with FOUR slice groups (one per wave,
 // slices k = g mod 4) that meet in LDS: a 256x256 output with 64 slices is 256 workgroups of 16-deep
 // chains instead of 64 workgroups of 64-deep ones (the kernel is latency-, not bandwidth-bound).
@@ -489,6 +658,20 @@ int launch_dw_tr(const void* dy, const void* x, float* dw, float* db, void* ws, 
     DwPlan p = plan(M, Nout, K);
     float* part = reinterpret_cast<float*>(ws);
     float* bpart = part + (int64_t)p.nslice * Nout * K;
+    static const bool no_dma = getenv("GF_DW_NODMA") != nullptr;      // A/B switch (tools/probe/time_dw.py)
+    if (Nout % 128 == 0 && K % 128 == 0 && !no_dma) {
+        const size_t dlds = (size_t)DM_NSTAGE * DM_STAGE;
+        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_dw_dma_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)dlds);
+        if (e2 != hipSuccess) return (int)e2;
+        linear_dw_dma_kernel<<<dim3(p.ntile * ((p.nslice + 7) / 8) * 8), 256, dlds, st>>>(
+            reinterpret_cast<const bf16_t*>(dy), reinterpret_cast<const bf16_t*>(x), part, bpart, M, Nout, K, p.rows);
+        if (int e3 = (int)hipGetLastError()) return e3;
+        int64_t nw2 = (int64_t)Nout * K;
+        const int nwb2 = (int)((nw2 / 4 + 63) / 64), nbb2 = db ? (Nout / 4 + 63) / 64 : 0;
+        linear_dw_reduce<<<dim3(nwb2 + nbb2), 256, 0, st>>>(part, bpart, dw, db, p.nslice, nw2, Nout, nwb2);
+        return (int)hipGetLastError();
+    }
     size_t lds = 4 * (size_t)TR_TILE * sizeof(bf16_t);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_dw_tr_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
