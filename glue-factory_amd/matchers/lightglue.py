@@ -77,7 +77,7 @@ def _lin(x, layer):
 def _ffn(ffn, x, msg):
     h = ops.linear_cat(x, msg, ffn[0].weight, ffn[0].bias)
     h = ops.ln_gelu(h, ffn[1].weight, ffn[1].bias, ffn[1].eps)
-    return x + _lin(h, ffn[3])
+    return ops.linear(h, ffn[3].weight, ffn[3].bias, res=x)      # residual fused into the GEMM epilogue
 
 
 class SelfBlock(nn.Module):

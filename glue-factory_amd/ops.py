@@ -243,19 +243,59 @@ def _lp(t, dtype):
     return t.to(dtype)
 
 
+# Forward GEMM: the tuned library GEMM (hipBLASLt) by default.  The hand-written kernel gf_linear_fwd (bias /
+# residual fused, bf16, 128-multiple outputs) is correct but measured 1.4x SLOWER than the library at these
+# tall-skinny shapes (44 vs 31 us for 131072 x 256 x 256), so it is opt-in: GF_AMD_HIP_GEMM=1.
+import os as _os
+_LIBRARY_GEMM = _os.environ.get("GF_AMD_HIP_GEMM", "0") != "1"
+
+
+def _gemm_ok(x2, wt):
+    return (not _LIBRARY_GEMM and x2.is_cuda and x2.dtype == torch.bfloat16 and wt.dtype == torch.bfloat16
+            and wt.shape[0] % 128 == 0 and wt.shape[1] % 32 == 0 and x2.stride(1) == 1 and wt.stride(1) == 1
+            and x2.stride(0) % 8 == 0 and wt.stride(0) % 8 == 0)
+
+
+def _linear_fwd(x2, wt, bias, res2=None, out=None):
+    """y [M,N] = x2 [M,K] wt[N,K]^T + bias (+ res2).  bias: the fp32 master (HIP path) -- cast for the library."""
+    M, K = x2.shape
+    N = wt.shape[0]
+    if _gemm_ok(x2, wt) and (res2 is None or (res2.dtype == x2.dtype and res2.stride(1) == 1 and res2.stride(0) % 4 == 0)):
+        y = torch.empty((M, N), dtype=x2.dtype, device=x2.device) if out is None else out
+        b32 = None if bias is None else bias.detach().float().contiguous()
+        _lib.check(_lib.load().gf_linear_fwd(_p(x2), _p(wt), _p(b32), _p(res2), _p(y), M, N, K, x2.stride(0), wt.stride(0),
+                                             0 if res2 is None else res2.stride(0), y.stride(0), _dt(x2), _stream()),
+                   "gf_linear_fwd")
+        return y
+    y = torch.nn.functional.linear(x2, wt, _lp(bias, x2.dtype))
+    if res2 is not None:
+        y = y.add_(res2) if out is None else out.copy_(y + res2)
+    return y
+
+
 class _Linear(torch.autograd.Function):
-    """y = x W^T + b with the forward / input-gradient GEMMs on the library (hipBLASLt) and the
-    weight / bias gradient (a tiny-output, 1e5-deep reduction) on the split-M MFMA kernel
-    gf_linear_dw, which returns fp32 gradients for the fp32 master parameters directly."""
+    """y = x W^T + b (+ res): forward on gf_linear_fwd (library fallback), input-gradient GEMM on the library
+    (hipBLASLt), weight / bias gradient (a tiny-output, 1e5-deep reduction) on gf_linear_dw, which returns fp32
+    gradients for the fp32 master parameters directly.  ``res`` is a fused residual (gradient = dy)."""
 
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, res=None):
         wt = _lp(w, x.dtype)
-        y = torch.nn.functional.linear(x, wt, _lp(b, x.dtype))
+        k = x.shape[-1]
+        x2 = x.reshape(-1, k)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        res2 = None
+        if res is not None:
+            res2 = res.reshape(-1, wt.shape[0])
+            if not res2.is_contiguous():
+                res2 = res2.contiguous()
+        y = _linear_fwd(x2, wt, b, res2).view(*x.shape[:-1], wt.shape[0])
         ctx.save_for_backward(x, wt)
         ctx.wdtype = w.dtype
         ctx.has_bias = b is not None
         ctx.bdtype = None if b is None else b.dtype
+        ctx.has_res = res is not None
         return y
 
     @staticmethod
@@ -281,13 +321,14 @@ class _Linear(torch.autograd.Function):
                                       _stream()), "gf_linear_dw")
             dw = dw32.to(ctx.wdtype)
             db = None if db32 is None else db32.to(ctx.bdtype)
-        return dx, dw, db
+        return dx, dw, db, (dy if ctx.has_res and ctx.needs_input_grad[3] else None)
 
 
-def linear(x, w, b=None):
-    """w, b: fp32 master parameters (or differentiable functions of them); x in the compute dtype."""
+def linear(x, w, b=None, res=None):
+    """w, b: fp32 master parameters (or differentiable functions of them); x (and the optional fused residual
+    ``res``, same shape as the output) in the compute dtype."""
     _chk(x)
-    return _Linear.apply(x, w, b)
+    return _Linear.apply(x, w, b, res)
 
 
 def _dw(dy2, x2, nout, k, with_bias):
@@ -310,8 +351,17 @@ class _LinearCat(torch.autograd.Function):
     def forward(ctx, x1, x2, w, b):
         k1 = x1.shape[-1]
         wt = _lp(w, x1.dtype)
-        y = torch.nn.functional.linear(x1, wt[:, :k1], _lp(b, x1.dtype))
-        y.view(-1, y.shape[-1]).addmm_(x2.reshape(-1, x2.shape[-1]), wt[:, k1:].t())
+        a2 = x1.reshape(-1, k1)
+        c2 = x2.reshape(-1, x2.shape[-1])
+        a2 = a2 if a2.is_contiguous() else a2.contiguous()
+        c2 = c2 if c2.is_contiguous() else c2.contiguous()
+        if _gemm_ok(a2, wt[:, :k1]) and _gemm_ok(c2, wt[:, k1:]):
+            y2 = _linear_fwd(a2, wt[:, :k1], b)
+            y2 = _linear_fwd(c2, wt[:, k1:], None, res2=y2, out=y2)       # second half accumulates in place
+            y = y2.view(*x1.shape[:-1], wt.shape[0])
+        else:
+            y = torch.nn.functional.linear(x1, wt[:, :k1], _lp(b, x1.dtype))
+            y.view(-1, y.shape[-1]).addmm_(c2, wt[:, k1:].t())
         ctx.save_for_backward(x1, x2, wt)
         ctx.wdtype = w.dtype
         ctx.bdtype = None if b is None else b.dtype

@@ -139,6 +139,15 @@ int gf_sinkhorn_bwd(const float* Z, const float* gout, const float* gsum_row, co
                     const float* u_hist, const float* v_hist, float* gZ, void* ws,
                     int B, int M, int N, int iters, void* stream);
 
+/* ---- forward GEMM of the block linears with fused epilogue (nn.Linear calls of lightglue.py:131-221,271-290):
+ *   y[m, n] = sum_k x[m, k] w[n, k] + bias[n] (+ res[m, n])     bf16 in/out, fp32 accumulation, fp32 bias
+ * x [M,K] (row stride ldx), w [N,K] (row stride ldw: a column slice of a wider weight is fine), res / y [M,N]
+ * (row strides ldr / ldy; y may alias res).  N % 128 == 0, K % 32 == 0 (GF_ERR_UNSUPPORTED otherwise: the caller
+ * uses the library GEMM).  `res` carries the block's residual "x +" (lightglue.py:163,221) or the first half
+ * of the FFN's concatenated input, so neither needs a separate pass. */
+int gf_linear_fwd(const void* x, const void* w, const float* bias, const void* res, void* y,
+                  int M, int N, int K, int64_t ldx, int64_t ldw, int64_t ldr, int64_t ldy, int dtype, void* stream);
+
 /* ---- weight / bias gradient of a linear layer (autograd of every nn.Linear on the path,
  * lightglue.py:131-221, 271-290): dW[n][k] = sum_m dY[m][n] X[m][k], db[n] = sum_m dY[m][n]
  * with dY [M,Nout], X [M,K] row-major in `dtype` and fp32 outputs dW [Nout,K], db [Nout]
