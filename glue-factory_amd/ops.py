@@ -4,6 +4,7 @@ PyTorch is plumbing here (device memory, streams, autograd graph); every op belo
 C ABI of include/gf_amd.h through ctypes with raw device pointers and the current HIP stream.
 There is no CPU or eager fallback: a non-CUDA tensor or a missing library raises.
 """
+import os
 import weakref
 
 import torch
@@ -246,8 +247,7 @@ def _lp(t, dtype):
 # Forward GEMM: the tuned library GEMM (hipBLASLt) by default.  The hand-written kernel gf_linear_fwd (bias /
 # residual fused, bf16, 128-multiple outputs) is correct but measured 1.4x SLOWER than the library at these
 # tall-skinny shapes (44 vs 31 us for 131072 x 256 x 256), so it is opt-in: GF_AMD_HIP_GEMM=1.
-import os as _os
-_LIBRARY_GEMM = _os.environ.get("GF_AMD_HIP_GEMM", "0") != "1"
+_LIBRARY_GEMM = os.environ.get("GF_AMD_HIP_GEMM", "0") != "1"
 
 
 def _gemm_ok(x2, wt):
