@@ -9,6 +9,7 @@ neighbour within ``pos_th`` px -> positive; nearest warped neighbour farther tha
 Runs on whatever device the keypoints live on (stock torch ops; the fused HIP
 nearest-neighbour kernel is the "next" row of SURVEY.md §8f).
 """
+import numpy as np
 import torch
 
 IGNORE_FEATURE = -2
@@ -246,3 +247,100 @@ def gt_matches_from_pose_depth_fused(kp0, kp1, data, pos_th=3, neg_th=5, cc_th=N
             "matching_scores0": (m0 > -1).float(), "matching_scores1": (m1 > -1).float(),
             "depth_keypoints0": d0, "depth_keypoints1": d1,
             "proj_0to1": kp0_1, "proj_1to0": kp1_0, "visible0": visible0, "visible1": visible1}
+
+
+# ------------------------------------------------------------------------------------------------ lines
+def _segments(lines):
+    """[B,L,2,2] / [B,L,P,2] / [B,L,4] -> [B,L,4] = (x0, y0, x1, y1)."""
+    if lines.shape[-2:] == (2, 2):
+        return lines.flatten(-2)
+    if lines.dim() == 4:
+        return torch.cat([lines[:, :, 0], lines[:, :, -1]], dim=2)
+    return lines
+
+
+def _close_point_counts(seg, pts, dist_th):
+    """count[b, a, c] = number of the sampled points pts[b, c, :, :] that lie within dist_th of segment seg[b, a]
+    and project onto it (the test of gt_generation.py:173-206, incl. its fp16-rounded segment length: the
+    direction is normalised by the half-precision norm, which the thresholds are sensitive to)."""
+    d = seg[..., 2:] - seg[..., :2]
+    length = torch.norm(d, dim=-1).half()                    # reference quirk, kept for identical labels
+    u = d / length.unsqueeze(-1)                             # [B,A,2] (promotes back to fp32)
+    rel = pts[:, None] - seg[..., None, None, 2:]            # [B,A,C,P,2], relative to the segment END point
+    if rel.is_cuda:                                          # the reference halves the big tensor on GPUs
+        rel, u = rel.half(), u.half()
+    along = rel[..., 0] * u[..., None, None, 0] + rel[..., 1] * u[..., None, None, 1]
+    perp = rel[..., 1] * u[..., None, None, 0] - rel[..., 0] * u[..., None, None, 1]
+    inside = (along <= 0) & (along.abs() <= length[..., None, None])
+    return ((perp.abs() < dist_th) & inside).sum(-1)
+
+
+@torch.no_grad()
+def gt_line_matches_from_homography(pred_lines0, pred_lines1, valid_lines0, valid_lines1, shape0, shape1, H,
+                                    npts=50, dist_th=5, overlap_th=0.2, min_visibility_th=0.2):
+    """Line ground truth under a homography (gluefactory/geometry/gt_generation.py:409-558): sample npts points
+    on every segment, warp them, count per segment pair how many warped samples fall on the other segment (both
+    ways), keep pairs whose two overlaps exceed overlap_th, solve the one-to-one assignment with the Hungarian
+    method on CPU (scipy, as the reference) and label the rest unmatched (-1) / ignored (-2, invalid lines).
+    Returns (assignment [B,L0,L1] bool, matches0 [B,L0], matches1 [B,L1])."""
+    from scipy.optimize import linear_sum_assignment
+    h0, w0 = shape0[-2:]
+    h1, w1 = shape1[-2:]
+    l0, l1 = _segments(pred_lines0.clone()), _segments(pred_lines1.clone())
+    b, n0, _ = l0.shape
+    n1 = l1.shape[1]
+    l0 = torch.min(torch.max(l0, torch.zeros_like(l0)), l0.new_tensor([w0 - 1, h0 - 1, w0 - 1, h0 - 1], dtype=torch.float))
+    l1 = torch.min(torch.max(l1, torch.zeros_like(l1)), l1.new_tensor([w1 - 1, h1 - 1, w1 - 1, h1 - 1], dtype=torch.float))
+
+    def samples(seg):                                        # [B,L,npts,2], end points included
+        step = (seg[..., 2:4] - seg[..., :2]) / (npts - 1)
+        t = torch.arange(npts).to(seg)
+        return seg[..., None, :2] + t[:, None] * step[..., None, :]
+
+    p0_in1 = warp_points(samples(l0).reshape(b, n0 * npts, 2), H, inverse=False).reshape(b, n0, npts, 2)
+    p1_in0 = warp_points(samples(l1).reshape(b, n1 * npts, 2), H, inverse=True).reshape(b, n1, npts, 2)
+
+    def mostly_outside(p, w, h):
+        out = (p < 0).any(-1) | (p >= torch.tensor([w, h]).to(p)).any(-1)
+        return out.float().mean(-1) >= (1 - min_visibility_th)
+
+    out_of0, out_of1 = mostly_outside(p1_in0, w0, h0), mostly_outside(p0_in1, w1, h1)   # [B,L1], [B,L0]
+    c0 = _close_point_counts(l0, p1_in0, dist_th)            # [B,L0,L1]
+    c1t = _close_point_counts(l1, p0_in1, dist_th).transpose(-1, -2)
+    both = c0 * c1t
+    mask_close = (c1t > npts * overlap_th) & (c0 > npts * overlap_th) & ~out_of0.unsqueeze(1) & ~out_of1.unsqueeze(-1)
+    unmatched0 = torch.all(~mask_close, dim=2) | out_of1
+    unmatched1 = torch.all(~mask_close, dim=1) | out_of0
+    ignore0, ignore1 = ~valid_lines0, ~valid_lines1
+
+    cost = -both.clone()
+    cost[unmatched0] = 1e6
+    cost[ignore0] = 1e6
+    cost = cost.transpose(1, 2)
+    cost[unmatched1] = 1e6
+    cost[ignore1] = 1e6
+    cost = cost.transpose(1, 2)
+    if both.numel() == 0:
+        none = torch.zeros(b, 0).to(mask_close)
+        return both.new_zeros(both.shape, dtype=torch.bool), none, none
+    pairs = torch.tensor(np.array([linear_sum_assignment(c) for c in cost.detach().cpu().numpy()])).to(both)
+    positive = both.new_zeros(both.shape, dtype=torch.bool)
+    positive[torch.arange(b)[:, None].repeat(1, pairs.shape[-1]).flatten(), pairs[:, 0].flatten(), pairs[:, 1].flatten()] = True
+    m0 = pairs.new_full((b, n0), UNMATCHED_FEATURE, dtype=torch.long)
+    m0.scatter_(-1, pairs[:, 0], pairs[:, 1])
+    m1 = pairs.new_full((b, n1), UNMATCHED_FEATURE, dtype=torch.long)
+    m1.scatter_(-1, pairs[:, 1], pairs[:, 0])
+    positive = positive & mask_close
+    positive[unmatched0] = False
+    positive[ignore0] = False
+    positive = positive.transpose(1, 2)
+    positive[unmatched1] = False
+    positive[ignore1] = False
+    positive = positive.transpose(1, 2)
+    m0[~positive.any(-1)] = UNMATCHED_FEATURE
+    m0[unmatched0] = UNMATCHED_FEATURE
+    m0[ignore0] = IGNORE_FEATURE
+    m1[~positive.any(-2)] = UNMATCHED_FEATURE
+    m1[unmatched1] = UNMATCHED_FEATURE
+    m1[ignore1] = IGNORE_FEATURE
+    return positive, m0, m1

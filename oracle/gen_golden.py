@@ -263,6 +263,33 @@ def gen_gt_depth(name, batch, n0, n1, seed):
     np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
 
 
+def gen_gt_lines(name, batch, n0, n1, seed):
+    from gluefactory.geometry.gt_generation import gt_line_matches_from_homography
+    from gluefactory.geometry.homography import warp_points_torch
+
+    g = torch.Generator().manual_seed(seed)
+    w, h = 320, 240
+    ang = 0.08
+    H = torch.tensor([[1.02 * np.cos(ang), -np.sin(ang), 6.0], [np.sin(ang), 0.98 * np.cos(ang), -4.0],
+                      [1e-5, -2e-5, 1.0]], dtype=torch.float32).repeat(batch, 1, 1)
+    wh = torch.tensor([w - 1.0, h - 1.0])
+    lines0 = torch.rand(batch, n0, 2, 2, generator=g) * wh
+    nm = (2 * n1) // 3                                     # images of some lines of view 0 (+ noise), then random ones
+    warped = warp_points_torch(lines0[:, :nm].reshape(batch, nm * 2, 2), H, inverse=False).reshape(batch, nm, 2, 2)
+    lines1 = torch.rand(batch, n1, 2, 2, generator=g) * wh
+    lines1[:, :nm] = warped + 1.5 * torch.randn(batch, nm, 2, 2, generator=g)
+    lines1 = lines1[:, torch.randperm(n1, generator=g)]
+    valid0 = torch.rand(batch, n0, generator=g) > 0.1
+    valid1 = torch.rand(batch, n1, generator=g) > 0.1
+    pos, m0, m1 = gt_line_matches_from_homography(lines0, lines1, valid0, valid1, (batch, 1, h, w), (batch, 1, h, w), H,
+                                                  npts=50, dist_th=5, overlap_th=0.2, min_visibility_th=0.5)
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), lines0=lines0.numpy(), lines1=lines1.numpy(),
+                        valid0=valid0.numpy(), valid1=valid1.numpy(), H=H.numpy(), hw=np.array([h, w]),
+                        assignment=pos.numpy(), matches0=m0.numpy(), matches1=m1.numpy())
+    print(name, "positives", pos.sum((1, 2)).tolist(), "unmatched0", (m0 == -1).sum(1).tolist(),
+          "ignored0", (m0 == -2).sum(1).tolist())
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     gen_lightglue("lightglue_small", batch=2, n0=40, n1=48, n_layers=2, dim=64, heads=4,
@@ -271,6 +298,7 @@ def main():
                   seed=23, size=(1024, 1024), store_params=False)
     gen_gt("gt_homography", batch=2, n0=96, n1=80, seed=5)
     gen_gt_depth("gt_depth", batch=2, n0=120, n1=100, seed=61)
+    gen_gt_lines("gt_lines", batch=2, n0=40, n1=36, seed=71)
     gen_superpoint("superpoint_open", seed=51)
     gen_gluestick("gluestick_d256", batch=2, n_kpts=40, n_lines=12, gnn=["self", "cross"] * 2, inter=[0], seed=41)
     gen_superglue("superglue_d256", batch=2, n0=60, n1=52, gnn=["self", "cross"] * 2, iters=20, seed=31)

@@ -64,3 +64,32 @@ def test_depth_matcher_plugin_surface():
     pred = m({**data, "keypoints0": kp0, "keypoints1": kp1})
     np.testing.assert_array_equal(pred["matches0"].numpy(), z["cc.matches0"])
     np.testing.assert_array_equal(pred["assignment"].numpy(), z["cc.assignment"])
+
+
+def test_line_gt_from_homography_matches_reference():
+    """gt_line_matches_from_homography vs vectors produced by the reference's gt_generation.py:409-558
+    (sampled-point overlap counts + Hungarian assignment, invalid lines ignored)."""
+    from glue_factory_amd.gt import gt_line_matches_from_homography
+    z = load_golden("gt_lines")
+    t = lambda k: torch.from_numpy(z[k])
+    h, w = (int(v) for v in z["hw"])
+    pos, m0, m1 = gt_line_matches_from_homography(t("lines0"), t("lines1"), t("valid0"), t("valid1"), (2, 1, h, w),
+                                                  (2, 1, h, w), t("H"), npts=50, dist_th=5, overlap_th=0.2,
+                                                  min_visibility_th=0.5)
+    np.testing.assert_array_equal(pos.numpy(), z["assignment"])
+    np.testing.assert_array_equal(m0.numpy(), z["matches0"])
+    np.testing.assert_array_equal(m1.numpy(), z["matches1"])
+    assert pos.sum() > 10 and (m0 == -2).sum() > 0 and (m0 == -1).sum() > 0
+
+
+def test_homography_matcher_with_lines_plugin_surface():
+    from glue_factory_amd.base_model import get_model
+    z = load_golden("gt_lines")
+    t = lambda k: torch.from_numpy(z[k])
+    h, w = (int(v) for v in z["hw"])
+    m = get_model("matchers.homography_matcher")({"use_points": False, "use_lines": True})
+    img = torch.zeros(2, 1, h, w)
+    pred = m({"H_0to1": t("H"), "lines0": t("lines0"), "lines1": t("lines1"), "valid_lines0": t("valid0"),
+              "valid_lines1": t("valid1"), "view0": {"image": img}, "view1": {"image": img}})
+    np.testing.assert_array_equal(pred["line_matches0"].numpy(), z["matches0"])
+    np.testing.assert_array_equal(pred["line_assignment"].numpy(), z["assignment"])
