@@ -1,52 +1,53 @@
-"""Ground-truth "matcher" from a homography (no-grad), the labelling step that feeds the loss.
+"""Ground-truth "matcher" from a homography (no-grad): the labelling step that feeds the loss.
 
-Plugin-surface mirror of gluefactory/models/matchers/homography_matcher.py:8-66 for the point
-branch (``use_points``); the assignment itself is ``glue_factory_amd.gt`` (restating
-gluefactory/geometry/gt_generation.py:109-161).  Line ground truth (``use_lines``: overlap counts of sampled
-line points + Hungarian assignment, gt_generation.py:409-558) runs through ``gt.gt_line_matches_from_homography``
-(torch for the counts, scipy on the host for the assignment, exactly as the reference)."""
+Plugin-surface mirror of gluefactory/models/matchers/homography_matcher.py:8-66 — same configuration keys,
+same required inputs, same output names.  Points (``use_points``) are labelled by ``glue_factory_amd.gt``
+(restating gluefactory/geometry/gt_generation.py:109-161; on a HIP device through the fused nearest-neighbour
+kernel gf_gt_nn, which never builds a [B,M,N] fp32 tensor).  Lines (``use_lines``) go through
+``gt.gt_line_matches_from_homography`` (gt_generation.py:409-558: torch overlap counts, Hungarian assignment
+on the host with scipy, exactly as the reference does it)."""
+from .. import gt as _gt
 from ..base_model import BaseModel
-from ..gt import gt_line_matches_from_homography, gt_matches_from_homography, gt_matches_from_homography_fused
+
+_POINT_KEYS = ("keypoints0", "keypoints1")
+_LINE_KEYS = ("lines0", "lines1", "valid_lines0", "valid_lines1")
 
 
 class HomographyMatcher(BaseModel):
-    default_conf = {
-        "use_points": True,
-        "th_positive": 3.0,
-        "th_negative": 3.0,
-        "use_lines": False,
-        "n_line_sampled_pts": 50,
-        "line_perp_dist_th": 5,
-        "overlap_th": 0.2,
-        "min_visibility_th": 0.5,
-        "with_reward": True,   # dense `reward` [B,M,N] output (unused by the matcher losses); False skips it
-    }
+    default_conf = dict(
+        use_points=True, th_positive=3.0, th_negative=3.0,                      # point labels
+        use_lines=False, n_line_sampled_pts=50, line_perp_dist_th=5,            # line labels
+        overlap_th=0.2, min_visibility_th=0.5,
+        with_reward=True,     # ours: False skips the dense [B,M,N] `reward` (unused by the matcher losses)
+    )
     required_data_keys = ["H_0to1"]
 
     def _init(self, conf):
-        if conf.use_points:
-            self.required_data_keys += ["keypoints0", "keypoints1"]
-        if conf.use_lines:
-            self.required_data_keys += ["lines0", "lines1", "valid_lines0", "valid_lines1"]
+        extra = (_POINT_KEYS if conf.use_points else ()) + (_LINE_KEYS if conf.use_lines else ())
+        self.required_data_keys = list(self.required_data_keys) + list(extra)
+
+    def _label_points(self, data):
+        c = self.conf
+        pts0, pts1, hom = data["keypoints0"], data["keypoints1"], data["H_0to1"]
+        on_gpu = pts0.is_cuda and pts0.shape[1] > 0 and pts1.shape[1] > 0
+        if on_gpu:            # fused HIP nearest-neighbour search
+            return _gt.gt_matches_from_homography_fused(pts0, pts1, hom, c.th_positive, c.th_negative,
+                                                        with_reward=c.with_reward)
+        return _gt.gt_matches_from_homography(pts0, pts1, hom, pos_th=c.th_positive, neg_th=c.th_negative)
+
+    def _label_lines(self, data):
+        c = self.conf
+        assignment, fwd, bwd = _gt.gt_line_matches_from_homography(
+            data["lines0"], data["lines1"], data["valid_lines0"], data["valid_lines1"],
+            data["view0"]["image"].shape, data["view1"]["image"].shape, data["H_0to1"],
+            c.n_line_sampled_pts, c.line_perp_dist_th, c.overlap_th, c.min_visibility_th)
+        return {"line_matches0": fwd, "line_matches1": bwd, "line_assignment": assignment}
 
     def _forward(self, data):
-        result = {}
-        if self.conf.use_points:
-            kp0, kp1 = data["keypoints0"], data["keypoints1"]
-            if kp0.is_cuda and kp0.shape[1] > 0 and kp1.shape[1] > 0:    # fused HIP nearest-neighbour search
-                result = gt_matches_from_homography_fused(kp0, kp1, data["H_0to1"], self.conf.th_positive,
-                                                          self.conf.th_negative, with_reward=self.conf.with_reward)
-            else:
-                result = gt_matches_from_homography(kp0, kp1, data["H_0to1"], pos_th=self.conf.th_positive,
-                                                    neg_th=self.conf.th_negative)
+        out = self._label_points(data) if self.conf.use_points else {}
         if self.conf.use_lines:
-            assignment, m0, m1 = gt_line_matches_from_homography(
-                data["lines0"], data["lines1"], data["valid_lines0"], data["valid_lines1"],
-                data["view0"]["image"].shape, data["view1"]["image"].shape, data["H_0to1"],
-                self.conf.n_line_sampled_pts, self.conf.line_perp_dist_th, self.conf.overlap_th,
-                self.conf.min_visibility_th)
-            result["line_matches0"], result["line_matches1"], result["line_assignment"] = m0, m1, assignment
-        return result
+            out.update(self._label_lines(data))
+        return out
 
     def loss(self, pred, data):
         raise NotImplementedError
