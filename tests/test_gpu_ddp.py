@@ -1,0 +1,66 @@
+"""The real HIP LightGlue under DistributedDataParallel: two processes share cuda:0 and talk over gloo
+(one MI355X is all the test box has; RCCL refuses two ranks on one device), with the reference's file://
+rendezvous.  Everything of the N>1 path except the RCCL transport itself runs here: DDP bucket hooks on our
+custom autograd nodes, the per-step precast cache under DDP, the do_backward agreement, the fused loss.
+After one SGD step on the sharded batch the weights must equal a single-process step on the whole batch."""
+import os
+import tempfile
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+L, N, B = 2, 192, 4
+
+
+def _model_and_data():
+    from glue_factory_amd.matchers.lightglue import LightGlue
+    from glue_factory_amd.synthetic import make_pairs, to_device
+    from oracle import lightglue_oracle as lgo
+    model = LightGlue({"n_layers": L}).cuda().train()
+    model.load_state_dict(lgo.init_params(L, 256, 4, seed=5))
+    data = to_device(make_pairs(B, N, dim=256, size=(640, 480), seed=6), "cuda")
+    return model, data
+
+
+def _worker(rank, world, lock, out):
+    from glue_factory_amd.train_step import TrainStep, init_distributed, reduce_losses, shard_batch
+    torch.cuda.set_device(0)
+    init_distributed("gloo", init_method="file://" + lock, rank=rank, world_size=world)
+    model, data = _model_and_data()
+    opt = torch.optim.SGD(model.parameters(), lr=0.05)
+    step = TrainStep(model, opt, amp_dtype=None, device_ids=[0])
+    assert step.distributed
+    losses = step(shard_batch(data, rank, world))
+    red = reduce_losses(losses)
+    torch.cuda.synchronize()
+    if rank == 0:
+        torch.save({"params": {k: v.detach().cpu() for k, v in model.state_dict().items()}, "red": red}, out)
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_ddp_step_equals_single_process():
+    from glue_factory_amd.train_step import TrainStep, reduce_losses
+    with tempfile.TemporaryDirectory() as d:
+        lock, out = os.path.join(d, "distributed_lock"), os.path.join(d, "out.pt")
+        mp.spawn(_worker, args=(2, lock, out), nprocs=2, join=True)
+        got = torch.load(out)
+    model, data = _model_and_data()
+    opt = torch.optim.SGD(model.parameters(), lr=0.05)
+    step = TrainStep(model, opt, amp_dtype=None)
+    losses = step(data)
+    ref = reduce_losses(losses)
+    assert abs(got["red"]["total"] - ref["total"]) < 1e-4 * max(1.0, abs(ref["total"]))
+    moved = 0
+    init = _model_and_data()[0].state_dict()
+    for k, v in model.state_dict().items():
+        a, b = got["params"][k], v.detach().cpu()
+        sc = max((b - init[k].cpu()).abs().max().item(), 1e-8) if b.dtype.is_floating_point else 1.0
+        if b.dtype.is_floating_point:
+            torch.testing.assert_close((a - init[k].cpu()) / sc, (b - init[k].cpu()) / sc, rtol=2e-3, atol=2e-3,
+                                       msg=lambda m: f"{k}: {m}")
+            moved += int((b - init[k].cpu()).abs().max() > 0)
+    assert moved > 40
