@@ -290,8 +290,124 @@ def gen_gt_lines(name, batch, n0, n1, seed):
           "ignored0", (m0 == -2).sum(1).tolist())
 
 
+def _data_checksum(data):
+    return np.array([float(sum(v.double().abs().sum() for v in data.values() if torch.is_tensor(v) and v.is_floating_point()))])
+
+
+def gen_lightglue_config(name, batch, n, n_layers, seed, size, stride=61):
+    """Compact golden of a BASELINE.json configuration run through the REFERENCE LightGlue itself (config 1:
+    B=4, N=512, L=4; config 2 shape at B=1: N=2048, L=9).  Inputs and weights are regenerated from the seed by
+    the test (checksums stored); stored are every loss entry, the eval-mode matcher metrics, the match
+    vectors, a strided sample of the (N+1)^2 log-assignment plus its row sums, and the gradient norm of every
+    parameter (full gradients for the small tensors)."""
+    params = lgo.init_params(n_layers, 256, 4, seed=seed)
+    data = make_pairs(batch, n, dim=256, size=size, seed=seed + 1)
+    model = ref_lightglue(n_layers, 256, 4, params, filter_threshold=0.0)
+    out = {}
+    model.eval()
+    with torch.no_grad():
+        pe = model(data)
+        le, me = model.loss(pe, {**pe, **data})
+    out.update(_np({k: pe[k] for k in ("matches0", "matches1", "matching_scores0", "matching_scores1")}, "eval."))
+    out.update(_np(me, "metric."))
+    out.update(_np({k: v for k, v in le.items() if torch.is_tensor(v)}, "evalloss."))
+    model.train()
+    pred = model(data)
+    losses, _ = model.loss(pred, {**pred, **data})
+    losses["total"].mean().backward()
+    la = pred["log_assignment"].detach()
+    out["train.la_sample"] = la.flatten(1)[:, ::stride].numpy()
+    out["train.la_rowsum"] = la.double().sum(2).float().numpy()
+    out["train.la_colsum"] = la.double().sum(1).float().numpy()
+    out["train.rowmax"] = la[:, :-1, :-1].max(2).values.numpy()
+    out.update(_np({k: pred[k] for k in ("matches0", "matches1", "matching_scores0")}, "train."))
+    out.update(_np({k: v for k, v in losses.items() if torch.is_tensor(v)}, "loss."))
+    for k, prm in model.named_parameters():
+        out["gradnorm." + k] = np.array([float(prm.grad.double().norm())])
+        if prm.grad.numel() <= 1024:
+            out["grad." + k] = prm.grad.numpy()
+    out["param_checksum"] = np.array([float(sum(v.double().abs().sum() for v in params.values()))])
+    out["data_checksum"] = _data_checksum(data)
+    out["meta"] = np.array([batch, n, n_layers, seed, size[0], size[1], stride])
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+    print(name, "total loss", losses["total"].tolist(), "matches", (pred["matches0"] > -1).sum(1).tolist(),
+          "metrics", {k: v.tolist() for k, v in me.items()})
+
+
+def gen_metrics(name, seed):
+    """matcher_metrics of the reference (models/utils/metrics.py:4-50) on seeded match / ground-truth vectors
+    with every label class present: correct and wrong matches, unmatched (-1) and ignored (-2) ground truth."""
+    from gluefactory.models.utils.metrics import matcher_metrics
+    g = torch.Generator().manual_seed(seed)
+    B, M, N = 3, 200, 180
+    gt = torch.randint(0, N, (B, M), generator=g)
+    r = torch.rand(B, M, generator=g)
+    gt = torch.where(r < 0.3, torch.full_like(gt, -1), gt)
+    gt = torch.where(r > 0.9, torch.full_like(gt, -2), gt)
+    m = gt.clone()
+    r2 = torch.rand(B, M, generator=g)
+    m = torch.where(r2 < 0.25, torch.randint(0, N, (B, M), generator=g), m)      # wrong matches
+    m = torch.where((r2 > 0.8), torch.full_like(m, -1), m)                        # missed
+    scores = torch.rand(B, M, generator=g) * (m > -1)
+    pred = {"matches0": m, "matching_scores0": scores}
+    data = {"gt_matches0": gt}
+    out = {"matches0": m.numpy(), "matching_scores0": scores.numpy(), "gt_matches0": gt.numpy()}
+    out.update(_np(matcher_metrics(pred, data), "metric."))
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+    print(name, {k: v.tolist() for k, v in matcher_metrics(pred, data).items()})
+
+
+def gen_lightglue_adaptive(name, n0, n1, n_layers, seed):
+    """Eval-only adaptive depth / width (lightglue.py:461-529, b == 1) of the REFERENCE on seeded weights whose
+    token-confidence / matchability biases are shifted so that the stop and the pruning actually trigger."""
+    base = lgo.init_params(n_layers, 256, 4, seed=seed)
+    data = make_pairs(1, n0, n1, dim=256, size=(640, 480), seed=seed + 1)
+    cases = {
+        # name: (param edits, depth_confidence, width_confidence)
+        "neutral": ({}, 0.95, 0.99),
+        # (an early stop before the last layer cannot be generated: the reference itself raises there --
+        #  `torch.stack(all_desc0)` of an empty list, lightglue.py:536 -- so only non-stopping cases exist)
+        "prune": ({}, -1, 0.5),
+        "prune_tok": ({"token_confidence.0.token.0.bias": 1.5, "token_confidence.1.token.0.bias": 2.0}, 0.999, 0.55),
+    }
+    out = {}
+    for cname, (edits, dc, wc) in cases.items():
+        params = {k: v.clone() for k, v in base.items()}
+        for k, val in edits.items():
+            params[k] = torch.full_like(params[k], val)
+        from gluefactory.models.matchers.lightglue import LightGlue
+        model = LightGlue({"n_layers": n_layers, "descriptor_dim": 256, "input_dim": 256, "num_heads": 4,
+                           "weights": None, "flash": False, "filter_threshold": 0.0,
+                           "depth_confidence": dc, "width_confidence": wc})
+        model.load_state_dict(params, strict=True)
+        model.eval()
+        with torch.no_grad():
+            pe = model(data)
+        for k in ("matches0", "matches1", "matching_scores0", "matching_scores1", "prune0", "prune1", "log_assignment"):
+            out[f"{cname}.{k}"] = pe[k].numpy()
+        out[f"{cname}.conf"] = np.array([dc, wc])
+        for k, val in edits.items():
+            out[f"{cname}.edit.{k}"] = np.array([val])
+        print(name, cname, "la", tuple(pe["log_assignment"].shape), "matches", int((pe["matches0"] > -1).sum()),
+              "prune0 hist", torch.bincount(pe["prune0"].long().flatten()).tolist())
+    out["meta"] = np.array([n0, n1, n_layers, seed])
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
+    only = set(sys.argv[1:])
+    if only:      # python oracle/gen_golden.py lightglue_config1 ...: regenerate the named fixtures only
+        todo = {
+            "lightglue_config1": lambda: gen_lightglue_config("lightglue_config1", 4, 512, 4, seed=101, size=(640, 480)),
+            "lightglue_n2048_l9": lambda: gen_lightglue_config("lightglue_n2048_l9", 1, 2048, 9, seed=103,
+                                                                size=(1024, 1024), stride=997),
+            "lightglue_adaptive": lambda: gen_lightglue_adaptive("lightglue_adaptive", 160, 200, 3, seed=107),
+            "metrics": lambda: gen_metrics("metrics", seed=109),
+        }
+        for k in only:
+            todo[k]()
+        return
     gen_lightglue("lightglue_small", batch=2, n0=40, n1=48, n_layers=2, dim=64, heads=4,
                   seed=11, size=(640, 480), store_params=True)
     gen_lightglue("lightglue_d256", batch=1, n0=72, n1=64, n_layers=2, dim=256, heads=4,
@@ -302,6 +418,10 @@ def main():
     gen_superpoint("superpoint_open", seed=51)
     gen_gluestick("gluestick_d256", batch=2, n_kpts=40, n_lines=12, gnn=["self", "cross"] * 2, inter=[0], seed=41)
     gen_superglue("superglue_d256", batch=2, n0=60, n1=52, gnn=["self", "cross"] * 2, iters=20, seed=31)
+    gen_lightglue_config("lightglue_config1", 4, 512, 4, seed=101, size=(640, 480))
+    gen_lightglue_config("lightglue_n2048_l9", 1, 2048, 9, seed=103, size=(1024, 1024), stride=997)
+    gen_lightglue_adaptive("lightglue_adaptive", 160, 200, 3, seed=107)
+    gen_metrics("metrics", seed=109)
 
 
 if __name__ == "__main__":

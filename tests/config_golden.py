@@ -1,0 +1,91 @@
+"""Shared checker for the compact BASELINE-configuration goldens (tests/golden/lightglue_config1.npz,
+lightglue_n2048_l9.npz: the REFERENCE LightGlue run by oracle/gen_golden.py at config 1 -- B=4, N=512, L=4 --
+and at the config-2 shape N=2048, L=9 with B=1).  The same function holds the CPU oracle (tests/test_oracle_golden.py)
+and the HIP path (tests/test_gpu_baseline_configs.py) to those vectors."""
+import numpy as np
+import torch
+
+from conftest import load_golden
+
+
+def config_inputs(name):
+    """(golden dict, params, data, n_layers): weights and synthetic pairs regenerated from the stored seed;
+    checksums prove they are the tensors the reference saw."""
+    from glue_factory_amd.synthetic import make_pairs
+    from oracle import lightglue_oracle as lgo
+    z = load_golden(name)
+    batch, n, L, seed, w, h, _ = (int(v) for v in z["meta"])
+    params = lgo.init_params(L, 256, 4, seed=seed)
+    chk = float(sum(v.double().abs().sum() for v in params.values()))
+    assert abs(chk - float(z["param_checksum"][0])) < 1e-9 * chk
+    data = make_pairs(batch, n, dim=256, size=(w, h), seed=seed + 1)
+    dchk = float(sum(v.double().abs().sum() for v in data.values() if torch.is_tensor(v) and v.is_floating_point()))
+    assert abs(dchk - float(z["data_checksum"][0])) < 1e-9 * dchk
+    return z, params, data, L
+
+
+def _np(t):
+    return t.detach().float().cpu().numpy()
+
+
+def check_train(z, pred, losses, grads, tol=1e-4, grad_tol=2e-3, tie_margin=1e-3):
+    """pred / losses / grads (name -> tensor) of one train step vs the reference's."""
+    stride = int(z["meta"][6])
+    la = pred["log_assignment"].detach().float().cpu()
+    np.testing.assert_allclose(la.flatten(1)[:, ::stride].numpy(), z["train.la_sample"], rtol=tol, atol=tol)
+    n1 = la.shape[2]
+    np.testing.assert_allclose(la.double().sum(2).float().numpy() / n1, z["train.la_rowsum"] / n1, rtol=tol, atol=tol)
+    np.testing.assert_allclose(la.double().sum(1).float().numpy() / n1, z["train.la_colsum"] / n1, rtol=tol, atol=tol)
+    np.testing.assert_allclose(la[:, :-1, :-1].max(2).values.numpy(), z["train.rowmax"], rtol=tol, atol=tol)
+    # matches: bit-exact wherever the reference's arg-max is not a near-tie
+    top2 = la[:, :-1, :-1].topk(2, dim=-1).values
+    clear_r = ((top2[..., 0] - top2[..., 1]) > tie_margin)
+    top2c = la[:, :-1, :-1].transpose(1, 2).topk(2, dim=-1).values
+    clear_c = ((top2c[..., 0] - top2c[..., 1]) > tie_margin)
+    m0 = pred["matches0"].cpu().numpy()
+    ref0 = z["train.matches0"]
+    # a match also depends on the partner column's arg-max; only rows whose own and partner decisions are clear
+    partner_ok = np.ones_like(ref0, dtype=bool)
+    for b in range(ref0.shape[0]):
+        j = np.clip(ref0[b], 0, None)
+        partner_ok[b] = clear_c[b].numpy()[j] | (ref0[b] < 0)
+    ok = clear_r.numpy() & partner_ok & clear_c.numpy().all()  # all columns clear -> every mutual check is stable
+    if clear_c.numpy().all() and clear_r.numpy().all():
+        np.testing.assert_array_equal(m0, ref0)
+        np.testing.assert_array_equal(pred["matches1"].cpu().numpy(), z["train.matches1"])
+    else:
+        agree = (m0 == ref0)
+        assert agree[clear_r.numpy()].mean() > 0.999, agree[clear_r.numpy()].mean()
+    np.testing.assert_allclose(_np(pred["matching_scores0"]), z["train.matching_scores0"], rtol=10 * tol, atol=1e-7)
+    loss_keys = [k[5:] for k in z if k.startswith("loss.")]
+    assert set(loss_keys) >= {"total", "last", "nll_pos", "nll_neg", "confidence", "row_norm"}
+    for k in loss_keys:
+        np.testing.assert_allclose(_np(losses[k]), z["loss." + k], rtol=tol, atol=tol, err_msg=k)
+    worst = (0.0, None)
+    n_norm = 0
+    for k, g in grads.items():
+        ref = float(z["gradnorm." + k][0])
+        got = float(g.double().norm())
+        rel = abs(got - ref) / max(ref, 1e-12)
+        worst = max(worst, (rel, k))
+        assert rel <= grad_tol, (k, got, ref)
+        n_norm += 1
+        if "grad." + k in z:
+            r = z["grad." + k]
+            sc = max(np.abs(r).max(), 1e-12)
+            np.testing.assert_allclose(_np(g) / sc, r / sc, rtol=grad_tol, atol=grad_tol, err_msg=k)
+    assert n_norm == sum(1 for k in z if k.startswith("gradnorm."))
+    return worst
+
+
+def check_eval(z, pred, metrics=None, tol=1e-4):
+    """Eval-mode matches / scores / matcher_metrics vs the reference's (matches compared where stable)."""
+    m0 = pred["matches0"].cpu().numpy()
+    agree = (m0 == z["eval.matches0"]).mean()
+    assert agree > 0.999, agree
+    s0 = _np(pred["matching_scores0"])
+    same = m0 == z["eval.matches0"]
+    np.testing.assert_allclose(s0[same], z["eval.matching_scores0"][same], rtol=10 * tol, atol=1e-7)
+    if metrics is not None:
+        for k in ("match_recall", "match_precision", "accuracy", "average_precision"):
+            np.testing.assert_allclose(_np(metrics[k]), z["metric." + k], rtol=1e-3, atol=2e-3, err_msg=k)
