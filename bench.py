@@ -1,29 +1,40 @@
-"""Benchmark of the matcher train-step hot path on MI355X.
+"""Benchmark of the SuperPoint + LightGlue train-step hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-One "step" = one full LightGlue train step (forward, loss, backward, Adam update) on one batch of
-synthetic SuperPoint-shaped keypoint pairs (BASELINE.json configs[1]: B=32 pairs per GPU,
-N=2048 keypoints, d=256, L=9, bf16 compute under autocast, inputs resident in HBM).  Data
-parallel over N GPUs is weak scaling (32 pairs per GPU) with DDP/RCCL gradient all-reduce.
+``--gpus N`` with N > 1 and no torchrun environment self-spawns N ranks (one process per GPU, RCCL) through
+``python -m torch.distributed.run`` on 127.0.0.1, the way gluefactory/train.py:727-734 spawns its workers;
+under torchrun (RANK / WORLD_SIZE set) it just joins.
+
+One "step" (the headline, BASELINE.json configs[1], scope P of SURVEY.md §8d) = frozen SuperPoint forward on a
+batch of 2x32 synthetic 1024x1024 images resident in HBM (stock PyTorch-ROCm convolutions, as north_star
+prescribes, + the fused HIP tails) -> homography ground truth (gf_gt_nn) -> one full LightGlue train step
+(forward, loss, backward, fused Adam) at B=32 pairs per GPU, N=2048 keypoints, d=256, L=9, bf16 compute.
+Data parallel over N GPUs is weak scaling (32 pairs per GPU) with DDP/RCCL gradient all-reduce.
 Rank 0 prints ONE JSON line (contract in the task statement) that also carries
-  "roofline":     live HIP-event timing of the dominant kernel vs the bf16 MFMA peak,
-  "cpu_baseline": the CPU oracle (port of the reference algorithm) timed on the host cores on a
-                  bounded sample (B=1 pair, same N/L) — reported, never the thing shipped.
+  "matcher_step":  the matcher-only scope (M): the same train step on keypoint pairs already resident in HBM
+                   (the reference's cached-feature training mode) -- the scope the roofline fractions refer to;
+  "roofline":      the dominant MFMA kernel (attention backward) timed live with HIP events on its stream vs
+                   the bf16 MFMA peak, "traffic" = HBM bytes per launch from the committed PMC passes;
+  "roofline_hbm":  the dominant HBM-bound kernels (assignment write, Sinkhorn iteration) vs the 8 TB/s peak;
+  "other_configs": BASELINE.json configs[3] (SuperGlue, 100 Sinkhorn iterations) and configs[4] (GlueStick);
+  "cpu_baseline":  the REFERENCE's own LightGlue (oracle/_ref, byte-compiled by oracle/build_ref.py) -- or,
+                   when that is absent, the oracle port -- timed on the host cores on a bounded sample.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# Library GEMM selection: replay the hipBLASLt/rocBLAS solutions tuned once on gfx950 for this
-# workload's GEMM shapes (PyTorch TunableOp, tuning itself disabled -> no timing side effects).
-# TunableOp reads "<name><device ordinal>.csv", so each rank gets a private copy of the table.
+# Library GEMM selection for the remaining library calls (SuperPoint is MIOpen; a few small GEMMs): replay
+# the hipBLASLt/rocBLAS solutions tuned once on gfx950 (PyTorch TunableOp, tuning itself disabled -> no timing
+# side effects).  TunableOp reads "<name><device ordinal>.csv", so each rank gets a private copy of the table.
 _TUNED = os.path.join(ROOT, "glue-factory_amd", "tunableop_gfx950.csv")
 if os.path.exists(_TUNED) and "PYTORCH_TUNABLEOP_ENABLED" not in os.environ:
     import shutil
@@ -39,11 +50,14 @@ if os.path.exists(_TUNED) and "PYTORCH_TUNABLEOP_ENABLED" not in os.environ:
 import torch  # noqa: E402  (after the TunableOp environment is set)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0            # HBM3E spec (6.3 TB/s achievable by a float4 copy), same guide
 N_KPTS, DIM, HEADS, LAYERS, BATCH = 2048, 256, 4, 9, 32
+IMG = 1024
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "roofline_traffic.json")
 
 
 def flops_per_pair_train(n=N_KPTS, d=DIM, L=LAYERS):
-    """Algorithmic FLOPs of one train step per pair: 3 x forward."""
+    """Algorithmic FLOPs of one matcher train step per pair: 3 x forward."""
     fwd = L * (76 * n * d * d + 14 * n * n * d) + (L + 1) * (4 * n * d * d + 2 * n * n * d)
     return 3 * fwd
 
@@ -59,18 +73,20 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--roofline-only", action="store_true", help="only time the attention kernels")
+    ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--roofline-only", action="store_true", help="only run the roofline kernels (rocprofv3 target)")
     ap.add_argument("--micro", action="store_true", help="print per-kernel micro timings and exit")
     ap.add_argument("--model", default="lightglue", choices=["lightglue", "superglue", "gluestick"],
-                    help="lightglue = the headline configs[1]; superglue / gluestick = configs[3] / [4] (extra lines)")
+                    help="lightglue = the headline; superglue / gluestick: time only that matcher step")
     ap.add_argument("--lines", type=int, default=512, help="gluestick: line segments per image")
     ap.add_argument("--sinkhorn-iters", type=int, default=100)
-    ap.add_argument("--no-pipeline", action="store_true",
-                    help="skip the secondary pipeline-scope measurement (SuperPoint forward + GT + matcher step)")
+    ap.add_argument("--matcher-only", action="store_true", help="skip the extractor: scope M becomes the only line")
     return ap.parse_args()
 
 
+# ------------------------------------------------------------------------------------------- kernel timing
 def time_kernel(fn, iters=10, warm=2):
+    """Average seconds per call, HIP events recorded on the stream the launchers use (torch's current stream)."""
     for _ in range(warm):
         fn()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -80,13 +96,22 @@ def time_kernel(fn, iters=10, warm=2):
         fn()
     ev1.record()
     torch.cuda.synchronize()
-    return ev0.elapsed_time(ev1) / iters * 1e-3   # seconds per launch
+    return ev0.elapsed_time(ev1) / iters * 1e-3
+
+
+def _traffic(key):
+    """Measured HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 (gfx950 half count) + WRITE_SIZE; collected by
+    tools/collect_pmc.sh over `bench.py --roofline-only`, summarised into profiles/roofline_traffic.json)."""
+    try:
+        with open(TRAFFIC_FILE) as f:
+            return json.load(f).get(key, {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
 
 
 def roofline_attention(batch, n, dtype):
-    """Dominant kernel: the self-attention backward (dK/dV kernel + dQ kernel of gf_attn_bwd) at
-    the step's own shape (2*batch images, H heads, N tokens, hd=64).  Algorithmic FLOPs per launch
-    = 2.5 x forward = 10*N*N*hd per (image, head); forward kernel reported beside it."""
+    """Dominant kernel: the self-attention backward (gf_attn_bwd) at the step's own shape (2*batch images, H
+    heads, N tokens, hd=64).  Algorithmic FLOPs per launch = 2.5 x forward = 10*N*N*hd per (image, head)."""
     from glue_factory_amd import ops
     B2, H, D = 2 * batch, HEADS, DIM // HEADS
     g = torch.Generator(device="cuda").manual_seed(0)
@@ -102,13 +127,59 @@ def roofline_attention(batch, n, dtype):
     f_bwd = 2.5 * f_fwd
     ach = f_bwd / t_bwd / 1e12
     return {
-        "bound": "mfma", "kernel": "gf_attn_bwd (attn_bwd_dq_kernel + attn_bwd_dkv_bf16_kernel)",
+        "bound": "mfma", "kernel": "gf_attn_bwd (attention backward kernels of one launch)",
         "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
-        "launch_ms": round(t_bwd * 1e3, 4),
+        "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": _traffic("gf_attn_bwd"),
+        "launch_ms": round(t_bwd * 1e3, 4), "algorithmic_flop_per_launch": f_bwd,
         "fwd_kernel": {"kernel": "attn_fwd_kernel", "launch_ms": round(t_fwd * 1e3, 4),
-                       "achieved": round(f_fwd / t_fwd / 1e12, 2)},
+                       "achieved": round(f_fwd / t_fwd / 1e12, 2),
+                       "frac": round(f_fwd / t_fwd / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                       "traffic": _traffic("attn_fwd_kernel")},
     }
+
+
+def roofline_hbm(batch, n, dtype, sinkhorn_iters=100):
+    """HBM regime: (1) the materialised log-assignment, one fp32 write of B*(N+1)^2*4 bytes
+    (gf_assign_write); (2) one Sinkhorn iteration = a row sweep + a column sweep over the couplings, algorithmic
+    2 * B*(N+1)^2*4 bytes per iteration and direction (SuperGlue, config 4); forward timed over all iterations."""
+    from glue_factory_amd import lib as L_
+    from glue_factory_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(0)
+    a = torch.randn(batch, n, 256, device="cuda", dtype=dtype, generator=g) * 0.3
+    b = torch.randn(batch, n, 256, device="cuda", dtype=dtype, generator=g) * 0.3
+    rb = torch.randn(batch, n, device="cuda", generator=g)
+    out = {}
+    t = time_kernel(lambda: ops.assign_write(a, b, rb, rb, rb, rb))
+    byt = batch * (n + 1) * (n + 1) * 4.0
+    out["assign_write"] = {"bound": "hbm", "kernel": "assign_write_kernel", "achieved": round(byt / t / 1e9, 1),
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(byt / t / 1e9 / HBM_PEAK_GBS, 4),
+                           "traffic": _traffic("assign_write_kernel"), "launch_ms": round(t * 1e3, 4),
+                           "algorithmic_bytes_per_launch": byt}
+    Z = torch.randn(batch, n + 1, n + 1, device="cuda", generator=g)
+    lib = L_.load()
+    ws = torch.empty(int(lib.gf_sinkhorn_ws_bytes(batch, n, n, sinkhorn_iters)), dtype=torch.uint8, device="cuda")
+    o = torch.empty_like(Z)
+    uh = torch.empty((sinkhorn_iters, batch, n + 1), device="cuda")
+    vh = torch.empty((sinkhorn_iters, batch, n + 1), device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    t = time_kernel(lambda: lib.gf_sinkhorn_fwd(Z.data_ptr(), o.data_ptr(), uh.data_ptr(), vh.data_ptr(), ws.data_ptr(),
+                                                batch, n, n, sinkhorn_iters, st), iters=3, warm=1)
+    byt = 2.0 * batch * (n + 1) * (n + 1) * 4.0 * sinkhorn_iters
+    out["sinkhorn_fwd"] = {"bound": "hbm", "kernel": f"gf_sinkhorn_fwd ({sinkhorn_iters} iterations, B={batch})",
+                           "achieved": round(byt / t / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(byt / t / 1e9 / HBM_PEAK_GBS, 4), "traffic": _traffic("gf_sinkhorn_fwd"),
+                           "launch_ms": round(t * 1e3, 3), "algorithmic_bytes_per_launch": byt}
+    G = torch.randn_like(Z)
+    gZ = torch.empty_like(Z)
+    gr, gc = G.sum(2).contiguous(), G.sum(1).contiguous()
+    t = time_kernel(lambda: lib.gf_sinkhorn_bwd(Z.data_ptr(), G.data_ptr(), gr.data_ptr(), gc.data_ptr(), uh.data_ptr(),
+                                                vh.data_ptr(), gZ.data_ptr(), ws.data_ptr(), batch, n, n,
+                                                sinkhorn_iters, st), iters=3, warm=1)
+    out["sinkhorn_bwd"] = {"bound": "hbm", "kernel": f"gf_sinkhorn_bwd ({sinkhorn_iters} iterations, B={batch})",
+                           "achieved": round(byt / t / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(byt / t / 1e9 / HBM_PEAK_GBS, 4), "traffic": _traffic("gf_sinkhorn_bwd"),
+                           "launch_ms": round(t * 1e3, 3), "algorithmic_bytes_per_launch": byt}
+    return out
 
 
 def micro_bench(batch, n, dtype):
@@ -138,14 +209,6 @@ def micro_bench(batch, n, dtype):
     out["ln_gelu_fwd_us"] = round(time_kernel(lambda: ops.ln_gelu(x, gam, bet)) * 1e6, 1)
     dy = torch.randn_like(y)
     out["ln_gelu_fwd+bwd_us"] = round(time_kernel(lambda: ops.ln_gelu(xr, gam, bet).backward(dy)) * 1e6, 1)
-    mean = torch.zeros(M, device=dev)
-    rstd = torch.ones(M, device=dev)
-    nblk = lib.gf_ln_gelu_nblk(M)
-    dxb, dgp, dbp = torch.empty_like(x), torch.empty(nblk, 512, device=dev), torch.empty(nblk, 512, device=dev)
-    out["ln_gelu_bwd_kernel_us"] = round(time_kernel(lambda: lib.gf_ln_gelu_bwd(
-        x.data_ptr(), gam.data_ptr(), bet.data_ptr(), mean.data_ptr(), rstd.data_ptr(), dy.data_ptr(), dxb.data_ptr(),
-        dgp.data_ptr(), dbp.data_ptr(), M, 512, 1 if dtype == torch.bfloat16 else 0,
-        torch.cuda.current_stream().cuda_stream)) * 1e6, 1)
     a = torch.randn(batch, n, 256, device=dev, dtype=dtype, generator=g) * 0.5
     b = torch.randn(batch, n, 256, device=dev, dtype=dtype, generator=g) * 0.5
     out["rows_lse_us"] = round(time_kernel(lambda: ops.rows_lse(a, b)) * 1e6, 1)
@@ -159,122 +222,88 @@ def micro_bench(batch, n, dtype):
     return out
 
 
-def cpu_baseline(n, layers):
-    """CPU oracle (port of the reference algorithm, oracle/lightglue_oracle.py) on the host cores:
-    full train step (forward + loss + backward) at B=1 pair, same N and L; pairs/s = 1/step.
-    torch's CPU backend collapses when given every hardware thread of a large host (measured:
-    541 s/step with 256 threads vs ~7 s with 8), so the thread count is calibrated on a small
-    problem first and the count actually used is what `cores` reports."""
-    from glue_factory_amd.synthetic import make_pairs
-    from oracle import lightglue_oracle as lgo
+# ------------------------------------------------------------------------------------------- CPU baseline
+def _calibrate_threads(step_small):
+    """torch's CPU backend collapses when given every hardware thread of a large host (measured: 541 s/step with
+    256 threads vs ~7 s with 8), so the thread count is calibrated on a small problem; `cores` reports it."""
     avail = os.cpu_count() or 1
-
-    def one_step(nn, ll, params, data):
-        t0 = time.time()
-        lgo.train_step_grads(params, data, ll, HEADS)
-        return time.time() - t0
-
-    def setup(nn, ll):
-        params = lgo.init_params(ll, DIM, HEADS, seed=0)
-        data = make_pairs(1, nn, dim=DIM, seed=1)
-        return params, dict(data, image_size0=data["view0"]["image_size"],
-                            image_size1=data["view1"]["image_size"])
-
-    small = setup(512, 1)
     best, cores = None, 1
     for nt in (8, 16, 32, 64):
         if nt > avail:
             break
         torch.set_num_threads(nt)
-        one_step(512, 1, *small)
-        dt = one_step(512, 1, *small)
+        step_small()
+        t0 = time.time()
+        step_small()
+        dt = time.time() - t0
         if best is None or dt < best:
             best, cores = dt, nt
     torch.set_num_threads(cores)
-    params, data = setup(n, layers)
-    cold = one_step(n, layers, params, data)       # warm-up (also the cold cost)
-    reps = 1 if cold > 12 else 2
-    dt = sum(one_step(n, layers, params, data) for _ in range(reps)) / reps
-    return {"value": round(1.0 / dt, 4), "unit": "image-pairs/s", "cores": cores, "kind": "port",
+    return cores, avail
+
+
+def cpu_baseline(n, layers):
+    """The reference's own CPU path beside the GPU number: full LightGlue train step (forward + loss + backward,
+    fp32, `flash: false` as in the training yamls) at B=1 pair, same N and L; pairs/s = 1 / step.
+    kind "reference": gluefactory's LightGlue module itself, from oracle/_ref (byte-compiled from /root/reference by
+    oracle/build_ref.py in the build container; the GPU box only has the .pyc files).  kind "port": the oracle
+    restatement (oracle/lightglue_oracle.py), used only when oracle/_ref is absent."""
+    from glue_factory_amd.synthetic import make_pairs
+    from oracle import build_ref
+    from oracle import lightglue_oracle as lgo
+
+    if build_ref.import_reference():
+        from gluefactory.models.matchers.lightglue import LightGlue as RefLightGlue
+        kind = "reference"
+
+        def make_step(nn_, ll):
+            params = lgo.init_params(ll, DIM, HEADS, seed=0)
+            model = RefLightGlue({"n_layers": ll, "descriptor_dim": DIM, "input_dim": DIM, "num_heads": HEADS,
+                                  "weights": None, "flash": False, "checkpointed": False}).train()
+            model.load_state_dict(params, strict=True)
+            data = make_pairs(1, nn_, dim=DIM, seed=1)
+
+            def step():
+                model.zero_grad(set_to_none=True)
+                pred = model(data)
+                losses, _ = model.loss(pred, {**pred, **data})
+                losses["total"].mean().backward()
+            return step
+    else:
+        kind = "port"
+
+        def make_step(nn_, ll):
+            params = lgo.init_params(ll, DIM, HEADS, seed=0)
+            data = make_pairs(1, nn_, dim=DIM, seed=1)
+            data = dict(data, image_size0=data["view0"]["image_size"], image_size1=data["view1"]["image_size"])
+            return lambda: lgo.train_step_grads(params, data, ll, HEADS)
+
+    cores, avail = _calibrate_threads(make_step(512, 1))
+    step = make_step(n, layers)
+    t0 = time.time()
+    step()                                       # warm-up (also the cold cost)
+    cold = time.time() - t0
+    reps = 1 if cold > 12 else (2 if cold > 5 else 4)
+    t0 = time.time()
+    for _ in range(reps):
+        step()
+    dt = (time.time() - t0) / reps
+    what = ("gluefactory.models.matchers.lightglue.LightGlue (the reference module, oracle/_ref)" if kind == "reference"
+            else "the torch-CPU oracle port")
+    return {"value": round(1.0 / dt, 4), "unit": "image-pairs/s", "cores": cores, "kind": kind,
             "sample": f"B=1 pair, N={n}, L={layers}, fp32, 1 warm + {reps} timed full train steps "
-                      f"({dt:.2f} s/step) of the torch-CPU oracle on {cores} of {avail} host threads"}
+                      f"({dt:.2f} s/step) of {what} on {cores} of {avail} host threads"}
 
 
-def pipeline_scope(args, stepper):
-    """Secondary scope (P): frozen SuperPoint forward on synthetic 1024x1024 images (stock library
-    convolutions + the fused HIP tails) + homography ground truth + the same matcher train step."""
-    import torch
-    from glue_factory_amd.extractors.superpoint_open import SuperPoint
-    from glue_factory_amd.gt import gt_matches_from_homography_fused as gt_matches_from_homography
-    sp = SuperPoint({"max_num_keypoints": args.kpts, "force_num_keypoints": True, "detection_threshold": 0.0,
-                     "nms_radius": 3}).cuda().eval()
-    g = torch.Generator(device="cuda").manual_seed(7)
-    img0 = torch.rand(args.batch, 1, 1024, 1024, device="cuda", generator=g)
-    img1 = img0.roll(8, -1)
-    Hm = torch.tensor([[1.0, 0, 8], [0, 1, 0], [0, 0, 1]], device="cuda")[None].repeat(args.batch, 1, 1)
-    size = torch.tensor([[1024.0, 1024.0]], device="cuda").repeat(args.batch, 1)
-
-    def extract():
-        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=args.dtype == "bf16"):
-            return sp({"image": torch.cat([img0, img1], 0)})
-
-    def pipeline_step():
-        f = extract()
-        b = args.batch
-        d = {"keypoints0": f["keypoints"][:b], "keypoints1": f["keypoints"][b:],
-             "descriptors0": f["descriptors"][:b], "descriptors1": f["descriptors"][b:],
-             "view0": {"image_size": size}, "view1": {"image_size": size}}
-        gt = gt_matches_from_homography(d["keypoints0"], d["keypoints1"], Hm, 3.0, 3.0)
-        d.update({"gt_assignment": gt["assignment"], "gt_assignment_col0": gt["assignment_col0"],
-                  "gt_matches0": gt["matches0"], "gt_matches1": gt["matches1"]})
-        return stepper(d)["total"].mean()
-
-    def timed(fn, n=3):
-        fn()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(n):
-            fn()
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / n
-
-    pipeline_step()                      # library autotuning of the convolutions happens here
-    te = timed(extract)
-    tp = timed(pipeline_step)
-    return {"value": round(args.batch / tp, 2), "unit": "image-pairs/s", "ms_per_step": round(tp * 1e3, 2),
-            "extractor_ms": round(te * 1e3, 2),
-            "scope": "frozen SuperPoint-open forward on 2x32 synthetic 1024x1024 images (library convolutions + fused HIP "
-                     "bias/ReLU/BN/pool and NMS kernels) + homography GT (gf_gt_nn) + LightGlue train step"}
-
-
-def main():
-    args = parse()
-    if args.micro:
-        torch.cuda.set_device(0)
-        print(json.dumps(micro_bench(args.batch, args.kpts, torch.bfloat16 if args.dtype == "bf16" else torch.float32)))
-        return
-    if args.roofline_only:
-        torch.cuda.set_device(0)
-        print(json.dumps(roofline_attention(args.batch, args.kpts,
-                                            torch.bfloat16 if args.dtype == "bf16" else torch.float32)))
-        return
-    from glue_factory_amd import lib
-    from glue_factory_amd.matchers.lightglue import LightGlue
-    from glue_factory_amd.synthetic import make_pairs, to_device
-    from glue_factory_amd.train_step import TrainStep, init_distributed
-    import torch.distributed as dist_mod
-
-    rank, world, local = init_distributed()          # RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local)
-    dist = dist_mod if world > 1 else None
-    lib.load()
-
+# ------------------------------------------------------------------------------------------- model setup
+def build_matcher(args, rank, name):
+    from glue_factory_amd.synthetic import make_pairs
     torch.manual_seed(0)
-    if args.model == "lightglue":
+    if name == "lightglue":
+        from glue_factory_amd.matchers.lightglue import LightGlue
         model = LightGlue({"n_layers": args.layers, "filter_threshold": 0.1}).cuda().train()
         cpu_data = make_pairs(args.batch, args.kpts, dim=DIM, seed=100 + rank)
-    elif args.model == "superglue":
+    elif name == "superglue":
         from glue_factory_amd.matchers.superglue import SuperGlue
         model = SuperGlue({"num_sinkhorn_iterations": args.sinkhorn_iters}).cuda().train()
         cpu_data = make_pairs(args.batch, args.kpts, dim=DIM, seed=100 + rank)
@@ -283,24 +312,54 @@ def main():
         from glue_factory_amd.synthetic import make_point_line_pairs
         model = GlueStick({}).cuda().train()
         cpu_data = make_point_line_pairs(args.batch, args.kpts, args.lines, dim=DIM, seed=100 + rank)
+    return model, cpu_data
+
+
+def make_stepper(args, model, local):
+    from glue_factory_amd.train_step import TrainStep
     opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)
-    stepper = TrainStep(model, opt, amp_dtype=torch.bfloat16 if args.dtype == "bf16" else None,
-                        device_ids=[local])
-    data = to_device(cpu_data, "cuda")
+    return TrainStep(model, opt, amp_dtype=torch.bfloat16 if args.dtype == "bf16" else None, device_ids=[local])
 
-    def step():
-        return stepper(data)["total"].mean()
 
-    def barrier():
-        if dist is not None:
-            dist.barrier(device_ids=[local])
-        torch.cuda.synchronize()
+def make_pipeline_step(args, stepper, rank):
+    """Scope P: frozen SuperPoint-open forward on 2 x batch synthetic IMG x IMG images (resident in HBM) ->
+    homography ground truth -> the matcher train step."""
+    from glue_factory_amd.extractors.superpoint_open import SuperPoint
+    from glue_factory_amd.gt import gt_matches_from_homography_fused
+    sp = SuperPoint({"max_num_keypoints": args.kpts, "force_num_keypoints": True, "detection_threshold": 0.0,
+                     "nms_radius": 3}).cuda().eval()
+    g = torch.Generator(device="cuda").manual_seed(7 + rank)
+    img0 = torch.rand(args.batch, 1, IMG, IMG, device="cuda", generator=g)
+    img1 = img0.roll(8, -1)
+    images = torch.cat([img0, img1], 0)
+    Hm = torch.tensor([[1.0, 0, 8], [0, 1, 0], [0, 0, 1]], device="cuda")[None].repeat(args.batch, 1, 1)
+    size = torch.tensor([[float(IMG), float(IMG)]], device="cuda").repeat(args.batch, 1)
+    b = args.batch
 
-    for _ in range(args.warmup):
+    def extract():
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=args.dtype == "bf16"):
+            return sp({"image": images})
+
+    def pipeline_step():
+        f = extract()
+        d = {"keypoints0": f["keypoints"][:b], "keypoints1": f["keypoints"][b:],
+             "descriptors0": f["descriptors"][:b], "descriptors1": f["descriptors"][b:],
+             "view0": {"image_size": size}, "view1": {"image_size": size}}
+        gt = gt_matches_from_homography_fused(d["keypoints0"], d["keypoints1"], Hm, 3.0, 3.0)
+        d.update({"gt_assignment": gt["assignment"], "gt_assignment_col0": gt["assignment_col0"],
+                  "gt_matches0": gt["matches0"], "gt_matches1": gt["matches1"]})
+        return stepper(d)["total"].mean()
+
+    return pipeline_step, extract
+
+
+def timed_steps(step, warmup, steps, barrier, dist):
+    """W untimed + exactly K timed steps, bracketed by barrier + synchronize on both sides; MAX over ranks."""
+    for _ in range(warmup):
         step()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         loss = step()
     barrier()
     dt = time.perf_counter() - t0
@@ -310,52 +369,139 @@ def main():
         dt = float(t.item())
     if not torch.isfinite(loss.detach()).item():
         raise RuntimeError("non-finite loss in the benchmark step")
+    return dt, float(loss.item())
 
+
+def other_config(args, name, local):
+    """BASELINE.json configs[3] / configs[4]: matcher train step of SuperGlue / GlueStick, inputs resident in HBM."""
+    from glue_factory_amd.synthetic import to_device
+    model, cpu_data = build_matcher(args, 0, name)
+    stepper = make_stepper(args, model, local)
+    data = to_device(cpu_data, "cuda")
+    steps = min(args.steps, 10)
+    dt, loss = timed_steps(lambda: stepper(data)["total"].mean(), min(args.warmup, 3), steps,
+                           torch.cuda.synchronize, None)
+    desc = (f"SuperGlue (18 GNN layers, {args.sinkhorn_iters} Sinkhorn iterations)" if name == "superglue"
+            else f"GlueStick ({args.kpts} keypoints + {args.lines} lines = {args.kpts + 2 * args.lines} tokens per image)")
+    out = {"value": round(args.batch * steps / dt, 2), "unit": "image-pairs/s", "ms_per_step": round(dt / steps * 1e3, 3),
+           "steps": steps, "workload": f"{desc} matcher train step, B={args.batch} pairs, N={args.kpts}, bf16, "
+                                       "inputs resident in HBM", "final_loss": round(loss, 4)}
+    del stepper, model, data
+    torch.cuda.empty_cache()
+    return out
+
+
+def self_spawn(args):
+    """`python bench.py --gpus N` without a torchrun environment: launch N ranks of this file on one node."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
+def main():
+    args = parse()
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_spawn(args))
+    if args.micro:
+        torch.cuda.set_device(0)
+        print(json.dumps(micro_bench(args.batch, args.kpts, dtype)))
+        return
+    if args.roofline_only:
+        torch.cuda.set_device(0)
+        out = {"roofline": roofline_attention(args.batch, args.kpts, dtype),
+               "roofline_hbm": roofline_hbm(args.batch, args.kpts, dtype, args.sinkhorn_iters)}
+        print(json.dumps(out))
+        return
+    from glue_factory_amd import lib
+    from glue_factory_amd.synthetic import to_device
+    from glue_factory_amd.train_step import init_distributed
+    import torch.distributed as dist_mod
+
+    rank, world, local = init_distributed()          # RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    dist = dist_mod if world > 1 else None
+    lib.load()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier(device_ids=[local])
+        torch.cuda.synchronize()
+
+    model, cpu_data = build_matcher(args, rank, args.model)
+    stepper = make_stepper(args, model, local)
+    data = to_device(cpu_data, "cuda")
+
+    def matcher_step():
+        return stepper(data)["total"].mean()
+
+    headline_is_pipeline = args.model == "lightglue" and not args.matcher_only
+    m_dt, m_loss = timed_steps(matcher_step, args.warmup, args.steps, barrier, dist)
     pairs = args.batch * world * args.steps
-    value = pairs / dt
-    if args.model != "lightglue":      # extra (non-headline) configurations: short report
+    matcher = {"value": round(pairs / m_dt, 2), "unit": "image-pairs/s", "ms_per_step": round(m_dt / args.steps * 1e3, 3),
+               "steps": args.steps,
+               "scope": "M: matcher train step (fwd + loss + bwd + Adam) on SuperPoint-shaped keypoint pairs resident in "
+                        "HBM (the reference's cached-feature training mode)",
+               "mfma_frac_step": round(pairs / m_dt * flops_per_pair_train(args.kpts, DIM, args.layers)
+                                       / world / (MFMA_BF16_PEAK_TFLOPS * 1e12), 4),
+               "final_loss": round(m_loss, 4)}
+    if not headline_is_pipeline:
         if rank == 0:
-            print(json.dumps({"metric": f"image-pairs/sec (train step) {args.model}", "value": round(value, 2),
-                              "unit": "image-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                              "ms_per_step": round(dt / args.steps * 1e3, 3), "dtype": args.dtype, "data": "synthetic",
-                              "config": {"workload": f"{args.model} matcher train step, {args.batch} pairs/GPU, "
-                                                     f"N={args.kpts}" + (f" + {args.lines} lines" if args.model == "gluestick" else "")
-                                                     + (f", {args.sinkhorn_iters} Sinkhorn iterations" if args.model == "superglue" else "")},
-                              "final_loss": round(float(loss.item()), 4)}), flush=True)
+            print(json.dumps({"metric": f"image-pairs/sec (train step) {args.model} matcher only", "n_gpus": world,
+                              "warmup": args.warmup, "dtype": args.dtype, "data": "synthetic",
+                              "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                              "config": {"workload": f"{args.model} matcher train step, {args.batch} pairs/GPU, N={args.kpts}"},
+                              **matcher}), flush=True)
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
         return
+
+    pipeline_step, extract = make_pipeline_step(args, stepper, rank)
+    pipeline_step()                                   # MIOpen's convolution search happens here, outside any timing
+    p_dt, p_loss = timed_steps(pipeline_step, args.warmup, args.steps, barrier, dist)
+    value = pairs / p_dt
+    t_ext = time_kernel(extract, iters=5, warm=1)
     out = {
         "metric": "image-pairs/sec (train step) SP+LightGlue N=2048 d=256 L=9",
         "value": round(value, 2), "unit": "image-pairs/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(p_dt / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": "configs[1]: LightGlue matcher train step (fwd+loss+bwd+Adam) on synthetic "
-                               "SuperPoint-shaped keypoint pairs resident in HBM (the reference's cached-feature training mode, "
-                               "two_view_pipeline allow_no_extract / README feature export); on-the-fly extraction is "
-                               "reported under 'pipeline'",
-                   "pairs_per_gpu": args.batch, "global_batch": args.batch * world,
-                   "keypoints": args.kpts, "descriptor_dim": DIM, "layers": args.layers,
-                   "parallelism": f"dp{world}"},
-        "mfma_frac_step": round(value * flops_per_pair_train(args.kpts, DIM, args.layers)
-                                / world / (MFMA_BF16_PEAK_TFLOPS * 1e12), 4),
-        "final_loss": round(float(loss.item()), 4),
+        "config": {"workload": "configs[1]: SuperPoint + LightGlue train step -- frozen SuperPoint-open forward on 2x32 "
+                               f"synthetic {IMG}x{IMG} images resident in HBM (stock PyTorch-ROCm convolutions + fused HIP "
+                               "tails), homography ground truth (gf_gt_nn), LightGlue fwd + loss + bwd + fused Adam",
+                   "pairs_per_gpu": args.batch, "global_batch": args.batch * world, "keypoints": args.kpts,
+                   "descriptor_dim": DIM, "layers": args.layers, "image_size": [IMG, IMG], "parallelism": f"dp{world}"},
+        "extractor_ms": round(t_ext * 1e3, 2), "final_loss": round(p_loss, 4),
+        "matcher_step": matcher,
     }
-    if rank == 0 and not args.no_pipeline and world == 1 and args.model == "lightglue":
-        # secondary scope (P): frozen SuperPoint forward on synthetic 1024x1024 images (stock
-        # PyTorch-ROCm conv, by design) + homography ground truth + the same matcher train step.
-        try:
-            out["pipeline"] = pipeline_scope(args, stepper)
-        except Exception as e:  # the secondary scope must never cost the headline line
-            out["pipeline"] = {"error": f"{type(e).__name__}: {e}"}
-    if rank == 0:
+    if rank == 0 and world == 1:
         if not args.no_roofline:
-            out["roofline"] = roofline_attention(args.batch, args.kpts,
-                                                 torch.bfloat16 if args.dtype == "bf16" else torch.float32)
-        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["roofline"] = roofline_attention(args.batch, args.kpts, dtype)
+                out["roofline_hbm"] = roofline_hbm(args.batch, args.kpts, dtype, args.sinkhorn_iters)
+            except Exception as e:   # a secondary measurement must never cost the headline line
+                out.setdefault("roofline", {"error": f"{type(e).__name__}: {e}"})
+        if not args.no_other_configs:
+            del stepper, model, data
+            torch.cuda.empty_cache()
+            oc = {}
+            for name in ("superglue", "gluestick"):
+                try:
+                    oc[name] = other_config(args, name, local)
+                except Exception as e:
+                    oc[name] = {"error": f"{type(e).__name__}: {e}"}
+            out["other_configs"] = oc
+        if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.kpts, args.layers)
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

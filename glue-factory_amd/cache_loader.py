@@ -58,9 +58,10 @@ def pad_local_features(pred, seq_l):
 
 def export_features(path, name, pred):
     """Write one image's extractor outputs (tensors without the batch dimension) as ``<path>/<name>.npz``."""
-    os.makedirs(path, exist_ok=True)
-    np.savez(os.path.join(path, f"{name}.npz"), **{k: v.detach().cpu().numpy() for k, v in pred.items()
-                                                   if torch.is_tensor(v)})
+    file = os.path.join(path, f"{name}.npz")
+    os.makedirs(os.path.dirname(file), exist_ok=True)       # image names usually carry a scene directory
+    np.savez(file, **{k: v.detach().cpu().numpy() for k, v in pred.items()
+      if torch.is_tensor(v)})
 
 
 def _collate(preds):

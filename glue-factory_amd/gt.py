@@ -28,7 +28,7 @@ def warp_points(points, H, inverse=False, eps=1e-5):
 
 
 @torch.no_grad()
-def gt_matches_from_homography_fused(kp0, kp1, H, pos_th=3.0, neg_th=3.0, with_reward=False):
+def gt_matches_from_homography_fused(kp0, kp1, H, pos_th=3.0, neg_th=6.0, with_reward=False):
     """Same labels through the HIP nearest-neighbour kernel (gf_gt_nn): no [B,M,N] fp32 tensor is
     built; the dense boolean ``assignment`` the plugin contract asks for is a zero-fill + scatter.
     ``reward`` (dense, unused by the matcher losses) is only produced on request (stock torch)."""
@@ -78,7 +78,7 @@ def gt_matches_from_homography_fused(kp0, kp1, H, pos_th=3.0, neg_th=3.0, with_r
 
 
 @torch.no_grad()
-def gt_matches_from_homography(kp0, kp1, H, pos_th=3.0, neg_th=3.0):
+def gt_matches_from_homography(kp0, kp1, H, pos_th=3.0, neg_th=6.0):
     b, m = kp0.shape[:2]
     n = kp1.shape[1]
     if m == 0 or n == 0:

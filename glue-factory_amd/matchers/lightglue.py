@@ -532,6 +532,8 @@ class LightGlue(nn.Module):
         gt = self._gt_sparse(data)
 
         def head(i):
+            # i = -1 is the LAST assignment module on the LAST stored descriptors, as the reference's
+            # loss_params(pred, -1) (lightglue.py:579-590): in eval mode only one layer is stored (L == 1).
             if layer_x is not None:
                 return self.log_assignment[i].stats_stacked(layer_x[i], rd0.shape[0])
             return self.log_assignment[i].stats(rd0[:, i], rd1[:, i])
@@ -541,7 +543,7 @@ class LightGlue(nn.Module):
                 return layer_x[i][:rd0.shape[0]], layer_x[i][rd0.shape[0]:]
             return rd0[:, i], rd1[:, i]
 
-        nll, stats = self._nll(head(L - 1), gt)
+        nll, stats = self._nll(head(-1), gt)
         losses = {"total": nll, "last": nll.clone().detach(), **stats}
         if self.training:
             losses["confidence"] = 0.0

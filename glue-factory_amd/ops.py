@@ -23,9 +23,19 @@ def _dt(t):
 
 
 def _chk(*ts):
+    """Every launcher enqueues on the CURRENT device's current stream with raw pointers: tensors on another
+    GPU would be touched from the wrong stream (faults or silent races), so that is an error, not a fallback."""
+    cur = None
     for t in ts:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise RuntimeError("glue_factory_amd ops need tensors on a HIP device (no CPU fallback)")
+        if cur is None:
+            cur = torch.cuda.current_device()
+        if t.device.index != cur:
+            raise RuntimeError(f"tensor on cuda:{t.device.index} but the current device is cuda:{cur}: call "
+                               "torch.cuda.set_device (one process per GPU) before using glue_factory_amd ops")
 
 
 def _stream():

@@ -4,7 +4,9 @@ Mirrors the semantics of the reference hot loop (gluefactory/train.py:465-517): 
 autocast forward, ``loss_fn(pred, data)``, mean of ``losses["total"]``, cross-rank agreement on
 whether the loss is differentiable (all_reduce PRODUCT, train.py:482-488), backward (DDP bucketed
 gradient all-reduce over RCCL/xGMI overlapped with the backward), optional gradient clipping,
-optimizer step.  Image pairs are independent, so the batch shards across ranks with no
+optimizer step; a NaN / non-finite loss (train.py:477-480) or gradient norm skips the update.  On the GPU path
+the skip decision never touches the host: the cross-rank flag is a device tensor handed to the fused optimiser as
+``found_inf``.  Image pairs are independent, so the batch shards across ranks with no
 data-path collective; the only collectives are the gradient all-reduce, the 4-byte flag and the
 logging reduce (train.py:525-531).
 
@@ -29,8 +31,9 @@ def init_distributed(backend=None, init_method=None, rank=None, world_size=None)
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     kw = {}
+    if torch.cuda.is_available():           # every launcher enqueues on the CURRENT device's stream (ops._chk)
+        torch.cuda.set_device(local % torch.cuda.device_count())
     if backend == "nccl":
-        torch.cuda.set_device(local)
         kw["device_id"] = torch.device("cuda", local)
     if init_method is not None:
         dist.init_process_group(backend, init_method=init_method, rank=rank, world_size=world_size, **kw)
@@ -39,15 +42,29 @@ def init_distributed(backend=None, init_method=None, rank=None, world_size=None)
     return rank, world_size, local
 
 
-def shard_batch(data, rank, world_size):
-    """Slice every batched tensor of a (nested) batch dict: global batch -> this rank's pairs
-    (what DistributedSampler + batch_size // n_gpus do in train.py:285-288)."""
+def _first_batch_dim(data):
     if isinstance(data, dict):
-        return {k: shard_batch(v, rank, world_size) for k, v in data.items()}
-    if torch.is_tensor(data) and data.dim() > 0:
-        b = data.shape[0]
-        assert b % world_size == 0, f"global batch {b} not divisible by world size {world_size}"
-        per = b // world_size
+        for v in data.values():
+            b = _first_batch_dim(v)
+            if b is not None:
+                return b
+    elif torch.is_tensor(data) and data.dim() > 0:
+        return data.shape[0]
+    return None
+
+
+def shard_batch(data, rank, world_size, batch_size=None):
+    """Slice the batched tensors of a (nested) batch dict: global batch -> this rank's pairs (what
+    DistributedSampler + batch_size // n_gpus do in train.py:285-288).  Only tensors whose leading dimension IS
+    the global batch size are sliced (``batch_size``; default: the leading dimension of the first tensor found);
+    anything else (tables, per-dataset constants) is passed through whole."""
+    if batch_size is None:
+        batch_size = _first_batch_dim(data)
+    if isinstance(data, dict):
+        return {k: shard_batch(v, rank, world_size, batch_size) for k, v in data.items()}
+    if torch.is_tensor(data) and data.dim() > 0 and data.shape[0] == batch_size:
+        assert batch_size % world_size == 0, f"global batch {batch_size} not divisible by world size {world_size}"
+        per = batch_size // world_size
         return data[rank * per:(rank + 1) * per]
     return data
 
@@ -56,7 +73,7 @@ class TrainStep:
     """step(data) -> dict of detached per-sample losses; one optimiser update per call."""
 
     def __init__(self, model, optimizer, amp_dtype=None, clip_grad=None, device_ids=None,
-                 bucket_cap_mb=16, find_unused_parameters=False):
+                 bucket_cap_mb=16, find_unused_parameters=False, check_grads=True):
         self.model = model
         self.optimizer = optimizer
         self.amp_dtype = amp_dtype
@@ -78,14 +95,22 @@ class TrainStep:
                                  find_unused_parameters=find_unused_parameters)
         p = next(model.parameters())
         self.device_type = p.device.type
-        self.skipped = 0
+        self.check_grads = check_grads
+        self._skipped_host = 0
+        self._skipped_dev = None
 
-    def _all_ranks_agree(self, flag, device):
-        if not self.distributed:
-            return flag
-        t = torch.tensor(float(flag), device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.PRODUCT)
-        return bool(t.item() > 0)
+    def _device_skip_supported(self):
+        """Fused CUDA optimisers take a device-side ``found_inf`` flag (the GradScaler protocol): the update is
+        skipped inside the fused kernel, so no host synchronisation is needed to decide it."""
+        opt = self.optimizer
+        return (self.device_type == "cuda" and getattr(opt, "_step_supports_amp_scaling", False)
+                and all(g.get("fused") for g in opt.param_groups))
+
+    @property
+    def skipped(self):
+        """Number of steps whose update was skipped (non-differentiable or non-finite loss / gradient norm on any
+        rank).  Reading it synchronises; the step itself never does on the fused path."""
+        return self._skipped_host + (int(self._skipped_dev.item()) if self._skipped_dev is not None else 0)
 
     def __call__(self, data):
         self.model.train()
@@ -95,18 +120,40 @@ class TrainStep:
             pred = self.fwd_model(data)
             losses, _ = self.model.loss(pred, {**pred, **data})
             loss = torch.mean(losses["total"])
-        do_backward = self._all_ranks_agree(loss.requires_grad, loss.device)
-        if do_backward:
-            loss.backward()
-            if self.clip_grad is not None:
-                gn = torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.clip_grad)
-                if not torch.isfinite(gn):
-                    self.skipped += 1
-                    return {k: v.detach() for k, v in losses.items() if torch.is_tensor(v)}
-            self.optimizer.step()
+        out = {k: v.detach() for k, v in losses.items() if torch.is_tensor(v)}
+        # train.py:477-488: skip the iteration on a NaN loss, and agree across ranks on whether the loss is
+        # differentiable (all_reduce PRODUCT of the flag).  Both conditions are folded into ONE device-side
+        # "bad" flag (MAX over ranks = the reference's PRODUCT of "good"); every rank always runs its backward
+        # (DDP's bucketed all-reduce needs all of them), and the flag gates the parameter update.
+        bad = (~torch.isfinite(loss.detach())).float().reshape(())
+        if not loss.requires_grad:
+            bad = bad + 1.0
+            # keep the autograd graph (and DDP's hooks) alive with an exactly-zero contribution
+            loss = loss.detach() + sum((p.sum() * 0.0 for p in self.model.parameters() if p.requires_grad))
+        if self.distributed:
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        loss.backward()
+        if self.clip_grad is not None:
+            gn = torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.clip_grad)   # no host sync
+            bad = torch.maximum(bad, (~torch.isfinite(gn)).float().reshape(()).to(bad.device))
+        elif self.check_grads:
+            # the reference's error_if_nonfinite try/except (train.py:498-510) for the un-clipped case
+            gsum = torch.stack(torch._foreach_norm([p.grad for p in self.model.parameters() if p.grad is not None])).sum()
+            bad = torch.maximum(bad, (~torch.isfinite(gsum)).float().reshape(()))
+        if self._device_skip_supported():
+            opt = self.optimizer
+            opt.found_inf = (bad > 0).float()
+            opt.grad_scale = torch.ones((), device=bad.device)
+            try:
+                opt.step()                     # fused kernel: no-op (and no step count) where found_inf != 0
+            finally:
+                del opt.found_inf, opt.grad_scale
+            self._skipped_dev = (bad > 0).long() if self._skipped_dev is None else self._skipped_dev + (bad > 0).long()
+        elif bool(bad.item() > 0):             # CPU / non-fused optimisers: one host read
+            self._skipped_host += 1
         else:
-            self.skipped += 1
-        return {k: v.detach() for k, v in losses.items() if torch.is_tensor(v)}
+            self.optimizer.step()
+        return out
 
 
 def reduce_losses(losses, dst=0):

@@ -1,0 +1,72 @@
+"""Recipe for oracle/_ref: the REFERENCE's own matcher modules as byte-compiled, sourceless Python.
+
+TEST / BENCH INFRASTRUCTURE ONLY.  The reference is Python, so "building" it means compiling the module
+closure of ``gluefactory.models.matchers.lightglue`` (+ the SuperGlue / GlueStick matchers and the two-view
+pipeline) from the sources WHERE THEY LIE under /root/reference into ``oracle/_ref/**.pyc`` -- outputs only; no
+reference source is copied into the repository, and ``oracle/_ref/`` is git-ignored (it travels to the GPU box with
+the snapshot, like the built libgf_amd.so).  Consumers: ``bench.py``'s ``cpu_baseline`` leg, which times the
+reference's LightGlue train step on the GPU box's host cores (``"kind": "reference"``), and nothing else.
+
+    python oracle/build_ref.py        # needs /root/reference (build container); no-op message otherwise
+"""
+import importlib
+import os
+import py_compile
+import shutil
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference"
+OUT = os.path.join(HERE, "_ref")
+STUBS = os.path.join(HERE, "stubs")          # omegaconf / kornia stand-ins (ours, tracked)
+TARGETS = ["gluefactory.models.matchers.lightglue", "gluefactory.models.utils.losses",
+           "gluefactory.models.utils.metrics", "gluefactory_nonfree.superglue",
+           "gluefactory.models.matchers.gluestick", "gluefactory.models.two_view_pipeline",
+           "gluefactory.models.base_model", "gluefactory.models"]
+
+
+def build(verbose=True):
+    if not os.path.isdir(os.path.join(REF, "gluefactory")):
+        if verbose:
+            print("oracle/build_ref.py: /root/reference not present; keeping the prebuilt oracle/_ref (if any)")
+        return False
+    saved_path, saved_mods = list(sys.path), set(sys.modules)
+    sys.path[:0] = [STUBS]
+    sys.path.append(REF)
+    try:
+        for t in TARGETS:
+            importlib.import_module(t)
+        files = sorted({os.path.abspath(m.__file__) for m in list(sys.modules.values())
+                        if getattr(m, "__file__", None) and os.path.abspath(m.__file__).startswith(REF + os.sep)
+                        and m.__file__.endswith(".py")})
+    finally:
+        sys.path[:] = saved_path
+        for k in set(sys.modules) - saved_mods:     # leave no reference module behind in this interpreter
+            if k.split(".")[0] in ("gluefactory", "gluefactory_nonfree", "omegaconf", "kornia"):
+                del sys.modules[k]
+    shutil.rmtree(OUT, ignore_errors=True)
+    for src in files:
+        rel = os.path.relpath(src, REF)
+        dst = os.path.join(OUT, rel[:-3] + ".pyc")      # sourceless layout: <pkg>/<module>.pyc
+        os.makedirs(os.path.dirname(dst), exist_ok=True)
+        py_compile.compile(src, cfile=dst, dfile=rel, doraise=True, optimize=0)
+    with open(os.path.join(OUT, "MANIFEST.txt"), "w") as f:
+        f.write("byte-compiled from /root/reference by oracle/build_ref.py with python %s\n" % sys.version.split()[0])
+        f.write("\n".join(os.path.relpath(s, REF) for s in files) + "\n")
+    if verbose:
+        print(f"oracle/_ref: {len(files)} reference modules byte-compiled")
+    return True
+
+
+def import_reference():
+    """Put oracle/_ref (+ the stand-ins) on sys.path; returns False when it has not been built."""
+    if not os.path.exists(os.path.join(OUT, "gluefactory", "models", "matchers", "lightglue.pyc")):
+        return False
+    for p in (OUT, STUBS):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    return True
+
+
+if __name__ == "__main__":
+    build()

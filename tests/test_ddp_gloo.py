@@ -72,3 +72,22 @@ def test_two_rank_gloo_equals_single_process():
         torch.testing.assert_close(a, b.detach(), rtol=1e-6, atol=1e-7)
     ref = reduce_losses(losses)
     assert abs(got["red"]["total"] - ref["total"]) < 1e-6 and abs(got["red"]["aux"] - ref["aux"]) < 1e-6
+
+
+def test_nan_loss_skips_the_update_and_shard_batch_keeps_tables():
+    """train.py:477-480: a NaN loss must not reach the weights; non-batched tensors are not sliced."""
+    model = Toy()
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    step = TrainStep(model, opt)
+    data = _batch()
+    before = [p.detach().clone() for p in model.parameters()]
+    bad = dict(data, t=data["t"].clone())
+    bad["t"][3, 2] = float("nan")
+    out = step(bad)
+    assert torch.isnan(out["total"]).any() and step.skipped == 1
+    assert all(torch.equal(a, b) for a, b in zip(before, model.parameters()))
+    step(data)
+    assert step.skipped == 1 and not all(torch.equal(a, b) for a, b in zip(before, model.parameters()))
+    d = dict(data, table=torch.arange(5.0), square=torch.ones(3, 3))
+    sh = shard_batch(d, 1, 2)
+    assert sh["x"].shape[0] == 4 and sh["table"].shape == (5,) and sh["square"].shape == (3, 3)

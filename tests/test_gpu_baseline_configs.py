@@ -20,10 +20,12 @@ pytestmark = pytest.mark.gpu
 from oracle import lightglue_oracle as lgo  # noqa: E402
 
 # ---- stated bf16 bounds (bf16 has an 8-bit mantissa: eps = 3.9e-3; errors accumulate over L layers) ----
-BF16_LA_MAX = {"lightglue_config1": 0.08, "lightglue_n2048_l9": 0.25}      # max |d log_assignment|
-BF16_LA_MEAN = {"lightglue_config1": 0.01, "lightglue_n2048_l9": 0.03}     # mean |d log_assignment|
+# measured on MI355X (round 2): config 1: max|dLA| 0.066, mean 0.0096, worst loss entry 1.5e-3, worst per-tensor gradient
+# error 1.4 % (median 0.5 %); N=2048/L=9: 0.19, 0.026, 2.9e-3, 1.8 % (median 0.7 %).  Bounds = about 2x that.
+BF16_LA_MAX = {"lightglue_config1": 0.12, "lightglue_n2048_l9": 0.3}      # max |d log_assignment|
+BF16_LA_MEAN = {"lightglue_config1": 0.02, "lightglue_n2048_l9": 0.05}     # mean |d log_assignment|
 BF16_LOSS_REL = 5e-3                                                        # every loss entry, relative
-BF16_GRAD_REL = {"lightglue_config1": 0.06, "lightglue_n2048_l9": 0.12}    # ||g - g_ref|| / ||g_ref|| per tensor
+BF16_GRAD_REL = {"lightglue_config1": 0.03, "lightglue_n2048_l9": 0.04}    # ||g - g_ref|| / ||g_ref|| per tensor
 
 
 def _model(params, L, **kw):
