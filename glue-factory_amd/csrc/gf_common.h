@@ -132,6 +132,22 @@ __device__ __forceinline__ float wave_allsum(float v) {
            __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
 }
 
+
+// Max over the 64 lanes, result in every lane (same DPP ladder as row16_allsum).
+__device__ __forceinline__ float row16_allmax(float v) {
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false)));
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false)));
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false)));
+    v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false)));
+    return v;
+}
+__device__ __forceinline__ float wave_allmax(float v) {
+    v = row16_allmax(v);
+    const int b = __builtin_bit_cast(int, v);
+    return fmaxf(fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0)), __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16))),
+                 fmaxf(__builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32)), __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48))));
+}
+
 // Logical block index such that consecutive logical blocks run on the same XCD (block b is
 // dispatched to XCD b % 8): each XCD walks one contiguous chunk of the logical range, so
 // blocks sharing K/V (or md1) panels hit the same private L2.  Bijective for any total.

@@ -9,8 +9,7 @@
 // reductions (new u), then sweeps the SAME LDS-resident rows column-wise to emit per-block
 // column (max, sum) partials for the new v, which a tiny second kernel combines.  Only the
 // iterates u^k, v^k are stored (2(N+1) floats per iteration) — no autograd tape of matrices.
-// The launcher walks the batch in chunks that fit the 256 MB Infinity Cache so the T
-// iterations of a chunk re-read Z from MALL instead of HBM.
+// This generic LDS path serves N + 1 > 2304; smaller problems take the register-resident fast path below.
 //
 // Backward (oracle/sinkhorn_oracle.py::backward_recurrence, verified against autograd):
 //   ubar^k_i    = [k==T] rowsum(G)_i - sum_j exp(Z_ij + u^k_i + v^k_j - log_nu_j) vbar^k_j
@@ -18,7 +17,6 @@
 //   dZ_ij = G_ij - sum_k [ exp(Z_ij+u^k_i+v^k_j-log_nu_j) vbar^k_j + exp(Z_ij+u^k_i-log_mu_i+v^{k-1}_j) ubar^k_i ]
 // i.e. T passes of the same one-read shape plus one final pass; every exponent is <= 0 up to
 // rounding (Q, R are sub-stochastic), so no max-shift is needed in the reverse sweep.
-#include <cstdlib>
 #include "gf_common.h"
 #include "gf_amd.h"
 
@@ -37,6 +35,8 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 struct Geo {
     int B, M, N, R, C, RB, nblk;
+    int Cp;                           // fast path: row stride of the padded copy (C rounded up to 4)
+    bool fast;                        // register-resident kernels (C <= 64*4*SKF_MAX_NS)
     float norm, lmu_last, lnu_last;   // log_mu = norm (i<M) | lmu_last ; log_nu = norm (j<N) | lnu_last
 };
 __device__ __forceinline__ float lmu(const Geo& g, int i) { return i < g.M ? g.norm : g.lmu_last; }
@@ -259,15 +259,393 @@ __global__ __launch_bounds__(256) void sk_final_bwd(const float* __restrict__ Z,
     }
 }
 
+
+// =================================================================================================
+// Fast path (C <= 2304): rows live in REGISTERS, one read of Z per iteration, no LDS staging
+// =================================================================================================
+// The generic kernels above spend their time moving every element global -> VGPR -> LDS (ds_write is the
+// slowest LDS instruction) -> VGPR four times.  Here a wave owns SKF_RPW whole rows, one after the other: a
+// row is NS float4 per lane (columns 4*(lane + 64 k) .. +3), loaded once with 16-byte coalesced loads from a
+// padded, log2e-prescaled copy Zp [Bc, R, Cp] (Cp = C rounded up to 4, pad = -inf; the copy is made once per
+// call, 1/T of the iteration traffic).  The next rows' loads are in flight while the current row is processed.
+//
+// One exponential per element and iteration: with ref_i = the previous u_i (log2 units, + SKF_SHIFT)
+//     e_ij   = exp2(Zp_ij + v_j + ref_i)                 (<= nu_j 2^SHIFT: column-normalised by the last v)
+//     rs_i   = sum_j e_ij          ->  u_i' = lmu_i - log2(rs_i) + ref_i           (the exact row update)
+//     S_j   += e_ij * f_i,  f_i = 2^SHIFT mu_i / rs_i   (= exp2(Zp_ij + v_j + u_i' + SHIFT), <= mu_i 2^SHIFT)
+//     v_j'   = v_j + lnu_j - log2(S_j) + SHIFT                                      (the exact column update)
+// i.e. the row pass and the column pass share the exponential; no running maxima are needed because after a
+// column (row) update every term is bounded by the column (row) marginal.  Only the very first row update
+// (u = v = 0, nothing normalised yet) uses ref_i = -max_j Z_ij.  SKF_SHIFT = 64 moves the representable
+// floor to a marginal of 2^-190; below that the sum is clamped (never NaN).
+// Column sums are kept per lane in registers over the wave's rows, combined over the 4 waves of a workgroup
+// through LDS once, and written as ONE partial row per 32 matrix rows (3 % of the Z traffic); a small second
+// kernel finishes v.  The backward sweep has the same shape (see skf_bwd_iter).
+#ifndef SK_CHUNK_MB
+#define SK_CHUNK_MB 300     // bytes of one batch chunk (MB): measured, 16-pair chunks stream fastest
+#endif
+#ifndef SKF_RPW_V
+#define SKF_RPW_V 8
+#endif
+#ifndef SKF_PF_V
+#define SKF_PF_V 2
+#endif
+constexpr int SKF_RPW = SKF_RPW_V;             // rows per wave
+constexpr int SKF_PF = SKF_PF_V;               // rows in flight ahead of the one being processed
+constexpr int SKF_NB = SKF_PF + 1;             // register row buffers (ring, statically indexed)
+constexpr int SKF_RPB = 4 * SKF_RPW;           // rows per workgroup (4 waves)
+constexpr float SKF_SHIFT = 64.f;
+constexpr int SKF_MAX_NS = 9;                  // C <= 2304
+
+__device__ __forceinline__ f32x4 splat4(float x) { f32x4 v = {x, x, x, x}; return v; }
+
+// Zp[b][i][4q..4q+3] = Z[b][i][..] * log2e, -inf past C.  One thread per float4 of Zp.
+__global__ __launch_bounds__(256) void skf_prescale(const float* __restrict__ Z, float* __restrict__ Zp, Geo g, int rows_total) {
+    const int nvec = g.Cp >> 2;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)rows_total * nvec) return;
+    const size_t row = idx / nvec;
+    const int q = (int)(idx - row * nvec);
+    const float* src = Z + row * g.C + 4 * q;
+    f32x4 o;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) o[c] = (4 * q + c < g.C) ? src[c] * GF_LOG2E : -INFINITY;
+    *reinterpret_cast<f32x4*>(Zp + row * g.Cp + 4 * q) = o;
+}
+
+template <int NS>
+__device__ __forceinline__ void skf_load_row(f32x4 (&z)[NS], const float* __restrict__ zrow, int lane, int nvec) {
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const int q = lane + 64 * k;
+        z[k] = q < nvec ? *reinterpret_cast<const f32x4*>(zrow + 4 * q) : splat4(-INFINITY);
+    }
+}
+
+// workgroup-level sum of the per-wave column accumulators -> one partial row
+template <int NS>
+__device__ __forceinline__ void skf_store_partial(const f32x4 (&S)[NS], f32x4* red, float* __restrict__ prow, int lane,
+                                                  int wave, int nvec) {
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const int q = lane + 64 * k;
+        if (q < nvec) red[wave * (NS * 64) + q] = S[k];
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < nvec; q += 256) {
+        const f32x4 a = red[q], b = red[NS * 64 + q], c = red[2 * NS * 64 + q], d = red[3 * NS * 64 + q];
+        *reinterpret_cast<f32x4*>(prow + 4 * q) = (a + b) + (c + d);
+    }
+}
+
+// grid (nblk, Bc).  v2 [Bc, Cp] (log2 units), u2 [Bc, R] read (previous) and written (new) in place.
+template <int NS, bool FIRST>
+__global__ __launch_bounds__(256, 2) void skf_fwd_iter(const float* __restrict__ Zp, const float* __restrict__ v2,
+                                                       float* __restrict__ u2, float* __restrict__ u_hist,
+                                                       float* __restrict__ part, Geo g) {
+    __shared__ f32x4 red[4 * NS * 64];
+    const int blk = blockIdx.x, b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nvec = g.Cp >> 2;
+    const int row0 = blk * SKF_RPB + wave * SKF_RPW;
+    const int nrows = min(SKF_RPW, g.R - row0);
+    f32x4 vv[NS], S[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const int q = lane + 64 * k;
+        vv[k] = (!FIRST && q < nvec) ? *reinterpret_cast<const f32x4*>(v2 + (size_t)b * g.Cp + 4 * q) : splat4(0.f);
+        S[k] = splat4(0.f);
+    }
+    if (nrows > 0) {
+        const float* zrow = Zp + ((size_t)b * g.R + row0) * g.Cp;
+        f32x4 zb[SKF_NB][NS];
+#pragma unroll
+        for (int p = 0; p < SKF_PF; ++p)
+            if (p < nrows) skf_load_row<NS>(zb[p], zrow + (size_t)p * g.Cp, lane, nvec);
+        for (int r0 = 0; r0 < nrows; r0 += SKF_NB) {
+#pragma unroll
+            for (int s_ = 0; s_ < SKF_NB; ++s_) {
+                const int r = r0 + s_;
+                if (r + SKF_PF < nrows)
+                    skf_load_row<NS>(zb[(s_ + SKF_PF) % SKF_NB], zrow + (size_t)(r + SKF_PF) * g.Cp, lane, nvec);
+                if (r >= nrows) continue;
+                f32x4 (&e)[NS] = zb[s_];
+                const int gi = row0 + r;
+                float ref;
+                if (FIRST) {
+                    float mx = -INFINITY;
+#pragma unroll
+                    for (int k = 0; k < NS; ++k)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) mx = fmaxf(mx, e[k][c]);
+                    ref = -wave_allmax(mx);
+                } else {
+                    ref = u2[(size_t)b * g.R + gi] + SKF_SHIFT;
+                }
+                float rs = 0.f;
+#pragma unroll
+                for (int k = 0; k < NS; ++k)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float x = fast_exp2(e[k][c] + vv[k][c] + ref);
+                        e[k][c] = x;
+                        rs += x;
+                    }
+                rs = fmaxf(wave_allsum(rs), 1.17549435e-38f);
+                const float lmu2 = lmu(g, gi) * GF_LOG2E, l2 = fast_log2(rs);
+                const float un = lmu2 - l2 + ref;
+                const float f = fast_exp2(lmu2 - l2 + SKF_SHIFT);
+#pragma unroll
+                for (int k = 0; k < NS; ++k)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) S[k][c] = fmaf(e[k][c], f, S[k][c]);
+                if (lane == 0) {
+                    u2[(size_t)b * g.R + gi] = un;
+                    u_hist[(size_t)b * g.R + gi] = un * GF_LN2;
+                }
+            }
+        }
+    }
+    skf_store_partial<NS>(S, red, part + ((size_t)b * g.nblk + blk) * g.Cp, lane, wave, nvec);
+}
+
+// sum of the nblk partial rows of 64 columns: 4 groups of threads take every 4th partial row, LDS combines them
+__device__ __forceinline__ float skf_colsum(const float* __restrict__ part, int b, int j, int cx, int grp, float (*ss)[64],
+                                            const Geo& g) {
+    const float* p = part + (size_t)b * g.nblk * g.Cp + j;
+    float s0 = 0.f, s1 = 0.f;
+    int k = grp;
+    for (; k + 4 < g.nblk; k += 8) { s0 += p[(size_t)k * g.Cp]; s1 += p[(size_t)(k + 4) * g.Cp]; }
+    if (k < g.nblk) s0 += p[(size_t)k * g.Cp];
+    ss[grp][cx] = s0 + s1;
+    __syncthreads();
+    return (ss[0][cx] + ss[1][cx]) + (ss[2][cx] + ss[3][cx]);
+}
+
+// grid (Cp/64 rounded up, Bc), 256 threads: v2' = v2 + lnu - log2(sum of partials) + SHIFT
+__global__ __launch_bounds__(256) void skf_cols_fwd(const float* __restrict__ part, float* __restrict__ v2,
+                                                    float* __restrict__ v_hist, int first, Geo g) {
+    __shared__ float ss[4][64];
+    const int cx = threadIdx.x & 63, grp = threadIdx.x >> 6, b = blockIdx.y;
+    const int j = blockIdx.x * 64 + cx, jc = min(j, g.Cp - 1);
+    const float tot = skf_colsum(part, b, jc, cx, grp, ss, g);
+    if (grp != 0 || j >= g.Cp) return;
+    float vn = 0.f;                                   // pad columns: any finite value (Zp is -inf there)
+    if (j < g.C) {
+        const float S = fmaxf(tot, 1.17549435e-38f);
+        vn = (first ? 0.f : v2[(size_t)b * g.Cp + j]) + lnu(g, j) * GF_LOG2E - fast_log2(S) + SKF_SHIFT;
+        v_hist[(size_t)b * g.C + j] = vn * GF_LN2;
+    }
+    v2[(size_t)b * g.Cp + j] = vn;
+}
+
+// ---- backward iteration k: e_ij = exp(Z_ij + u^k_i + v^k_j - lnu_j) (<= 1, columns sum to 1) serves both sums:
+//   ubar^k_i     = base_i - sum_j e_ij vbar^k_j
+//   vbar^{k-1}_j = -c_j sum_i e_ij w_i,   w_i = ubar^k_i exp(-lmu_i),  c_j = exp(v^{k-1}_j - v^k_j + lnu_j)
+// (exp(Z_ij + u^k_i - lmu_i + v^{k-1}_j) = e_ij exp(-lmu_i) c_j); c_j is applied by skf_cols_bwd.
+template <int NS>
+__global__ __launch_bounds__(256, 2) void skf_bwd_iter(const float* __restrict__ Zp, const float* __restrict__ uk,
+                                                       const float* __restrict__ a2p, const float* __restrict__ vbp,
+                                                       const float* __restrict__ base, float* __restrict__ ubar_out,
+                                                       float* __restrict__ part, Geo g) {
+    // a2p [Bc, Cp] = (v^k - lnu) log2e, vbp [Bc, Cp] = vbar^k, both zero in the pad columns (written by
+    // skf_cols_bwd / skf_bwd_prep)
+    __shared__ f32x4 red[4 * NS * 64];
+    const int blk = blockIdx.x, b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nvec = g.Cp >> 2;
+    const int row0 = blk * SKF_RPB + wave * SKF_RPW;
+    const int nrows = min(SKF_RPW, g.R - row0);
+    f32x4 a2[NS], vb[NS], S[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const int q = lane + 64 * k;
+        a2[k] = q < nvec ? *reinterpret_cast<const f32x4*>(a2p + (size_t)b * g.Cp + 4 * q) : splat4(0.f);
+        vb[k] = q < nvec ? *reinterpret_cast<const f32x4*>(vbp + (size_t)b * g.Cp + 4 * q) : splat4(0.f);
+        S[k] = splat4(0.f);
+    }
+    if (nrows > 0) {
+        const float* zrow = Zp + ((size_t)b * g.R + row0) * g.Cp;
+        f32x4 zb[SKF_NB][NS];
+#pragma unroll
+        for (int p = 0; p < SKF_PF; ++p)
+            if (p < nrows) skf_load_row<NS>(zb[p], zrow + (size_t)p * g.Cp, lane, nvec);
+        for (int r0 = 0; r0 < nrows; r0 += SKF_NB) {
+#pragma unroll
+            for (int s_ = 0; s_ < SKF_NB; ++s_) {
+                const int r = r0 + s_;
+                if (r + SKF_PF < nrows)
+                    skf_load_row<NS>(zb[(s_ + SKF_PF) % SKF_NB], zrow + (size_t)(r + SKF_PF) * g.Cp, lane, nvec);
+                if (r >= nrows) continue;
+                f32x4 (&e)[NS] = zb[s_];
+                const int gi = row0 + r;
+                const float u2 = uk[(size_t)b * g.R + gi] * GF_LOG2E;
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < NS; ++k)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float x = fast_exp2(e[k][c] + a2[k][c] + u2);
+                        e[k][c] = x;
+                        acc = fmaf(x, vb[k][c], acc);
+                    }
+                acc = wave_allsum(acc);
+                const float ub = (base ? base[(size_t)b * g.R + gi] : 0.f) - acc;
+                const float w = ub * fast_exp2(-lmu(g, gi) * GF_LOG2E);
+#pragma unroll
+                for (int k = 0; k < NS; ++k)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) S[k][c] = fmaf(e[k][c], w, S[k][c]);
+                if (lane == 0) ubar_out[(size_t)b * g.R + gi] = ub;
+            }
+        }
+    }
+    skf_store_partial<NS>(S, red, part + ((size_t)b * g.nblk + blk) * g.Cp, lane, wave, nvec);
+}
+
+// grid (Cp/64 rounded up, Bc): vbar^{k-1}_j = -exp(v^{k-1}_j - v^k_j + lnu_j) * sum of partials   (v^0 = 0);
+// also the padded inputs of the NEXT reverse iteration (k-1): a2p = (v^{k-1} - lnu) log2e, vbp = vbar^{k-1}
+__global__ __launch_bounds__(256) void skf_cols_bwd(const float* __restrict__ part, const float* __restrict__ vk,
+                                                    const float* __restrict__ vprev, float* __restrict__ vbar_out,
+                                                    float* __restrict__ a2p, float* __restrict__ vbp, Geo g) {
+    __shared__ float ss[4][64];
+    const int cx = threadIdx.x & 63, grp = threadIdx.x >> 6, b = blockIdx.y;
+    const int j = blockIdx.x * 64 + cx, jc = min(j, g.Cp - 1);
+    const float tot = skf_colsum(part, b, jc, cx, grp, ss, g);
+    if (grp != 0 || j >= g.Cp) return;
+    float vbn = 0.f, a2n = 0.f;
+    if (j < g.C) {
+        const float vp = vprev ? vprev[(size_t)b * g.C + j] : 0.f;
+        vbn = -__expf(vp - vk[(size_t)b * g.C + j] + lnu(g, j)) * tot;
+        a2n = (vp - lnu(g, j)) * GF_LOG2E;
+        vbar_out[(size_t)b * g.C + j] = vbn;
+    }
+    a2p[(size_t)b * g.Cp + j] = a2n;
+    vbp[(size_t)b * g.Cp + j] = vbn;
+}
+
+// first reverse iteration (k = T): a2p from v^T, vbp = colsum(G)
+__global__ __launch_bounds__(256) void skf_bwd_prep(const float* __restrict__ vT, const float* __restrict__ gsum_col,
+                                                    float* __restrict__ a2p, float* __restrict__ vbp, Geo g) {
+    const int j = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (j >= g.Cp) return;
+    const bool ok = j < g.C;
+    a2p[(size_t)b * g.Cp + j] = ok ? (vT[(size_t)b * g.C + j] - lnu(g, j)) * GF_LOG2E : 0.f;
+    vbp[(size_t)b * g.Cp + j] = ok ? gsum_col[(size_t)b * g.C + j] : 0.f;
+}
+
+// ---- final gradient: dZ = G - sum_k [ e1^k vbar^k_j + e2^k ubar^k_i ] as ONE rank-2T product on the matrix cores.
+// With the last iterates as reference, E_ij = exp(Z_ij + u^T_i + v^T_j - lnu_j) (<= 1: its columns sum to 1),
+//   e1^k_ij vbar^k_j = E_ij * exp(u^k_i - u^T_i)                   * [exp(v^k_j - v^T_j) vbar^k_j]
+//   e2^k_ij ubar^k_i = E_ij * [exp(u^k_i - u^T_i - lmu_i) ubar^k_i] * exp(v^{k-1}_j - v^T_j + lnu_j)
+// so dZ = G - E o (P Q^T) with P [R, 2T], Q [C, 2T].  The product runs on
+// v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains); the differences of iterates are small (Sinkhorn contracts), the
+// exponents are clamped to +-80 so that nothing can overflow.  2T is padded to a multiple of 16 with zeros.
+// P/Q layout: [pairs, R or C, KP] row-major, k contiguous.
+__device__ __forceinline__ float exp_clamped(float x) { return __expf(fminf(fmaxf(x, -80.f), 80.f)); }
+
+// grid (ceil(max(R,C)/256), T, Bc): thread = one row (or column) of one iteration's two factor columns
+__global__ __launch_bounds__(256) void skf_factors(const float* __restrict__ u_hist, const float* __restrict__ v_hist,
+                                                   const float* __restrict__ ubar_hist, const float* __restrict__ vbar_hist,
+                                                   float* __restrict__ P, float* __restrict__ Q, int T, int KP,
+                                                   size_t ustride, size_t vstride, Geo g) {
+    const int x = blockIdx.x * 256 + threadIdx.x, k = blockIdx.y + 1, b = blockIdx.z;
+    if (x < g.R) {
+        const float uk = u_hist[(size_t)(k - 1) * ustride + (size_t)b * g.R + x];
+        const float uT = u_hist[(size_t)(T - 1) * ustride + (size_t)b * g.R + x];
+        const float ub = ubar_hist[(size_t)(k - 1) * ustride + (size_t)b * g.R + x];
+        float* p = P + ((size_t)b * g.R + x) * KP + 2 * (k - 1);
+        p[0] = exp_clamped(uk - uT);
+        p[1] = exp_clamped(uk - uT - lmu(g, x)) * ub;
+    }
+    if (x < g.C) {
+        const float vk = v_hist[(size_t)(k - 1) * vstride + (size_t)b * g.C + x];
+        const float vT = v_hist[(size_t)(T - 1) * vstride + (size_t)b * g.C + x];
+        const float vp = k >= 2 ? v_hist[(size_t)(k - 2) * vstride + (size_t)b * g.C + x] : 0.f;
+        const float vb = vbar_hist[(size_t)k * vstride + (size_t)b * g.C + x];
+        float* q = Q + ((size_t)b * g.C + x) * KP + 2 * (k - 1);
+        q[0] = exp_clamped(vk - vT) * vb;
+        q[1] = exp_clamped(vp - vT + lnu(g, x));
+    }
+    if (k == T) {                                   // zero the k padding once
+        for (int c = 2 * T; c < KP; ++c) {
+            if (x < g.R) P[((size_t)b * g.R + x) * KP + c] = 0.f;
+            if (x < g.C) Q[((size_t)b * g.C + x) * KP + c] = 0.f;
+        }
+    }
+}
+
+// grid (ceil(C/64) * ceil(R/64), Bc), 256 threads: one wave = one 32 x 32 tile of the 64 x 64 block
+__global__ __launch_bounds__(256) void skf_final_bwd(const float* __restrict__ Z, const float* __restrict__ G,
+                                                     const float* __restrict__ P, const float* __restrict__ Q,
+                                                     const float* __restrict__ uT, const float* __restrict__ vT,
+                                                     float* __restrict__ gZ, int KP, Geo g) {
+    const int ncb = (g.C + 63) / 64;
+    const int b = blockIdx.y, rb = blockIdx.x / ncb, cb = blockIdx.x % ncb;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int i0 = rb * 64 + (wave >> 1) * 32, j0 = cb * 64 + (wave & 1) * 32;
+    if (i0 >= g.R || j0 >= g.C) return;
+    const float* prow = P + ((size_t)b * g.R + min(i0 + l31, g.R - 1)) * KP + 8 * hi;
+    const float* qrow = Q + ((size_t)b * g.C + min(j0 + l31, g.C - 1)) * KP + 8 * hi;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int s_ = 0; s_ < KP; s_ += 16) mma32(acc, ld_frag8(prow + s_), ld_frag8(qrow + s_));
+    const int j = j0 + l31;
+    if (j >= g.C) return;
+    const float cj = vT[(size_t)b * g.C + j] - lnu(g, j);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = i0 + crow(r, hi);
+        if (i < g.R) {
+            const size_t idx = ((size_t)b * g.R + i) * g.C + j;
+            const float E = __expf(Z[idx] + uT[(size_t)b * g.R + i] + cj);
+            gZ[idx] = G[idx] - E * acc[r];
+        }
+    }
+}
+
+template <int NS> int skf_fwd_launch(const float* Zp, float* v2, float* u2, float* u_hist, float* v_hist, float* part,
+                                     const Geo& g, int bc, int iters, hipStream_t st) {
+    for (int it = 0; it < iters; ++it) {
+        float* uh = u_hist + (size_t)it * g.B * g.R;
+        if (it == 0) skf_fwd_iter<NS, true><<<dim3(g.nblk, bc), 256, 0, st>>>(Zp, v2, u2, uh, part, g);
+        else skf_fwd_iter<NS, false><<<dim3(g.nblk, bc), 256, 0, st>>>(Zp, v2, u2, uh, part, g);
+        skf_cols_fwd<<<dim3((g.Cp + 63) / 64, bc), 256, 0, st>>>(part, v2, v_hist + (size_t)it * g.B * g.C, it == 0, g);
+    }
+    return (int)hipGetLastError();
+}
+template <int NS> int skf_bwd_launch(const float* Zp, const float* u_hist, const float* v_hist, const float* gsum_row,
+                                     const float* gsum_col, float* ubar_hist, float* vbar_hist, float* part, float* a2p,
+                                     float* vbp, const Geo& g, int bc, int iters, hipStream_t st) {
+    // all pointers already offset to the chunk's first pair; history strides are g.B * R (or C)
+    skf_bwd_prep<<<dim3((g.Cp + 255) / 256, bc), 256, 0, st>>>(v_hist + (size_t)(iters - 1) * g.B * g.C, gsum_col, a2p, vbp, g);
+    for (int k = iters; k >= 1; --k) {
+        const float* uk = u_hist + (size_t)(k - 1) * g.B * g.R;
+        const float* vk = v_hist + (size_t)(k - 1) * g.B * g.C;
+        const float* vp = k >= 2 ? v_hist + (size_t)(k - 2) * g.B * g.C : nullptr;
+        skf_bwd_iter<NS><<<dim3(g.nblk, bc), 256, 0, st>>>(Zp, uk, a2p, vbp, k == iters ? gsum_row : nullptr,
+                                                           ubar_hist + (size_t)(k - 1) * g.B * g.R, part, g);
+        skf_cols_bwd<<<dim3((g.Cp + 63) / 64, bc), 256, 0, st>>>(part, vk, vp, vbar_hist + (size_t)(k - 1) * g.B * g.C,
+                                                                 a2p, vbp, g);
+    }
+    return (int)hipGetLastError();
+}
 const size_t LDS_BUDGET = 160 * 1024 - 512;
 
 Geo make_geo(int B, int M, int N) {
     Geo g;
     g.B = B; g.M = M; g.N = N; g.R = M + 1; g.C = N + 1;
-    // rows per block: bounded by LDS (RB rows + 4 column vectors), at most 16
-    size_t rb = (LDS_BUDGET - 4 * (size_t)g.C * 4 - 512) / ((size_t)g.C * 4);
-    static const int cap = getenv("GF_SK_RB") ? atoi(getenv("GF_SK_RB")) : 16;   // tuning knob
-    g.RB = (int)(rb > (size_t)cap ? (size_t)cap : rb);
+    g.Cp = (g.C + 3) & ~3;
+    g.fast = (g.Cp >> 2) <= 64 * SKF_MAX_NS;
+    if (g.fast) {
+        g.RB = SKF_RPB;
+    } else {
+        // generic path: rows per block bounded by LDS (RB rows + 4 column vectors), at most 16
+        size_t rb = (LDS_BUDGET - 4 * (size_t)g.C * 4 - 512) / ((size_t)g.C * 4);
+        g.RB = (int)(rb > 16 ? 16 : rb);
+    }
     g.nblk = g.RB > 0 ? (g.R + g.RB - 1) / g.RB : 0;
     g.norm = -logf((float)(M + N));
     g.lmu_last = logf((float)N) + g.norm;
@@ -275,15 +653,48 @@ Geo make_geo(int B, int M, int N) {
     return g;
 }
 
+// Pairs per chunk (balanced over the batch).  Measured on MI355X (tools/probe/time_sinkhorn.py, B=32, N=2048, T=100,
+// forward ms): chunks of 1 / 2 / 4 / 8 / 16 / 32 pairs = 49.0 / 28.3 / 17.9 / 12.8 / 11.2 / 11.8 -- small chunks are
+// launch/latency-bound and keeping a chunk under the Infinity Cache size (8 pairs = 134 MB) buys nothing: the row
+// sweep streams at ~5 TB/s either way.  The chunk only bounds the padded copy / factor workspaces.
 int batch_chunk(const Geo& g) {
-    // keep one chunk's Z (+ partials) inside the 256 MB Infinity Cache
-    size_t per = (size_t)g.R * g.C * 4 + 2 * (size_t)g.nblk * g.C * 4;
-    int ch = (int)((size_t)176 * 1024 * 1024 / per);
-    return ch < 1 ? 1 : (ch > g.B ? g.B : ch);
+    size_t per = g.fast ? (size_t)g.R * g.Cp * 4 + (size_t)g.nblk * g.Cp * 4
+                        : (size_t)g.R * g.C * 4 + 2 * (size_t)g.nblk * g.C * 4;
+    int ch = (int)((size_t)SK_CHUNK_MB * 1024 * 1024 / per);
+    ch = ch < 1 ? 1 : (ch > g.B ? g.B : ch);
+    const int nch = (g.B + ch - 1) / ch;
+    return (g.B + nch - 1) / nch;
 }
 
 size_t rows_lds(const Geo& g, bool bwd) {
     return ((size_t)g.RB * g.C + 4 + (bwd ? 3 : 1) * (size_t)g.C + 2 * (size_t)g.RB) * 4 + 64;
+}
+
+// workspace carve (floats): [ partials | u cur | v cur | ubar hist | vbar hist | Zp (fast path) ]
+struct Ws { float *part, *ucur, *vcur, *ubar_hist, *vbar_hist, *zp, *a2p, *vbp, *P, *Q; int KP; size_t total; };
+Ws carve(void* ws, const Geo& g, int iters) {
+    Ws w;
+    float* p = reinterpret_cast<float*>(ws);
+    const size_t wid = g.fast ? g.Cp : g.C;
+    w.part = p;       p += 2 * (size_t)g.B * g.nblk * wid;
+    w.ucur = p;       p += (size_t)g.B * g.R;
+    w.vcur = p;       p += (size_t)g.B * wid;
+    w.ubar_hist = p;  p += (size_t)(iters + 1) * g.B * g.R;
+    w.vbar_hist = p;  p += (size_t)(iters + 1) * g.B * g.C;
+    p += (4 - ((p - reinterpret_cast<float*>(ws)) & 3)) & 3;      // 16-byte aligned Zp
+    w.zp = p;
+    w.KP = (2 * iters + 15) & ~15;
+    w.a2p = w.vbp = w.P = w.Q = nullptr;
+    if (g.fast) {
+        const size_t ch = (size_t)batch_chunk(g);
+        p += ch * g.R * g.Cp;
+        w.a2p = p;  p += (size_t)g.B * g.Cp;
+        w.vbp = p;  p += (size_t)g.B * g.Cp;
+        w.P = p;    p += ch * g.R * w.KP;        // rank-2T factors of the final gradient (backward only)
+        w.Q = p;    p += ch * g.C * w.KP;
+    }
+    w.total = (size_t)(p - reinterpret_cast<float*>(ws)) * 4 + 1024;
+    return w;
 }
 
 }  // namespace
@@ -292,10 +703,7 @@ extern "C" int64_t gf_sinkhorn_ws_bytes(int B, int M, int N, int iters) {
     if (B <= 0 || M <= 0 || N <= 0 || iters < 0) return GF_ERR_SHAPE;
     Geo g = make_geo(B, M, N);
     if (g.RB < 1) return GF_ERR_UNSUPPORTED;
-    size_t part = 2 * (size_t)B * g.nblk * g.C * 4;
-    size_t cur = (size_t)B * (g.R + g.C) * 4;
-    size_t hist = (size_t)(iters + 1) * B * ((size_t)g.R + g.C) * 4;   // ubar / vbar history (backward)
-    return (int64_t)(part + cur + hist + 1024);
+    return (int64_t)carve(nullptr, g, iters).total;
 }
 
 extern "C" int gf_sinkhorn_fwd(const float* Z, float* out, float* u_hist, float* v_hist, void* ws,
@@ -303,31 +711,57 @@ extern "C" int gf_sinkhorn_fwd(const float* Z, float* out, float* u_hist, float*
     if (B <= 0 || M <= 0 || N <= 0 || iters < 0) return GF_ERR_SHAPE;
     Geo g = make_geo(B, M, N);
     if (g.RB < 1) return GF_ERR_UNSUPPORTED;
+    if (reinterpret_cast<uintptr_t>(ws) & 15) return GF_ERR_ALIGN;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    float* pm = reinterpret_cast<float*>(ws);
-    float* ps = pm + (size_t)B * g.nblk * g.C;
-    float* ucur = ps + (size_t)B * g.nblk * g.C;
-    float* vcur = ucur + (size_t)B * g.R;
-    const size_t lds = rows_lds(g, false);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sk_rows_fwd),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
+    const Ws w = carve(ws, g, iters);
     const int ch = batch_chunk(g);
     const size_t zs = (size_t)g.R * g.C;
+    const size_t lds = g.fast ? 0 : rows_lds(g, false);
+    if (!g.fast) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sk_rows_fwd),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
     for (int b0 = 0; b0 < B; b0 += ch) {
         const int bc = (B - b0) < ch ? (B - b0) : ch;
-        for (int it = 0; it < iters; ++it) {
-            sk_rows_fwd<<<dim3(g.nblk, bc), SK_THREADS, lds, st>>>(
-                Z + b0 * zs, it == 0 ? nullptr : vcur + (size_t)b0 * g.C, ucur + (size_t)b0 * g.R,
-                u_hist + ((size_t)it * B + b0) * g.R, pm + (size_t)b0 * g.nblk * g.C,
-                ps + (size_t)b0 * g.nblk * g.C, g);
-            sk_cols_fwd<<<dim3((g.C + 63) / 64, bc), 256, 0, st>>>(
-                pm + (size_t)b0 * g.nblk * g.C, ps + (size_t)b0 * g.nblk * g.C, vcur + (size_t)b0 * g.C,
-                v_hist + ((size_t)it * B + b0) * g.C, g);
+        if (g.fast) {
+            if (iters > 0) {
+                const size_t nv4 = (size_t)bc * g.R * (g.Cp >> 2);
+                skf_prescale<<<dim3((unsigned)((nv4 + 255) / 256)), 256, 0, st>>>(Z + b0 * zs, w.zp, g, bc * g.R);
+                const int ns = ((g.Cp >> 2) + 63) / 64;
+                float* part = w.part + (size_t)b0 * g.nblk * g.Cp;
+                float* u2 = w.ucur + (size_t)b0 * g.R;
+                float* v2 = w.vcur + (size_t)b0 * g.Cp;
+                float* uh = u_hist + (size_t)b0 * g.R;
+                float* vh = v_hist + (size_t)b0 * g.C;
+                int rc = [&]() -> int {
+#define SKF_CALL_FWD(NSV) skf_fwd_launch<NSV>(w.zp, v2, u2, uh, vh, part, g, bc, iters, st)
+                    switch (ns) {
+                        case 1: return SKF_CALL_FWD(1); case 2: return SKF_CALL_FWD(2); case 3: return SKF_CALL_FWD(3);
+                        case 4: return SKF_CALL_FWD(4); case 5: return SKF_CALL_FWD(5); case 6: return SKF_CALL_FWD(6);
+                        case 7: return SKF_CALL_FWD(7); case 8: return SKF_CALL_FWD(8); default: return SKF_CALL_FWD(9);
+                    }
+#undef SKF_CALL_FWD
+                }();
+                if (rc) return rc;
+            }
+        } else {
+            float* pm = w.part;
+            float* ps = pm + (size_t)B * g.nblk * g.C;
+            for (int it = 0; it < iters; ++it) {
+                sk_rows_fwd<<<dim3(g.nblk, bc), SK_THREADS, lds, st>>>(
+                    Z + b0 * zs, it == 0 ? nullptr : w.vcur + (size_t)b0 * g.C, w.ucur + (size_t)b0 * g.R,
+                    u_hist + ((size_t)it * B + b0) * g.R, pm + (size_t)b0 * g.nblk * g.C,
+                    ps + (size_t)b0 * g.nblk * g.C, g);
+                sk_cols_fwd<<<dim3((g.C + 63) / 64, bc), 256, 0, st>>>(
+                    pm + (size_t)b0 * g.nblk * g.C, ps + (size_t)b0 * g.nblk * g.C, w.vcur + (size_t)b0 * g.C,
+                    v_hist + ((size_t)it * B + b0) * g.C, g);
+            }
         }
+        // out = Z + u + v - norm with the final iterates (natural-log units = the last history entries)
         sk_final_fwd<<<dim3((g.C + 255) / 256, g.R, bc), 256, 0, st>>>(
-            Z + b0 * zs, iters ? ucur + (size_t)b0 * g.R : nullptr, iters ? vcur + (size_t)b0 * g.C : nullptr,
-            out + b0 * zs, g);
+            Z + b0 * zs, iters ? u_hist + ((size_t)(iters - 1) * B + b0) * g.R : nullptr,
+            iters ? v_hist + ((size_t)(iters - 1) * B + b0) * g.C : nullptr, out + b0 * zs, g);
     }
     return (int)hipGetLastError();
 }
@@ -338,41 +772,74 @@ extern "C" int gf_sinkhorn_bwd(const float* Z, const float* gout, const float* g
     if (B <= 0 || M <= 0 || N <= 0 || iters < 0) return GF_ERR_SHAPE;
     Geo g = make_geo(B, M, N);
     if (g.RB < 1) return GF_ERR_UNSUPPORTED;
+    if (reinterpret_cast<uintptr_t>(ws) & 15) return GF_ERR_ALIGN;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    float* psum = reinterpret_cast<float*>(ws);
-    float* skip = psum + 2 * (size_t)B * g.nblk * g.C + (size_t)B * (g.R + g.C);
-    float* ubar_hist = skip;                                   // [iters, B, R]   (index k-1)
-    float* vbar_hist = ubar_hist + (size_t)(iters + 1) * B * g.R;  // [iters+1, B, C] (index k, k = 0..T)
+    const Ws w = carve(ws, g, iters);
+    float* ubar_hist = w.ubar_hist;                            // [iters, B, R]   (index k-1)
+    float* vbar_hist = w.vbar_hist;                            // [iters+1, B, C] (index k, k = 0..T)
     const size_t zs = (size_t)g.R * g.C;
     if (iters == 0) {
         hipError_t e = hipMemcpyAsync(gZ, gout, (size_t)B * zs * 4, hipMemcpyDeviceToDevice, st);
         return (int)e;
     }
-    const size_t lds = rows_lds(g, true);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sk_rows_bwd),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
+    const size_t lds = g.fast ? 0 : rows_lds(g, true);
+    hipError_t e = hipSuccess;
+    if (!g.fast) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(sk_rows_bwd),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
     // vbar^T = colsum(G)
     e = hipMemcpyAsync(vbar_hist + (size_t)iters * B * g.C, gsum_col, (size_t)B * g.C * 4, hipMemcpyDeviceToDevice, st);
     if (e != hipSuccess) return (int)e;
     const int ch = batch_chunk(g);
     for (int b0 = 0; b0 < B; b0 += ch) {
         const int bc = (B - b0) < ch ? (B - b0) : ch;
-        for (int k = iters; k >= 1; --k) {
-            const float* uk = u_hist + ((size_t)(k - 1) * B + b0) * g.R;
-            const float* vk = v_hist + ((size_t)(k - 1) * B + b0) * g.C;
-            const float* vp = k >= 2 ? v_hist + ((size_t)(k - 2) * B + b0) * g.C : nullptr;
-            sk_rows_bwd<<<dim3(g.nblk, bc), SK_THREADS, lds, st>>>(
-                Z + b0 * zs, uk, vk, vp, vbar_hist + ((size_t)k * B + b0) * g.C,
-                k == iters ? gsum_row + (size_t)b0 * g.R : nullptr,
-                ubar_hist + ((size_t)(k - 1) * B + b0) * g.R, psum + (size_t)b0 * g.nblk * g.C, g);
-            sk_cols_bwd<<<dim3((g.C + 63) / 64, bc), 256, 0, st>>>(
-                psum + (size_t)b0 * g.nblk * g.C, vbar_hist + ((size_t)(k - 1) * B + b0) * g.C, g);
+        if (g.fast) {
+            const size_t nv4 = (size_t)bc * g.R * (g.Cp >> 2);
+            skf_prescale<<<dim3((unsigned)((nv4 + 255) / 256)), 256, 0, st>>>(Z + b0 * zs, w.zp, g, bc * g.R);
+            const int ns = ((g.Cp >> 2) + 63) / 64;
+            float* part = w.part + (size_t)b0 * g.nblk * g.Cp;
+            int rc = [&]() -> int {
+#define SKF_CALL_BWD(NSV) skf_bwd_launch<NSV>(w.zp, u_hist + (size_t)b0 * g.R, v_hist + (size_t)b0 * g.C,          \
+                                              gsum_row + (size_t)b0 * g.R, gsum_col + (size_t)b0 * g.C,              \
+                                              ubar_hist + (size_t)b0 * g.R, vbar_hist + (size_t)b0 * g.C, part,      \
+                                              w.a2p + (size_t)b0 * g.Cp, w.vbp + (size_t)b0 * g.Cp, g, bc, iters, st)
+                switch (ns) {
+                    case 1: return SKF_CALL_BWD(1); case 2: return SKF_CALL_BWD(2); case 3: return SKF_CALL_BWD(3);
+                    case 4: return SKF_CALL_BWD(4); case 5: return SKF_CALL_BWD(5); case 6: return SKF_CALL_BWD(6);
+                    case 7: return SKF_CALL_BWD(7); case 8: return SKF_CALL_BWD(8); default: return SKF_CALL_BWD(9);
+                }
+#undef SKF_CALL_BWD
+            }();
+            if (rc) return rc;
+        } else {
+            float* psum = w.part;
+            for (int k = iters; k >= 1; --k) {
+                const float* uk = u_hist + ((size_t)(k - 1) * B + b0) * g.R;
+                const float* vk = v_hist + ((size_t)(k - 1) * B + b0) * g.C;
+                const float* vp = k >= 2 ? v_hist + ((size_t)(k - 2) * B + b0) * g.C : nullptr;
+                sk_rows_bwd<<<dim3(g.nblk, bc), SK_THREADS, lds, st>>>(
+                    Z + b0 * zs, uk, vk, vp, vbar_hist + ((size_t)k * B + b0) * g.C,
+                    k == iters ? gsum_row + (size_t)b0 * g.R : nullptr,
+                    ubar_hist + ((size_t)(k - 1) * B + b0) * g.R, psum + (size_t)b0 * g.nblk * g.C, g);
+                sk_cols_bwd<<<dim3((g.C + 63) / 64, bc), 256, 0, st>>>(
+                    psum + (size_t)b0 * g.nblk * g.C, vbar_hist + ((size_t)(k - 1) * B + b0) * g.C, g);
+            }
         }
-        sk_final_bwd<<<dim3((g.C + 255) / 256, (g.R + 7) / 8, bc), 256, 0, st>>>(
-            Z + b0 * zs, gout + b0 * zs, u_hist + (size_t)b0 * g.R, v_hist + (size_t)b0 * g.C,
-            ubar_hist + (size_t)b0 * g.R, vbar_hist + (size_t)B * g.C + (size_t)b0 * g.C, gZ + b0 * zs, iters,
-            (size_t)B * g.R, (size_t)B * g.C, (size_t)B * g.R, (size_t)B * g.C, g);
+        if (g.fast) {
+            skf_factors<<<dim3((max(g.R, g.C) + 255) / 256, iters, bc), 256, 0, st>>>(
+                u_hist + (size_t)b0 * g.R, v_hist + (size_t)b0 * g.C, ubar_hist + (size_t)b0 * g.R,
+                vbar_hist + (size_t)b0 * g.C, w.P, w.Q, iters, w.KP, (size_t)B * g.R, (size_t)B * g.C, g);
+            skf_final_bwd<<<dim3(((g.C + 63) / 64) * ((g.R + 63) / 64), bc), 256, 0, st>>>(
+                Z + b0 * zs, gout + b0 * zs, w.P, w.Q, u_hist + ((size_t)(iters - 1) * B + b0) * g.R,
+                v_hist + ((size_t)(iters - 1) * B + b0) * g.C, gZ + b0 * zs, w.KP, g);
+        } else {
+            sk_final_bwd<<<dim3((g.C + 255) / 256, (g.R + 7) / 8, bc), 256, 0, st>>>(
+                Z + b0 * zs, gout + b0 * zs, u_hist + (size_t)b0 * g.R, v_hist + (size_t)b0 * g.C,
+                ubar_hist + (size_t)b0 * g.R, vbar_hist + (size_t)B * g.C + (size_t)b0 * g.C, gZ + b0 * zs, iters,
+                (size_t)B * g.R, (size_t)B * g.C, (size_t)B * g.R, (size_t)B * g.C, g);
+        }
     }
     return (int)hipGetLastError();
 }
