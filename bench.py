@@ -47,7 +47,9 @@ if os.path.exists(_TUNED) and "PYTORCH_TUNABLEOP_ENABLED" not in os.environ:
     os.environ["PYTORCH_TUNABLEOP_TUNING"] = "0"
     os.environ["PYTORCH_TUNABLEOP_FILENAME"] = os.path.join(_dir, "table.csv")
 
-import torch  # noqa: E402  (after the TunableOp environment is set)
+os.environ.setdefault("MIOPEN_FIND_MODE", "3")   # stock-convolution solution selection, see glue_factory_amd/__init__.py
+
+import torch  # noqa: E402  (after the library-selection environment is set)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0            # HBM3E spec (6.3 TB/s achievable by a float4 copy), same guide

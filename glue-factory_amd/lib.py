@@ -31,6 +31,7 @@ SIGNATURES = {
     "gf_sinkhorn_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "gf_sinkhorn_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "gf_linear_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _L, _I, _P],
+    "gf_gemm": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _L, _L, _L, _I, _P],
     "gf_linear_dw_ws_bytes": [_I, _I, _I],
     "gf_linear_dw": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "gf_bn_nblk": [_I],

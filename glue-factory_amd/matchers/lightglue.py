@@ -98,8 +98,12 @@ class SelfBlock(nn.Module):
         b, n, d = x.shape
         w = self.Wqkv.weight.index_select(0, self._perm)
         bias = self.Wqkv.bias.index_select(0, self._perm)
-        qkv = ops.linear(x, w, bias).view(b, n, 3, self.heads, self.head_dim)
-        ctx = ops.self_attention_rotary(qkv, theta, cs)           # [b,n,H,hd]
+        if ops.gemm_takes(d, 3 * d, x.dtype):     # q, k leave the GEMM already rotated (rotary epilogue)
+            qkv = ops.linear(x, w, bias, rotary_cs=cs, rot_n=2 * d).view(b, n, 3, self.heads, self.head_dim)
+            ctx = ops.self_attention_rotary(qkv, theta, cs, pre_rotated=True)      # [b,n,H,hd]
+        else:
+            qkv = ops.linear(x, w, bias).view(b, n, 3, self.heads, self.head_dim)
+            ctx = ops.self_attention_rotary(qkv, theta, cs)
         msg = _lin(ctx.view(b, n, d), self.out_proj)
         return _ffn(self.ffn, x, msg)
 

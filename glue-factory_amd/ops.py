@@ -110,12 +110,13 @@ class _SelfAttentionRotary(torch.autograd.Function):
     they carry the gradient to posenc.Wr); cs [B,N,D] = interleaved (cos, sin) of theta."""
 
     @staticmethod
-    def forward(ctx, qkv, theta, cs):
+    def forward(ctx, qkv, theta, cs, pre_rotated=False):
         _chk(qkv, cs)
         B, N, three, H, D = qkv.shape
         assert three == 3 and qkv.is_contiguous() and cs.is_contiguous() and cs.dtype == torch.float32
         L = _lib.load()
-        _lib.check(L.gf_rotary_qk(_p(qkv), _p(cs), B, N, H, D, 0, _dt(qkv), _stream()), "gf_rotary_qk")
+        if not pre_rotated:      # else: q and k left the Wqkv GEMM already rotated (gf_gemm's rotary epilogue)
+            _lib.check(L.gf_rotary_qk(_p(qkv), _p(cs), B, N, H, D, 0, _dt(qkv), _stream()), "gf_rotary_qk")
         o, lse = attn_fwd_raw(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], D ** -0.5)
         ctx.save_for_backward(qkv, cs, o, lse)
         ctx.theta_dtype = theta.dtype
@@ -131,11 +132,11 @@ class _SelfAttentionRotary(torch.autograd.Function):
         dtheta = torch.empty((B, N, D // 2), dtype=torch.float32, device=qkv.device)
         _lib.check(_lib.load().gf_rotary_qk_bwd(_p(dqkv), _p(qkv), _p(cs), _p(dtheta), B, N, H, D,
                                                 _dt(qkv), _stream()), "gf_rotary_qk_bwd")
-        return dqkv, dtheta.to(ctx.theta_dtype), None
+        return dqkv, dtheta.to(ctx.theta_dtype), None, None
 
 
-def self_attention_rotary(qkv, theta, cs):
-    return _SelfAttentionRotary.apply(qkv, theta, cs)
+def self_attention_rotary(qkv, theta, cs, pre_rotated=False):
+    return _SelfAttentionRotary.apply(qkv, theta, cs, pre_rotated)
 
 
 class _CrossAttention(torch.autograd.Function):
@@ -254,33 +255,114 @@ def _lp(t, dtype):
     return t.to(dtype)
 
 
-# Forward GEMM: the tuned library GEMM (hipBLASLt) by default.  The hand-written kernel gf_linear_fwd (bias /
-# residual fused, bf16, 128-multiple outputs) is correct but measured 1.4x SLOWER than the library at these
-# tall-skinny shapes (44 vs 31 us for 131072 x 256 x 256), so it is opt-in: GF_AMD_HIP_GEMM=1.
-_LIBRARY_GEMM = os.environ.get("GF_AMD_HIP_GEMM", "0") != "1"
+# ---- GEMMs of the linear layers: the hand-written weight-streaming kernel gf_gemm (csrc/gemm_ws.hip) is the path of
+# every forward and input-gradient GEMM it supports (N % 32 == 0, K a power of two in [32, 512] -- [32, 256] in fp32 --
+# or a sum of such pieces, which are accumulated through the fused residual input).  Anything else (3- or 5-channel
+# encoder inputs, 1-channel heads) is a tiny library call.
+_GEMM_KMAX = {torch.bfloat16: 512, torch.float32: 256}
 
 
-def _gemm_ok(x2, wt):
-    return (not _LIBRARY_GEMM and x2.is_cuda and x2.dtype == torch.bfloat16 and wt.dtype == torch.bfloat16
-            and wt.shape[0] % 128 == 0 and wt.shape[1] % 32 == 0 and x2.stride(1) == 1 and wt.stride(1) == 1
-            and x2.stride(0) % 8 == 0 and wt.stride(0) % 8 == 0)
+def _k_pieces(k, dtype):
+    """Split K into power-of-two pieces gf_gemm takes (largest first); None if impossible."""
+    kmax = _GEMM_KMAX.get(dtype)
+    if kmax is None or k < 32:
+        return None
+    out, rest = [], k
+    while rest:
+        piece = min(kmax, 1 << (rest.bit_length() - 1))
+        if piece < 32:
+            return None
+        out.append(piece)
+        rest -= piece
+    return out
 
 
-def _linear_fwd(x2, wt, bias, res2=None, out=None):
-    """y [M,N] = x2 [M,K] wt[N,K]^T + bias (+ res2).  bias: the fp32 master (HIP path) -- cast for the library."""
-    M, K = x2.shape
+def _row_ok(t, dtype):
+    al = 8 if dtype == torch.bfloat16 else 4
+    return t.stride(1) == 1 and t.stride(0) % al == 0 and t.data_ptr() % 16 == 0
+
+
+def gemm(x2, wt, bias=None, res2=None, out=None, x2b=None, cs=None, rot_n=0):
+    """y [M,N] = [x2 | x2b] wt^T (+ bias) (+ res2), optional rotary epilogue; x2 / x2b / wt / res2 2-D with unit inner
+    stride, all in the compute dtype (bias: any float dtype).  ``out`` may alias ``res2``.  Returns y."""
+    M, K0 = x2.shape
     N = wt.shape[0]
-    if _gemm_ok(x2, wt) and (res2 is None or (res2.dtype == x2.dtype and res2.stride(1) == 1 and res2.stride(0) % 4 == 0)):
-        y = torch.empty((M, N), dtype=x2.dtype, device=x2.device) if out is None else out
-        b32 = None if bias is None else bias.detach().float().contiguous()
-        _lib.check(_lib.load().gf_linear_fwd(_p(x2), _p(wt), _p(b32), _p(res2), _p(y), M, N, K, x2.stride(0), wt.stride(0),
-                                             0 if res2 is None else res2.stride(0), y.stride(0), _dt(x2), _stream()),
-                   "gf_linear_fwd")
+    dtype = x2.dtype
+    K1 = 0 if x2b is None else x2b.shape[1]
+    ok = (x2.is_cuda and dtype in _GEMM_KMAX and wt.dtype == dtype and N % 32 == 0 and _row_ok(x2, dtype)
+          and _row_ok(wt, dtype) and (x2b is None or (x2b.dtype == dtype and _row_ok(x2b, dtype)))
+          and (res2 is None or (res2.dtype == dtype and _row_ok(res2, dtype)))
+          and (out is None or _row_ok(out, dtype)))
+    plan = None
+    if ok:
+        if x2b is not None and K1 == K0 and _k_pieces(K0 + K1, dtype) == [K0 + K1]:
+            plan = "two"
+        else:
+            p0 = _k_pieces(K0, dtype)
+            p1 = _k_pieces(K1, dtype) if x2b is not None else []
+            if p0 is not None and p1 is not None:
+                plan = "pieces"
+    if plan is None:                                  # library fallback for the odd shapes
+        xx = x2 if x2b is None else torch.cat([x2, x2b], 1)
+        y = torch.nn.functional.linear(xx, wt, None if bias is None else _lp(bias, dtype))
+        if res2 is not None:
+            y = y + res2
+        if cs is not None:
+            raise RuntimeError("rotary epilogue needs the gf_gemm path")
+        if out is not None:
+            out.copy_(y)
+            return out
         return y
-    y = torch.nn.functional.linear(x2, wt, _lp(bias, x2.dtype))
-    if res2 is not None:
-        y = y.add_(res2) if out is None else out.copy_(y + res2)
+    L = _lib.load()
+    y = torch.empty((M, N), dtype=dtype, device=x2.device) if out is None else out
+    b32 = None if bias is None else bias.detach().float().contiguous()
+    st = _stream()
+    dt = _dt(x2)
+    if plan == "two":
+        _lib.check(L.gf_gemm(_p(x2), _p(x2b), _p(wt), _p(b32), _p(res2), _p(y), _p(cs), rot_n, M, N, K0, K1,
+                             x2.stride(0), x2b.stride(0), wt.stride(0), 0 if res2 is None else res2.stride(0),
+                             y.stride(0), dt, st), "gf_gemm")
+        return y
+    # K pieces: the first call carries bias / residual, the others accumulate into y through the residual input;
+    # a rotary epilogue rides on the last one
+    pieces = [(x2, k0, n) for k0, n in _offsets(_k_pieces(K0, dtype))]
+    if x2b is not None:
+        pieces += [(x2b, k0, n) for k0, n in _offsets(_k_pieces(K1, dtype))]
+    wofs = 0
+    for i, (src, k0, n) in enumerate(pieces):
+        first, last = i == 0, i == len(pieces) - 1
+        xs = src[:, k0:k0 + n]
+        ws = wt[:, wofs:wofs + n]
+        r = res2 if first else y
+        _lib.check(L.gf_gemm(_p(xs), None, _p(ws), _p(b32) if first else None, _p(r), _p(y),
+                             _p(cs) if last else None, rot_n if last else 0, M, N, n, 0,
+                             xs.stride(0), 0, ws.stride(0), 0 if r is None else r.stride(0), y.stride(0), dt, st),
+                   "gf_gemm")
+        wofs += n
     return y
+
+
+def gemm_takes(k, n, dtype):
+    """True when a [*, k] x [n, k]^T product runs as ONE gf_gemm launch (needed for its rotary epilogue)."""
+    return n % 32 == 0 and _k_pieces(k, dtype) == [k]
+
+
+def _offsets(sizes):
+    out, o = [], 0
+    for n in sizes:
+        out.append((o, n))
+        o += n
+    return out
+
+
+def _linear_fwd(x2, wt, bias, res2=None, out=None, cs=None, rot_n=0):
+    """y [M,N] = x2 [M,K] wt[N,K]^T + bias (+ res2).  bias: the fp32 master."""
+    return gemm(x2, wt, bias, res2, out, cs=cs, rot_n=rot_n)
+
+
+def _wt_t(wt):
+    """[N,K] compute-dtype weight -> contiguous [K,N] (the "weight" of the input-gradient GEMM dx = dy W)."""
+    return wt.t().contiguous()
 
 
 class _Linear(torch.autograd.Function):
@@ -289,7 +371,7 @@ class _Linear(torch.autograd.Function):
     gradients for the fp32 master parameters directly.  ``res`` is a fused residual (gradient = dy)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, res=None):
+    def forward(ctx, x, w, b, res=None, cs=None, rot_n=0):
         wt = _lp(w, x.dtype)
         k = x.shape[-1]
         x2 = x.reshape(-1, k)
@@ -300,7 +382,7 @@ class _Linear(torch.autograd.Function):
             res2 = res.reshape(-1, wt.shape[0])
             if not res2.is_contiguous():
                 res2 = res2.contiguous()
-        y = _linear_fwd(x2, wt, b, res2).view(*x.shape[:-1], wt.shape[0])
+        y = _linear_fwd(x2, wt, b, res2, cs=cs, rot_n=rot_n).view(*x.shape[:-1], wt.shape[0])
         ctx.save_for_backward(x, wt)
         ctx.wdtype = w.dtype
         ctx.has_bias = b is not None
@@ -317,7 +399,7 @@ class _Linear(torch.autograd.Function):
             dy2 = dy2.contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = (dy2 @ wt).view(x.shape)
+            dx = gemm(dy2, _wt_t(wt)).view(x.shape)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             x2 = x.reshape(-1, k)
             if not x2.is_contiguous():
@@ -331,14 +413,19 @@ class _Linear(torch.autograd.Function):
                                       _stream()), "gf_linear_dw")
             dw = dw32.to(ctx.wdtype)
             db = None if db32 is None else db32.to(ctx.bdtype)
-        return dx, dw, db, (dy if ctx.has_res and ctx.needs_input_grad[3] else None)
+        return dx, dw, db, (dy if ctx.has_res and ctx.needs_input_grad[3] else None), None, None
 
 
-def linear(x, w, b=None, res=None):
+def linear(x, w, b=None, res=None, rotary_cs=None, rot_n=0):
     """w, b: fp32 master parameters (or differentiable functions of them); x (and the optional fused residual
-    ``res``, same shape as the output) in the compute dtype."""
+    ``res``, same shape as the output) in the compute dtype.  ``rotary_cs`` [.., 64] fp32 interleaved (cos, sin):
+    the output channels [0, rot_n) leave the GEMM already rotated (the buffer then belongs to
+    self_attention_rotary(pre_rotated=True), whose backward hands the UN-rotated gradient back to this node)."""
     _chk(x)
-    return _Linear.apply(x, w, b, res)
+    if rotary_cs is not None:
+        rotary_cs = rotary_cs.reshape(-1, rotary_cs.shape[-1])
+        assert rotary_cs.shape[-1] == 64 and rotary_cs.dtype == torch.float32 and rotary_cs.is_contiguous()
+    return _Linear.apply(x, w, b, res, rotary_cs, rot_n)
 
 
 def _dw(dy2, x2, nout, k, with_bias):
@@ -365,13 +452,7 @@ class _LinearCat(torch.autograd.Function):
         c2 = x2.reshape(-1, x2.shape[-1])
         a2 = a2 if a2.is_contiguous() else a2.contiguous()
         c2 = c2 if c2.is_contiguous() else c2.contiguous()
-        if _gemm_ok(a2, wt[:, :k1]) and _gemm_ok(c2, wt[:, k1:]):
-            y2 = _linear_fwd(a2, wt[:, :k1], b)
-            y2 = _linear_fwd(c2, wt[:, k1:], None, res2=y2, out=y2)       # second half accumulates in place
-            y = y2.view(*x1.shape[:-1], wt.shape[0])
-        else:
-            y = torch.nn.functional.linear(x1, wt[:, :k1], _lp(b, x1.dtype))
-            y.view(-1, y.shape[-1]).addmm_(c2, wt[:, k1:].t())
+        y = gemm(a2, wt, b, x2b=c2).view(*x1.shape[:-1], wt.shape[0])
         ctx.save_for_backward(x1, x2, wt)
         ctx.wdtype = w.dtype
         ctx.bdtype = None if b is None else b.dtype
@@ -385,8 +466,8 @@ class _LinearCat(torch.autograd.Function):
         dy2 = dy.reshape(-1, nout)
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
-        dx1 = (dy2 @ wt[:, :k1]).view(x1.shape) if ctx.needs_input_grad[0] else None
-        dx2 = (dy2 @ wt[:, k1:]).view(x2.shape) if ctx.needs_input_grad[1] else None
+        dx1 = gemm(dy2, _wt_t(wt[:, :k1])).view(x1.shape) if ctx.needs_input_grad[0] else None
+        dx2 = gemm(dy2, _wt_t(wt[:, k1:])).view(x2.shape) if ctx.needs_input_grad[1] else None
         dw = db = None
         if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
             a = x1.reshape(-1, k1)

@@ -139,6 +139,21 @@ int gf_sinkhorn_bwd(const float* Z, const float* gout, const float* gsum_row, co
                     const float* u_hist, const float* v_hist, float* gZ, void* ws,
                     int B, int M, int N, int iters, void* stream);
 
+/* ---- weight-streaming GEMM of the tall-and-skinny linear layers (default path of every nn.Linear / Conv1d(k=1)
+ * forward and, with the transposed weight, of every input-gradient GEMM: lightglue.py:131-221,271-290,
+ * superglue.py:70-160, gluestick.py:465-586):
+ *   y[m, n] = sum_k [x0 | x1][m, k] w[n, k] + bias[n] (+ res[m, n]), then optionally the rotary rotation
+ *   (lightglue.py:42-49) of channel pairs (2i, 2i+1) of the output channels [0, rot_n) by cs[m, (n mod 64)] =
+ *   interleaved (cos, sin) of token m (cs [M, 64] fp32; head dim 64).
+ * x0 [M, K0] (row stride ld0), x1 [M, K1] or NULL (K1 = 0 or K1 == K0: the FFN input cat[x, message] without the
+ * concatenation), w [N, K0+K1] (row stride ldw), res / y [M, N] (y may alias res), bias fp32 or NULL.
+ * dtype GF_F32 (exact fp32 MFMA) or GF_BF16 (fp32 accumulation).  Supported: N % 32 == 0 and
+ * K0 + K1 in {32, 64, 128, 256, 512} (fp32: <= 256); otherwise GF_ERR_UNSUPPORTED (the host splits K or uses the
+ * library).  Rows of x / w 16-byte aligned, rows of y / res 8-byte (bf16) or 16-byte (fp32) aligned. */
+int gf_gemm(const void* x0, const void* x1, const void* w, const float* bias, const void* res, void* y,
+            const float* cs, int rot_n, int M, int N, int K0, int K1,
+            int64_t ld0, int64_t ld1, int64_t ldw, int64_t ldr, int64_t ldy, int dtype, void* stream);
+
 /* ---- forward GEMM of the block linears with fused epilogue (nn.Linear calls of lightglue.py:131-221,271-290):
  *   y[m, n] = sum_k x[m, k] w[n, k] + bias[n] (+ res[m, n])     bf16 in/out, fp32 accumulation, fp32 bias
  * x [M,K] (row stride ldx), w [N,K] (row stride ldw: a column slice of a wider weight is fine), res / y [M,N]

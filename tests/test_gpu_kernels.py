@@ -362,39 +362,79 @@ def test_rows_lse_argmax_fused(dtype, M, N):
             assert (lse == -7.0).all()
 
 
-@pytest.mark.parametrize("M,N,K", [(1000, 256, 256), (4096, 768, 256), (777, 256, 512), (128, 128, 32)])
-def test_linear_fwd_kernel(M, N, K):
-    """gf_linear_fwd (bf16 NT GEMM, LDS-DMA ring) with fused bias / residual, strided weight slice and
-    in-place accumulation, against an fp32 torch reference."""
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("M,N,K", [(1000, 256, 256), (4096, 768, 256), (777, 256, 512), (128, 128, 32), (333, 64, 64),
+                                   (5000, 512, 128), (31, 32, 256)])
+def test_gemm_kernel(M, N, K, dtype):
+    """gf_gemm (weight-streaming GEMM) through the C ABI: fused bias / residual (incl. y aliasing res), strided weight
+    slice, against an fp64 torch reference.  fp32 mode must be fp32-exact (1e-5), bf16 within bf16 rounding."""
     from glue_factory_amd import lib as L_
     from glue_factory_amd.ops import _p, _stream
+    if dtype == torch.float32 and K > 256:
+        pytest.skip("fp32 K > 256 goes through the K-split of ops.gemm (covered below)")
     g = torch.Generator(device="cuda").manual_seed(M + N + K)
-    x = torch.randn(M, K, device="cuda", generator=g).bfloat16()
-    wide = (torch.randn(N, K + 64, device="cuda", generator=g) / K ** 0.5).bfloat16()
+    x = torch.randn(M, K, device="cuda", generator=g).to(dtype)
+    wide = (torch.randn(N, K + 64, device="cuda", generator=g) / K ** 0.5).to(dtype)
     w = wide[:, 32:32 + K]                                  # column slice: row stride K + 64
     bias = torch.randn(N, device="cuda", generator=g)
-    res = torch.randn(M, N, device="cuda", generator=g).bfloat16()
+    res = torch.randn(M, N, device="cuda", generator=g).to(dtype)
     lib = L_.load()
+    dt = 1 if dtype == torch.bfloat16 else 0
 
     def run(b, r, y):
-        L_.check(lib.gf_linear_fwd(_p(x), _p(w), _p(b), _p(r), _p(y), M, N, K, x.stride(0), w.stride(0),
-                                   0 if r is None else r.stride(0), y.stride(0), 1, _stream()), "gf_linear_fwd")
+        L_.check(lib.gf_gemm(_p(x), None, _p(w), _p(b), _p(r), _p(y), None, 0, M, N, K, 0, x.stride(0), 0, w.stride(0),
+                             0 if r is None else r.stride(0), y.stride(0), dt, _stream()), "gf_gemm")
         return y
 
-    ref = x.float() @ w.float().t()
-    tol = dict(rtol=2e-2, atol=2e-2)
-    torch.testing.assert_close(run(None, None, torch.empty(M, N, device="cuda", dtype=torch.bfloat16)).float(), ref, **tol)
-    torch.testing.assert_close(run(bias, None, torch.empty(M, N, device="cuda", dtype=torch.bfloat16)).float(),
-                               ref + bias, **tol)
+    ref = x.double() @ w.double().t()
+    tol = dict(rtol=2e-2, atol=2e-2) if dtype == torch.bfloat16 else dict(rtol=1e-5, atol=1e-5)
+    new = lambda: torch.full((M, N), float("nan"), device="cuda", dtype=dtype)   # noqa: E731
+    torch.testing.assert_close(run(None, None, new()).double(), ref, **tol)
+    torch.testing.assert_close(run(bias, None, new()).double(), ref + bias.double(), **tol)
     y = res.clone()
-    torch.testing.assert_close(run(bias, y, y).float(), ref + bias + res.float(), **tol)     # y aliases res
-    # tighter: against the same bf16-rounded result the library produces
-    lib_y = torch.nn.functional.linear(x, w, bias.bfloat16())
-    assert (run(bias, None, torch.empty_like(lib_y)).float() - lib_y.float()).abs().max() < 0.08
+    torch.testing.assert_close(run(bias, y, y).double(), ref + bias.double() + res.double(), **tol)     # y aliases res
+    if dtype == torch.bfloat16:   # tighter: against the bf16-rounded result the library produces
+        lib_y = torch.nn.functional.linear(x, w, bias.bfloat16())
+        assert (run(bias, None, new()).float() - lib_y.float()).abs().max() < 0.08
 
 
-def test_linear_and_ffn_residual_match_library_path(monkeypatch):
-    """ops.linear(..., res=) / ops.linear_cat on the HIP GEMM vs the library path (same op, GF switch)."""
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_gemm_two_sources_rotary_and_k_pieces(dtype):
+    """ops.gemm: the two-source form (FFN cat input), K split into power-of-two pieces (768 = 512 + 256; fp32 512 =
+    256 + 256) accumulated through the residual input, and the rotary epilogue vs apply_cached_rotary_emb."""
+    from glue_factory_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(5)
+    tol = dict(rtol=2e-2, atol=3e-2) if dtype == torch.bfloat16 else dict(rtol=1e-5, atol=2e-5)
+    M = 1500
+    a = torch.randn(M, 256, device="cuda", generator=g).to(dtype)
+    b = torch.randn(M, 256, device="cuda", generator=g).to(dtype)
+    w = (torch.randn(512, 512, device="cuda", generator=g) / 22).to(dtype)
+    bias = torch.randn(512, device="cuda", generator=g)
+    ref = torch.cat([a, b], 1).double() @ w.double().t() + bias.double()
+    torch.testing.assert_close(ops.gemm(a, w, bias, x2b=b).double(), ref, **tol)
+    # K = 768 (GlueStick line MLP, Wqkv input gradient): pieces 512 + 256 (bf16) / 256 x 3 (fp32)
+    x = torch.randn(M, 768, device="cuda", generator=g).to(dtype)
+    w2 = (torch.randn(256, 768, device="cuda", generator=g) / 27).to(dtype)
+    r = torch.randn(M, 256, device="cuda", generator=g).to(dtype)
+    ref = x.double() @ w2.double().t() + bias[:256].double() + r.double()
+    tol2 = dict(rtol=3e-2, atol=5e-2) if dtype == torch.bfloat16 else tol      # bf16: one extra rounding per piece
+    torch.testing.assert_close(ops.gemm(x, w2, bias[:256], res2=r).double(), ref, **tol2)
+    # rotary epilogue on the first 512 of 768 output channels
+    x = torch.randn(M, 256, device="cuda", generator=g).to(dtype)
+    w3 = (torch.randn(768, 256, device="cuda", generator=g) / 16).to(dtype)
+    b3 = torch.randn(768, device="cuda", generator=g)
+    theta = torch.randn(M, 32, device="cuda", generator=g, dtype=torch.float64)
+    cs = torch.stack((torch.cos(theta), torch.sin(theta)), -1).flatten(-2).float().contiguous()     # [M, 64]
+    y = (x.double() @ w3.double().t() + b3.double()).view(M, 3, 4, 32, 2)
+    c, s_ = torch.cos(theta)[:, None, None, :], torch.sin(theta)[:, None, None, :]
+    rot = torch.stack((y[..., 0] * c - y[..., 1] * s_, y[..., 1] * c + y[..., 0] * s_), -1)
+    ref = torch.cat([rot[:, :2], y[:, 2:]], 1).reshape(M, 768)
+    torch.testing.assert_close(ops.gemm(x, w3, b3, cs=cs, rot_n=512).double(), ref, **tol)
+
+
+def test_linear_and_ffn_residual_match_torch():
+    """ops.linear(..., res=) / ops.linear_cat forward and all gradients (gf_gemm forward and input-gradient GEMMs,
+    gf_linear_dw) vs the same graph in stock torch fp32."""
     from glue_factory_amd import ops
     g = torch.Generator(device="cuda").manual_seed(1)
     x = torch.randn(2, 300, 256, device="cuda", generator=g).bfloat16().requires_grad_(True)
@@ -403,12 +443,15 @@ def test_linear_and_ffn_residual_match_library_path(monkeypatch):
     b = torch.randn(512, device="cuda", generator=g).requires_grad_(True)
     w3 = (torch.randn(256, 512, device="cuda", generator=g) / 22).requires_grad_(True)
     outs = []
-    for lib_gemm in (False, True):
-        monkeypatch.setattr(ops, "_LIBRARY_GEMM", lib_gemm)
+    for ours in (True, False):
         for t in (x, m, w, b, w3):
             t.grad = None
-        h = ops.linear_cat(x, m, w, b)
-        y = ops.linear(h, w3, None, res=x)
+        if ours:
+            h = ops.linear_cat(x, m, w, b)
+            y = ops.linear(h, w3, None, res=x)
+        else:
+            h = torch.nn.functional.linear(torch.cat([x, m], -1).float(), w, b)
+            y = torch.nn.functional.linear(h.bfloat16().float(), w3) + x.float()
         y.float().square().mean().backward()
         outs.append([y.detach().float()] + [t.grad.detach().float().clone() for t in (x, m, w, b, w3)])
     for a, r in zip(*outs):

@@ -1,7 +1,7 @@
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "grid_sampler" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if "sample_desc" in r["Kernel_Name"] or "grid_sampler" in r["Kernel_Name"]]
 print("calls:", len(idx))
 start = idx[-4] + 1
 seg = rows[start:idx[-1] + 1]
