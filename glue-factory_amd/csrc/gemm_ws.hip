@@ -48,6 +48,15 @@ struct GwParams {
 #ifndef GW_ABL
 #define GW_ABL 0                              // probe ablations: 1 no global stores, 2 x rows all = row 0 (cached), 3 no MFMA
 #endif
+#ifndef GW_TRACE
+#define GW_TRACE 0
+#endif
+#if GW_TRACE
+__device__ unsigned long long gw_trace_buf[16 * 4096];
+#define GW_STAMP(i) do { if (lane == 0 && (wave == 0)) gw_trace_buf[blockIdx.x * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define GW_STAMP(i)
+#endif
 constexpr int GW_SCRATCH = 8192;              // wave-private LDS scratch: 32 rows x 256 B
 
 // 16-byte chunk c of row `row` (cpr chunks per row, a power of two) sits at chunk position swz(row, c) of its LDS row:
@@ -213,11 +222,14 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_ws_kernel(GwParams p) {
         }
     };
 
+    GW_STAMP(0);
     stage_load(0);
     Frag<T> xf[R][KF];
     load_x(xf, blockIdx.x);
+    GW_STAMP(1);
     stage_store(0);
     __syncthreads();
+    GW_STAMP(2);
 
     // per-lane swizzle key of the weight rows in byte units, with the lane's half (hi) folded in
     const int swz_key = (gw_swz(l31, 0, CPR) << 4) ^ ((sizeof(T) == 2 ? 16 : 32) * hi);
@@ -293,13 +305,17 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_ws_kernel(GwParams p) {
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
+                if (s == 0 && t == 0) GW_STAMP(3);
 #pragma unroll
                 for (int rr = 0; rr < R; ++rr) flush(acc[rr], ntl, n0 + 32 * t, m_wave + 32 * rr);
+                if (s == 0 && t == 0) GW_STAMP(4);
             }
+            if (s < 4) GW_STAMP(5 + 2 * s);
             if (gs + 1 < total) {                         // slice gs+1 -> the other buffer (free since the last barrier)
                 stage_store(gs + 1);
                 __syncthreads();
             }
+            if (s < 4) GW_STAMP(6 + 2 * s);
         }
         if (bi + 1 < myblocks) load_x(xf, blk + gridDim.x);
     }
@@ -340,6 +356,12 @@ template <typename T, bool TWO> int gw_dispatch(const GwParams& p, int K, hipStr
 }
 
 }  // namespace
+
+#if GW_TRACE
+extern "C" int gf_gemm_trace(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(gw_trace_buf), sizeof(unsigned long long) * n);
+}
+#endif
 
 extern "C" int gf_gemm(const void* x0, const void* x1, const void* w, const float* bias, const void* res, void* y,
                        const float* cs, int rot_n, int M, int N, int K0, int K1,
