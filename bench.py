@@ -47,7 +47,7 @@ if os.path.exists(_TUNED) and "PYTORCH_TUNABLEOP_ENABLED" not in os.environ:
     os.environ["PYTORCH_TUNABLEOP_TUNING"] = "0"
     os.environ["PYTORCH_TUNABLEOP_FILENAME"] = os.path.join(_dir, "table.csv")
 
-os.environ.setdefault("MIOPEN_FIND_MODE", "3")   # stock-convolution solution selection, see glue_factory_amd/__init__.py
+import glue_factory_amd  # noqa: E402,F401  (sets the MIOpen find-db / find mode of the stock convolutions before torch runs one)
 
 import torch  # noqa: E402  (after the library-selection environment is set)
 

@@ -15,11 +15,32 @@ import os as _os
 # Let the stock convolution library take channels-last activations as they are (the fused extractor path keeps
 # them NHWC end to end); PyTorch-ROCm reads this once, at its first convolution call.
 _os.environ.setdefault("PYTORCH_MIOPEN_SUGGEST_NHWC", "1")
-# MIOpen solution selection for the stock convolutions of the extractor, unless the user already chose one: find mode
-# 3 ("fast find": pick from the find-db / heuristics immediately) instead of the default hybrid search.  Measured on
-# MI355X for SuperPoint-open (tools/probe/sp_variants.py, 64 x 1024^2, bf16): first call 62 s -> 0.3 s and steady state
-# 45.8 -> 38.1 ms per forward (the default search settles on split-K kernels that need a zero-filled output).  Set
-# here, at package import, so that it is in the environment before the library serves its first convolution.
+# MIOpen solution selection for the stock convolutions of the extractor -- the same idea as the TunableOp table of the
+# library GEMMs: miopen_db/ holds the user find-db / perf-db written by ONE exhaustive search on MI355X
+# (torch.backends.cudnn.benchmark on SuperPoint-open, 64 x 1024^2, bf16, channels-last: tools/probe/sp_variants.py
+# benchmark with MIOPEN_USER_DB_PATH set).  Replaying it (find mode 3 = take the find-db entry immediately) gives
+# first call 0.3 s instead of 62 s and 37.9 instead of 45.8 ms per forward: the search prefers the composable-kernel
+# implicit GEMM over the default ASM one, which needs a zero-filled output.  Shapes that are not in the table fall back
+# to MIOpen's heuristics.  Both variables are left alone when the user set them; the table is copied to a private
+# directory because the library writes to its user db.
+def _miopen_db():
+    import shutil as _sh
+    import tempfile as _tf
+    src = _os.path.join(__path__[0], "miopen_db")      # __path__[0] = the source directory (see the import shim)
+    if "MIOPEN_USER_DB_PATH" in _os.environ or not _os.path.isdir(src):
+        return
+    dst = _os.path.join(_tf.gettempdir(), "gf_amd_miopen_db_%d_%s" % (_os.getuid(), _os.environ.get("LOCAL_RANK", "0")))
+    try:
+        _os.makedirs(dst, exist_ok=True)
+        for name in _os.listdir(src):
+            if name.endswith(".txt") and not _os.path.exists(_os.path.join(dst, name)):
+                _sh.copyfile(_os.path.join(src, name), _os.path.join(dst, name))
+        _os.environ["MIOPEN_USER_DB_PATH"] = dst
+    except OSError:
+        pass
+
+
+_miopen_db()
 _os.environ.setdefault("MIOPEN_FIND_MODE", "3")
 
 __version__ = "0.1.0"
