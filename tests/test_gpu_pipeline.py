@@ -67,3 +67,32 @@ def test_pipeline_train_step_and_overfit():
     for _ in range(15):
         last = step(data)["total"].mean().item()
     assert last < 0.95 * first, (first, last)
+
+
+def test_triplet_pipeline_with_hip_lightglue():
+    """TripletPipeline (triplet_pipeline.py:23-99) around the real HIP matcher: the three pairs stacked into one
+    matcher call (3B pairs per launch) give the same log-assignment as pair-by-pair and as plain two-view calls."""
+    from glue_factory_amd.base_model import get_model
+    from glue_factory_amd.synthetic import to_device
+    P3 = get_model("glue_factory_amd.triplet_pipeline")
+    conf = {"extractor": {"name": "extractors.superpoint_open", "max_num_keypoints": 96, "force_num_keypoints": True,
+                          "detection_threshold": 0.0, "nms_radius": 3, "trainable": False},
+            "matcher": {"name": "matchers.lightglue", "n_layers": 2, "filter_threshold": 0.0}}
+    torch.manual_seed(0)
+    batched = P3({**conf, "batch_triplets": True}).cuda().eval()
+    pairwise = P3({**conf, "batch_triplets": False}).cuda().eval()
+    pairwise.load_state_dict(batched.state_dict())
+    g = torch.Generator().manual_seed(3)
+    size = torch.tensor([[160.0, 120.0]]).repeat(2, 1)
+    data = to_device({f"view{i}": {"image": torch.rand(2, 3, 120, 160, generator=g), "image_size": size}
+                      for i in range(3)}, "cuda")
+    with torch.no_grad():
+        pb, pp = batched(data), pairwise(data)
+    for idx in ("0to1", "0to2", "1to2"):
+        assert pb[idx]["log_assignment"].shape == (2, 97, 97)
+        torch.testing.assert_close(pb[idx]["log_assignment"], pp[idx]["log_assignment"], rtol=1e-4, atol=1e-4)
+        assert torch.equal(pb[idx]["matches0"], pp[idx]["matches0"])
+    two = {k: v for k, v in data.items() if k != "view2"}
+    with torch.no_grad():
+        p2 = batched(two)
+    torch.testing.assert_close(p2["log_assignment"], pb["0to1"]["log_assignment"], rtol=1e-4, atol=1e-4)
