@@ -31,6 +31,10 @@ SIGNATURES = {
     "gf_sinkhorn_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "gf_sinkhorn_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "gf_linear_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _L, _I, _P],
+    "gf_line_csr": [_P, _P, _P, _I, _I, _I, _P],
+    "gf_line_gather": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "gf_line_segsum": [_P, _L, _P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "gf_line_expand": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "gf_gemm": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _L, _L, _L, _I, _P],
     "gf_linear_dw_ws_bytes": [_I, _I, _I],
     "gf_linear_dw": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],

@@ -16,7 +16,7 @@ What runs where
   * line layers (gather of junction descriptors, endpoint MLP, mean scatter back; :589-691) and
     the line head (:336-376, 2*Nl x 2*Nl scores, two endpoint pairings) work on <= 1024-row
     tensors and stay on stock torch ops.
-``line_attention: True`` is not implemented (no shipped config uses it).
+``line_attention: True`` runs the same kernels with a per-junction softmax weighting (stock torch for the weights).
 """
 from pathlib import Path
 
@@ -71,22 +71,41 @@ class GNNLayer(nn.Module):
 
 
 class LineLayer(nn.Module):
+    """gluestick.py:589-691 on the HIP line kernels (csrc/line_layer.hip): gather of the two junction descriptors of
+    every endpoint + the endpoint encoding -> MLP (gf_gemm + fused BatchNorm/ReLU) -> mean over the endpoints of each
+    junction fused with the residual add, all on channels-last tensors; ``line_attention`` weighs the endpoints of a
+    junction by a softmax over them (proj_node / proj_neigh, :623-639) instead of averaging."""
+
     def __init__(self, feature_dim, line_attention=False):
         super().__init__()
-        if line_attention:
-            raise NotImplementedError("line_attention=True is not part of the accelerated path")
         self.dim = feature_dim
         self.mlp = MLP([feature_dim * 3, feature_dim * 2, feature_dim], do_bn=True)
+        self.line_attention = line_attention
+        if line_attention:
+            self.proj_node = nn.Conv1d(feature_dim, feature_dim, kernel_size=1)
+            self.proj_neigh = nn.Conv1d(2 * feature_dim, feature_dim, kernel_size=1)
 
-    def forward(self, ldesc, line_enc, junc_idx, halves):
-        """ldesc [B',N,D], line_enc [B',2Nl,D], junc_idx [B',2Nl] -> ldesc + mean endpoint update."""
-        b, n, d = ldesc.shape
-        idx = junc_idx[..., None].expand(-1, -1, d)
-        ld = ldesc.gather(1, idx)
-        ld2 = ld.reshape(b, -1, 2, d).flip(2).reshape(b, -1, d)
-        upd = _mlp_cl(self.mlp, torch.cat([ld, ld2, line_enc.to(ld.dtype)], -1), halves)
-        agg = torch.zeros_like(ldesc).scatter_reduce(1, idx, upd, reduce="mean", include_self=False)
-        return ldesc + agg
+    def _attention(self, msg, ldesc, junc_idx):
+        """Per-endpoint weights: softmax over the endpoints that share a junction of <proj_node(x_j), proj_neigh([x_other,
+        enc])> / sqrt(D), with the reference's global max shift and its epsilon (gluestick.py:623-639)."""
+        d = self.dim
+        query = _conv_cl(ldesc, self.proj_node).float()
+        query = query.gather(1, junc_idx[..., None].expand(-1, -1, d))
+        key = _conv_cl(msg[..., d:].contiguous(), self.proj_neigh).float()
+        prob = (query * key).sum(-1) / d ** 0.5
+        prob = torch.exp(prob - prob.max())
+        denom = torch.zeros_like(ldesc[..., 0], dtype=torch.float32).scatter_reduce(
+            1, junc_idx, prob, reduce="sum", include_self=False)
+        return prob / (denom.gather(1, junc_idx) + 1e-8)
+
+    def forward(self, ldesc, line_enc, junc_idx, halves, graph):
+        """ldesc [B',N,D], line_enc [B',2Nl,D], junc_idx [B',2Nl], graph = ops.line_graph(junc_idx, N)."""
+        order, seg = graph
+        msg = ops.line_gather(ldesc, line_enc.to(ldesc.dtype), junc_idx, order, seg)
+        upd = _mlp_cl(self.mlp, msg, halves)
+        if self.line_attention:
+            upd = upd * self._attention(msg, ldesc, junc_idx)[..., None].to(upd.dtype)
+        return ops.line_aggregate(ldesc, upd, junc_idx, order, seg, mean=not self.line_attention)
 
 
 class AttentionalGNN(nn.Module):
@@ -246,6 +265,7 @@ class GlueStick(BaseModel):
                       normalize_keypoints(data["lines1"].flatten(1, 2), size1).reshape(b, nl1, 2, 2))
             lsc = cat2(data["line_scores0"].float(), data["line_scores1"].float())
             lenc = [self.lenc(l_, s_, halves) for l_, s_ in zip(ln, lsc)]
+            graphs = [ops.line_graph(ji, x.shape[1]) for ji, x in zip(jidx, xs)]   # shared by all line layers
         inter_desc = {}
         inter = self.gnn.inter_supervision
         for i, layer in enumerate(self.gnn.layers):
@@ -257,7 +277,8 @@ class GlueStick(BaseModel):
                 xs = [xs[0] + d0 * layer.update.scaling, xs[1] + d1 * layer.update.scaling]
             if layer.type == "self" and have_lines:
                 for _ in range(self.gnn.num_line_iterations):
-                    xs = [self.gnn.line_layers[i // 2](x, le, ji, halves) for x, le, ji in zip(xs, lenc, jidx)]
+                    xs = [self.gnn.line_layers[i // 2](x, le, ji, halves, gr)
+                          for x, le, ji, gr in zip(xs, lenc, jidx, graphs)]
             if inter is not None and (i // 2) in inter and cross:
                 inter_desc[i // 2] = xs
         split = (lambda t: (t[0][:b], t[0][b:])) if stacked else (lambda t: (t[0], t[1]))

@@ -993,3 +993,85 @@ def batch_norm_act(x, bn, relu=True):
         return y
     rstd = torch.rsqrt(bn.running_var.float() + bn.eps)
     return _BatchNormAct.apply(x, bn.weight, bn.bias, bn.running_mean, rstd, bn.eps, False, relu, False)[0]
+
+
+# ------------------------------------------------------------------------------ GlueStick line message passing
+@torch.no_grad()
+def line_graph(idx, n):
+    """idx [B,E] int64 junction of every line endpoint -> (order [B,E] int32: endpoints grouped by junction, stable;
+    seg [B,n+1] int32: segment starts).  Built once per forward: all line layers (and the backward) share it."""
+    _chk(idx)
+    idx = idx.contiguous()
+    B, E = idx.shape
+    order = torch.empty((B, E), dtype=torch.int32, device=idx.device)
+    seg = torch.empty((B, n + 1), dtype=torch.int32, device=idx.device)
+    _lib.check(_lib.load().gf_line_csr(_p(idx), _p(order), _p(seg), B, E, n, _stream()), "gf_line_csr")
+    return order, seg
+
+
+def _segsum(s0, s1, order, seg, base, B, E, N, D, mode):
+    out = torch.empty((B, N, D), dtype=s0.dtype, device=s0.device)
+    _lib.check(_lib.load().gf_line_segsum(_p(s0), s0.stride(1), _p(s1), 0 if s1 is None else s1.stride(1), _p(order),
+                                          _p(seg), _p(base), _p(out), B, E, N, D, mode, _dt(s0), _stream()),
+               "gf_line_segsum")
+    return out
+
+
+class _LineGather(torch.autograd.Function):
+    """msg [B,E,3D] = [x[idx[e]] | x[idx[e^1]] | enc[e]] (gluestick.py:609-621); backward: deterministic segment sums."""
+
+    @staticmethod
+    def forward(ctx, x, enc, idx, order, seg):
+        _chk(x, enc, idx)
+        x, enc, idx = x.contiguous(), enc.contiguous(), idx.contiguous()
+        B, N, D = x.shape
+        E = idx.shape[1]
+        msg = torch.empty((B, E, 3 * D), dtype=x.dtype, device=x.device)
+        _lib.check(_lib.load().gf_line_gather(_p(x), _p(idx), _p(enc), _p(msg), B, E, N, D, _dt(x), _stream()),
+                   "gf_line_gather")
+        ctx.save_for_backward(order, seg)
+        ctx.dims = (B, E, N, D)
+        return msg
+
+    @staticmethod
+    def backward(ctx, dmsg):
+        order, seg = ctx.saved_tensors
+        B, E, N, D = ctx.dims
+        if not dmsg.is_contiguous():
+            dmsg = dmsg.contiguous()
+        dx = _segsum(dmsg[:, :, :D], dmsg[:, :, D:2 * D], order, seg, None, B, E, N, D, 0)
+        return dx, dmsg[:, :, 2 * D:], None, None, None
+
+
+class _LineAggregate(torch.autograd.Function):
+    """x + (mean | sum) over the endpoints on each junction of upd [B,E,D] (gluestick.py:660-700)."""
+
+    @staticmethod
+    def forward(ctx, x, upd, idx, order, seg, mean):
+        _chk(x, upd, idx)
+        x, upd = x.contiguous(), upd.contiguous()
+        B, N, D = x.shape
+        E = upd.shape[1]
+        out = _segsum(upd, None, order, seg, x, B, E, N, D, 1 if mean else 0)
+        ctx.save_for_backward(idx.contiguous(), seg)
+        ctx.dims = (B, E, N, D, mean)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        idx, seg = ctx.saved_tensors
+        B, E, N, D, mean = ctx.dims
+        if not g.is_contiguous():
+            g = g.contiguous()
+        dupd = torch.empty((B, E, D), dtype=g.dtype, device=g.device)
+        _lib.check(_lib.load().gf_line_expand(_p(g), _p(idx), _p(seg), _p(dupd), B, E, N, D, 1 if mean else 0, _dt(g),
+                                              _stream()), "gf_line_expand")
+        return g, dupd, None, None, None, None
+
+
+def line_gather(x, enc, idx, order, seg):
+    return _LineGather.apply(x, enc, idx, order, seg)
+
+
+def line_aggregate(x, upd, idx, order, seg, mean=True):
+    return _LineAggregate.apply(x, upd, idx, order, seg, mean)

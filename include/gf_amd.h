@@ -139,6 +139,22 @@ int gf_sinkhorn_bwd(const float* Z, const float* gout, const float* gsum_row, co
                     const float* u_hist, const float* v_hist, float* gZ, void* ws,
                     int B, int M, int N, int iters, void* stream);
 
+/* ---- GlueStick line message passing (gluestick.py:589-691): endpoints e = 0..E-1 (E = 2 Nl, partner e ^ 1) sit on
+ * junctions idx[b, e] in [0, N).
+ * gf_line_csr:    order [B, E] int32 (endpoints grouped by junction, stable) and seg [B, N+1] int32 (segment starts).
+ * gf_line_gather: msg [B, E, 3D] = [x[idx[e]] | x[idx[e^1]] | enc[e]]  (get_endpoint_update's MLP input, :609-621).
+ * gf_line_segsum: out [B, N, D] = base (or 0) + scale_j * sum_{e on j} (s0[b, e, :D] + s1[b, e^1, :D]); s0 / s1 are
+ *                 [B, E, ld] views (row strides ld0 / ld1 in elements, s1 may be NULL); mode 0: scale = 1 (weighted
+ *                 sum of line attention, :660-680), mode 1: scale = 1 / count (scatter_reduce "mean", :683-697).
+ * gf_line_expand: d [B, E, D] = scale_{idx[e]} * g[b, idx[e]]  (backward of the aggregation). */
+int gf_line_csr(const int64_t* idx, int* order, int* seg, int B, int E, int N, void* stream);
+int gf_line_gather(const void* x, const int64_t* idx, const void* enc, void* msg, int B, int E, int N, int D,
+                   int dtype, void* stream);
+int gf_line_segsum(const void* s0, int64_t ld0, const void* s1, int64_t ld1, const int* order, const int* seg,
+                   const void* base, void* out, int B, int E, int N, int D, int mode, int dtype, void* stream);
+int gf_line_expand(const void* g, const int64_t* idx, const int* seg, void* d, int B, int E, int N, int D,
+                   int mode, int dtype, void* stream);
+
 /* ---- weight-streaming GEMM of the tall-and-skinny linear layers (default path of every nn.Linear / Conv1d(k=1)
  * forward and, with the transposed weight, of every input-gradient GEMM: lightglue.py:131-221,271-290,
  * superglue.py:70-160, gluestick.py:465-586):

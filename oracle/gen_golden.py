@@ -132,7 +132,7 @@ def gen_superglue(name, batch, n0, n1, gnn, iters, seed):
                         G=G.numpy(), gscores=scores.grad.numpy(), galpha=alpha.grad.numpy())
 
 
-def gen_gluestick(name, batch, n_kpts, n_lines, gnn, inter, seed):
+def gen_gluestick(name, batch, n_kpts, n_lines, gnn, inter, seed, line_attention=False):
     """Reference GlueStick (weights=None) on a synthetic point+line batch: eval + train forward,
     every loss entry and all gradient norms."""
     from gluefactory.models.matchers.gluestick import GlueStick
@@ -141,7 +141,9 @@ def gen_gluestick(name, batch, n_kpts, n_lines, gnn, inter, seed):
 
     params = gso.init_params(256, gnn_layers=len(gnn), inter=inter, seed=seed)
     data = make_point_line_pairs(batch, n_kpts, n_lines, dim=256, size=(640, 480), seed=seed + 1)
-    model = GlueStick({"weights": None, "GNN_layers": gnn, "inter_supervision": inter})
+    if line_attention:
+        gso.add_line_attention_params(params, seed=seed + 2)
+    model = GlueStick({"weights": None, "GNN_layers": gnn, "inter_supervision": inter, "line_attention": line_attention})
     res = model.load_state_dict(params, strict=True)
     assert not res.missing_keys and not res.unexpected_keys
     out = {}
@@ -404,6 +406,8 @@ def main():
                                                                 size=(1024, 1024), stride=997),
             "lightglue_adaptive": lambda: gen_lightglue_adaptive("lightglue_adaptive", 160, 200, 3, seed=107),
             "metrics": lambda: gen_metrics("metrics", seed=109),
+            "gluestick_lineattn": lambda: gen_gluestick("gluestick_lineattn", batch=2, n_kpts=36, n_lines=14,
+                                                        gnn=["self", "cross"] * 2, inter=[0], seed=43, line_attention=True),
         }
         for k in only:
             todo[k]()
@@ -422,6 +426,8 @@ def main():
     gen_lightglue_config("lightglue_n2048_l9", 1, 2048, 9, seed=103, size=(1024, 1024), stride=997)
     gen_lightglue_adaptive("lightglue_adaptive", 160, 200, 3, seed=107)
     gen_metrics("metrics", seed=109)
+    gen_gluestick("gluestick_lineattn", batch=2, n_kpts=36, n_lines=14, gnn=["self", "cross"] * 2, inter=[0], seed=43,
+                  line_attention=True)
 
 
 if __name__ == "__main__":

@@ -62,6 +62,21 @@ def init_params(dim=256, kenc_layers=(32, 64, 128, 256), gnn_layers=18, inter=No
     return p
 
 
+def add_line_attention_params(p, seed=0, dim=256):
+    """Seeded parameters of LineLayer's proj_node / proj_neigh (gluestick.py:596-597) for every line layer found in
+    ``p`` (used by the line_attention golden; the oracle functions themselves cover line_attention=False only)."""
+    g = torch.Generator().manual_seed(seed)
+    k = 0
+    while f"gnn.line_layers.{k}.mlp.0.weight" in p:
+        base = f"gnn.line_layers.{k}."
+        p[base + "proj_node.weight"] = torch.randn(dim, dim, 1, generator=g) / dim ** 0.5
+        p[base + "proj_node.bias"] = torch.randn(dim, generator=g) * 0.1
+        p[base + "proj_neigh.weight"] = torch.randn(dim, 2 * dim, 1, generator=g) / (2 * dim) ** 0.5
+        p[base + "proj_neigh.bias"] = torch.randn(dim, generator=g) * 0.1
+        k += 1
+    return p
+
+
 def trainable_names(p):
     return [k for k in p if not k.endswith(("running_mean", "running_var", "num_batches_tracked"))]
 

@@ -15,15 +15,23 @@ def _data(z, device):
     return d
 
 
-def test_gluestick_module_vs_reference_golden():
+@pytest.mark.parametrize("name", ["gluestick_d256", "gluestick_lineattn"])
+def test_gluestick_module_vs_reference_golden(name):
+    """Whole GlueStick step (HIP line kernels: gf_line_csr / gather / segsum / expand; gf_gemm MLPs) vs the reference's
+    outputs, losses and gradient norms; ``gluestick_lineattn`` runs LineLayer with line_attention=True."""
     from glue_factory_amd.base_model import get_model
     from oracle import gluestick_oracle as gso
-    z = load_golden("gluestick_d256")
+    z = load_golden(name)
     nl, seed = int(z["meta"][3]), int(z["meta"][4])
     inter = [int(v) for v in z["meta"][5:]]
     params = gso.init_params(256, gnn_layers=nl, inter=inter, seed=seed)
+    attn = name.endswith("lineattn")
+    if attn:
+        gso.add_line_attention_params(params, seed=seed + 2)
+    chk = float(sum(v.double().abs().sum() for v in params.values()))
+    assert abs(chk - float(z["param_checksum"][0])) < 1e-6 * chk
     GS = get_model("glue_factory_amd.matchers.gluestick")
-    model = GS({"GNN_layers": ["self", "cross"] * (nl // 2), "inter_supervision": inter})
+    model = GS({"GNN_layers": ["self", "cross"] * (nl // 2), "inter_supervision": inter, "line_attention": attn})
     res = model.load_state_dict(params, strict=True)
     assert not res.missing_keys and not res.unexpected_keys
     model = model.cuda()

@@ -457,3 +457,58 @@ def test_linear_and_ffn_residual_match_torch():
     for a, r in zip(*outs):
         sc = r.abs().max().item() + 1e-6
         torch.testing.assert_close(a / sc, r / sc, rtol=3e-2, atol=3e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("mean", [True, False])
+def test_line_message_passing_kernels(dtype, mean):
+    """gf_line_csr / gather / segsum / expand (GlueStick LineLayer, gluestick.py:609-700) vs torch gather + flip + cat +
+    scatter_reduce, forward and backward, with shared junctions, junctions without lines and keypoint-only rows."""
+    from glue_factory_amd import ops
+    g = torch.Generator().manual_seed(3)
+    B, NL, N, D = 3, 37, 120, 256
+    E = 2 * NL
+    idx = torch.randint(0, 50, (B, E), generator=g)               # junctions 0..49 shared a lot, 50..119 never used
+    idx[0, :10] = 7                                               # one crowded junction
+    x = torch.randn(B, N, D, generator=g)
+    enc = torch.randn(B, E, D, generator=g)
+    wt = torch.randn(B, E, D, generator=g)                         # stands in for the MLP: upd = msg-part product
+    gout = torch.randn(B, N, D, generator=g)
+
+    def ref(x, enc):
+        ix = idx[..., None].expand(-1, -1, D)
+        ld = x.gather(1, ix)
+        ld2 = ld.reshape(B, NL, 2, D).flip(2).reshape(B, E, D)
+        msg = torch.cat([ld, ld2, enc], -1)
+        upd = (msg[..., :D] - 0.5 * msg[..., D:2 * D] + msg[..., 2 * D:]) * wt
+        agg = torch.zeros_like(x).scatter_reduce(1, ix, upd, reduce="mean" if mean else "sum", include_self=False)
+        return msg, x + agg
+
+    xr, er = x.double().requires_grad_(True), enc.double().requires_grad_(True)
+    wt = wt.double()
+    msg_r, out_r = ref(xr, er)
+    (out_r * gout.double()).sum().backward()
+    wt = wt.float()
+
+    xc = x.to(dtype).cuda().requires_grad_(True)
+    ec = enc.to(dtype).cuda().requires_grad_(True)
+    ic = idx.cuda()
+    order, seg = ops.line_graph(ic, N)
+    # the segment table is a stable grouping of the endpoints by junction
+    o, sg = order.cpu().long(), seg.cpu().long()
+    for b in range(B):
+        assert sg[b, 0] == 0 and sg[b, -1] == E
+        grouped = idx[b][o[b]]
+        assert torch.equal(grouped, grouped.sort(stable=True).values)
+        assert torch.equal(o[b], idx[b].sort(stable=True).indices)
+    msg = ops.line_gather(xc, ec, ic, order, seg)
+    upd = (msg[..., :D] - 0.5 * msg[..., D:2 * D] + msg[..., 2 * D:]) * wt.cuda().to(dtype)
+    out = ops.line_aggregate(xc, upd, ic, order, seg, mean=mean)
+    (out.float() * gout.cuda()).sum().backward()
+    tol = dict(rtol=1e-5, atol=1e-5) if dtype == torch.float32 else dict(rtol=3e-2, atol=6e-2)
+    if dtype == torch.float32:
+        assert torch.equal(msg.detach().cpu(), msg_r.detach().float())
+    torch.testing.assert_close(out.detach().float().cpu().double(), out_r.detach(), **tol)
+    sc = xr.grad.abs().max().item()
+    torch.testing.assert_close(xc.grad.float().cpu().double() / sc, xr.grad / sc, **tol)
+    torch.testing.assert_close(ec.grad.float().cpu().double(), er.grad, **tol)
