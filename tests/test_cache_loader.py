@@ -67,3 +67,58 @@ def test_pipeline_uses_cached_features_without_extractor(tmp_path):
             "view1": {"image": torch.rand(1, 1, 32, 32), "cache": cache}}
     pred = pipe(data)
     assert torch.equal(pred["keypoints0"], cache["keypoints"]) and torch.equal(pred["descriptors1"], cache["descriptors"])
+
+
+@pytest.mark.skipif(not __import__("os").path.isdir("/root/reference/gluefactory"), reason="reference checkout not present")
+def test_cache_loader_equals_reference_loader_on_the_same_files(tmp_path):
+    """The REFERENCE's CacheLoader (gluefactory/models/cache_loader.py:59-141), reading the very .npz files ours
+    reads through the h5py stand-in of oracle/stubs, against ours: key sets, dtypes (numeric_type), scaling of
+    keypoints / lines by data["scales"], padding lengths, zero padding, collation.  Randomly padded entries are
+    compared on the real (un-padded) region and on their ranges (the two implementations draw differently)."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    stubs = os.path.join(root, "oracle", "stubs")
+    sys.path.insert(0, stubs)
+    sys.path.append("/root/reference")
+    try:
+        from gluefactory.models.cache_loader import CacheLoader as RefLoader
+    finally:
+        sys.path.remove("/root/reference")
+        sys.path.remove(stubs)
+    g = torch.Generator().manual_seed(5)
+    names, counts = ["scene/a.jpg", "scene/b.jpg", "c"], (40, 25, 33)
+    for n, k in zip(names, counts):
+        export_features(str(tmp_path), n, {
+            "keypoints": torch.rand(k, 2, generator=g, dtype=torch.float64) * 200,
+            "keypoint_scores": torch.rand(k, generator=g, dtype=torch.float64),
+            "descriptors": torch.randn(k, 16, generator=g, dtype=torch.float64),
+            "scales": torch.rand(k, generator=g), "oris": torch.rand(k, generator=g),
+            "lines": torch.rand(6, 2, 2, generator=g) * 200, "image_id": torch.tensor(k)})
+    data = {"name": names, "scales": torch.tensor([[2.0, 2.0], [0.5, 0.5], [1.5, 1.5]])}
+    for numeric in ("float32", "float64", None):
+        conf = {"path": str(tmp_path), "add_data_path": False, "numeric_type": numeric,
+                "data_keys": ["keypoints", "keypoint_scores", "descriptors", "scales", "oris"],
+                "padding_fn": "pad_local_features", "padding_length": 48}
+        torch.manual_seed(0)
+        ref = RefLoader({**conf, "path": str(tmp_path / "features.h5")})(dict(data))
+        torch.manual_seed(0)
+        ours = CacheLoader(conf)(dict(data))
+        assert set(ours) == set(ref)
+        for k in ref:
+            assert ours[k].shape == ref[k].shape and ours[k].dtype == ref[k].dtype, (k, numeric)
+            for i, c in enumerate(counts):
+                torch.testing.assert_close(ours[k][i, :c], ref[k][i, :c], rtol=0, atol=0, msg=lambda m: f"{k}[{i}]: {m}")
+                if k in ("keypoint_scores", "scales", "oris"):          # "zeros" padding
+                    assert (ours[k][i, c:] == 0).all() and (ref[k][i, c:] == 0).all()
+                else:                                                    # random padding: same range rule
+                    lo, hi = ref[k][i, :c].amin(), ref[k][i, :c].amax()
+                    for t in (ours[k], ref[k]):
+                        assert (t[i, c:] >= lo).all() and (t[i, c:] <= hi).all()
+    # un-padded single image, all keys, no collation: identical tensors (incl. the integer entry and the scaled lines)
+    conf = {"path": str(tmp_path), "add_data_path": False, "collate": False}
+    one = {"name": ["c"], "scales": torch.tensor([[1.5, 1.5]])}
+    ref = RefLoader({**conf, "path": str(tmp_path / "features.h5")})(dict(one))
+    ours = CacheLoader(conf)(dict(one))
+    assert set(ours) == set(ref)
+    for k in ref:
+        assert ours[k].dtype == ref[k].dtype and torch.equal(ours[k], ref[k]), k
