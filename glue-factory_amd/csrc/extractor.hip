@@ -90,6 +90,72 @@ __global__ __launch_bounds__(256) void bias_act_bn_pool_kernel(const T* __restri
 // and two byte masks: 151 KB at r = 4); every pooling is separable (row pass into a scratch plane, column
 // pass back) with register windows.  Pixels outside the image are -inf for the
 // score pools and "no maximum" for the mask pools, which is what clipping the window means.
+// ---- first VGG block on a 1-channel image ---------------------------------------------------------------------
+// backbone.0.0 (superpoint_open.py:98-100: Conv2d(1, C, 3, padding=1) -> ReLU -> BatchNorm2d(eval)) is not
+// GEMM-shaped -- 9 multiply-adds per output value -- but its OUTPUT is the largest tensor of the extractor
+// (B x H x W x C: 8.6 GB for 64 images of 1024^2 in bf16).  Through the library it costs a convolution that writes
+// that tensor plus the tail pass that reads and rewrites it; here ONE kernel reads the image and writes the finished
+// channels-last activation once.  A workgroup owns a 32 x 32 pixel tile (fp32 copy of the 34 x 34 input window in
+// LDS, zero outside the image); lane = (pixel column, group of 8 channels) keeps its 8 x 9 weights and the
+// per-channel bias / scale / shift in registers; a wave's store covers 8 pixels x 128 contiguous bytes (C = 64 bf16).
+// The products are fp32 on the T-rounded image and weights (what the library computes from the same operands);
+// bias, ReLU and the batch-norm affine act on the fp32 sum -- one rounding.
+template <typename T, bool RELU, int C>
+__global__ __launch_bounds__(256) void conv1_fused_kernel(const T* __restrict__ img, const T* __restrict__ wgt,
+                                                          const float* __restrict__ bias, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, T* __restrict__ out, int H, int W) {
+    constexpr int CG = C / 8;                 // lanes per pixel (8 channels each)
+    constexpr int PX = 256 / CG;              // pixels per workgroup row
+    constexpr int TY = 32;
+    __shared__ float tile[(TY + 2) * (PX + 2)];
+    const int b = blockIdx.z, y0 = blockIdx.y * TY, x0 = blockIdx.x * PX;
+    const T* im = img + (int64_t)b * H * W;
+    for (int i = threadIdx.x; i < (TY + 2) * (PX + 2); i += 256) {
+        const int y = y0 - 1 + i / (PX + 2), x = x0 - 1 + i % (PX + 2);
+        tile[i] = (y >= 0 && y < H && x >= 0 && x < W) ? to_f32(im[(int64_t)y * W + x]) : 0.f;
+    }
+    const int cg = threadIdx.x % CG, px = threadIdx.x / CG;
+    float w[8][9], bi[8], sc[8], sh[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) w[c][t] = to_f32(wgt[(8 * cg + c) * 9 + t]);
+        bi[c] = bias[8 * cg + c];
+        sc[c] = scale[8 * cg + c];
+        sh[c] = shift[8 * cg + c];
+    }
+    __syncthreads();
+    const int x = x0 + px;
+    for (int ly = 0; ly < TY; ++ly) {
+        const int y = y0 + ly;
+        if (y >= H) break;
+        float v[9];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) v[3 * dy + dx] = tile[(ly + dy) * (PX + 2) + px + dx];
+        float o[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float a = 0.f;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) a = fmaf(w[c][t], v[t], a);
+            a += bi[c];
+            if (RELU) a = fmaxf(a, 0.f);
+            o[c] = fmaf(a, sc[c], sh[c]);
+        }
+        if (x < W) {
+            T* dst = out + (((int64_t)b * H + y) * W + x) * C + 8 * cg;
+            if constexpr (sizeof(T) == 2) {
+                st_vec<T>(dst, o);
+            } else {
+                st4(dst, o[0], o[1], o[2], o[3]);
+                st4(dst + 4, o[4], o[5], o[6], o[7]);
+            }
+        }
+    }
+}
+
 #ifndef NMS_THREADS_V
 #define NMS_THREADS_V 1024
 #endif
@@ -301,5 +367,20 @@ extern "C" int gf_sample_descriptors(const void* map, const float* kpts, float* 
         sample_desc_kernel<float><<<grid, 256, 0, st>>>((const float*)map, kpts, out, total, N, h, w, C, 1.f / stride);
     else
         return GF_ERR_DTYPE;
+    return (int)hipGetLastError();
+}
+
+extern "C" int gf_conv1_bias_act_bn(const void* img, const void* w, const float* bias, const float* scale,
+                                    const float* shift, void* out, int B, int H, int W, int C, int relu, int dtype,
+                                    void* stream) {
+    if (B <= 0 || H <= 0 || W <= 0) return GF_ERR_SHAPE;
+    if (C != 64) return GF_ERR_UNSUPPORTED;
+    if (dtype != GF_F32 && dtype != GF_BF16) return GF_ERR_DTYPE;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid((W + 31) / 32, (H + 31) / 32, B);
+#define GF_C1(T, RELU) conv1_fused_kernel<T, RELU, 64><<<grid, 256, 0, st>>>((const T*)img, (const T*)w, bias, scale, shift, (T*)out, H, W)
+    if (dtype == GF_BF16) { if (relu) GF_C1(bf16_t, true); else GF_C1(bf16_t, false); }
+    else { if (relu) GF_C1(float, true); else GF_C1(float, false); }
+#undef GF_C1
     return (int)hipGetLastError();
 }

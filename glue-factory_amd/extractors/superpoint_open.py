@@ -143,6 +143,21 @@ class SuperPoint(BaseModel):
             "gf_bias_act_bn_nhwc")
         return out
 
+    def _first_block(self, name, blk, x, params):
+        """backbone.0.0 on a 1-channel image: 3x3 convolution + bias + ReLU + BatchNorm(eval) -> channels-last, ONE
+        HIP kernel (gf_conv1_bias_act_bn): the extractor's largest activation is written once instead of being
+        written by the library convolution and rewritten by the tail pass."""
+        from .. import lib as _lib
+        w, bias, scale, shift = params[name]
+        b, _, h, wd = x.shape
+        xin = x.reshape(b, h, wd).contiguous()
+        out = torch.empty((b, 64, h, wd), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        _lib.check(_lib.load().gf_conv1_bias_act_bn(
+            xin.data_ptr(), w.reshape(64, 9).contiguous().data_ptr(), bias.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+            out.data_ptr(), b, h, wd, 64, int(isinstance(blk.activation, nn.ReLU)),
+            1 if x.dtype == torch.bfloat16 else 0, torch.cuda.current_stream().cuda_stream), "gf_conv1_bias_act_bn")
+        return out
+
     def _fused_features(self, image):
         dtype = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else torch.float32
         if dtype not in (torch.bfloat16, torch.float32):
@@ -158,7 +173,12 @@ class SuperPoint(BaseModel):
             blocks = [m for m in stage if isinstance(m, VGGBlock)]
             has_pool = any(isinstance(m, nn.MaxPool2d) for m in stage)
             for bi, blk in enumerate(blocks):
-                x = self._fused_block(f"backbone.{si}.{bi}", blk, x, params, pool=has_pool and bi == len(blocks) - 1)
+                pool = has_pool and bi == len(blocks) - 1
+                if si == 0 and bi == 0 and not pool and x.shape[1] == 1 and blk.conv.out_channels == 64 \
+                        and blk.conv.kernel_size == (3, 3):
+                    x = self._first_block(f"backbone.{si}.{bi}", blk, x, params)      # conv + tail in one kernel
+                else:
+                    x = self._fused_block(f"backbone.{si}.{bi}", blk, x, params, pool=pool)
         det = self._fused_block("detector.0", self.detector[0], x, params)
         det = self._fused_block("detector.1", self.detector[1], det, params)
         desc = self._fused_block("descriptor.0", self.descriptor[0], x, params)

@@ -227,6 +227,11 @@ int gf_gt_nn(const float* own, const float* own_warped, const float* oth, const 
  *   plus the border removal of :160-164 (out = -1 inside `border` pixels of the frame; 0 disables). */
 int gf_bias_act_bn_nhwc(const void* x, void* y, const float* bias, const float* scale, const float* shift,
                         int B, int H, int W, int C, int relu, int pool, int dtype, void* stream);
+/* gf_conv1_bias_act_bn: the whole first VGG block on a 1-channel image (superpoint_open.py:98-100:
+ *   Conv2d(1, 64, 3, padding=1) -> +bias -> ReLU -> BatchNorm2d(eval)) in one pass: img [B,H,W], w [64,1,3,3] (both
+ *   `dtype`), out [B,H,W,64] channels-last -- the largest activation of the extractor is written exactly once. */
+int gf_conv1_bias_act_bn(const void* img, const void* w, const float* bias, const float* scale, const float* shift,
+                         void* out, int B, int H, int W, int C, int relu, int dtype, void* stream);
 int gf_nms_scores(const float* scores, float* out, int B, int H, int W, int radius, int border, void* stream);
 /* gf_sample_descriptors: sample_descriptors (:10-16) fused with the dense map's L2 normalisation (:149):
  *   out[b,n,:] = normalize(sum over the 4 bilinear corners of w_k * normalize(map[b,y_k,x_k,:])), zero padding,

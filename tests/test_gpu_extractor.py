@@ -94,3 +94,24 @@ def test_sample_descriptors_kernel(dtype):
                                              1 if dtype == torch.bfloat16 else 0, torch.cuda.current_stream().cuda_stream),
              "gf_sample_descriptors")
     torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 70, 45), (1, 64, 96)])
+def test_first_block_kernel(dtype, shape):
+    """gf_conv1_bias_act_bn (Conv2d(1,64,3,pad 1) + bias + ReLU + BatchNorm(eval), superpoint_open.py:98-100) vs the
+    stock modules; ragged tile sizes, borders (zero padding)."""
+    from glue_factory_amd import lib as L_
+    B, H, W = shape
+    g = torch.Generator(device="cuda").manual_seed(H)
+    img = torch.rand(B, 1, H, W, device="cuda", generator=g).to(dtype)
+    w = (torch.randn(64, 1, 3, 3, device="cuda", generator=g) * 0.3).to(dtype)
+    bias, scale, shift = (torch.randn(64, device="cuda", generator=g) for _ in range(3))
+    ref = torch.nn.functional.conv2d(img.float(), w.float(), bias, padding=1)
+    ref = torch.relu(ref) * scale.view(1, 64, 1, 1) + shift.view(1, 64, 1, 1)
+    out = torch.empty((B, 64, H, W), dtype=dtype, device="cuda", memory_format=torch.channels_last)
+    L_.check(L_.load().gf_conv1_bias_act_bn(img.data_ptr(), w.data_ptr(), bias.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                            out.data_ptr(), B, H, W, 64, 1, 1 if dtype == torch.bfloat16 else 0,
+                                            torch.cuda.current_stream().cuda_stream), "gf_conv1_bias_act_bn")
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    torch.testing.assert_close(out.float(), ref, rtol=tol, atol=tol)
