@@ -82,6 +82,7 @@ def parse():
                     help="lightglue = the headline; superglue / gluestick: time only that matcher step")
     ap.add_argument("--lines", type=int, default=512, help="gluestick: line segments per image")
     ap.add_argument("--sinkhorn-iters", type=int, default=100)
+    ap.add_argument("--no-graph", action="store_true", help="launch the step kernel by kernel instead of replaying a hipGraph")
     ap.add_argument("--matcher-only", action="store_true", help="skip the extractor: scope M becomes the only line")
     return ap.parse_args()
 
@@ -319,8 +320,13 @@ def build_matcher(args, rank, name):
 
 def make_stepper(args, model, local):
     from glue_factory_amd.train_step import TrainStep
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)
-    return TrainStep(model, opt, amp_dtype=torch.bfloat16 if args.dtype == "bf16" else None, device_ids=[local])
+    import torch.distributed as dist_
+    single = not (dist_.is_available() and dist_.is_initialized() and dist_.get_world_size() > 1)
+    graph = single and not args.no_graph
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True, capturable=graph)
+    # one process: the whole matcher step is captured once and replayed as a hipGraph (TrainStep(graph=True))
+    return TrainStep(model, opt, amp_dtype=torch.bfloat16 if args.dtype == "bf16" else None, device_ids=[local],
+                     graph=graph)
 
 
 def make_pipeline_step(args, stepper, rank):

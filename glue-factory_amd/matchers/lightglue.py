@@ -484,6 +484,16 @@ class LightGlue(nn.Module):
         with torch.autocast(device_type="cuda", enabled=False):
             return self._loss(pred, data)
 
+    def _layer_weights(self, L, gamma, device):
+        """Deep-supervision weights of lightglue.py:596-606 as a device tensor, built once (a host -> device copy
+        inside the step would break hipGraph capture and costs a launch per step)."""
+        key = (L, float(gamma), str(device))
+        cache = self.__dict__.setdefault("_w_cache", {})
+        if key not in cache:
+            w = [gamma ** (L - i - 1) if gamma > 0.0 else i + 1 for i in range(L - 1)] + [1.0]
+            cache[key] = torch.tensor(w, device=device, dtype=torch.float32)
+        return cache[key]
+
     def _loss_fused(self, pred, data, gt):
         """Training loss on the batch-stacked per-layer descriptors: one fused HIP node per layer
         (ops.lg_layer_loss) and a handful of [L,B] tensor ops for the whole step."""
@@ -512,8 +522,7 @@ class LightGlue(nn.Module):
         bal = self.conf.loss.nll_balancing
         nll = bal * nll_pos + (1 - bal) * nll_neg                     # [L, B]
         gamma = self.conf.loss.gamma
-        w = [gamma ** (L - i - 1) if gamma > 0.0 else i + 1 for i in range(L - 1)] + [1.0]
-        w = torch.tensor(w, device=acc.device, dtype=torch.float32)
+        w = self._layer_weights(L, gamma, acc.device)
         total = (nll * w[:, None]).sum(0) / w.sum()
         losses = {"total": total, "last": nll[-1].detach(), "assignment_nll": nll[-1], "nll_pos": nll_pos[-1],
                   "nll_neg": nll_neg[-1], "num_matchable": gt["num_pos"],

@@ -218,7 +218,7 @@ def cross_attention_stacked(p):
 # ---- per-step low-precision copies of the fp32 master parameters -------------------------------
 # Every linear casts its weight / bias to the compute dtype; done one by one that is two tiny kernels per
 # layer per step.  precast() converts a whole parameter list with one multi-tensor copy into a flat buffer
-# and _lp() serves the views while the parameter's version counter is unchanged (the optimiser bumps it).
+# and _lp() serves the views made by the precast() of the CURRENT forward.
 _LP_CACHE = {}        # id(param) -> (param._version, dtype, view)
 _LP_FLAT = {}         # (key, dtype) -> (flat buffer, [views], [params])
 
@@ -237,12 +237,19 @@ def precast(params, dtype, key="default"):
             off += sz
         slot = (flat, views, params)
         _LP_FLAT[(key, dtype)] = slot
-    elif all(_LP_CACHE.get(id(p_), (None,))[0] == p_._version for p_ in params):
-        return                       # nothing changed since the last cast (e.g. two forwards per step)
+    # Always re-cast: one multi-tensor copy (~20 us for 12 M parameters).  Skipping it when no ``_version`` moved is
+    # NOT safe -- a fused / capturable optimiser step, ``param.data = ...`` or a replayed hipGraph change the values
+    # without bumping the version counter (measured: stale bf16 weights in an eval forward after fused Adam steps).
     with torch.no_grad():
         torch._foreach_copy_(slot[1], [p_.detach() for p_ in params])
     for p_, v in zip(params, slot[1]):
         _LP_CACHE[id(p_)] = (p_._version, dtype, v, weakref.ref(p_))
+
+
+def invalidate_precast():
+    """Forget the per-parameter cache entries (the flat buffers stay): needed when parameters change without a
+    version bump, e.g. after a captured optimiser step is replayed from a hipGraph."""
+    _LP_CACHE.clear()
 
 
 def _lp(t, dtype):
@@ -923,7 +930,7 @@ class _BatchNormAct(torch.autograd.Function):
             part = torch.empty((L.gf_bn_nblk(M), 2, C), dtype=torch.float32, device=x.device)
             _lib.check(L.gf_bn_stats(_p(x), _p(part), M, C, _dt(x), _stream()), "gf_bn_stats")
             s = part.sum(0)
-            n_t = s.new_tensor(float(M))
+            n_t = torch.full((), float(M), dtype=s.dtype, device=s.device)      # device-side fill: capturable
             if sync:
                 import torch.distributed as dist
                 packed = torch.cat([s.flatten(), n_t[None]])
@@ -934,7 +941,7 @@ class _BatchNormAct(torch.autograd.Function):
             rstd = torch.rsqrt(var + eps).contiguous()
         else:
             mean, rstd = mean_in.float().contiguous(), rstd_in.float().contiguous()
-            var, n_t = mean.new_zeros(C), mean.new_tensor(float(M))
+            var, n_t = mean.new_zeros(C), torch.full((), float(M), dtype=mean.dtype, device=mean.device)
         y = torch.empty_like(x)
         _lib.check(L.gf_bn_act_fwd(_p(x), _p(mean), _p(rstd), _p(g32), _p(b32), _p(y), M, C, int(relu), _dt(x),
                                    _stream()), "gf_bn_act_fwd")

@@ -4,7 +4,7 @@ Mirrors the semantics of the reference hot loop (gluefactory/train.py:465-517): 
 autocast forward, ``loss_fn(pred, data)``, mean of ``losses["total"]``, cross-rank agreement on
 whether the loss is differentiable (all_reduce PRODUCT, train.py:482-488), backward (DDP bucketed
 gradient all-reduce over RCCL/xGMI overlapped with the backward), optional gradient clipping,
-optimizer step; a NaN / non-finite loss (train.py:477-480) or gradient norm skips the update.  On the GPU path
+optimizer step (optionally the whole step as ONE hipGraph replay: ``graph=True``); a NaN / non-finite loss (train.py:477-480) or gradient norm skips the update.  On the GPU path
 the skip decision never touches the host: the cross-rank flag is a device tensor handed to the fused optimiser as
 ``found_inf``.  Image pairs are independent, so the batch shards across ranks with no
 data-path collective; the only collectives are the gradient all-reduce, the 4-byte flag and the
@@ -73,7 +73,7 @@ class TrainStep:
     """step(data) -> dict of detached per-sample losses; one optimiser update per call."""
 
     def __init__(self, model, optimizer, amp_dtype=None, clip_grad=None, device_ids=None,
-                 bucket_cap_mb=16, find_unused_parameters=False, check_grads=True):
+                 bucket_cap_mb=16, find_unused_parameters=False, check_grads=True, graph=False, graph_warmup=2):
         self.model = model
         self.optimizer = optimizer
         self.amp_dtype = amp_dtype
@@ -98,6 +98,15 @@ class TrainStep:
         self.check_grads = check_grads
         self._skipped_host = 0
         self._skipped_dev = None
+        # hipGraph replay of the whole step (forward, loss, backward, optimiser): ~1200 launches per LightGlue step
+        # leave a few per cent of the GPU idle between kernels when they are issued one by one.  Needs: single
+        # process (no DDP hooks inside a capture), a fused + capturable optimiser, no host synchronisation in the
+        # step (the fused skip path above), fixed shapes.  The first ``graph_warmup`` calls run eagerly, the next
+        # one is captured and replayed; a batch of different shapes is run eagerly and re-captured.
+        self.graph = bool(graph) and self.device_type == "cuda" and not self.distributed
+        self.graph_warmup = graph_warmup
+        self._calls = 0
+        self._g = None            # (shape signature, CUDAGraph, static inputs, static outputs)
 
     def _device_skip_supported(self):
         """Fused CUDA optimisers take a device-side ``found_inf`` flag (the GradScaler protocol): the update is
@@ -113,6 +122,31 @@ class TrainStep:
         return self._skipped_host + (int(self._skipped_dev.item()) if self._skipped_dev is not None else 0)
 
     def __call__(self, data):
+        self._calls += 1
+        if not self.graph or self._calls <= self.graph_warmup:
+            return self._step(data)
+        sig = _signature(data)
+        if self._g is None or self._g[0] != sig:
+            self._capture(data, sig)
+        _, g, static_in, static_out = self._g
+        _copy_into(static_in, data)
+        g.replay()
+        from . import ops as _ops       # parameters changed behind the precast cache's back (no version bump)
+        _ops.invalidate_precast()
+        return static_out
+
+    def _capture(self, data, sig):
+        if not (self._device_skip_supported() and all(g_.get("capturable") for g_ in self.optimizer.param_groups)):
+            raise RuntimeError("TrainStep(graph=True) needs a fused, capturable optimiser "
+                               "(e.g. torch.optim.Adam(..., fused=True, capturable=True))")
+        static_in = _clone_tree(data)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            static_out = self._step(static_in)
+        self._g = (sig, g, static_in, static_out)
+
+    def _step(self, data):
         self.model.train()
         self.optimizer.zero_grad(set_to_none=True)
         with torch.autocast(self.device_type, dtype=self.amp_dtype or torch.bfloat16,
@@ -148,12 +182,38 @@ class TrainStep:
                 opt.step()                     # fused kernel: no-op (and no step count) where found_inf != 0
             finally:
                 del opt.found_inf, opt.grad_scale
-            self._skipped_dev = (bad > 0).long() if self._skipped_dev is None else self._skipped_dev + (bad > 0).long()
+            if self._skipped_dev is None:
+                self._skipped_dev = torch.zeros((), dtype=torch.long, device=bad.device)
+            self._skipped_dev.add_((bad > 0).long())      # in place: also accumulates under graph replay
         elif bool(bad.item() > 0):             # CPU / non-fused optimisers: one host read
             self._skipped_host += 1
         else:
             self.optimizer.step()
         return out
+
+
+def _signature(data):
+    if isinstance(data, dict):
+        return tuple((k, _signature(v)) for k, v in sorted(data.items()))
+    if torch.is_tensor(data):
+        return (tuple(data.shape), data.dtype, data.device)
+    return None
+
+
+def _clone_tree(data):
+    if isinstance(data, dict):
+        return {k: _clone_tree(v) for k, v in data.items()}
+    if torch.is_tensor(data):
+        return data.detach().clone()
+    return data
+
+
+def _copy_into(static, data):
+    for k, v in data.items():
+        if isinstance(v, dict):
+            _copy_into(static[k], v)
+        elif torch.is_tensor(v) and static[k] is not v:
+            static[k].copy_(v, non_blocking=True)
 
 
 def reduce_losses(losses, dst=0):

@@ -179,3 +179,41 @@ def test_fixed_length_positives_equal_dense_nonzero():
     for k in out[0][1]:
         sc = max(out[1][1][k].abs().max().item(), 1e-9)
         torch.testing.assert_close(out[0][1][k] / sc, out[1][1][k] / sc, rtol=1e-4, atol=1e-5, msg=lambda m: f"{k}: {m}")
+
+
+def test_train_step_hipgraph_replay_equals_eager():
+    """TrainStep(graph=True): the whole step (forward, fused loss, backward, fused Adam) captured once and replayed
+    gives the same weights and losses as launching it kernel by kernel, on changing batches; a NaN batch is skipped
+    inside the replay (device-side flag) and an eval forward afterwards sees the updated weights."""
+    from glue_factory_amd.synthetic import make_pairs
+    from glue_factory_amd.train_step import TrainStep
+    L = 2
+    params = lgo.init_params(L, 256, 4, seed=21)
+    batches = [_to_cuda(make_pairs(2, 256, dim=256, size=(640, 480), seed=30 + i)) for i in range(6)]
+    results = []
+    for use_graph in (False, True):
+        model = _model(params, L).train()
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True, capturable=True)
+        step = TrainStep(model, opt, amp_dtype=torch.bfloat16, graph=use_graph, graph_warmup=2)
+        losses = []
+        for i, b in enumerate(batches):
+            if i == 4:       # poisoned batch: must not touch the weights in either mode
+                b = dict(b, descriptors0=b["descriptors0"].clone())
+                b["descriptors0"][0, 0, 0] = float("nan")
+            out = step(b)
+            losses.append(out["total"].clone())
+        assert step.skipped == 1
+        assert (step._g is not None) == use_graph
+        model.eval()
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+            ev = model(batches[0])["log_assignment"].clone()
+        results.append((losses, {k: p.detach().clone() for k, p in model.named_parameters()}, ev))
+    (l0, p0, e0), (l1, p1, e1) = results
+    for i, (a, b) in enumerate(zip(l0, l1)):
+        if i == 4:
+            assert torch.isnan(a).any() and torch.isnan(b).any()
+            continue
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5, msg=lambda m: f"step {i}: {m}")
+    for k in p0:
+        torch.testing.assert_close(p0[k], p1[k], rtol=1e-5, atol=1e-6, msg=lambda m: f"{k}: {m}")
+    torch.testing.assert_close(e0, e1, rtol=1e-4, atol=1e-4)
