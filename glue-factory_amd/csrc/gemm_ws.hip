@@ -42,6 +42,9 @@ struct GwParams {
 #ifndef GW_R256
 #define GW_R256 1                             // 32-row blocks per wave at K = 256 (bf16)
 #endif
+#ifndef GW_NW256
+#define GW_NW256 8                            // waves per workgroup at K = 256 (bf16); 8 measured 4-6 % faster than 4 at N = 256, 512
+#endif
 #ifndef GW_GRID
 #define GW_GRID 0                             // > 0: persistent grid of that many workgroups
 #endif
@@ -88,6 +91,10 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_ws_kernel(GwParams p) {
 
     const T* wg = reinterpret_cast<const T*>(p.w);
     char* scr = smem + 2 * SLICE + wave * GW_SCRATCH;       // this wave's scratch
+    // bias in LDS: a global load in the epilogue would be consumed after earlier output stores, and vmcnt retires in
+    // order and counts stores on this part -- every flush would wait for the previous flush's store acknowledgements
+    float* bias_s = reinterpret_cast<float*>(smem + 2 * SLICE + NW * GW_SCRATCH);   // [N] (zeros without a bias)
+    for (int n = threadIdx.x; n < p.N; n += 64 * NW) bias_s[n] = p.bias ? p.bias[n] : 0.f;
 
     // ---- weight staging through registers (issue early / write late): the next slice's coalesced 16-byte loads are
     // issued before the current slice's MFMAs and written to LDS (swizzled) after them, one barrier per slice.  (An
@@ -175,11 +182,8 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_ws_kernel(GwParams p) {
         const int q = lane & 7;                              // channels [8 q, 8 q + 8) of the 64
         if (8 * q < 32 * ntl) {
             const int n = nt0 + 8 * q;
-            f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
-            if (p.bias) {
-                b0 = *reinterpret_cast<const f32x4*>(p.bias + n);
-                b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
-            }
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias_s + n);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias_s + n + 4);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int row = 8 * j + (lane >> 3);
@@ -323,7 +327,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_ws_kernel(GwParams p) {
 
 template <typename T, int KF, int R, bool TWO, int NW> int gw_launch(const GwParams& p, hipStream_t st) {
     constexpr int ROWB = 16 * KF * (int)sizeof(T);
-    constexpr size_t lds = 2 * (size_t)(ROWB * 32 > 16384 ? ROWB * 32 : 16384) + NW * GW_SCRATCH;
+    const size_t lds = 2 * (size_t)(ROWB * 32 > 16384 ? ROWB * 32 : 16384) + NW * GW_SCRATCH + (size_t)p.N * 4;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ws_kernel<T, KF, R, TWO, NW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
@@ -341,7 +345,7 @@ template <typename T, bool TWO> int gw_dispatch(const GwParams& p, int K, hipStr
             case 32: return gw_launch<T, 2, 2, TWO, 4>(p, st);
             case 64: return gw_launch<T, 4, 2, TWO, 4>(p, st);
             case 128: return gw_launch<T, 8, 2, TWO, 4>(p, st);
-            case 256: return gw_launch<T, 16, GW_R256, TWO, 4>(p, st);
+            case 256: return gw_launch<T, 16, GW_R256, TWO, GW_NW256>(p, st);
             case 512: return gw_launch<T, 32, 1, TWO, 8>(p, st);     // 32 KB slices: one 8-wave group per CU
         }
     } else {
