@@ -901,6 +901,214 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void attn_bwd_dkv_bf16_kernel(Attn
     }
 }
 
+// ===========================================================================================
+// bf16 forward and dQ on the same staging scheme as the dK/dV kernel above
+// ===========================================================================================
+// K and V tiles (64 keys x 128 B, row-major, chunk-swizzled by fswz) arrive by LDS-DMA into a 3-stage ring; the
+// score MFMAs read K rows with ds_read_b128, the second product reads V^T (forward) or K^T (dQ) straight from the
+// row-major tile with ds_read_b64_tr_b16 -- no transposed copy, no staging registers, no bank conflicts (the
+// register-staged kernels spent 36-43 % of their LDS cycles on conflicts of the transposed-tile stores).
+// One wave owns 64 query rows (two 32-row blocks: every K / V fragment feeds two MFMAs), 4 waves per workgroup.
+constexpr int FQ_STAGE = 2 * FT_TILE;          // K tile | V tile
+constexpr int FQ_NSTAGE = 3;
+
+struct FqAddr { unsigned aR[4], aT[4]; };      // per-lane LDS read addresses of stage 0 (see attn_bwd_dkv_bf16_kernel)
+
+__device__ __forceinline__ FqAddr fq_addresses(unsigned lds0, int lane) {
+    const int l31 = lane & 31, hi = lane >> 5, s16 = lane & 15, half = (lane >> 4) & 1;
+    FqAddr a;
+    const unsigned rb = l31 * 128 + 16 * (hi ^ fswz(l31));
+#pragma unroll
+    for (int s = 0; s < 4; ++s) a.aR[s] = lds0 + (rb ^ (32 * s));
+    const int bq = s16 >> 3;
+    const unsigned tb = (4 * hi + (s16 >> 2)) * 128 + 8 * (s16 & 1) + 16 * ((2 * half + ((s16 & 3) >> 1)) ^ (4 * bq + hi));
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int db = 0; db < 2; ++db) a.aT[2 * u + db] = lds0 + (tb ^ (32 * u) ^ (64 * db));
+    return a;
+}
+
+// DMA of one 64-row tile of a [rows, 64] bf16 matrix (row stride ld): wave w moves pieces 2w, 2w+1 (8 rows each)
+__device__ __forceinline__ void fq_issue(const bf16_t* base, int64_t ld, int row0, int nmax, char* dst, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int piece = 2 * wave + i;
+        const int r = piece * 8 + (lane >> 3);
+        const int col = ((lane & 7) ^ fswz(r)) * 8;
+        dma16(base + (int64_t)min(row0 + r, nmax - 1) * ld + col, dst + piece * 1024);
+    }
+}
+
+// transposed operand [t][db] of the 32-row block KB of the tile at byte offset BASE (rows 16t + 4hi + {0..3} and + 8)
+#define GF_FQ_TR(dst, BASE, KB, t, db) dst[t][db][0] = lds_rdtr<BASE + KB * 4096 + t * 2048>(aT[db]); \
+                                       dst[t][db][1] = lds_rdtr<BASE + KB * 4096 + t * 2048 + 1024>(aT[2 + db]);
+
+__global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const unsigned lds0 = (unsigned)(size_t)smem;
+    const int nqb = (p.Nq + 255) / 256;
+    const int total = nqb * p.H * p.B;
+    int lb = xcd_remap(blockIdx.x, total);
+    const int qb = lb % nqb, h = (lb / nqb) % p.H, b = lb / (nqb * p.H);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int qrow0 = qb * 256 + wave * 64 + l31;
+
+    const bf16_t* qp = reinterpret_cast<const bf16_t*>(p.q) + b * p.sqb + h * p.sqh;
+    const bf16_t* kp = reinterpret_cast<const bf16_t*>(p.k) + b * p.skb + h * p.skh;
+    const bf16_t* vp = reinterpret_cast<const bf16_t*>(p.v) + b * p.svb + h * p.svh;
+
+    const int nt = (p.Nk + 63) / 64;
+    auto issue_tile = [&](int t, int stage) {
+        char* sb = smem + stage * FQ_STAGE;
+        fq_issue(kp, p.skn, t * 64, p.Nk, sb, wave, lane);
+        fq_issue(vp, p.svn, t * 64, p.Nk, sb + FT_TILE, wave, lane);
+    };
+    issue_tile(0, 0);
+    if (nt > 1) issue_tile(1, 1);
+
+    bf16x8 qf[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            qf[j][s] = *reinterpret_cast<const bf16x8*>(qp + (int64_t)min(qrow0 + 32 * j, p.Nq - 1) * p.sqn + 16 * s + 8 * hi);
+
+    f32x16 o[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[j][db][r] = 0.f;
+    float m[2] = {GF_NEG_BIG, GF_NEG_BIG}, lsum[2] = {0.f, 0.f};
+    const float c = p.scale * GF_LOG2E;
+    const FqAddr ad = fq_addresses(lds0, lane);
+
+    int stage = 0;
+    for (int t = 0; t < nt; ++t) {
+        if (t + 1 >= nt) wait_vm<0>();                            // tile t landed (this wave's pieces)
+        else wait_vm<4>();
+        __builtin_amdgcn_s_barrier();                             // ... everyone's; the stage of tile t-1 is free
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 2 < nt) issue_tile(t + 2, stage == 0 ? 2 : stage - 1);
+        const unsigned so = stage * FQ_STAGE;
+        unsigned aR[4], aT[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { aR[i] = ad.aR[i] + so; aT[i] = ad.aT[i] + so; }
+        const int kv0 = t * 64;
+
+        // ---- S^T[key][q] for both 32-key blocks: all eight K fragments requested up front
+        u32x4 ka[2][4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) ka[0][s] = lds_rd128<0>(aR[s]);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) ka[1][s] = lds_rd128<4096>(aR[s]);
+        f32x16 sc[2][2];                                          // [q block j][key block kb]
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sc[j][kb][r] = 0.f;
+        wait_lgkm<4>();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            tie(ka[0][s]);
+            mma16(sc[0][0], as_frag(ka[0][s]), qf[0][s]);
+            mma16(sc[1][0], as_frag(ka[0][s]), qf[1][s]);
+        }
+        // V^T fragments of this tile: requested now, consumed after the softmax
+        u32x2 vt0[2][2][2], vt1[2][2][2];
+        GF_FQ_TR(vt0, FT_TILE, 0, 0, 0) GF_FQ_TR(vt0, FT_TILE, 0, 0, 1) GF_FQ_TR(vt0, FT_TILE, 0, 1, 0) GF_FQ_TR(vt0, FT_TILE, 0, 1, 1)
+        wait_lgkm<8>();
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            tie(ka[1][s]);
+            mma16(sc[0][1], as_frag(ka[1][s]), qf[0][s]);
+            mma16(sc[1][1], as_frag(ka[1][s]), qf[1][s]);
+        }
+
+        if (kv0 + 64 > p.Nk) {   // ragged last tile: keys past Nk never win the max and get P = 0
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (kv0 + kb * 32 + crow(r, hi) >= p.Nk) sc[j][kb][r] = -INFINITY;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[j][kb][r]);
+            mx = fmaxf(mx, xhalf(mx)) * c;
+            if (__any(mx > m[j] + RescaleThr<bf16_t>::value)) {
+                const float mnew = fmaxf(m[j], mx);
+                const float alpha = fast_exp2(m[j] - mnew);
+                m[j] = mnew;
+                lsum[j] *= alpha;
+#pragma unroll
+                for (int db = 0; db < 2; ++db)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[j][db][r] *= alpha;
+            }
+            float ps = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float e = fast_exp2(fmaf(sc[j][kb][r], c, -m[j]));
+                    sc[j][kb][r] = e;
+                    ps += e;
+                }
+            lsum[j] += ps;
+        }
+        // ---- O^T[d][q] += V^T[d][key] P[key][q]; each V^T fragment feeds both query blocks.  The second key block's
+        // V^T fragments are requested while the first block's MFMAs run (lgkmcnt holds at most 15 requests)
+        wait_lgkm<0>();
+        GF_FQ_TR(vt1, FT_TILE, 1, 0, 0) GF_FQ_TR(vt1, FT_TILE, 1, 0, 1) GF_FQ_TR(vt1, FT_TILE, 1, 1, 0) GF_FQ_TR(vt1, FT_TILE, 1, 1, 1)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const bf16x8 p0 = cvt_frag(sc[0][0], tt), p1 = cvt_frag(sc[1][0], tt);
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                tie(vt0[tt][db][0]); tie(vt0[tt][db][1]);
+                const bf16x8 vf = as_frag(vt0[tt][db][0], vt0[tt][db][1]);
+                mma16(o[0][db], vf, p0);
+                mma16(o[1][db], vf, p1);
+            }
+        }
+        wait_lgkm<0>();
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const bf16x8 p0 = cvt_frag(sc[0][1], tt), p1 = cvt_frag(sc[1][1], tt);
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                tie(vt1[tt][db][0]); tie(vt1[tt][db][1]);
+                const bf16x8 vf = as_frag(vt1[tt][db][0], vt1[tt][db][1]);
+                mma16(o[0][db], vf, p0);
+                mma16(o[1][db], vf, p1);
+            }
+        }
+        stage = stage == 2 ? 0 : stage + 1;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int qrow = qrow0 + 32 * j;
+        const float l = lsum[j] + xhalf(lsum[j]);
+        if (qrow < p.Nq) {
+            bf16_t* op = reinterpret_cast<bf16_t*>(p.o) + b * p.sob + h * p.soh + (int64_t)qrow * p.son;
+            store_row<bf16_t, 64>(op, o[j], 1.f / l, hi);
+            if (hi == 0) p.lse[((int64_t)b * p.H + h) * p.Nq + qrow] = (m[j] + fast_log2(l)) * GF_LN2;
+        }
+    }
+}
+
 template <typename T, int HD> size_t fwd_lds() { return 2 * (Lay<T, HD>::ROWMAJOR + Lay<T, HD>::TRANSP) * sizeof(T); }
 template <typename T, int HD> size_t dq_lds() { return 2 * (2 * Lay<T, HD>::ROWMAJOR + Lay<T, HD>::TRANSP) * sizeof(T); }
 template <typename T, int HD> size_t dkv_lds() {
@@ -918,6 +1126,14 @@ template <typename K> int set_lds(K kern, size_t bytes) {
 
 template <typename T> int launch_fwd(const AttnParams& p, hipStream_t st) {
     int total = ((p.Nq + 255) / 256) * p.H * p.B;
+#ifndef GF_ATTN_FWD_V1
+    if constexpr (sizeof(T) == 2) {
+        const size_t l2 = FQ_NSTAGE * FQ_STAGE;
+        if (int e = set_lds(attn_fwd_bf16_kernel, l2)) return e;
+        attn_fwd_bf16_kernel<<<dim3(total), dim3(256), l2, st>>>(p);
+        return (int)hipGetLastError();
+    }
+#endif
     size_t lds = fwd_lds<T, 64>();
     if (int e = set_lds(attn_fwd_kernel<T, 64>, lds)) return e;
     attn_fwd_kernel<T, 64><<<dim3(total), dim3(256), lds, st>>>(p);
