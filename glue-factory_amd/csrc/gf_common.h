@@ -159,5 +159,28 @@ __device__ __forceinline__ int xcd_remap(int bid, int total) {
     return base + idx;
 }
 
+// Small fp32 fills / copies as KERNELS.  Not hipMemsetAsync / hipMemcpyAsync: inside a captured hipGraph those become
+// memset / memcpy nodes, and on ROCm 7.2 such nodes were observed to be dropped from some replays when eager work
+// (the extractor) is queued on the same stream between replays (the loss accumulators then held stale pool memory
+// while the kernels around them ran correctly).  Kernel nodes are not affected.
+namespace {
+__global__ void gf_fill_f32_kernel(float* p, float v, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+__global__ void gf_copy_f32_kernel(float* __restrict__ d, const float* __restrict__ s, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) d[i] = s[i];
+}
+}  // namespace
+static inline hipError_t gf_zero_f32(float* p, size_t n, hipStream_t st) {
+    if (n) gf_fill_f32_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(p, 0.f, n);
+    return hipGetLastError();
+}
+static inline hipError_t gf_copy_f32(float* d, const float* s, size_t n, hipStream_t st) {
+    if (n) gf_copy_f32_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st>>>(d, s, n);
+    return hipGetLastError();
+}
+
 // chunk sizes for 16-byte vector staging
 template <typename T> struct Vec16 { static constexpr int N = 16 / sizeof(T); };

@@ -195,7 +195,7 @@ extern "C" int gf_lg_loss_fwd(const void* md0, const void* md1, const float* z0,
     if (dtype != GF_F32 && dtype != GF_BF16) return GF_ERR_DTYPE;
     if ((t0 == nullptr) != (t1 == nullptr)) return GF_ERR_SHAPE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (hipError_t e = hipMemsetAsync(acc, 0, sizeof(float) * 4 * B, st)) return (int)e;
+    if (hipError_t e = gf_zero_f32(acc, (size_t)4 * B, st)) return (int)e;
     if (P > 0) {
         const dim3 grid((unsigned)((P + 4 * POS_CHUNK - 1) / (4 * POS_CHUNK)));
         if (dtype == GF_BF16)

@@ -779,7 +779,7 @@ extern "C" int gf_sinkhorn_bwd(const float* Z, const float* gout, const float* g
     float* vbar_hist = w.vbar_hist;                            // [iters+1, B, C] (index k, k = 0..T)
     const size_t zs = (size_t)g.R * g.C;
     if (iters == 0) {
-        hipError_t e = hipMemcpyAsync(gZ, gout, (size_t)B * zs * 4, hipMemcpyDeviceToDevice, st);
+        hipError_t e = gf_copy_f32(gZ, gout, (size_t)B * zs, st);
         return (int)e;
     }
     const size_t lds = g.fast ? 0 : rows_lds(g, true);
@@ -790,7 +790,7 @@ extern "C" int gf_sinkhorn_bwd(const float* Z, const float* gout, const float* g
         if (e != hipSuccess) return (int)e;
     }
     // vbar^T = colsum(G)
-    e = hipMemcpyAsync(vbar_hist + (size_t)iters * B * g.C, gsum_col, (size_t)B * g.C * 4, hipMemcpyDeviceToDevice, st);
+    e = gf_copy_f32(vbar_hist + (size_t)iters * B * g.C, gsum_col, (size_t)B * g.C, st);
     if (e != hipSuccess) return (int)e;
     const int ch = batch_chunk(g);
     for (int b0 = 0; b0 < B; b0 += ch) {

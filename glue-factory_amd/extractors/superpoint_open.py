@@ -117,6 +117,9 @@ class SuperPoint(BaseModel):
                 shift = (bn.bias.float() - bn.running_mean.float() * scale).contiguous()
                 w = blk.conv.weight.detach().to(dtype).contiguous(memory_format=torch.channels_last)
                 out[name] = (w, blk.conv.bias.detach().float().contiguous(), scale, shift)
+                if dtype == torch.bfloat16 and tuple(blk.conv.weight.shape) == (64, 64, 3, 3):
+                    # [tap][c_out][c_in] for the register-resident weights of gf_conv3x3_c64
+                    out[name + "/taps"] = blk.conv.weight.detach().permute(2, 3, 0, 1).to(dtype).contiguous()
         self._fused_cache = (key, out)
         return out
 
@@ -141,6 +144,22 @@ class SuperPoint(BaseModel):
             y.data_ptr(), out.data_ptr(), bias.data_ptr(), scale.data_ptr(), shift.data_ptr(), b, h, wd, c_out,
             int(relu), int(pool), 1 if y.dtype == torch.bfloat16 else 0, torch.cuda.current_stream().cuda_stream),
             "gf_bias_act_bn_nhwc")
+        return out
+
+    def _conv64_block(self, name, blk, x, params, pool):
+        """64 -> 64 channel 3x3 block in bf16 (backbone.0.1, 1.0, 1.1): convolution, bias, ReLU, BatchNorm(eval) and
+        the 2x2 max-pool in ONE HIP kernel (gf_conv3x3_c64, implicit GEMM with register-resident weights)."""
+        from .. import lib as _lib
+        _, bias, scale, shift = params[name]
+        b, _, h, wd = x.shape
+        if not x.is_contiguous(memory_format=torch.channels_last):
+            x = x.contiguous(memory_format=torch.channels_last)
+        out = torch.empty((b, 64, h // 2, wd // 2) if pool else (b, 64, h, wd), dtype=x.dtype, device=x.device,
+                          memory_format=torch.channels_last)
+        _lib.check(_lib.load().gf_conv3x3_c64(
+            x.data_ptr(), params[name + "/taps"].data_ptr(), bias.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+            out.data_ptr(), b, h, wd, int(isinstance(blk.activation, nn.ReLU)), int(pool), 1,
+            torch.cuda.current_stream().cuda_stream), "gf_conv3x3_c64")
         return out
 
     def _first_block(self, name, blk, x, params):
@@ -177,6 +196,9 @@ class SuperPoint(BaseModel):
                 if si == 0 and bi == 0 and not pool and x.shape[1] == 1 and blk.conv.out_channels == 64 \
                         and blk.conv.kernel_size == (3, 3):
                     x = self._first_block(f"backbone.{si}.{bi}", blk, x, params)      # conv + tail in one kernel
+                elif f"backbone.{si}.{bi}/taps" in params and x.shape[2] % 8 == 0 and x.shape[3] % 32 == 0 \
+                        and blk.conv.padding == (1, 1) and blk.conv.stride == (1, 1):
+                    x = self._conv64_block(f"backbone.{si}.{bi}", blk, x, params, pool)
                 else:
                     x = self._fused_block(f"backbone.{si}.{bi}", blk, x, params, pool=pool)
         det = self._fused_block("detector.0", self.detector[0], x, params)

@@ -46,6 +46,7 @@ SIGNATURES = {
     "gf_gt_nn": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "gf_bias_act_bn_nhwc": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "gf_conv1_bias_act_bn": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "gf_conv3x3_c64": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "gf_nms_scores": [_P, _P, _I, _I, _I, _I, _I, _P],
     "gf_sample_descriptors": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "gf_rowdot_nblk": [_I],

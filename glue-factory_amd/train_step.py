@@ -101,7 +101,9 @@ class TrainStep:
         # hipGraph replay of the whole step (forward, loss, backward, optimiser): ~1200 launches per LightGlue step
         # leave a few per cent of the GPU idle between kernels when they are issued one by one.  Needs: single
         # process (no DDP hooks inside a capture), a fused + capturable optimiser, no host synchronisation in the
-        # step (the fused skip path above), fixed shapes.  The first ``graph_warmup`` calls run eagerly, the next
+        # step (the fused skip path above), fixed shapes, and only KERNEL nodes in the capture: memset / memcpy nodes
+        # were observed to be dropped from some replays on ROCm 7.2 when eager work is queued between replays (see
+        # csrc/gf_common.h gf_zero_f32), so the launchers never call hipMemsetAsync / hipMemcpyAsync.  The first ``graph_warmup`` calls run eagerly, the next
         # one is captured and replayed; a batch of different shapes is run eagerly and re-captured.
         self.graph = bool(graph) and self.device_type == "cuda" and not self.distributed
         self.graph_warmup = graph_warmup

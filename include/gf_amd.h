@@ -232,6 +232,13 @@ int gf_bias_act_bn_nhwc(const void* x, void* y, const float* bias, const float* 
  *   `dtype`), out [B,H,W,64] channels-last -- the largest activation of the extractor is written exactly once. */
 int gf_conv1_bias_act_bn(const void* img, const void* w, const float* bias, const float* scale, const float* shift,
                          void* out, int B, int H, int W, int C, int relu, int dtype, void* stream);
+/* gf_conv3x3_c64: one 64 -> 64 channel VGG block (superpoint_open.py:37-75 VGGBlock, :98-105 backbone.0.1 / 1.0 / 1.1:
+ *   Conv2d(64, 64, 3, padding=1) -> +bias -> ReLU -> BatchNorm2d(eval) [-> MaxPool2d(2, 2)]) as one implicit-GEMM
+ *   kernel.  x [B,H,W,64] channels-last bf16, w [9 taps (ky*3+kx)][64 c_out][64 c_in] bf16, y [B,H,W,64] or, with
+ *   pool != 0, [B,H/2,W/2,64].  dtype must be GF_BF16 (GF_ERR_DTYPE), H % 8 == 0 and W % 32 == 0
+ *   (GF_ERR_UNSUPPORTED: the caller uses the library convolution + gf_bias_act_bn_nhwc). */
+int gf_conv3x3_c64(const void* x, const void* w, const float* bias, const float* scale, const float* shift, void* y,
+                   int B, int H, int W, int relu, int pool, int dtype, void* stream);
 int gf_nms_scores(const float* scores, float* out, int B, int H, int W, int radius, int border, void* stream);
 /* gf_sample_descriptors: sample_descriptors (:10-16) fused with the dense map's L2 normalisation (:149):
  *   out[b,n,:] = normalize(sum over the 4 bilinear corners of w_k * normalize(map[b,y_k,x_k,:])), zero padding,

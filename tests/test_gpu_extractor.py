@@ -115,3 +115,38 @@ def test_first_block_kernel(dtype, shape):
                                             torch.cuda.current_stream().cuda_stream), "gf_conv1_bias_act_bn")
     tol = 1e-5 if dtype == torch.float32 else 2e-2
     torch.testing.assert_close(out.float(), ref, rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("pool", [False, True])
+@pytest.mark.parametrize("shape", [(1, 8, 32), (2, 16, 96), (3, 64, 64), (1, 256, 288)])
+def test_conv3x3_c64_kernel(shape, pool):
+    """gf_conv3x3_c64 (Conv2d(64,64,3,pad 1) + bias + ReLU + BatchNorm(eval) [+ MaxPool 2x2], superpoint_open.py:37-75)
+    vs the stock fp32 ops on the same bf16 inputs: single tile (all borders), several tiles per image / images per
+    launch (persistent loop, double-buffered window), more tiles than workgroups.  bf16 output: tolerance = bf16
+    rounding of the result (2^-8 relative) + fp32 accumulation order."""
+    from glue_factory_amd import lib as L_
+    B, H, W = shape
+    g = torch.Generator(device="cuda").manual_seed(H * 7 + W)
+    x = torch.randn(B, 64, H, W, device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(64, 64, 3, 3, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+    bias, scale, shift = (torch.randn(64, device="cuda", generator=g) for _ in range(3))
+    ref = torch.nn.functional.conv2d(x.float(), w.float(), bias, padding=1)
+    ref = torch.relu(ref) * scale.view(1, 64, 1, 1) + shift.view(1, 64, 1, 1)
+    if pool:
+        ref = torch.nn.functional.max_pool2d(ref, 2, 2)
+    taps = w.permute(2, 3, 0, 1).contiguous()
+    out = torch.full(ref.shape, float("nan"), dtype=torch.bfloat16, device="cuda").contiguous(memory_format=torch.channels_last)
+    L_.check(L_.load().gf_conv3x3_c64(x.data_ptr(), taps.data_ptr(), bias.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                      out.data_ptr(), B, H, W, 1, int(pool), 1, torch.cuda.current_stream().cuda_stream),
+             "gf_conv3x3_c64")
+    torch.testing.assert_close(out.float(), ref, rtol=8e-3, atol=8e-3)
+
+
+def test_conv3x3_c64_rejects():
+    from glue_factory_amd import lib as L_
+    z = torch.zeros(64, device="cuda")
+    lib = L_.load()
+    assert lib.gf_conv3x3_c64(z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(),
+                              1, 8, 32, 1, 0, 0, None) == -4          # fp32: GF_ERR_DTYPE
+    assert lib.gf_conv3x3_c64(z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(),
+                              1, 12, 32, 1, 0, 1, None) == -1         # H % 8: GF_ERR_UNSUPPORTED

@@ -217,3 +217,37 @@ def test_train_step_hipgraph_replay_equals_eager():
     for k in p0:
         torch.testing.assert_close(p0[k], p1[k], rtol=1e-5, atol=1e-6, msg=lambda m: f"{k}: {m}")
     torch.testing.assert_close(e0, e1, rtol=1e-4, atol=1e-4)
+
+
+def test_hipgraph_replays_with_eager_work_between_and_no_host_sync():
+    """The benchmark's pipeline pattern: eager kernels (there: the extractor) queued between replays of the captured
+    step, and no host synchronisation for dozens of steps.  Every replay's reported losses must equal the eager
+    run's.  (Regression: with a hipMemsetAsync inside the capture, ROCm 7.2 dropped the memset node from some
+    replays in exactly this pattern and the loss accumulators read stale pool memory -- csrc/gf_common.h.)"""
+    from glue_factory_amd.synthetic import make_pairs
+    from glue_factory_amd.train_step import TrainStep
+    L = 2
+    params = lgo.init_params(L, 256, 4, seed=22)
+    batch = _to_cuda(make_pairs(2, 256, dim=256, size=(640, 480), seed=40))
+    img = torch.rand(8, 64, 512, 512, device="cuda")
+    conv = torch.nn.Conv2d(64, 64, 3, padding=1).cuda()
+
+    def eager_work():
+        with torch.no_grad():
+            y = img
+            for _ in range(6):
+                y = torch.relu(conv(y))
+            return y.mean()
+
+    runs = []
+    for use_graph in (False, True):
+        model = _model(params, L).train()
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True, capturable=True)
+        step = TrainStep(model, opt, amp_dtype=torch.bfloat16, graph=use_graph, graph_warmup=2)
+        losses = []
+        for _ in range(40):
+            eager_work()
+            losses.append(step(batch)["total"].mean())      # no .item(): nothing synchronises inside the loop
+        torch.cuda.synchronize()
+        runs.append(torch.stack(losses))
+    torch.testing.assert_close(runs[0], runs[1], rtol=1e-4, atol=1e-4)
