@@ -15,7 +15,7 @@ import sys
 
 tag, root = sys.argv[1], sys.argv[2]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KEEP = ("attn_", "assign_write", "sk_", "sinkhorn")
+KEEP = ("attn_", "assign_write", "sk_", "skf_", "sinkhorn")
 agg = collections.defaultdict(lambda: [0.0, 0])
 for f in glob.glob(os.path.join(root, "pmc*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
@@ -58,11 +58,12 @@ def per_dispatch(sub, counter):
     return tot, disp
 
 
-def group(subs, launches_from):
+def group(subs, launches_from, half=()):
     """HBM bytes per launch for a launch made of the kernels matching `subs`; the launch count is the dispatch count
-    of the kernel matching `launches_from` (one dispatch of it per launch)."""
-    fetch = sum(per_dispatch(s, "FETCH_SIZE")[0] for s in subs)
-    write = sum(per_dispatch(s, "WRITE_SIZE")[0] for s in subs)
+    of the kernel matching `launches_from` (one dispatch of it per launch).  Kernels in `half` are shared by two
+    launch groups (one dispatch in each): half of their total is charged to this one."""
+    fetch = sum(per_dispatch(s, "FETCH_SIZE")[0] for s in subs) + sum(per_dispatch(s, "FETCH_SIZE")[0] for s in half) / 2
+    write = sum(per_dispatch(s, "WRITE_SIZE")[0] for s in subs) + sum(per_dispatch(s, "WRITE_SIZE")[0] for s in half) / 2
     n = per_dispatch(launches_from, "FETCH_SIZE")[1]
     if not n or fetch + write == 0:
         return None
@@ -74,8 +75,11 @@ def group(subs, launches_from):
 
 out = {"gf_attn_bwd": group(["attn_bwd"], "attn_bwd_dq"), "attn_fwd_kernel": group(["attn_fwd"], "attn_fwd"),
        "assign_write_kernel": group(["assign_write"], "assign_write"),
-       "gf_sinkhorn_fwd": group(["sk_rows_fwd", "sk_cols_fwd", "sk_final_fwd", "sk_fwd"], "sk_final_fwd"),
-       "gf_sinkhorn_bwd": group(["sk_rows_bwd", "sk_cols_bwd", "sk_final_bwd", "sk_bwd"], "sk_final_bwd")}
+       # N <= 2304: the register-resident "skf_" kernels (one launch = prescale + T iterations + final pass)
+       "gf_sinkhorn_fwd": group(["sk_rows_fwd", "sk_cols_fwd", "sk_final_fwd", "sk_fwd", "skf_fwd_iter", "skf_cols_fwd"],
+                                "sk_final_fwd", half=["skf_prescale"]),
+       "gf_sinkhorn_bwd": group(["sk_rows_bwd", "sk_cols_bwd", "sk_final_bwd", "sk_bwd", "skf_bwd_iter", "skf_cols_bwd",
+                                 "skf_bwd_prep", "skf_factors", "skf_final_bwd"], "skf_final_bwd", half=["skf_prescale"])}
 out = {k: v for k, v in out.items() if v}
 out["source"] = f"tools/collect_pmc.sh {tag}: rocprofv3 --pmc passes over `bench.py --roofline-only`"
 json.dump(out, open(os.path.join(ROOT, "profiles", "roofline_traffic.json"), "w"), indent=1)
