@@ -18,6 +18,10 @@
 #include "gf_common.h"
 #include "gf_amd.h"
 
+#ifndef GF_BWD_SPLIT      // workgroups per column block of the dual-softmax backward (probe builds override it)
+#define GF_BWD_SPLIT 4
+#endif
+
 namespace {
 
 template <typename T, int D> struct ALay {
@@ -308,6 +312,7 @@ __global__ __launch_bounds__(256) void assign_write_kernel(HeadParams p) {
         v0 = sb ? sb[min(si, p.Ns - 1)] : 0.f;
         v1 = 0.f;
     };
+    float esum = 0.f;       // sum of exp(out) over this lane's entries (rows < Ns, all columns): the "row_norm" statistic
     auto body = [&](const T* tile, const float* vec0, const float*, int s0) {
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
@@ -321,8 +326,11 @@ __global__ __launch_bounds__(256) void assign_write_kernel(HeadParams p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     int si = s0 + kb * 32 + 8 * g + 4 * hi + e;
-                    if (si < p.Ns && orow < p.No)
-                        out[(int64_t)si * ldo + orow] = p.alpha * s[4 * g + e] + b4[e] + ocb;
+                    if (si < p.Ns && orow < p.No) {
+                        const float v = p.alpha * s[4 * g + e] + b4[e] + ocb;
+                        out[(int64_t)si * ldo + orow] = v;
+                        if (p.f0) esum += fast_exp2(v * GF_LOG2E);
+                    }
                 }
             }
         }
@@ -331,9 +339,16 @@ __global__ __launch_bounds__(256) void assign_write_kernel(HeadParams p) {
     // dustbins: last row for the owned columns, last column by the first block, corner once
     if (orow < p.No && hi == 0) out[(int64_t)p.Ns * ldo + orow] = p.g1 ? p.g1[(int64_t)b * p.No + orow] : 0.f;
     if (ob == 0) {
-        for (int si = threadIdx.x; si < p.Ns; si += 256)
-            out[(int64_t)si * ldo + p.No] = p.g0 ? p.g0[(int64_t)b * p.Ns + si] : 0.f;
+        for (int si = threadIdx.x; si < p.Ns; si += 256) {
+            const float v = p.g0 ? p.g0[(int64_t)b * p.Ns + si] : 0.f;
+            out[(int64_t)si * ldo + p.No] = v;
+            if (p.f0) esum += fast_exp2(v * GF_LOG2E);
+        }
         if (threadIdx.x == 0) out[(int64_t)p.Ns * ldo + p.No] = p.corner;
+    }
+    if (p.f0) {
+        esum = wave_allsum(esum);
+        if ((threadIdx.x & 63) == 0) atomicAdd(p.f0 + b, esum);
     }
 }
 
@@ -497,11 +512,13 @@ extern "C" int gf_rows_lse_argmax(const void* a, const void* b, const float* bia
 
 extern "C" int gf_assign_write(const void* a, const void* b, const float* rowbias, const float* colbias,
                                const float* bin_col, const float* bin_row, float alpha, float corner,
-                               float* out, int B, int M, int N, int D, int dtype, void* stream) {
+                               float* out, float* expsum, int B, int M, int N, int D, int dtype, void* stream) {
     // owner = columns (b rows), streamed = rows (a rows)
     HeadParams p = {};
     p.own = b; p.oth = a; p.B = B; p.No = N; p.Ns = M; p.sbias = rowbias; p.obias = colbias;
-    p.alpha = alpha; p.corner = corner; p.g0 = bin_col; p.g1 = bin_row; p.out = out;
+    p.alpha = alpha; p.corner = corner; p.g0 = bin_col; p.g1 = bin_row; p.out = out; p.f0 = expsum;
+    if (expsum)
+        if (hipError_t e = gf_zero_f32(expsum, (size_t)B, reinterpret_cast<hipStream_t>(stream))) return (int)e;
     return launch(K_WRITE, p, D, dtype, stream);
 }
 
@@ -512,8 +529,7 @@ extern "C" int gf_dual_softmax_bwd(const void* a, const void* b, const float* r,
     HeadParams p = {};
     p.own = b; p.oth = a; p.B = B; p.No = N; p.Ns = M;
     p.g0 = r; p.g1 = c; p.g2 = gr; p.g3 = gc; p.G = G; p.ldg = ldg; p.galpha = galpha; p.out = dS;
-    static const int forced = getenv("GF_BWD_SPLIT") ? atoi(getenv("GF_BWD_SPLIT")) : 0;
-    p.nsplit = forced > 0 ? forced : 4;     // 227 -> 172 us at B=32, N=2048 (1 -> 4 workgroups per column block)
+    p.nsplit = GF_BWD_SPLIT;                // 227 -> 172 us at B=32, N=2048 (1 -> 4 workgroups per column block)
     return launch(K_BWD, p, D, dtype, stream);
 }
 

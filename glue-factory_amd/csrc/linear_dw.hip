@@ -12,6 +12,10 @@
 #include "gf_common.h"
 #include "gf_amd.h"
 
+#ifndef GF_DW_WG          // workgroup slots of one dW round (two per CU); probe builds override it
+#define GF_DW_WG 512
+#endif
+
 namespace {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -611,9 +615,8 @@ DwPlan plan(int M, int Nout, int K) {
     p.ntile = ((Nout + 127) / 128) * ((K + 127) / 128);
     // One full round of two workgroups per CU (512 slots): slices = floor(512 / tiles), so no workgroup is
     // left for a second, nearly empty round (12 tiles x 43 slices = 516 workgroups ran 27 % slower).
-    // Measured on MI355X at M = 131072 with the 4-group reduce.  GF_DW_WG overrides (tuning knob).
-    static const int forced = getenv("GF_DW_WG") ? atoi(getenv("GF_DW_WG")) : 0;
-    const int total_wg = forced > 0 ? forced : 512;
+    // Measured on MI355X at M = 131072 with the 4-group reduce.  (-DGF_DW_WG=... in probe builds.)
+    const int total_wg = GF_DW_WG;
     // slices are dealt to the 8 XCDs round-robin: keep (slices per XCD) x tiles within that XCD's 64 slots
     int per_xcd = (total_wg / 8) / p.ntile;
     if (per_xcd < 1) per_xcd = 1;
@@ -658,8 +661,7 @@ int launch_dw_tr(const void* dy, const void* x, float* dw, float* db, void* ws, 
     DwPlan p = plan(M, Nout, K);
     float* part = reinterpret_cast<float*>(ws);
     float* bpart = part + (int64_t)p.nslice * Nout * K;
-    static const bool no_dma = getenv("GF_DW_NODMA") != nullptr;      // A/B switch (tools/probe/time_dw.py)
-    if (Nout % 128 == 0 && K % 128 == 0 && !no_dma) {
+    if (Nout % 128 == 0 && K % 128 == 0) {
         const size_t dlds = (size_t)DM_NSTAGE * DM_STAGE;
         hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_dw_dma_kernel),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)dlds);

@@ -24,13 +24,12 @@ SIGNATURES = {
                     _S, _S, _S, _S, _S, _S, _S, _S, _F, _I, _P],
     "gf_rows_lse": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "gf_rows_argmax": [_P, _P, _P, _F, _P, _P, _I, _I, _I, _I, _I, _P],
-    "gf_assign_write": [_P, _P, _P, _P, _P, _P, _F, _F, _P, _I, _I, _I, _I, _I, _P],
+    "gf_assign_write": [_P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _I, _I, _I, _I, _I, _P],
     "gf_dual_softmax_bwd": [_P, _P, _P, _P, _P, _P, _P, _L, _F, _P, _I, _I, _I, _I, _I, _P],
     "gf_filter_matches": [_P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _P],
     "gf_sinkhorn_ws_bytes": [_I, _I, _I, _I],
     "gf_sinkhorn_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "gf_sinkhorn_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
-    "gf_linear_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _L, _I, _P],
     "gf_line_csr": [_P, _P, _P, _I, _I, _I, _P],
     "gf_line_gather": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "gf_line_segsum": [_P, _L, _P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],

@@ -176,9 +176,9 @@ class MatchAssignment(nn.Module):
                 "lz0": lz[:b], "lz1": lz[b:], "bin0": lnz[:b], "bin1": lnz[b:]}
 
     @staticmethod
-    def materialize(h):
+    def materialize(h, with_expsum=False):
         return ops.assign_write(h["md0"], h["md1"], h["lz0"] - h["r"], h["lz1"] - h["c"],
-                                h["bin0"], h["bin1"], alpha=2.0, corner=0.0)
+                                h["bin0"], h["bin1"], alpha=2.0, corner=0.0, with_expsum=with_expsum)
 
     @staticmethod
     @torch.no_grad()
@@ -342,14 +342,15 @@ class LightGlue(nn.Module):
             head = self.log_assignment[conf.n_layers - 1].stats_stacked(x, b)
         else:
             head = self.log_assignment[conf.n_layers - 1].stats(desc0, desc1)
-        scores = MatchAssignment.materialize(head)
+        # the `row_norm` statistic of the loss (lightglue.py:602) is accumulated while the matrix is written
+        scores, expsum = MatchAssignment.materialize(head, with_expsum=True)
         am = MatchAssignment.argmaxes(head)
         m0, m1, ms0, ms1 = ops.filter_matches(am["max0"], am["arg0"], am["arg1"], conf.filter_threshold)
         if stacked and self.training:
             # ref_descriptors are detached copies in this mode: the loss differentiates through the private
             # stacked list below (identical values), which keeps every gradient batch-stacked.
             rd0, rd1 = torch.stack(all0, 1), torch.stack(all1, 1)
-            extra = {"_layer_desc": layer_x, "_final_head": head}
+            extra = {"_layer_desc": layer_x, "_final_head": head, "_row_norm": expsum / (scores.shape[1] - 1)}
         else:
             rd0, rd1 = torch.stack(all0, 1), torch.stack(all1, 1)
             extra = {}
@@ -532,7 +533,8 @@ class LightGlue(nn.Module):
         else:
             losses["confidence"] = torch.zeros_like(total)
         with torch.no_grad():
-            losses["row_norm"] = pred["log_assignment"].exp()[:, :-1].sum(2).mean(1)
+            rn = pred.get("_row_norm")
+            losses["row_norm"] = rn if rn is not None else pred["log_assignment"].exp()[:, :-1].sum(2).mean(1)
         losses["total"] = losses["total"] + losses["confidence"]
         return losses, {}
 

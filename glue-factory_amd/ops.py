@@ -373,9 +373,9 @@ def _wt_t(wt):
 
 
 class _Linear(torch.autograd.Function):
-    """y = x W^T + b (+ res): forward on gf_linear_fwd (library fallback), input-gradient GEMM on the library
-    (hipBLASLt), weight / bias gradient (a tiny-output, 1e5-deep reduction) on gf_linear_dw, which returns fp32
-    gradients for the fp32 master parameters directly.  ``res`` is a fused residual (gradient = dy)."""
+    """y = x W^T + b (+ res) (+ rotary epilogue): forward and input-gradient GEMM on gf_gemm (library GEMM only for
+    shapes outside its plans), weight / bias gradient (a tiny-output, 1e5-deep reduction) on gf_linear_dw, which
+    returns fp32 gradients for the fp32 master parameters directly.  ``res`` is a fused residual (gradient = dy)."""
 
     @staticmethod
     def forward(ctx, x, w, b, res=None, cs=None, rot_n=0):
@@ -765,8 +765,9 @@ class _AssignWrite(torch.autograd.Function):
     """out[b,i,j] = alpha a_i.b_j + rowbias_i + colbias_j, plus dustbin column/row/corner."""
 
     @staticmethod
-    def forward(ctx, a, b, rowbias, colbias, bin_col, bin_row, alpha, corner):
+    def forward(ctx, a, b, rowbias, colbias, bin_col, bin_row, alpha, corner, expsum=None):
         # corner: python float, or a 0-d / [B] tensor (differentiable, e.g. SuperGlue's bin_score)
+        # expsum: optional [B] fp32 buffer, filled with sum_{i<M, j<=N} exp(out) (not differentiable)
         _chk(a, b, rowbias, colbias, bin_col, bin_row)
         corner_t = corner if torch.is_tensor(corner) else None
         corner = 0.0 if corner_t is not None else corner
@@ -776,7 +777,7 @@ class _AssignWrite(torch.autograd.Function):
         rb, cb, bc, br = (t.float().contiguous() for t in (rowbias, colbias, bin_col, bin_row))
         out = torch.empty((B, M + 1, N + 1), dtype=torch.float32, device=a.device)
         _lib.check(_lib.load().gf_assign_write(_p(a), _p(b), _p(rb), _p(cb), _p(bc), _p(br),
-                                               float(alpha), float(corner), _p(out), B, M, N, D,
+                                               float(alpha), float(corner), _p(out), _p(expsum), B, M, N, D,
                                                _dt(a), _stream()), "gf_assign_write")
         if corner_t is not None:
             out[:, -1, -1] = corner_t.detach().float()
@@ -800,11 +801,15 @@ class _AssignWrite(torch.autograd.Function):
         if ctx.corner_shape is not None:
             gcorner = G[:, -1, -1].sum() if len(ctx.corner_shape) == 0 else G[:, -1, -1].reshape(ctx.corner_shape)
         return (da, db, core.sum(2).to(d[0]), core.sum(1).to(d[1]), G[:, :-1, -1].to(d[2]),
-                G[:, -1, :-1].to(d[3]), None, gcorner)
+                G[:, -1, :-1].to(d[3]), None, gcorner, None)
 
 
-def assign_write(a, b, rowbias, colbias, bin_col, bin_row, alpha=2.0, corner=0.0):
-    return _AssignWrite.apply(a, b, rowbias, colbias, bin_col, bin_row, alpha, corner)
+def assign_write(a, b, rowbias, colbias, bin_col, bin_row, alpha=2.0, corner=0.0, with_expsum=False):
+    """-> out [B,M+1,N+1]; with_expsum: (out, expsum [B]) where expsum = exp(out)[:, :-1].sum((1, 2)), detached."""
+    if not with_expsum:
+        return _AssignWrite.apply(a, b, rowbias, colbias, bin_col, bin_row, alpha, corner)
+    expsum = torch.empty((a.shape[0],), dtype=torch.float32, device=a.device)
+    return _AssignWrite.apply(a, b, rowbias, colbias, bin_col, bin_row, alpha, corner, expsum), expsum
 
 
 @torch.no_grad()

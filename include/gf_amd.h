@@ -99,10 +99,13 @@ int gf_rows_lse_argmax(const void* a, const void* b, const float* bias_z, const 
  *   out[b,i,N] = bin_col[b,i];  out[b,M,j] = bin_row[b,j];  out[b,M,N] = corner
  * out is [B, M+1, N+1] fp32 contiguous.  LightGlue: alpha=2, rowbias = logsig(z0) - r,
  * colbias = logsig(z1) - c, bin_col = logsig(-z0), bin_row = logsig(-z1), corner = 0.
- * GlueStick (gluestick.py:772-783): alpha=1, rowbias=-r/2, colbias=-c/2, bins from the caller. */
+ * GlueStick (gluestick.py:772-783): alpha=1, rowbias=-r/2, colbias=-c/2, bins from the caller.
+ * expsum (NULL or [B] fp32): expsum[b] = sum_{i<M, j<=N} exp(out[b,i,j]), accumulated while the entries are in
+ * registers -- the reference's `row_norm` statistic (lightglue.py:602: scores.exp()[:, :-1].sum(2).mean(1) =
+ * expsum / M) without re-reading the matrix; fp32 atomics, so its last bits depend on the scheduling. */
 int gf_assign_write(const void* a, const void* b, const float* rowbias, const float* colbias,
                     const float* bin_col, const float* bin_row, float alpha, float corner,
-                    float* out, int B, int M, int N, int D, int dtype, void* stream);
+                    float* out, float* expsum, int B, int M, int N, int D, int dtype, void* stream);
 
 /* gf_dual_softmax_bwd: the N x N part of the head's backward.  With r_i = LSE_j S_ij and
  * c_j = LSE_i S_ij (gf_rows_lse), gr = dL/dr and gc = dL/dc:
@@ -169,15 +172,6 @@ int gf_line_expand(const void* g, const int64_t* idx, const int* seg, void* d, i
 int gf_gemm(const void* x0, const void* x1, const void* w, const float* bias, const void* res, void* y,
             const float* cs, int rot_n, int M, int N, int K0, int K1,
             int64_t ld0, int64_t ld1, int64_t ldw, int64_t ldr, int64_t ldy, int dtype, void* stream);
-
-/* ---- forward GEMM of the block linears with fused epilogue (nn.Linear calls of lightglue.py:131-221,271-290):
- *   y[m, n] = sum_k x[m, k] w[n, k] + bias[n] (+ res[m, n])     bf16 in/out, fp32 accumulation, fp32 bias
- * x [M,K] (row stride ldx), w [N,K] (row stride ldw: a column slice of a wider weight is fine), res / y [M,N]
- * (row strides ldr / ldy; y may alias res).  N % 128 == 0, K % 32 == 0 (GF_ERR_UNSUPPORTED otherwise: the caller
- * uses the library GEMM).  `res` carries the block's residual "x +" (lightglue.py:163,221) or the first half
- * of the FFN's concatenated input, so neither needs a separate pass. */
-int gf_linear_fwd(const void* x, const void* w, const float* bias, const void* res, void* y,
-                  int M, int N, int K, int64_t ldx, int64_t ldw, int64_t ldr, int64_t ldy, int dtype, void* stream);
 
 /* ---- weight / bias gradient of a linear layer (autograd of every nn.Linear on the path,
  * lightglue.py:131-221, 271-290): dW[n][k] = sum_m dY[m][n] X[m][k], db[n] = sum_m dY[m][n]

@@ -177,8 +177,10 @@ def test_assignment_head(dtype, B, M, N, D):
     z0d, z1d = z0.clone().requires_grad_(True), z1.clone().requires_grad_(True)
     r, c = ops.dual_lse(ad, bd)
     lz0, lz1 = torch.nn.functional.logsigmoid(z0d), torch.nn.functional.logsigmoid(z1d)
-    out = ops.assign_write(ad, bd, lz0 - r, lz1 - c, torch.nn.functional.logsigmoid(-z0d),
-                           torch.nn.functional.logsigmoid(-z1d), alpha=2.0, corner=0.0)
+    out, expsum = ops.assign_write(ad, bd, lz0 - r, lz1 - c, torch.nn.functional.logsigmoid(-z0d),
+                                   torch.nn.functional.logsigmoid(-z1d), alpha=2.0, corner=0.0, with_expsum=True)
+    # the fused "row_norm" accumulator = exp of what was written, dustbin column in, dustbin row out (lightglue.py:602)
+    torch.testing.assert_close(expsum, out.detach().exp()[:, :-1].sum((1, 2)), rtol=1e-5, atol=1e-6)
     tol = dict(rtol=1e-4, atol=1e-4) if dtype == torch.float32 else dict(rtol=2e-2, atol=8e-2)
     torch.testing.assert_close(r.detach().cpu().double(), sim.logsumexp(2).detach(), **tol)
     torch.testing.assert_close(c.detach().cpu().double(), sim.logsumexp(1).detach(), **tol)
