@@ -37,7 +37,11 @@ constexpr int C3_IW = C3_TW + 2, C3_IH = C3_TH + 2;        // input window
 constexpr int C3_NPIX = C3_IW * C3_IH;                     // 340 pixels
 constexpr int C3_PIECES = 44;                              // 1-KiB DMA pieces (8 pixels each) per window
 constexpr int C3_INBUF = C3_PIECES * 1024;                 // bytes of one input buffer
-constexpr int C3_OUT = C3_TH * C3_TW * 128;                // bytes of the output staging tile
+constexpr int C3_OUT = C3_TH * C3_TW * 128;                // bytes of one output staging tile
+constexpr int C3_STAGE = 2 * C3_INBUF;                     // LDS map: 2 input windows | 2 staging tiles | constants
+constexpr int C3_CST = C3_STAGE + 2 * C3_OUT;
+constexpr int C3_WL = C3_CST + 3 * 64 * 4;                 // 4 weight fragments x 1 KiB (tap 8, channels 32..63)
+constexpr int C3_LDS = C3_WL + 4096;
 
 template <int OFF> __device__ __forceinline__ u32x4 c3_rd128(unsigned a) {
     u32x4 v;
@@ -55,57 +59,67 @@ struct C3Params {
     int B, H, W, relu;
 };
 
-template <bool POOL>
+template <bool POOL, bool RELU>
 __global__ __launch_bounds__(256, 1) void conv3x3_c64_kernel(C3Params p) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const unsigned lds0 = (unsigned)(size_t)smem;
-    char* outb = smem + 2 * C3_INBUF;                       // output staging tile [8][32 px][128 B], chunk-swizzled
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
     const int tx_n = p.W / C3_TW, ty_n = p.H / C3_TH;
     const int tiles = tx_n * ty_n * p.B;
 
     // ---- weights: A operands, lane = output channel 32 nt + l31, elements cin 16 ks + 8 hi .. + 8 of tap t
+    // (all but the last tap's second channel block, which does not fit the register file next to the accumulators
+    // and the staging traffic: those 4 fragments are re-read from LDS for the last two MFMA groups of every tile)
     bf16x8 wf[2][9][4];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-                wf[nt][t][ks] = *reinterpret_cast<const bf16x8*>(p.w + ((t * 64 + 32 * nt + l31) * 64 + 16 * ks + 8 * hi));
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(p.w + ((t * 64 + 32 * nt + l31) * 64 + 16 * ks + 8 * hi));
+                if (nt == 1 && t == 8) {
+                    if (wave == 0) *reinterpret_cast<bf16x8*>(smem + C3_WL + ks * 1024 + lane * 16) = v;
+                } else {
+                    wf[nt][t][ks] = v;
+                }
+            }
     // epilogue constants [bias | scale | shift][64] in LDS (read per tile: registers are full of weights)
-    float* cst = reinterpret_cast<float*>(smem + 2 * C3_INBUF + C3_OUT);
+    float* cst = reinterpret_cast<float*>(smem + C3_CST);
     if (threadIdx.x < 64) {
         cst[threadIdx.x] = p.bias[threadIdx.x];
         cst[64 + threadIdx.x] = p.scale[threadIdx.x];
         cst[128 + threadIdx.x] = p.shift[threadIdx.x];
     }
 
+    struct Tile { int b, y0, x0; };
+    auto coords = [&](int tile) {
+        Tile t;
+        t.b = tile / (tx_n * ty_n);
+        const int r = tile - t.b * (tx_n * ty_n);
+        const int ty = r / tx_n;
+        t.y0 = ty * C3_TH; t.x0 = (r - ty * tx_n) * C3_TW;
+        return t;
+    };
     // ---- input window DMA: piece q = LDS chunk positions [64 q, 64 q + 64) = pixels 8 q .. 8 q + 7; the lane for chunk
     // position (pixel pp, slot c') fetches logical chunk c' ^ ((pp >> 1) & 7) of that pixel (swizzle on the source).
-    auto issue = [&](int tile, int buf) {
-        const int b = tile / (tx_n * ty_n), r = tile % (tx_n * ty_n);
-        const int y0 = (r / tx_n) * C3_TH, x0 = (r % tx_n) * C3_TW;
-        const bf16_t* img = p.x + (int64_t)b * p.H * p.W * 64;
-#pragma unroll
-        for (int i = 0; i < C3_PIECES / 4; ++i) {
-            const int q = wave + 4 * i;
-            const int pp = min(q * 8 + (lane >> 3), C3_NPIX - 1);
-            const int iy = pp / C3_IW, ix = pp - iy * C3_IW;
-            const int gy = min(max(y0 - 1 + iy, 0), p.H - 1), gx = min(max(x0 - 1 + ix, 0), p.W - 1);
-            const int c = (lane & 7) ^ ((pp >> 1) & 7);
-            __builtin_amdgcn_global_load_lds((c3_glb_void*)(img + ((int64_t)gy * p.W + gx) * 64 + c * 8),
-                                             (c3_lds_void*)(smem + buf * C3_INBUF + q * 1024), 16, 0, 0);
-        }
+    // Out-of-image halo pixels are fetched clamped (any valid address) and zeroed after landing (zero_halo).
+    auto issue_piece = [&](const Tile& t, int buf, int i) {
+        const int q = wave + 4 * i;
+        const int pp = min(q * 8 + (lane >> 3), C3_NPIX - 1);
+        const int iy = (pp * 241) >> 13, ix = pp - iy * C3_IW;             // pp / 34 for pp < 340
+        const int gy = min(max(t.y0 - 1 + iy, 0), p.H - 1), gx = min(max(t.x0 - 1 + ix, 0), p.W - 1);
+        const int c = (lane & 7) ^ ((pp >> 1) & 7);
+        const bf16_t* img = p.x + (int64_t)t.b * p.H * p.W * 64;
+        __builtin_amdgcn_global_load_lds((c3_glb_void*)(img + ((int64_t)gy * p.W + gx) * 64 + c * 8),
+                                         (c3_lds_void*)(smem + buf * C3_INBUF + q * 1024), 16, 0, 0);
     };
     // halo pixels outside the image -> 0 (after the DMA of every wave landed)
-    auto zero_halo = [&](int tile, int buf) {
-        const int r = tile % (tx_n * ty_n);
-        const int y0 = (r / tx_n) * C3_TH, x0 = (r % tx_n) * C3_TW;
+    auto zero_halo = [&](const Tile& t, int buf) {
         for (int pp = threadIdx.x; pp < C3_NPIX; pp += 256) {
             const int iy = pp / C3_IW, ix = pp - iy * C3_IW;
-            const int gy = y0 - 1 + iy, gx = x0 - 1 + ix;
+            const int gy = t.y0 - 1 + iy, gx = t.x0 - 1 + ix;
             if (gy < 0 || gy >= p.H || gx < 0 || gx >= p.W) {
                 u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
@@ -113,28 +127,89 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c64_kernel(C3Params p) {
             }
         }
     };
-    auto is_border = [&](int tile) {
-        const int r = tile % (tx_n * ty_n);
-        const int ty = r / tx_n, tx = r % tx_n;
-        return ty == 0 || tx == 0 || ty == ty_n - 1 || tx == tx_n - 1;
+    auto is_border = [&](const Tile& t) {
+        return t.y0 == 0 || t.x0 == 0 || t.y0 == p.H - C3_TH || t.x0 == p.W - C3_TW;
     };
 
-    int tile = blockIdx.x;
-    if (tile >= tiles) return;
-    issue(tile, 0);
+    // ---- finished tiles leave through a double-buffered staging tile ([8][32 px][128 B], chunks swizzled by
+    // (px >> 1) & 7): tile i is written to staging[i & 1] by its owner lanes right after its MFMA loop and goes
+    // to HBM -- whole 128-byte pixels, [2x2 max-pooled] -- from INSIDE the MFMA loop of tile i + 1.
+    constexpr int NSTORE = POOL ? 4 : 8;                    // store steps per thread and tile
+    auto store_addr = [&](const Tile& t, int k) -> bf16_t* {
+        const int u = threadIdx.x + 256 * k;
+        if (!POOL) {
+            const int opx = u >> 3, c = u & 7;
+            return p.y + ((((int64_t)t.b * p.H + t.y0 + (opx >> 5)) * p.W + t.x0 + (opx & 31)) * 64 + c * 8);
+        }
+        const int py = u >> 7, px = (u >> 3) & 15, c = u & 7;
+        return p.y + ((((int64_t)t.b * (p.H / 2) + t.y0 / 2 + py) * (p.W / 2) + t.x0 / 2 + px) * 64 + c * 8);
+    };
+    // LDS byte address of (staging buffer sb, pixel opx, logical chunk c)
+    auto stage_at = [&](int sb, int opx, int c) { return C3_STAGE + sb * C3_OUT + opx * 128 + ((c ^ ((opx >> 1) & 7)) << 4); };
+    u32x4 sv[POOL ? 2 : 1];                                 // staging values in flight (read one MFMA group ahead)
+    float pm[POOL ? 8 : 1];                                 // pool: running max of the 2x2 window (upper pixel row first)
+    // non-pool: step k = chunk k.  pool: step k = (chunk k >> 1, pixel row k & 1): two reads, running max, store at odd k
+    auto store_read = [&](int sb, int k) {
+        if (!POOL) {
+            const int u = threadIdx.x + 256 * k;
+            sv[0] = c3_rd128<0>(lds0 + stage_at(sb, u >> 3, u & 7));
+        } else {
+            const int u = threadIdx.x + 256 * (k >> 1);
+            const int py = u >> 7, px = (u >> 3) & 15, c = u & 7;
+#pragma unroll
+            for (int d = 0; d < 2; ++d) sv[d] = c3_rd128<0>(lds0 + stage_at(sb, (2 * py + (k & 1)) * C3_TW + 2 * px + d, c));
+        }
+    };
+    auto store_write = [&](const Tile& t, int k) {          // the values of store_read(.., k) have landed
+        if (!POOL) {
+            c3_tie(sv[0]);
+            if (!(C3_ABL & 8)) *reinterpret_cast<u32x4*>(store_addr(t, k)) = sv[0];
+        } else {
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                c3_tie(sv[d]);
+                const bf16x8 vv = __builtin_bit_cast(bf16x8, sv[d]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pm[e] = (d || (k & 1)) ? fmaxf(pm[e], (float)vv[e]) : (float)vv[e];
+            }
+            if (k & 1) {
+                const bf16x8 o = {(bf16_t)pm[0], (bf16_t)pm[1], (bf16_t)pm[2], (bf16_t)pm[3],
+                                  (bf16_t)pm[4], (bf16_t)pm[5], (bf16_t)pm[6], (bf16_t)pm[7]};
+                if (!(C3_ABL & 8)) *reinterpret_cast<bf16x8*>(store_addr(t, k >> 1)) = o;
+            }
+        }
+    };
+
+    unsigned ab[4][3];
+#pragma unroll
+    for (int ro = 0; ro < 4; ++ro)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int pp = (2 * wave + ro) * C3_IW + l31 + dx;
+            ab[ro][dx] = lds0 + (unsigned)(pp * 128 + ((hi ^ ((pp >> 1) & 7)) << 4));
+        }
+    const int T = (tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;     // my tiles: blockIdx.x + i gridDim.x
+    if (T <= 0) return;
+    Tile cur = coords(blockIdx.x), prev = cur;
+#pragma unroll
+    for (int i = 0; i < C3_PIECES / 4; ++i) issue_piece(cur, 0, i);
     c3_wait_vm<0>();
-    __builtin_amdgcn_s_barrier();
-    if (is_border(tile)) {
-        zero_halo(tile, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (is_border(cur)) {
+        zero_halo(cur, 0);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
 
-    int buf = 0;
-    for (; tile < tiles; tile += gridDim.x, buf ^= 1) {
-        const int next = tile + gridDim.x;
-        if (next < tiles && !(C3_ABL & 2)) issue(next, buf ^ 1);
+    for (int i = 0; i < T; ++i) {
+        const int buf = i & 1;
+        // No branches inside the MFMA loop: the last tile re-fetches its own window (unused), and tile 0 "stores" the
+        // still-unwritten staging buffer to its OWN output pixels, which the same threads overwrite with the real
+        // values one phase later (same thread, same address: program order holds).
+        const bool has_next = i + 1 < T;
+        const Tile nxt = coords(blockIdx.x + (has_next ? i + 1 : i) * gridDim.x);
 
-        // ---- 144 MFMAs: acc[nt][r] (32 channels x 32 pixels of tile row 2 wave + r)
+        // ---- 144 MFMAs: acc[nt][r] (32 channels x 32 pixels of tile row 2 wave + r); between them the next window's
+        // DMA pieces are issued and the previous tile's staging buffer is drained to HBM
         f32x16 acc[2][2];
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
@@ -144,11 +219,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c64_kernel(C3Params p) {
                 for (int k = 0; k < 16; ++k) acc[nt][r][k] = 0.f;
         // B operand of (tap, ks, r): pixel pp = (2 wave + r + dy) * 34 + l31 + dx, chunk 2 ks + hi, swizzled:
         // byte address = pp * 128 + (((hi ^ v) * 16) ^ (32 ks)), v = (pp >> 1) & 7
-        auto base = [&](int t, int r) {
-            const int pp = (2 * wave + r + t / 3) * C3_IW + l31 + t % 3;
-            return lds0 + (unsigned)(buf * C3_INBUF + pp * 128 + ((hi ^ ((pp >> 1) & 7)) << 4));
-        };
+        // (only 4 window rows x 3 dx distinct addresses per lane: row = r + dy)
+        auto base = [&](int t, int r) { return ab[r + t / 3][t % 3] + (unsigned)(buf * C3_INBUF); };
         u32x4 ra[4], rb[4];                                      // [ks], double buffer over (tap, row) groups
+        u32x4 wl[4];                                             // the LDS-resident weight fragments
         if (!(C3_ABL & 4)) {
             const unsigned a = base(0, 0);
 #pragma unroll
@@ -157,35 +231,44 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c64_kernel(C3Params p) {
 #pragma unroll
         for (int g = 0; g < ((C3_ABL & 4) ? 0 : 18); ++g) {
             const int t = g >> 1, r = g & 1;
-            u32x4 (&cur)[4] = (g & 1) ? rb : ra;
-            u32x4 (&nxt)[4] = (g & 1) ? ra : rb;
+            u32x4 (&cur_)[4] = (g & 1) ? rb : ra;
+            u32x4 (&nxt_)[4] = (g & 1) ? ra : rb;
+            // store chunk k of the previous tile: its staging read is issued here (ahead of this group's B reads, so the
+            // counted wait below covers it) and goes to HBM after this group's MFMAs
+            const int k = POOL ? ((g & 3) == 1 && g < 16 ? g >> 2 : -1) : (g >= 1 && g <= 8 ? g - 1 : -1);
+            if (k >= 0) store_read(buf ^ 1, k);
             if (g + 1 < 18) {
                 const unsigned a = base((g + 1) >> 1, (g + 1) & 1);
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) nxt[ks] = c3_rd128<0>(a ^ (32u * ks));
-                c3_wait_lgkm<4>();                               // this group's four fragments landed
+                for (int ks = 0; ks < 4; ++ks) nxt_[ks] = c3_rd128<0>(a ^ (32u * ks));
+                c3_wait_lgkm<4>();                               // this group's four fragments (and older reads) landed
             } else {
                 c3_wait_lgkm<0>();
             }
+            if (g < C3_PIECES / 4 && !(C3_ABL & 2)) issue_piece(nxt, buf ^ 1, g);
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) c3_tie(cur[ks]);
+            for (int ks = 0; ks < 4; ++ks) c3_tie(cur_[ks]);
+            if (g == 15) {               // (behind group 16's B reads: landed by group 16's counted wait)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) wl[ks] = c3_rd128<0>(lds0 + C3_WL + ks * 1024 + lane * 16);
+            }
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
-                    acc[nt][r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt][t][ks], __builtin_bit_cast(bf16x8, cur[ks]), acc[nt][r], 0, 0, 0);
+                for (int ks = 0; ks < 4; ++ks) {
+                    bf16x8 wv;
+                    if (nt == 1 && t == 8) { c3_tie(wl[ks]); wv = __builtin_bit_cast(bf16x8, wl[ks]); }
+                    else wv = wf[nt][t][ks];
+                    acc[nt][r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, __builtin_bit_cast(bf16x8, cur_[ks]), acc[nt][r], 0, 0, 0);
+                }
+            if (k >= 0) store_write(prev, k);
         }
 
-        // ---- tail on the fp32 sums, bf16 into the staging tile: pixel (2 wave + r, l31), channels 8-byte groups
+        // ---- tail on the fp32 sums, bf16 into staging[buf]: pixel (2 wave + r, l31), channels in 8-byte groups
         if (C3_ABL & 1) {
 #pragma unroll
             for (int r = 0; r < 2; ++r) { asm volatile("" ::"v"(acc[0][r]), "v"(acc[1][r])); }
-        } else
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int opx = (2 * wave + r) * C3_TW + l31;
-            char* orow = outb + opx * 128;
-            const int v = (opx >> 1) & 7;
+        } else {
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -194,64 +277,39 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c64_kernel(C3Params p) {
                     const f32x4 cb = *reinterpret_cast<const f32x4*>(cst + c0);
                     const f32x4 cs = *reinterpret_cast<const f32x4*>(cst + 64 + c0);
                     const f32x4 ch = *reinterpret_cast<const f32x4*>(cst + 128 + c0);
-                    float o[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float a = acc[nt][r][4 * g + e] + cb[e];
-                        if (p.relu) a = fmaxf(a, 0.f);
-                        o[e] = fmaf(a, cs[e], ch[e]);
-                    }
-                    // channels 32 nt + 8 g + 4 hi + e -> 16-byte chunk 4 nt + g (swizzled), half hi
-                    st4(reinterpret_cast<bf16_t*>(orow + (((4 * nt + g) ^ v) << 4) + 8 * hi), o[0], o[1], o[2], o[3]);
-                }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // staging tile complete; input buffer `buf` free
-
-        // ---- store (whole 128-byte pixels, coalesced) [+ 2x2 max-pool]
-        if (!(C3_ABL & 9)) {
-            const int b = tile / (tx_n * ty_n), r_ = tile % (tx_n * ty_n);
-            const int y0 = (r_ / tx_n) * C3_TH, x0 = (r_ % tx_n) * C3_TW;
-            if (!POOL) {
-                bf16_t* dst = p.y + (((int64_t)b * p.H + y0) * p.W + x0) * 64;
+                    for (int r = 0; r < 2; ++r) {
+                        const int opx = (2 * wave + r) * C3_TW + l31;
+                        float o[4];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int u = threadIdx.x + 256 * i;             // chunk index: row i, pixel u/8 % 32, chunk u % 8
-                    const int opx = u >> 3, c = u & 7;
-                    const u32x4 val = *reinterpret_cast<const u32x4*>(outb + opx * 128 + ((c ^ ((opx >> 1) & 7)) << 4));
-                    *reinterpret_cast<u32x4*>(dst + ((int64_t)(opx >> 5) * p.W + (opx & 31)) * 64 + c * 8) = val;
-                }
-            } else {
-                bf16_t* dst = p.y + (((int64_t)b * (p.H / 2) + y0 / 2) * (p.W / 2) + x0 / 2) * 64;
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int u = threadIdx.x + 256 * i;             // pooled chunk: row u / 128, pixel u / 8 % 16, chunk u % 8
-                    const int py = u >> 7, px = (u >> 3) & 15, c = u & 7;
-                    float m[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
-#pragma unroll
-                    for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-                        for (int dx = 0; dx < 2; ++dx) {
-                            const int opx = (2 * py + dy) * C3_TW + 2 * px + dx;
-                            const bf16x8 vv = *reinterpret_cast<const bf16x8*>(outb + opx * 128 + ((c ^ ((opx >> 1) & 7)) << 4));
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], (float)vv[e]);
+                        for (int e = 0; e < 4; ++e) {
+                            float a = acc[nt][r][4 * g + e] + cb[e];
+                            if (RELU) a = fmaxf(a, 0.f);
+                            o[e] = fmaf(a, cs[e], ch[e]);
                         }
-                    const bf16x8 o = {(bf16_t)m[0], (bf16_t)m[1], (bf16_t)m[2], (bf16_t)m[3],
-                                      (bf16_t)m[4], (bf16_t)m[5], (bf16_t)m[6], (bf16_t)m[7]};
-                    *reinterpret_cast<bf16x8*>(dst + ((int64_t)py * (p.W / 2) + px) * 64 + c * 8) = o;
+                        // channels 32 nt + 8 g + 4 hi + e -> 16-byte chunk 4 nt + g (swizzled), half hi
+                        st4(reinterpret_cast<bf16_t*>(smem + stage_at(buf, opx, 4 * nt + g) + 8 * hi), o[0], o[1], o[2], o[3]);
+                    }
                 }
-            }
         }
-        // ---- next window landed?  (vmcnt retires in order: the stores above were issued after the DMA)
-        if (next < tiles) {
-            if (POOL) c3_wait_vm<2>(); else c3_wait_vm<8>();
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // everyone's DMA landed; staging tile read
-            if (is_border(next)) {
-                zero_halo(next, buf ^ 1);
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            }
+        // one barrier per tile: staging[buf] complete, staging[buf ^ 1] drained, window[buf] consumed, and (after
+        // each wave waited for its own pieces) window[buf ^ 1] landed
+        c3_wait_vm<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (has_next && is_border(nxt)) {
+            zero_halo(nxt, buf ^ 1);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        prev = cur; cur = nxt;
+    }
+    // ---- drain: the last tile's staging buffer
+    {
+        const int sb = (T - 1) & 1;
+#pragma unroll
+        for (int k = 0; k < NSTORE; ++k) {
+            store_read(sb, k);
+            c3_wait_lgkm<0>();
+            store_write(prev, k);
         }
     }
 }
@@ -266,19 +324,14 @@ extern "C" int gf_conv3x3_c64(const void* x, const void* w, const float* bias, c
     C3Params p;
     p.x = static_cast<const bf16_t*>(x); p.w = static_cast<const bf16_t*>(w); p.bias = bias; p.scale = scale; p.shift = shift;
     p.y = static_cast<bf16_t*>(y); p.B = B; p.H = H; p.W = W; p.relu = relu;
-    const size_t lds = 2 * C3_INBUF + C3_OUT + 3 * 64 * sizeof(float);
+    const size_t lds = C3_LDS;
     const int tiles = (W / C3_TW) * (H / C3_TH) * B;
     const int grid = tiles < 256 ? tiles : 256;            // one persistent workgroup per CU
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    hipError_t e;
-    if (pool) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        conv3x3_c64_kernel<true><<<dim3(grid), 256, lds, st>>>(p);
-    } else {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        conv3x3_c64_kernel<false><<<dim3(grid), 256, lds, st>>>(p);
-    }
+    void (*k)(C3Params) = pool ? (relu ? conv3x3_c64_kernel<true, true> : conv3x3_c64_kernel<true, false>)
+                               : (relu ? conv3x3_c64_kernel<false, true> : conv3x3_c64_kernel<false, false>);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    k<<<dim3(grid), 256, lds, st>>>(p);
     return (int)hipGetLastError();
 }
