@@ -7,16 +7,18 @@ subclass, same ``default_conf`` / ``required_data_keys`` and ``state_dict`` name
 ``final_line_proj``, ``inter_line_proj.*``, ``bin_score``, ``line_bin_score``).
 
 What runs where
-  * GNN layers: the SuperGlue building blocks of ``superglue.py`` (library GEMMs over stacked
+  * GNN layers: the SuperGlue building blocks of ``superglue.py`` (``gf_gemm`` over stacked
     channels-last activations, MFMA flash attention with the head-fastest channel order folded
     into the weights, one BatchNorm call per image);
   * point assignment (gluestick.py:772-783, bin-augmented averaged double softmax): the row /
     column log-sum-exp come from ``gf_rows_lse`` tiles of md0 md1^T (the bin joins through a
     logaddexp on the [B,N] vectors) and the (N+1)^2 matrix is written once by ``gf_assign_write``;
-  * line layers (gather of junction descriptors, endpoint MLP, mean scatter back; :589-691) and
-    the line head (:336-376, 2*Nl x 2*Nl scores, two endpoint pairings) work on <= 1024-row
-    tensors and stay on stock torch ops.
-``line_attention: True`` runs the same kernels with a per-junction softmax weighting (stock torch for the weights).
+  * line layers (:589-691): junction gather, endpoint MLP input, mean scatter back on the HIP line
+    kernels (``ops.line_graph`` builds the CSR once per forward; ``gf_line_gather`` / ``gf_line_segsum``
+    / ``gf_line_expand``), MLP on ``gf_gemm`` + the fused BatchNorm op; ``line_attention: True`` runs the
+    same kernels with a per-junction softmax weighting (the small softmax itself in stock torch);
+  * the line head (:336-376, 2*Nl x 2*Nl scores, two endpoint pairings) works on <= 1024-row tensors
+    and stays on stock torch ops.
 """
 from pathlib import Path
 

@@ -6,13 +6,16 @@ names and shapes (Conv1d weights stay ``(out, in, 1)``, BatchNorm running statis
 
 What runs where
   * Conv1d(k=1) layers are GEMMs over channels-last activations ``[2B, N, C]`` (both images
-    stacked; hipBLASLt through torch);
+    stacked) on ``gf_gemm`` (forward and input gradient, fused bias / two-source concat) and
+    ``gf_linear_dw`` (weight gradient); only the 3-channel input layer of the keypoint
+    encoder (K = 3) falls outside the kernel's plans and uses the library;
   * attention (superglue.py:112-135): the MFMA flash kernels of csrc/attention.hip.  The
     reference puts the head index FASTEST in the channel dimension (``view(b, dim, h, n)``);
     the projection weight rows (and the merge weight columns) are gathered once so the kernels
     see ``[.., head, channel]`` with contiguous channels — no activation shuffles;
-  * BatchNorm (+ReLU) stays stock torch (``nn.BatchNorm1d`` / SyncBatchNorm-convertible), with
-    one call per image exactly like the reference (batch statistics per image set);
+  * BatchNorm (+ReLU) is the fused HIP op ``ops.batch_norm_act`` on the ``nn.BatchNorm1d`` modules'
+    parameters / running statistics (SyncBatchNorm-convertible: the sums are all-reduced inside
+    the op), one call per image exactly like the reference (batch statistics per image set);
   * couplings ``[[scores/sqrt(d), a],[a, a]]`` are written in one pass by ``gf_assign_write``
     from MFMA tiles (no ``sim`` tensor, no torch.cat), then the log-domain Sinkhorn iterations
     and their hand-derived reverse sweep run in csrc/sinkhorn.hip (superglue.py:186-214);
