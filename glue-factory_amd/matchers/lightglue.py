@@ -74,10 +74,12 @@ def _lin(x, layer):
     return ops.linear(x, layer.weight, layer.bias)
 
 
-def _ffn(ffn, x, msg):
-    h = ops.linear_cat(x, msg, ffn[0].weight, ffn[0].bias)
+def _ffn(ffn, x, msg, chain=None):
+    """x + ffn(cat(x, msg)).  ``chain``: the GradChain of x (its three consumers in a block are this residual, the
+    FFN input and the block's projection): the residual and FFN-input gradients ride in GEMM epilogues."""
+    h = ops.linear_cat(x, msg, ffn[0].weight, ffn[0].bias, chain1=chain)
     h = ops.ln_gelu(h, ffn[1].weight, ffn[1].bias, ffn[1].eps)
-    return ops.linear(h, ffn[3].weight, ffn[3].bias, res=x)      # residual fused into the GEMM epilogue
+    return ops.linear(h, ffn[3].weight, ffn[3].bias, res=x, res_chain=chain)   # residual fused into the GEMM epilogue
 
 
 class SelfBlock(nn.Module):
@@ -98,14 +100,17 @@ class SelfBlock(nn.Module):
         b, n, d = x.shape
         w = self.Wqkv.weight.index_select(0, self._perm)
         bias = self.Wqkv.bias.index_select(0, self._perm)
+        # x feeds the projection, the FFN input and the residual: one gradient chain, closed by the projection
+        chain = ops.GradChain(3) if x.requires_grad and torch.is_grad_enabled() else None
         if ops.gemm_takes(d, 3 * d, x.dtype):     # q, k leave the GEMM already rotated (rotary epilogue)
-            qkv = ops.linear(x, w, bias, rotary_cs=cs, rot_n=2 * d).view(b, n, 3, self.heads, self.head_dim)
+            qkv = ops.linear(x, w, bias, rotary_cs=cs, rot_n=2 * d, chain=chain, chain_last=True)
+            qkv = qkv.view(b, n, 3, self.heads, self.head_dim)
             ctx = ops.self_attention_rotary(qkv, theta, cs, pre_rotated=True)      # [b,n,H,hd]
         else:
-            qkv = ops.linear(x, w, bias).view(b, n, 3, self.heads, self.head_dim)
+            qkv = ops.linear(x, w, bias, chain=chain, chain_last=True).view(b, n, 3, self.heads, self.head_dim)
             ctx = ops.self_attention_rotary(qkv, theta, cs)
         msg = _lin(ctx.view(b, n, d), self.out_proj)
-        return _ffn(self.ffn, x, msg)
+        return _ffn(self.ffn, x, msg, chain)
 
 
 class CrossBlock(nn.Module):
@@ -117,16 +122,17 @@ class CrossBlock(nn.Module):
         self.to_out = nn.Linear(dim, dim, bias=True)
         self.ffn = _ffn_modules(dim)
 
-    def _proj(self, x):
+    def _proj(self, x, chain=None):
         w = torch.cat([self.to_qk.weight, self.to_v.weight], 0)
         bias = torch.cat([self.to_qk.bias, self.to_v.bias], 0)
-        return ops.linear(x, w, bias).view(x.shape[0], x.shape[1], 2, self.heads, self.head_dim)
+        return ops.linear(x, w, bias, chain=chain, chain_last=True).view(x.shape[0], x.shape[1], 2, self.heads, self.head_dim)
 
     def forward_stacked(self, x):
         """x [2B,N,C]: image 0 in the first half of the batch, image 1 in the second."""
         b2, n, d = x.shape
-        m = ops.cross_attention_stacked(self._proj(x))
-        return _ffn(self.ffn, x, _lin(m.view(b2, n, d), self.to_out))
+        chain = ops.GradChain(3) if x.requires_grad and torch.is_grad_enabled() else None
+        m = ops.cross_attention_stacked(self._proj(x, chain))
+        return _ffn(self.ffn, x, _lin(m.view(b2, n, d), self.to_out), chain)
 
     def forward(self, x0, x1):
         m0, m1 = ops.cross_attention(self._proj(x0), self._proj(x1))

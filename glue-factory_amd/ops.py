@@ -372,13 +372,42 @@ def _wt_t(wt):
     return wt.t().contiguous()
 
 
+class GradChain:
+    """Sums the gradient contributions of ONE tensor that feeds several linears of a block (residual, FFN input,
+    projection) inside the GEMM epilogues instead of leaving them to autograd's accumulation (one 3-pass add kernel
+    per extra consumer): every consumer but the designated last one parks its contribution here and returns no
+    gradient; the last one's input-gradient GEMM adds the parked sum in its residual epilogue and returns the total.
+    The last consumer must be the one whose backward runs last -- true by data dependence for the transformer blocks
+    (the projection's gradient needs the attention backward, which needs the FFN's) and checked by the counter."""
+    __slots__ = ("acc", "got", "expected")
+
+    def __init__(self, consumers):
+        self.acc, self.got, self.expected = None, 0, consumers - 1
+
+    def park(self, g):
+        self.acc = g
+        self.got += 1
+
+    def take(self):
+        if self.got != self.expected:
+            raise RuntimeError(f"GradChain: {self.got} of {self.expected} contributions arrived before the last consumer")
+        acc, self.acc, self.got = self.acc, None, 0
+        return acc
+
+
+def _flat2(t, n):
+    t2 = t.reshape(-1, n)
+    return t2 if t2.is_contiguous() else t2.contiguous()
+
+
 class _Linear(torch.autograd.Function):
     """y = x W^T + b (+ res) (+ rotary epilogue): forward and input-gradient GEMM on gf_gemm (library GEMM only for
     shapes outside its plans), weight / bias gradient (a tiny-output, 1e5-deep reduction) on gf_linear_dw, which
     returns fp32 gradients for the fp32 master parameters directly.  ``res`` is a fused residual (gradient = dy)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, res=None, cs=None, rot_n=0):
+    def forward(ctx, x, w, b, res=None, cs=None, rot_n=0, chain=None, chain_last=False, res_chain=None):
+        ctx.chain, ctx.chain_last, ctx.res_chain = chain, chain_last, res_chain
         wt = _lp(w, x.dtype)
         k = x.shape[-1]
         x2 = x.reshape(-1, k)
@@ -405,8 +434,18 @@ class _Linear(torch.autograd.Function):
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
         dx = dw = db = None
+        dres = dy if ctx.has_res and ctx.needs_input_grad[3] else None
+        if dres is not None and ctx.res_chain is not None:       # first link of the residual tensor's chain
+            ctx.res_chain.park(_flat2(dres, nout))
+            dres = None
         if ctx.needs_input_grad[0]:
-            dx = gemm(dy2, _wt_t(wt)).view(x.shape)
+            ch = ctx.chain
+            if ch is None:
+                dx = gemm(dy2, _wt_t(wt)).view(x.shape)
+            elif ctx.chain_last:
+                dx = gemm(dy2, _wt_t(wt), res2=ch.take()).view(x.shape)
+            else:
+                ch.park(gemm(dy2, _wt_t(wt), res2=ch.acc))
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             x2 = x.reshape(-1, k)
             if not x2.is_contiguous():
@@ -420,19 +459,24 @@ class _Linear(torch.autograd.Function):
                                       _stream()), "gf_linear_dw")
             dw = dw32.to(ctx.wdtype)
             db = None if db32 is None else db32.to(ctx.bdtype)
-        return dx, dw, db, (dy if ctx.has_res and ctx.needs_input_grad[3] else None), None, None
+        return dx, dw, db, dres, None, None, None, None, None
 
 
-def linear(x, w, b=None, res=None, rotary_cs=None, rot_n=0):
+def linear(x, w, b=None, res=None, rotary_cs=None, rot_n=0, chain=None, chain_last=False, res_chain=None):
     """w, b: fp32 master parameters (or differentiable functions of them); x (and the optional fused residual
     ``res``, same shape as the output) in the compute dtype.  ``rotary_cs`` [.., 64] fp32 interleaved (cos, sin):
     the output channels [0, rot_n) leave the GEMM already rotated (the buffer then belongs to
-    self_attention_rotary(pre_rotated=True), whose backward hands the UN-rotated gradient back to this node)."""
+    self_attention_rotary(pre_rotated=True), whose backward hands the UN-rotated gradient back to this node).
+    ``chain`` / ``res_chain``: GradChain of x / of res (see there); only used when that tensor requires grad."""
     _chk(x)
     if rotary_cs is not None:
         rotary_cs = rotary_cs.reshape(-1, rotary_cs.shape[-1])
         assert rotary_cs.shape[-1] == 64 and rotary_cs.dtype == torch.float32 and rotary_cs.is_contiguous()
-    return _Linear.apply(x, w, b, res, rotary_cs, rot_n)
+    if not x.requires_grad:
+        chain = None
+    if res is None or not res.requires_grad:
+        res_chain = None
+    return _Linear.apply(x, w, b, res, rotary_cs, rot_n, chain, chain_last, res_chain)
 
 
 def _dw(dy2, x2, nout, k, with_bias):
@@ -452,7 +496,8 @@ class _LinearCat(torch.autograd.Function):
     lightglue.py:163 / :219-220)."""
 
     @staticmethod
-    def forward(ctx, x1, x2, w, b):
+    def forward(ctx, x1, x2, w, b, chain1=None):
+        ctx.chain1 = chain1
         k1 = x1.shape[-1]
         wt = _lp(w, x1.dtype)
         a2 = x1.reshape(-1, k1)
@@ -473,7 +518,13 @@ class _LinearCat(torch.autograd.Function):
         dy2 = dy.reshape(-1, nout)
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
-        dx1 = gemm(dy2, _wt_t(wt[:, :k1])).view(x1.shape) if ctx.needs_input_grad[0] else None
+        dx1 = None
+        if ctx.needs_input_grad[0]:
+            ch = ctx.chain1
+            if ch is None:
+                dx1 = gemm(dy2, _wt_t(wt[:, :k1])).view(x1.shape)
+            else:                                   # a middle link: the parked residual gradient rides in the epilogue
+                ch.park(gemm(dy2, _wt_t(wt[:, :k1]), res2=ch.acc))
         dx2 = gemm(dy2, _wt_t(wt[:, k1:])).view(x2.shape) if ctx.needs_input_grad[1] else None
         dw = db = None
         if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
@@ -485,12 +536,12 @@ class _LinearCat(torch.autograd.Function):
             dwb, _ = _dw(dy2, c, nout, k - k1, False)
             dw = torch.cat([dwa, dwb], 1).to(ctx.wdtype)
             db = None if db32 is None else db32.to(ctx.bdtype)
-        return dx1, dx2, dw, db
+        return dx1, dx2, dw, db, None
 
 
-def linear_cat(x1, x2, w, b=None):
+def linear_cat(x1, x2, w, b=None, chain1=None):
     _chk(x1, x2)
-    return _LinearCat.apply(x1, x2, w, b)
+    return _LinearCat.apply(x1, x2, w, b, chain1 if x1.requires_grad else None)
 
 
 class _RowDot(torch.autograd.Function):
