@@ -74,12 +74,12 @@ def _lin(x, layer):
     return ops.linear(x, layer.weight, layer.bias)
 
 
-def _ffn(ffn, x, msg, chain=None):
+def _ffn(ffn, x, msg, chain=None, out=None):
     """x + ffn(cat(x, msg)).  ``chain``: the GradChain of x (its three consumers in a block are this residual, the
     FFN input and the block's projection): the residual and FFN-input gradients ride in GEMM epilogues."""
     h = ops.linear_cat(x, msg, ffn[0].weight, ffn[0].bias, chain1=chain)
     h = ops.ln_gelu(h, ffn[1].weight, ffn[1].bias, ffn[1].eps)
-    return ops.linear(h, ffn[3].weight, ffn[3].bias, res=x, res_chain=chain)   # residual fused into the GEMM epilogue
+    return ops.linear(h, ffn[3].weight, ffn[3].bias, res=x, res_chain=chain, out=out)   # residual fused into the GEMM epilogue
 
 
 class SelfBlock(nn.Module):
@@ -127,12 +127,12 @@ class CrossBlock(nn.Module):
         bias = torch.cat([self.to_qk.bias, self.to_v.bias], 0)
         return ops.linear(x, w, bias, chain=chain, chain_last=True).view(x.shape[0], x.shape[1], 2, self.heads, self.head_dim)
 
-    def forward_stacked(self, x):
+    def forward_stacked(self, x, out=None):
         """x [2B,N,C]: image 0 in the first half of the batch, image 1 in the second."""
         b2, n, d = x.shape
         chain = ops.GradChain(3) if x.requires_grad and torch.is_grad_enabled() else None
         m = ops.cross_attention_stacked(self._proj(x, chain))
-        return _ffn(self.ffn, x, _lin(m.view(b2, n, d), self.to_out), chain)
+        return _ffn(self.ffn, x, _lin(m.view(b2, n, d), self.to_out), chain, out)
 
     def forward(self, x0, x1):
         m0, m1 = ops.cross_attention(self._proj(x0), self._proj(x1))
@@ -324,14 +324,19 @@ class LightGlue(nn.Module):
         if stacked:   # both images share every GEMM / kernel launch
             x = x_in if x_in is not None else torch.cat([desc0, desc1], 0)
             theta, cs = self.posenc(torch.cat([kpts0, kpts1], 0))
+            # training: every layer's output is written straight into its slice of ONE [L, 2B, N, C] buffer by the
+            # layer's last GEMM, so the public ref_descriptors are views of it (no stack of L copies)
+            lbuf = torch.empty((conf.n_layers, 2 * b, m, x.shape[-1]), dtype=x.dtype, device=x.device) \
+                if self.training and x.is_cuda else None
             for i, layer in enumerate(self.transformers):
                 x = layer.self_attn(x, theta, cs)
-                x = layer.cross_attn.forward_stacked(x)
+                x = layer.cross_attn.forward_stacked(x, out=None if lbuf is None else lbuf[i])
                 if self.training or i == conf.n_layers - 1:
                     layer_x.append(x)
-                    with torch.no_grad():      # public copies; gradients flow through the stacked list
-                        all0.append(x[:b])
-                        all1.append(x[b:])
+                    if lbuf is None:
+                        with torch.no_grad():      # public copies; gradients flow through the stacked list
+                            all0.append(x[:b])
+                            all1.append(x[b:])
             desc0, desc1 = x[:b], x[b:]
         else:
             th0, cs0 = self.posenc(kpts0)
@@ -353,9 +358,12 @@ class LightGlue(nn.Module):
         am = MatchAssignment.argmaxes(head)
         m0, m1, ms0, ms1 = ops.filter_matches(am["max0"], am["arg0"], am["arg1"], conf.filter_threshold)
         if stacked and self.training:
-            # ref_descriptors are detached copies in this mode: the loss differentiates through the private
+            # ref_descriptors are detached in this mode: the loss differentiates through the private
             # stacked list below (identical values), which keeps every gradient batch-stacked.
-            rd0, rd1 = torch.stack(all0, 1), torch.stack(all1, 1)
+            if lbuf is not None:
+                rd0, rd1 = lbuf.detach()[:, :b].transpose(0, 1), lbuf.detach()[:, b:].transpose(0, 1)   # [B, L, N, C] views
+            else:
+                rd0, rd1 = torch.stack(all0, 1), torch.stack(all1, 1)
             extra = {"_layer_desc": layer_x, "_final_head": head, "_row_norm": expsum / (scores.shape[1] - 1)}
         else:
             rd0, rd1 = torch.stack(all0, 1), torch.stack(all1, 1)

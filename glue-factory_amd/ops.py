@@ -406,7 +406,7 @@ class _Linear(torch.autograd.Function):
     returns fp32 gradients for the fp32 master parameters directly.  ``res`` is a fused residual (gradient = dy)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, res=None, cs=None, rot_n=0, chain=None, chain_last=False, res_chain=None):
+    def forward(ctx, x, w, b, res=None, cs=None, rot_n=0, chain=None, chain_last=False, res_chain=None, out=None):
         ctx.chain, ctx.chain_last, ctx.res_chain = chain, chain_last, res_chain
         wt = _lp(w, x.dtype)
         k = x.shape[-1]
@@ -418,7 +418,8 @@ class _Linear(torch.autograd.Function):
             res2 = res.reshape(-1, wt.shape[0])
             if not res2.is_contiguous():
                 res2 = res2.contiguous()
-        y = _linear_fwd(x2, wt, b, res2, cs=cs, rot_n=rot_n).view(*x.shape[:-1], wt.shape[0])
+        out2 = None if out is None else out.view(-1, wt.shape[0])       # caller-owned destination (contiguous rows)
+        y = _linear_fwd(x2, wt, b, res2, out=out2, cs=cs, rot_n=rot_n).view(*x.shape[:-1], wt.shape[0])
         ctx.save_for_backward(x, wt)
         ctx.wdtype = w.dtype
         ctx.has_bias = b is not None
@@ -459,15 +460,16 @@ class _Linear(torch.autograd.Function):
                                       _stream()), "gf_linear_dw")
             dw = dw32.to(ctx.wdtype)
             db = None if db32 is None else db32.to(ctx.bdtype)
-        return dx, dw, db, dres, None, None, None, None, None
+        return dx, dw, db, dres, None, None, None, None, None, None
 
 
-def linear(x, w, b=None, res=None, rotary_cs=None, rot_n=0, chain=None, chain_last=False, res_chain=None):
+def linear(x, w, b=None, res=None, rotary_cs=None, rot_n=0, chain=None, chain_last=False, res_chain=None, out=None):
     """w, b: fp32 master parameters (or differentiable functions of them); x (and the optional fused residual
     ``res``, same shape as the output) in the compute dtype.  ``rotary_cs`` [.., 64] fp32 interleaved (cos, sin):
     the output channels [0, rot_n) leave the GEMM already rotated (the buffer then belongs to
     self_attention_rotary(pre_rotated=True), whose backward hands the UN-rotated gradient back to this node).
-    ``chain`` / ``res_chain``: GradChain of x / of res (see there); only used when that tensor requires grad."""
+    ``chain`` / ``res_chain``: GradChain of x / of res (see there); only used when that tensor requires grad.
+    ``out``: optional destination with the output's shape (e.g. a slice of a per-layer buffer): written, and returned."""
     _chk(x)
     if rotary_cs is not None:
         rotary_cs = rotary_cs.reshape(-1, rotary_cs.shape[-1])
@@ -476,7 +478,7 @@ def linear(x, w, b=None, res=None, rotary_cs=None, rot_n=0, chain=None, chain_la
         chain = None
     if res is None or not res.requires_grad:
         res_chain = None
-    return _Linear.apply(x, w, b, res, rotary_cs, rot_n, chain, chain_last, res_chain)
+    return _Linear.apply(x, w, b, res, rotary_cs, rot_n, chain, chain_last, res_chain, out)
 
 
 def _dw(dy2, x2, nout, k, with_bias):
