@@ -1109,6 +1109,172 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
     }
 }
 
+
+// ===========================================================================================
+// Assignment-head backward, one side (lightglue.py:256-290 autograd; the "dual softmax" part):
+//   S_so = oth_s . own_o,   dS_so = exp(S_so - ns_s) gs_s + exp(S_so - no_o) go_o,   dOwn_o = sum_s dS_so oth_s
+// with (ns, gs) / (no, go) the log-sum-exp normaliser and incoming coefficient of the streamed row / of the owner.
+// Called twice (owner = md1 rows -> d md1, owner = md0 rows -> d md0): no [B,N,N] dS tensor is written and no
+// library GEMM follows.  It lives in this file because it IS the attention forward's machinery with D = 256: the
+// streamed [64 x 256] tile is four 64 x 64 sub-tiles in the forward's LDS-DMA ring layout, S^T comes from row
+// fragments (ds_read_b128), dS goes from the accumulator registers straight into the second product, whose other
+// operand oth^T is read with ds_read_b64_tr_b16 from the SAME tile.  One wave owns 32 owner rows and the whole
+// 256-wide output row (8 accumulator tiles): one wave per SIMD, 512-register budget.
+// ===========================================================================================
+constexpr int HB_TILE = 4 * FT_TILE;                 // 64 rows x 256 channels
+constexpr int HB_STAGE = HB_TILE + 1024;             // + ns | gs (64 floats each) | spare copies
+constexpr int HB_NSTAGE = 3;
+
+struct HeadBwdParams {
+    const bf16_t* own; const bf16_t* oth;            // [B, No, 256], [B, Ns, 256]
+    const float* no; const float* go;                // [B, No]
+    const float* ns; const float* gs;                // [B, Ns]
+    bf16_t* down;                                    // [B, No, 256]
+    int B, No, Ns;
+};
+
+__global__ __launch_bounds__(256, 1) void head_bwd_bf16_kernel(HeadBwdParams p) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const unsigned lds0 = (unsigned)(size_t)smem;
+    const int nob = (p.No + 127) / 128;
+    const int lb = xcd_remap(blockIdx.x, nob * p.B);
+    const int ob = lb % nob, b = lb / nob;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int orow = ob * 128 + wave * 32 + l31;
+    const int old_ = min(orow, p.No - 1);
+    const bf16_t* ownp = p.own + ((int64_t)b * p.No + old_) * 256;
+    const bf16_t* othp = p.oth + (int64_t)b * p.Ns * 256;
+    const float* nsp = p.ns + (int64_t)b * p.Ns;
+    const float* gsp = p.gs + (int64_t)b * p.Ns;
+
+    const int nt = (p.Ns + 63) / 64;
+    auto issue_tile = [&](int t, int stage) {
+        char* sb = smem + stage * HB_STAGE;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) fq_issue(othp + 64 * c, 256, t * 64, p.Ns, sb + c * FT_TILE, wave, lane);
+        // per-row vectors: waves 0 / 1 bring ns / gs, waves 2 / 3 the same into spare slots (equal vmcnt in every wave)
+        const float* src = (wave & 1) ? gsp : nsp;
+        dma4(src + min(t * 64 + lane, p.Ns - 1), sb + HB_TILE + (wave & 1) * 256 + (wave >> 1) * 512);
+    };
+    issue_tile(0, 0);
+    if (nt > 1) issue_tile(1, 1);
+
+    bf16x8 of[16];                                     // owner row: B operand of S^T, k-step 4c + s
+#pragma unroll
+    for (int k = 0; k < 16; ++k) of[k] = *reinterpret_cast<const bf16x8*>(ownp + 16 * k + 8 * hi);
+    const float no2 = p.no[(int64_t)b * p.No + old_] * GF_LOG2E;
+    const float go = p.go[(int64_t)b * p.No + old_];
+
+    f32x16 acc[8];                                     // dOwn^T[d][o]: d-tile 2c + db
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    const FqAddr ad = fq_addresses(lds0, lane);
+
+    int stage = 0;
+    for (int t = 0; t < nt; ++t) {
+        if (t + 1 >= nt) wait_vm<0>();                            // tile t landed (this wave's pieces)
+        else wait_vm<9>();
+        __builtin_amdgcn_s_barrier();                             // ... everyone's; the stage of tile t-1 is free
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 2 < nt) issue_tile(t + 2, stage == 0 ? 2 : stage - 1);
+        const unsigned so = stage * HB_STAGE;
+        unsigned aR[4], aT[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { aR[i] = ad.aR[i] + so; aT[i] = ad.aT[i] + so; }
+        const unsigned aV = lds0 + so + HB_TILE + 16 * hi;        // ns of rows 8 g + 4 hi .. + 3 (gs: + 256 bytes)
+        const int s0 = t * 64;
+        const bool ragged = s0 + 64 > p.Ns;
+
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            // ---- S^T[s][o] for 32 streamed rows: 16 k-steps, fragments requested 8 at a time
+            f32x16 sc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+            // (never more than 12 LDS requests in flight: the counter holds 15)
+            u32x4 vn[4], vg[4], ka[4], kc[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                vn[g] = kb ? lds_rd128<128>(aV + 32 * g) : lds_rd128<0>(aV + 32 * g);
+                vg[g] = kb ? lds_rd128<256 + 128>(aV + 32 * g) : lds_rd128<256>(aV + 32 * g);
+            }
+#define GF_HB_RD(dst, c) _Pragma("unroll") for (int s = 0; s < 4; ++s) dst[s] = lds_rd128<(c) * FT_TILE>(aR[s] + kb * 4096);
+#define GF_HB_S(src, c) _Pragma("unroll") for (int s = 0; s < 4; ++s) { tie(src[s]); mma16(sc, as_frag(src[s]), of[4 * (c) + s]); }
+            GF_HB_RD(ka, 0)
+            wait_lgkm<4>();                                       // the row vectors
+            GF_HB_RD(kc, 1)
+            wait_lgkm<4>();
+            GF_HB_S(ka, 0)
+            GF_HB_RD(ka, 2)
+            wait_lgkm<4>();
+            GF_HB_S(kc, 1)
+            GF_HB_RD(kc, 3)
+            wait_lgkm<4>();
+            GF_HB_S(ka, 2)
+            wait_lgkm<0>();
+            GF_HB_S(kc, 3)
+#undef GF_HB_RD
+#undef GF_HB_S
+
+            // oth^T fragments of sub-tile 0 are requested before the exponentials
+            u32x2 va[2][2][2], vb[2][2][2];
+#define GF_HB_TR(dst, c) if (kb == 0) { GF_FQ_TR(dst, (c) * FT_TILE, 0, 0, 0) GF_FQ_TR(dst, (c) * FT_TILE, 0, 0, 1)   \
+                                        GF_FQ_TR(dst, (c) * FT_TILE, 0, 1, 0) GF_FQ_TR(dst, (c) * FT_TILE, 0, 1, 1) } \
+                         else         { GF_FQ_TR(dst, (c) * FT_TILE, 1, 0, 0) GF_FQ_TR(dst, (c) * FT_TILE, 1, 0, 1)   \
+                                        GF_FQ_TR(dst, (c) * FT_TILE, 1, 1, 0) GF_FQ_TR(dst, (c) * FT_TILE, 1, 1, 1) }
+            GF_HB_TR(va, 0)
+
+            // ---- dS (rows crow(r, hi) of this 32-row block)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                tie(vn[g]); tie(vg[g]);
+                const f32x4 n4 = __builtin_bit_cast(f32x4, vn[g]), g4 = __builtin_bit_cast(f32x4, vg[g]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float x = sc[4 * g + e];
+                    float v = fast_exp2((x - n4[e]) * GF_LOG2E) * g4[e] + fast_exp2(fmaf(x, GF_LOG2E, -no2)) * go;
+                    if (ragged && s0 + kb * 32 + 8 * g + 4 * hi + e >= p.Ns) v = 0.f;
+                    sc[4 * g + e] = v;
+                }
+            }
+            const bf16x8 p0 = cvt_frag(sc, 0), p1 = cvt_frag(sc, 1);
+
+            // ---- dOwn^T[d][o] += oth^T[d][s] dS[s][o]: sub-tile c feeds d-tiles 2c, 2c + 1 for both 16-row k-steps
+#define GF_HB_MMA(src, c)                                                                                  \
+            _Pragma("unroll") for (int db = 0; db < 2; ++db) {                                             \
+                tie(src[0][db][0]); tie(src[0][db][1]); tie(src[1][db][0]); tie(src[1][db][1]);            \
+                mma16(acc[2 * (c) + db], as_frag(src[0][db][0], src[0][db][1]), p0);                       \
+                mma16(acc[2 * (c) + db], as_frag(src[1][db][0], src[1][db][1]), p1);                       \
+            }
+            wait_lgkm<0>();
+            GF_HB_TR(vb, 1)
+            GF_HB_MMA(va, 0)
+            wait_lgkm<0>();
+            GF_HB_TR(va, 2)
+            GF_HB_MMA(vb, 1)
+            wait_lgkm<0>();
+            GF_HB_TR(vb, 3)
+            GF_HB_MMA(va, 2)
+            wait_lgkm<0>();
+            GF_HB_MMA(vb, 3)
+#undef GF_HB_MMA
+#undef GF_HB_TR
+        }
+        stage = stage == 2 ? 0 : stage + 1;
+    }
+    if (orow < p.No) {
+        bf16_t* dst = p.down + ((int64_t)b * p.No + orow) * 256;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const f32x16 pair[2] = {acc[2 * c], acc[2 * c + 1]};
+            store_row<bf16_t, 64>(dst + 64 * c, pair, 1.f, hi);
+        }
+    }
+}
+
 template <typename T, int HD> size_t fwd_lds() { return 2 * (Lay<T, HD>::ROWMAJOR + Lay<T, HD>::TRANSP) * sizeof(T); }
 template <typename T, int HD> size_t dq_lds() { return 2 * (2 * Lay<T, HD>::ROWMAJOR + Lay<T, HD>::TRANSP) * sizeof(T); }
 template <typename T, int HD> size_t dkv_lds() {
@@ -1226,4 +1392,24 @@ extern "C" int gf_attn_bwd(const void* q, const void* k, const void* v, const vo
     if (dtype == GF_F32) return launch_bwd<float>(p, st);
     if (dtype == GF_BF16) return launch_bwd<bf16_t>(p, st);
     return GF_ERR_DTYPE;
+}
+
+extern "C" int gf_head_bwd(const void* a, const void* b, const float* r, const float* c, const float* gr, const float* gc,
+                           void* da, void* db, int B, int M, int N, int D, int dtype, void* stream) {
+    if (B <= 0 || M <= 0 || N <= 0) return GF_ERR_SHAPE;
+    if (dtype != GF_BF16 || D != 256) return GF_ERR_UNSUPPORTED;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const size_t lds = (size_t)HB_NSTAGE * HB_STAGE;
+    if (int e = set_lds(head_bwd_bf16_kernel, lds)) return e;
+    HeadBwdParams p;
+    // d md1: owner = md1 rows (columns of S), streamed = md0 rows
+    p.own = static_cast<const bf16_t*>(b); p.oth = static_cast<const bf16_t*>(a); p.no = c; p.go = gc; p.ns = r; p.gs = gr;
+    p.down = static_cast<bf16_t*>(db); p.B = B; p.No = N; p.Ns = M;
+    head_bwd_bf16_kernel<<<dim3(((N + 127) / 128) * B), dim3(256), lds, st>>>(p);
+    if (int e = (int)hipGetLastError()) return e;
+    // d md0: owner = md0 rows, streamed = md1 rows
+    p.own = static_cast<const bf16_t*>(a); p.oth = static_cast<const bf16_t*>(b); p.no = r; p.go = gr; p.ns = c; p.gs = gc;
+    p.down = static_cast<bf16_t*>(da); p.No = M; p.Ns = N;
+    head_bwd_bf16_kernel<<<dim3(((M + 127) / 128) * B), dim3(256), lds, st>>>(p);
+    return (int)hipGetLastError();
 }

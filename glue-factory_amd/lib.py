@@ -26,6 +26,7 @@ SIGNATURES = {
     "gf_rows_argmax": [_P, _P, _P, _F, _P, _P, _I, _I, _I, _I, _I, _P],
     "gf_assign_write": [_P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _I, _I, _I, _I, _I, _P],
     "gf_dual_softmax_bwd": [_P, _P, _P, _P, _P, _P, _P, _L, _F, _P, _I, _I, _I, _I, _I, _P],
+    "gf_head_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "gf_filter_matches": [_P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _P],
     "gf_sinkhorn_ws_bytes": [_I, _I, _I, _I],
     "gf_sinkhorn_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],

@@ -664,6 +664,23 @@ def rows_argmax(a, b, colbias=None, alpha=1.0):
     return vmax, arg
 
 
+def _head_bwd(a, b, r, c, gr, gc, da, db):
+    """da = dS b, db = dS^T a for dS = P_row * gr + P_col * gc (module docstring of _DualLSE), written into the given
+    buffers.  bf16 / D = 256: the fused gf_head_bwd (no dS tensor); otherwise dS is written once and two batched
+    products follow."""
+    B, M, D = a.shape
+    N = b.shape[1]
+    if a.dtype == torch.bfloat16 and D == 256 and da.is_contiguous() and db.is_contiguous():
+        _lib.check(_lib.load().gf_head_bwd(_p(a), _p(b), _p(r), _p(c), _p(gr), _p(gc), _p(da), _p(db), B, M, N, D,
+                                           _dt(a), _stream()), "gf_head_bwd")
+        return
+    dS = torch.empty((B, M, N), dtype=a.dtype, device=a.device)
+    _lib.check(_lib.load().gf_dual_softmax_bwd(_p(a), _p(b), _p(r), _p(c), _p(gr), _p(gc), None, 0,
+                                               0.0, _p(dS), B, M, N, D, _dt(a), _stream()), "gf_dual_softmax_bwd")
+    torch.bmm(dS, b, out=da)
+    torch.bmm(dS.transpose(1, 2), a, out=db)
+
+
 class _DualLSE(torch.autograd.Function):
     """(r, c) = (LSE_j S_ij, LSE_i S_ij) for S = a b^T, never materialising S.
     Backward: dS = P_row * gr + P_col * gc (written once in the compute dtype), then two GEMMs."""
@@ -683,12 +700,8 @@ class _DualLSE(torch.autograd.Function):
         N = b.shape[1]
         gr = torch.zeros_like(r) if gr is None else gr.float().contiguous()
         gc = torch.zeros_like(c) if gc is None else gc.float().contiguous()
-        dS = torch.empty((B, M, N), dtype=a.dtype, device=a.device)
-        _lib.check(_lib.load().gf_dual_softmax_bwd(_p(a), _p(b), _p(r), _p(c), _p(gr), _p(gc), None, 0,
-                                                   0.0, _p(dS), B, M, N, D, _dt(a), _stream()),
-                   "gf_dual_softmax_bwd")
-        da = torch.bmm(dS, b)
-        db = torch.bmm(dS.transpose(1, 2), a)
+        da, db = torch.empty_like(a), torch.empty_like(b)
+        _head_bwd(a, b, r, c, gr, gc, da, db)
         return da, db
 
 
@@ -717,13 +730,8 @@ class _DualLSEStacked(torch.autograd.Function):
         a, b = md[:B], md[B:]
         gr = torch.zeros_like(r) if gr is None else gr.float().contiguous()
         gc = torch.zeros_like(c) if gc is None else gc.float().contiguous()
-        dS = torch.empty((B, N, N), dtype=md.dtype, device=md.device)
-        _lib.check(_lib.load().gf_dual_softmax_bwd(_p(a), _p(b), _p(r), _p(c), _p(gr), _p(gc), None, 0,
-                                                   0.0, _p(dS), B, N, N, D, _dt(md), _stream()),
-                   "gf_dual_softmax_bwd")
         d = torch.empty_like(md)
-        torch.bmm(dS, b, out=d[:B])
-        torch.bmm(dS.transpose(1, 2), a, out=d[B:])
+        _head_bwd(a, b, r, c, gr, gc, d[:B], d[B:])
         return d
 
 
@@ -798,12 +806,8 @@ class _LGLayerLoss(torch.autograd.Function):
         _lib.check(lib.gf_lg_loss_bwd_tokens(_p(z[:B]), _p(z[B:]), _p(neg0), _p(neg1), *tp, _p(pb), _p(pi), _p(pj), P,
                                              _p(gacc), _p(dz[:B]), _p(dz[B:]), *dtp, _p(grc[0]), _p(grc[1]),
                                              B, N, N, _stream()), "gf_lg_loss_bwd_tokens")
-        dS = torch.empty((B, N, N), dtype=md.dtype, device=md.device)
-        _lib.check(lib.gf_dual_softmax_bwd(_p(a), _p(b), _p(r), _p(c), _p(grc[0]), _p(grc[1]), None, 0, 0.0, _p(dS),
-                                           B, N, N, D, _dt(md), _stream()), "gf_dual_softmax_bwd")
         d = torch.empty_like(md)
-        torch.bmm(dS, b, out=d[:B])
-        torch.bmm(dS.transpose(1, 2), a, out=d[B:])
+        _head_bwd(a, b, r, c, grc[0], grc[1], d[:B], d[B:])
         _lib.check(lib.gf_lg_loss_bwd_rows(_p(a), _p(b), _p(pb), _p(pi), _p(pj), P, _p(gacc), _p(d[:B]), _p(d[B:]),
                                            B, N, N, D, _dt(md), _stream()), "gf_lg_loss_bwd_rows")
         return d, dz, dt, None, None, None, None, None, None

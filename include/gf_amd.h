@@ -119,6 +119,15 @@ int gf_dual_softmax_bwd(const void* a, const void* b, const float* r, const floa
                         float galpha, void* dS, int B, int M, int N, int D, int dtype,
                         void* stream);
 
+/* gf_head_bwd: the same backward WITHOUT the dS tensor and without the two GEMMs (bf16, D == 256; anything else
+ * returns GF_ERR_UNSUPPORTED and the caller uses gf_dual_softmax_bwd + its own products):
+ *   da[b,i,:] = sum_j dS_ij b[b,j,:],   db[b,j,:] = sum_i dS_ij a[b,i,:],
+ *   dS_ij = exp(S_ij - r_i) gr[b,i] + exp(S_ij - c_j) gc[b,j]            (S = a b^T, lightglue.py:256-290 autograd)
+ * Two passes of one kernel (owner rows of b, then of a): S tiles recomputed on the matrix cores, dS formed in
+ * registers and fed straight into the second product.  da [B,M,D], db [B,N,D] in `dtype`, contiguous rows. */
+int gf_head_bwd(const void* a, const void* b, const float* r, const float* c, const float* gr, const float* gc,
+                void* da, void* db, int B, int M, int N, int D, int dtype, void* stream);
+
 /* ---- mutual nearest neighbour filter (lightglue.py:293-309, superglue.py:301-311,
  * gluestick.py:321-334) from the row/column arg-max vectors:
  * max0 [B,M] (log-score of the row maximum), arg0 [B,M], arg1 [B,N] ->

@@ -514,3 +514,32 @@ def test_line_message_passing_kernels(dtype, mean):
     sc = xr.grad.abs().max().item()
     torch.testing.assert_close(xc.grad.float().cpu().double() / sc, xr.grad / sc, **tol)
     torch.testing.assert_close(ec.grad.float().cpu().double(), er.grad, **tol)
+
+
+@pytest.mark.parametrize("shape", [(2, 128, 128), (3, 200, 333), (1, 64, 1), (2, 2048, 2048)])
+def test_head_bwd_fused(shape):
+    """gf_head_bwd (assignment-head backward without the dS tensor: da = dS b, db = dS^T a with
+    dS = exp(S - r) gr + exp(S - c) gc, lightglue.py:256-290 autograd) vs an fp64 restatement on the same bf16 inputs;
+    ragged row / column counts, a single column, the benchmark size.  Tolerance: bf16 rounding of dS (2^-9 relative per
+    entry) and of the outputs, relative to the largest output entry."""
+    from glue_factory_amd import lib as L_
+    B, M, N = shape
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    a = (torch.randn(B, M, 256, device="cuda", generator=g) * 0.25).to(torch.bfloat16)
+    b = (torch.randn(B, N, 256, device="cuda", generator=g) * 0.25).to(torch.bfloat16)
+    gr = torch.randn(B, M, device="cuda", generator=g)
+    gc = torch.randn(B, N, device="cuda", generator=g)
+    S = torch.bmm(a.double(), b.double().transpose(1, 2))
+    r, c = S.logsumexp(2), S.logsumexp(1)
+    dS = (S - r[:, :, None]).exp() * gr.double()[:, :, None] + (S - c[:, None, :]).exp() * gc.double()[:, None, :]
+    da_ref, db_ref = torch.bmm(dS, b.double()), torch.bmm(dS.transpose(1, 2), a.double())
+    da = torch.full((B, M, 256), float("nan"), device="cuda", dtype=torch.bfloat16)
+    db = torch.full((B, N, 256), float("nan"), device="cuda", dtype=torch.bfloat16)
+    r32, c32 = r.float().contiguous(), c.float().contiguous()
+    L_.check(L_.load().gf_head_bwd(a.data_ptr(), b.data_ptr(), r32.data_ptr(), c32.data_ptr(),
+                                   gr.data_ptr(), gc.data_ptr(), da.data_ptr(), db.data_ptr(), B, M, N, 256, 1,
+                                   torch.cuda.current_stream().cuda_stream), "gf_head_bwd")
+    for name, x, y in (("da", da, da_ref), ("db", db, db_ref)):
+        sc = y.abs().max().item()
+        err = (x.double() - y).abs().max().item() / sc
+        assert err < 1.5e-2, f"{name}: max error {err:.3e} of the largest entry"
