@@ -450,7 +450,7 @@ def main():
         torch.cuda.synchronize()
 
     model, cpu_data = build_matcher(args, rank, args.model)
-    stepper = make_stepper(args, model, local)
+    stepper = make_stepper(args, model, local, allow_graph=args.model == "lightglue")   # the others' losses read nonzero()
     data = to_device(cpu_data, "cuda")
 
     def matcher_step():

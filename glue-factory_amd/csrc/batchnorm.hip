@@ -141,6 +141,72 @@ int launch_apply(const void* x, const void* dy, const float* mean, const float* 
     return (int)hipGetLastError();
 }
 
+
+// Everything between the per-block partial sums and the apply pass, in one launch per direction (was ~15 tiny
+// tensor kernels per BatchNorm call: sum over blocks, divisions, clamp, rsqrt, the running-statistics update).
+// fwd: part [nblk][2][C] = (sum x, sum x^2) -> mean, var (biased), rstd; running_mean / running_var (may be NULL)
+//      updated in place with `momentum` and the unbiased variance, as torch.nn.BatchNorm1d does.
+// (256 threads = 32 channels x 8 block groups: the <= 512 partials of a channel are summed 8-way in parallel, then
+// through LDS -- a single thread per channel walking 512 dependent loads took ~100 us)
+__device__ __forceinline__ void bn_block_sums(const float* __restrict__ part, int nblk, int C, int c, float& s0, float& s1) {
+    __shared__ float red[2][8][32];
+    const int cl = threadIdx.x & 31, kg = threadIdx.x >> 5;
+    float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+    if (c < C) {
+        int k = kg;
+        for (; k + 8 < nblk; k += 16) {
+            a0 += part[(int64_t)k * 2 * C + c];
+            a1 += part[(int64_t)k * 2 * C + C + c];
+            b0 += part[(int64_t)(k + 8) * 2 * C + c];
+            b1 += part[(int64_t)(k + 8) * 2 * C + C + c];
+        }
+        if (k < nblk) {
+            a0 += part[(int64_t)k * 2 * C + c];
+            a1 += part[(int64_t)k * 2 * C + C + c];
+        }
+    }
+    red[0][kg][cl] = a0 + b0;
+    red[1][kg][cl] = a1 + b1;
+    __syncthreads();
+    s0 = s1 = 0.f;
+    if (kg == 0) {
+#pragma unroll
+        for (int g = 0; g < 8; ++g) { s0 += red[0][g][cl]; s1 += red[1][g][cl]; }
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const float* __restrict__ part, int nblk, int C, float n, float eps,
+                                                              float momentum, float* __restrict__ mean, float* __restrict__ var,
+                                                              float* __restrict__ rstd, float* __restrict__ run_mean,
+                                                              float* __restrict__ run_var) {
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+    float s0, s1;
+    bn_block_sums(part, nblk, C, c, s0, s1);
+    if (threadIdx.x >= 32 || c >= C) return;
+    const float m = s0 / n;
+    const float v = fmaxf(s1 / n - m * m, 0.f);
+    mean[c] = m;
+    var[c] = v;
+    rstd[c] = rsqrtf(v + eps);
+    if (run_mean) {
+        run_mean[c] = run_mean[c] * (1.f - momentum) + m * momentum;
+        run_var[c] = run_var[c] * (1.f - momentum) + v * (n / fmaxf(n - 1.f, 1.f)) * momentum;
+    }
+}
+// bwd: part = (sum dz, sum dz * xhat) -> dbeta, dgamma (the sums) and m1 = sum dz / n, m2 = sum dz xhat / n
+__global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const float* __restrict__ part, int nblk, int C, float inv_n,
+                                                              float* __restrict__ dbeta, float* __restrict__ dgamma,
+                                                              float* __restrict__ m1, float* __restrict__ m2) {
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+    float s0, s1;
+    bn_block_sums(part, nblk, C, c, s0, s1);
+    if (threadIdx.x >= 32 || c >= C) return;
+    dbeta[c] = s0;
+    dgamma[c] = s1;
+    m1[c] = s0 * inv_n;
+    m2[c] = s1 * inv_n;
+}
+
 }  // namespace
 
 extern "C" int gf_bn_nblk(int M) { return bn_blocks(M); }
@@ -180,4 +246,21 @@ extern "C" int gf_bn_bwd_dx(const void* x, const void* dy, const float* mean, co
     if (dtype == GF_F32) return launch_apply<float, 1>(x, dy, mean, rstd, gamma, beta, m1, m2, dx, M, C, relu, st);
     if (dtype == GF_BF16) return launch_apply<bf16_t, 1>(x, dy, mean, rstd, gamma, beta, m1, m2, dx, M, C, relu, st);
     return GF_ERR_DTYPE;
+}
+
+extern "C" int gf_bn_finalize_fwd(const float* part, int nblk, int C, float n, float eps, float momentum,
+                                  float* mean, float* var, float* rstd, float* run_mean, float* run_var, void* stream) {
+    if (nblk <= 0 || C <= 0 || n <= 0.f) return GF_ERR_SHAPE;
+    if ((run_mean == nullptr) != (run_var == nullptr)) return GF_ERR_SHAPE;
+    bn_finalize_fwd_kernel<<<dim3((C + 31) / 32), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
+        part, nblk, C, n, eps, momentum, mean, var, rstd, run_mean, run_var);
+    return (int)hipGetLastError();
+}
+
+extern "C" int gf_bn_finalize_bwd(const float* part, int nblk, int C, float n, float* dbeta, float* dgamma,
+                                  float* m1, float* m2, void* stream) {
+    if (nblk <= 0 || C <= 0 || n <= 0.f) return GF_ERR_SHAPE;
+    bn_finalize_bwd_kernel<<<dim3((C + 31) / 32), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
+        part, nblk, C, 1.f / n, dbeta, dgamma, m1, m2);
+    return (int)hipGetLastError();
 }

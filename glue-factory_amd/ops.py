@@ -983,60 +983,87 @@ class _BatchNormAct(torch.autograd.Function):
     only y is differentiable."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, mean_in, rstd_in, eps, training, relu, sync):
+    def forward(ctx, x, gamma, beta, mean_in, rstd_in, eps, training, relu, sync, run_mean=None, run_var=None,
+                momentum=0.0):
+        """run_mean / run_var (fp32, contiguous) given: updated in place by the finalize kernel (single-process
+        training); otherwise the caller updates the running statistics from the returned mean / var / n."""
         _chk(x)
         M, C = x.shape
         L = _lib.load()
         g32, b32 = gamma.float().contiguous(), beta.float().contiguous()
         if training:
-            part = torch.empty((L.gf_bn_nblk(M), 2, C), dtype=torch.float32, device=x.device)
+            nblk = L.gf_bn_nblk(M)
+            part = torch.empty((nblk, 2, C), dtype=torch.float32, device=x.device)
             _lib.check(L.gf_bn_stats(_p(x), _p(part), M, C, _dt(x), _stream()), "gf_bn_stats")
-            s = part.sum(0)
-            n_t = torch.full((), float(M), dtype=s.dtype, device=s.device)      # device-side fill: capturable
             if sync:
                 import torch.distributed as dist
+                s = part.sum(0)
+                n_t = torch.full((), float(M), dtype=s.dtype, device=s.device)      # device-side fill: capturable
                 packed = torch.cat([s.flatten(), n_t[None]])
                 dist.all_reduce(packed)
                 s, n_t = packed[:-1].view(2, C), packed[-1]
-            mean = (s[0] / n_t).contiguous()
-            var = (s[1] / n_t - mean * mean).clamp(min=0.0)
-            rstd = torch.rsqrt(var + eps).contiguous()
+                mean = (s[0] / n_t).contiguous()
+                var = (s[1] / n_t - mean * mean).clamp(min=0.0)
+                rstd = torch.rsqrt(var + eps).contiguous()
+            else:       # one kernel: block sums -> mean / var / rstd (+ running statistics)
+                mvr = torch.empty((3, C), dtype=torch.float32, device=x.device)
+                mean, var, rstd = mvr[0], mvr[1], mvr[2]
+                _lib.check(L.gf_bn_finalize_fwd(_p(part), nblk, C, float(M), float(eps), float(momentum), _p(mean),
+                                                _p(var), _p(rstd), _p(run_mean), _p(run_var), _stream()),
+                           "gf_bn_finalize_fwd")
+                n_t = float(M)
         else:
             mean, rstd = mean_in.float().contiguous(), rstd_in.float().contiguous()
-            var, n_t = mean.new_zeros(C), torch.full((), float(M), dtype=mean.dtype, device=mean.device)
+            var, n_t = mean.new_zeros(C), float(M)
         y = torch.empty_like(x)
         _lib.check(L.gf_bn_act_fwd(_p(x), _p(mean), _p(rstd), _p(g32), _p(b32), _p(y), M, C, int(relu), _dt(x),
                                    _stream()), "gf_bn_act_fwd")
-        ctx.save_for_backward(x, mean, rstd, g32, b32, n_t)
+        if torch.is_tensor(n_t):
+            ctx.save_for_backward(x, mean, rstd, g32, b32, n_t)
+            ctx.n = None
+        else:
+            ctx.save_for_backward(x, mean, rstd, g32, b32)
+            ctx.n = n_t
+            n_t = torch.empty(0, device=x.device)          # placeholder output (the count is a host constant here)
         ctx.cfg = (training, relu, sync, gamma.dtype, beta.dtype)
         ctx.mark_non_differentiable(mean, var, n_t)
         return y, mean, var, n_t
 
     @staticmethod
     def backward(ctx, dy, _gm, _gv, _gn):
-        x, mean, rstd, g32, b32, n_t = ctx.saved_tensors
+        if ctx.n is None:
+            x, mean, rstd, g32, b32, n_t = ctx.saved_tensors
+        else:
+            x, mean, rstd, g32, b32 = ctx.saved_tensors
+            n_t = None
         training, relu, sync, gdt, bdt = ctx.cfg
         M, C = x.shape
         if not dy.is_contiguous():
             dy = dy.contiguous()
         L = _lib.load()
-        part = torch.empty((L.gf_bn_nblk(M), 2, C), dtype=torch.float32, device=x.device)
+        nblk = L.gf_bn_nblk(M)
+        part = torch.empty((nblk, 2, C), dtype=torch.float32, device=x.device)
         _lib.check(L.gf_bn_bwd_stats(_p(x), _p(dy), _p(mean), _p(rstd), _p(g32), _p(b32), _p(part), M, C,
                                      int(relu), _dt(x), _stream()), "gf_bn_bwd_stats")
-        s = part.sum(0)
-        dbeta, dgamma = s[0].clone(), s[1].clone()          # local sums: DDP averages parameter grads
-        if training:
-            if sync:
+        if training and not sync:
+            out = torch.empty((4, C), dtype=torch.float32, device=x.device)
+            dbeta, dgamma, m1, m2 = out[0], out[1], out[2], out[3]
+            _lib.check(L.gf_bn_finalize_bwd(_p(part), nblk, C, float(M), _p(dbeta), _p(dgamma), _p(m1), _p(m2),
+                                            _stream()), "gf_bn_finalize_bwd")
+        else:
+            s = part.sum(0)
+            dbeta, dgamma = s[0].clone(), s[1].clone()          # local sums: DDP averages parameter grads
+            if training:
                 import torch.distributed as dist
                 s = s.contiguous()
                 dist.all_reduce(s)
-            m1, m2 = (s[0] / n_t).contiguous(), (s[1] / n_t).contiguous()
-        else:
-            m1 = m2 = torch.zeros(C, dtype=torch.float32, device=x.device)
+                m1, m2 = (s[0] / n_t).contiguous(), (s[1] / n_t).contiguous()
+            else:
+                m1 = m2 = torch.zeros(C, dtype=torch.float32, device=x.device)
         dx = torch.empty_like(x)
         _lib.check(L.gf_bn_bwd_dx(_p(x), _p(dy), _p(mean), _p(rstd), _p(g32), _p(b32), _p(m1), _p(m2), _p(dx),
                                   M, C, int(relu), _dt(x), _stream()), "gf_bn_bwd_dx")
-        return dx, dgamma.to(gdt), dbeta.to(bdt), None, None, None, None, None, None
+        return dx, dgamma.to(gdt), dbeta.to(bdt), None, None, None, None, None, None, None, None, None
 
 
 def batch_norm_act(x, bn, relu=True):
@@ -1051,9 +1078,20 @@ def batch_norm_act(x, bn, relu=True):
         import torch.distributed as dist
         sync = (isinstance(bn, torch.nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized()
                 and dist.get_world_size() > 1)
-        y, mean, var, n_t = _BatchNormAct.apply(x, bn.weight, bn.bias, None, None, bn.eps, True, relu, sync)
-        if bn.training and bn.track_running_stats:
+        track = bn.training and bn.track_running_stats
+        fused_running = (track and not sync and bn.momentum is not None and bn.running_mean.dtype == torch.float32
+                         and bn.running_mean.is_contiguous() and bn.running_var.is_contiguous())
+        if fused_running:       # the finalize kernel updates the running statistics in place
+            y = _BatchNormAct.apply(x, bn.weight, bn.bias, None, None, bn.eps, True, relu, sync,
+                                    bn.running_mean, bn.running_var, float(bn.momentum))[0]
             with torch.no_grad():
+                bn.num_batches_tracked += 1
+            return y
+        y, mean, var, n_t = _BatchNormAct.apply(x, bn.weight, bn.bias, None, None, bn.eps, True, relu, sync)
+        if track:
+            with torch.no_grad():
+                if not torch.is_tensor(n_t) or n_t.numel() == 0:
+                    n_t = torch.full((), float(x.shape[0]), dtype=torch.float32, device=x.device)
                 bn.num_batches_tracked += 1
                 mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
                 unbiased = var * (n_t / (n_t - 1).clamp(min=1.0))

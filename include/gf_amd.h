@@ -209,6 +209,15 @@ int gf_bn_bwd_stats(const void* x, const void* dy, const float* mean, const floa
 int gf_bn_bwd_dx(const void* x, const void* dy, const float* mean, const float* rstd,
                  const float* gamma, const float* beta, const float* m1, const float* m2,
                  void* dx, int M, int C, int relu, int dtype, void* stream);
+/* gf_bn_finalize_fwd / _bwd: the glue between the partial sums and the apply pass in ONE launch each (single
+ * process; under SyncBatchNorm the caller all-reduces the summed partials itself and finalises on the host side):
+ *   fwd: mean, var (biased), rstd = 1/sqrt(var + eps) from part = gf_bn_stats' output and the row count n; when
+ *        run_mean / run_var are given they are updated in place as nn.BatchNorm1d does (momentum, unbiased variance);
+ *   bwd: dbeta = sum dz, dgamma = sum dz xhat and m1 = dbeta / n, m2 = dgamma / n from gf_bn_bwd_stats' output. */
+int gf_bn_finalize_fwd(const float* part, int nblk, int C, float n, float eps, float momentum,
+                       float* mean, float* var, float* rstd, float* run_mean, float* run_var, void* stream);
+int gf_bn_finalize_bwd(const float* part, int nblk, int C, float n, float* dbeta, float* dgamma,
+                       float* m1, float* m2, void* stream);
 
 /* ---- ground-truth nearest neighbours under a homography (gluefactory/geometry/gt_generation.py:120-150)
  * For every point i of the "own" set [B,No,2] (own = its coordinates, own_warped = the same points
