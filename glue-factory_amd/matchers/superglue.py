@@ -81,7 +81,7 @@ def _mlp_cl(seq, x, halves, x2=None):
                 x = torch.relu(y) if relu else y
             else:
                 parts = x.reshape(halves, (b // halves) * n, c)
-                x = torch.stack([ops.batch_norm_act(parts[k], layer, relu) for k in range(halves)]).reshape(b, n, c)
+                x = ops.batch_norm_act_sets(parts, layer, relu).reshape(b, n, c)
             i += int(relu)
         else:
             x = layer(x)

@@ -1066,6 +1066,78 @@ class _BatchNormAct(torch.autograd.Function):
         return dx, dgamma.to(gdt), dbeta.to(bdt), None, None, None, None, None, None, None, None, None
 
 
+class _BatchNormActSets(torch.autograd.Function):
+    """act(BatchNorm(x[h])) for h = 0..H-1 on x [H,M,C]: H independent statistics sets through the SAME BatchNorm
+    module (the reference calls its MLP once per image: superglue.py:70-79 via :276-283), single-process training.
+    One node: no select / stack copies around the per-image calls, running statistics updated set after set."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, relu, run_mean, run_var, momentum):
+        _chk(x)
+        H, M, C = x.shape
+        L = _lib.load()
+        g32, b32 = gamma.float().contiguous(), beta.float().contiguous()
+        nblk = L.gf_bn_nblk(M)
+        part = torch.empty((nblk, 2, C), dtype=torch.float32, device=x.device)
+        mvr = torch.empty((H, 3, C), dtype=torch.float32, device=x.device)
+        y = torch.empty_like(x)
+        st, dt = _stream(), _dt(x)
+        for h in range(H):
+            _lib.check(L.gf_bn_stats(_p(x[h]), _p(part), M, C, dt, st), "gf_bn_stats")
+            _lib.check(L.gf_bn_finalize_fwd(_p(part), nblk, C, float(M), float(eps), float(momentum), _p(mvr[h, 0]),
+                                            _p(mvr[h, 1]), _p(mvr[h, 2]), _p(run_mean), _p(run_var), st),
+                       "gf_bn_finalize_fwd")
+            _lib.check(L.gf_bn_act_fwd(_p(x[h]), _p(mvr[h, 0]), _p(mvr[h, 2]), _p(g32), _p(b32), _p(y[h]), M, C,
+                                       int(relu), dt, st), "gf_bn_act_fwd")
+        ctx.save_for_backward(x, mvr, g32, b32)
+        ctx.cfg = (relu, gamma.dtype, beta.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mvr, g32, b32 = ctx.saved_tensors
+        relu, gdt, bdt = ctx.cfg
+        H, M, C = x.shape
+        if not dy.is_contiguous():
+            dy = dy.contiguous()
+        L = _lib.load()
+        nblk = L.gf_bn_nblk(M)
+        part = torch.empty((nblk, 2, C), dtype=torch.float32, device=x.device)
+        out = torch.empty((H, 4, C), dtype=torch.float32, device=x.device)
+        dx = torch.empty_like(x)
+        st, dt = _stream(), _dt(x)
+        for h in range(H):
+            mean, rstd = mvr[h, 0], mvr[h, 2]
+            _lib.check(L.gf_bn_bwd_stats(_p(x[h]), _p(dy[h]), _p(mean), _p(rstd), _p(g32), _p(b32), _p(part), M, C,
+                                         int(relu), dt, st), "gf_bn_bwd_stats")
+            _lib.check(L.gf_bn_finalize_bwd(_p(part), nblk, C, float(M), _p(out[h, 0]), _p(out[h, 1]), _p(out[h, 2]),
+                                            _p(out[h, 3]), st), "gf_bn_finalize_bwd")
+            _lib.check(L.gf_bn_bwd_dx(_p(x[h]), _p(dy[h]), _p(mean), _p(rstd), _p(g32), _p(b32), _p(out[h, 2]),
+                                      _p(out[h, 3]), _p(dx[h]), M, C, int(relu), dt, st), "gf_bn_bwd_dx")
+        dbeta, dgamma = (out[0, 0], out[0, 1]) if H == 1 else (out[:, 0].sum(0), out[:, 1].sum(0))
+        return dx, dgamma.to(gdt), dbeta.to(bdt), None, None, None, None, None
+
+
+def batch_norm_act_sets(x, bn, relu=True):
+    """x [H,M,C]: ``batch_norm_act`` applied to each of the H sets in turn (set h sees the running statistics already
+    updated by set h-1, exactly like H consecutive module calls), as ONE autograd node where that is possible."""
+    assert x.dim() == 3
+    if not x.is_contiguous():
+        x = x.contiguous()
+    import torch.distributed as dist
+    sync = (isinstance(bn, torch.nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized()
+            and dist.get_world_size() > 1)
+    if (bn.training and bn.track_running_stats and not sync and bn.momentum is not None
+            and bn.running_mean.dtype == torch.float32 and bn.running_mean.is_contiguous()
+            and bn.running_var.is_contiguous()):
+        y = _BatchNormActSets.apply(x, bn.weight, bn.bias, bn.eps, relu, bn.running_mean, bn.running_var,
+                                    float(bn.momentum))
+        with torch.no_grad():
+            bn.num_batches_tracked += x.shape[0]
+        return y
+    return torch.stack([batch_norm_act(x[h], bn, relu) for h in range(x.shape[0])])
+
+
 def batch_norm_act(x, bn, relu=True):
     """x [M,C] channels-last through ``bn`` (an nn.BatchNorm1d / SyncBatchNorm that owns the affine
     parameters and running statistics), then ReLU when ``relu``.  Training mode uses batch statistics
