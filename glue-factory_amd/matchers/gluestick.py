@@ -272,7 +272,9 @@ class GlueStick(BaseModel):
         inter = self.gnn.inter_supervision
         for i, layer in enumerate(self.gnn.layers):
             cross = layer.type == "cross"
-            if stacked:
+            if stacked and not torch.is_tensor(layer.update.scaling) and layer.update.scaling == 1.0:
+                xs = [layer.update(xs[0], cross=cross, halves=2, residual=True)]      # residual inside the last GEMM
+            elif stacked:
                 xs = [xs[0] + layer.update(xs[0], cross=cross, halves=2) * layer.update.scaling]
             else:
                 d0, d1 = layer.update.forward_pair(xs[0], xs[1], cross=cross)

@@ -57,20 +57,25 @@ def _conv_cl(x, conv, rows=None, cols=None):
     return ops.linear(x, w, b)
 
 
-def _mlp_cl(seq, x, halves, x2=None):
+def _mlp_cl(seq, x, halves, x2=None, res=None, chain=None):
     """Run an MLP Sequential (Conv1d / BatchNorm1d / ReLU) on channels-last x [B',N,C].
     BatchNorm (+ the ReLU that follows it) is one fused HIP pass pair, applied per image set
     (``halves`` = 2 when two images are stacked on the batch axis), reproducing the reference's
-    one-call-per-image statistics and running-stat updates."""
+    one-call-per-image statistics and running-stat updates.  ``res``: added to the output inside the last
+    convolution's GEMM epilogue; ``chain``: ops.GradChain of x (= res) for the first convolution and the residual."""
     layers = list(seq)
     i = 0
     if x2 is not None:      # first conv on cat[x, x2] without building the concatenation
         first = layers[0]
-        x = ops.linear_cat(x, x2, first.weight.squeeze(-1), first.bias)
+        x = ops.linear_cat(x, x2, first.weight.squeeze(-1), first.bias, chain1=chain)
         i = 1
     while i < len(layers):
         layer = layers[i]
-        if isinstance(layer, nn.Conv1d):
+        if isinstance(layer, nn.Conv1d) and i == len(layers) - 1 and res is not None \
+                and layer.out_channels % 8 == 0 and layer.in_channels % 8 == 0:
+            x = ops.linear(x, layer.weight.squeeze(-1), layer.bias, res=res, res_chain=chain)
+            res = None
+        elif isinstance(layer, nn.Conv1d):
             x = _conv_cl(x, layer)
         elif isinstance(layer, nn.modules.batchnorm._BatchNorm):
             relu = i + 1 < len(layers) and isinstance(layers[i + 1], nn.ReLU)
@@ -86,7 +91,7 @@ def _mlp_cl(seq, x, halves, x2=None):
         else:
             x = layer(x)
         i += 1
-    return x
+    return x if res is None else x + res
 
 
 def normalize_keypoints(kpts, size=None, shape=None):
@@ -123,10 +128,10 @@ class MultiHeadedAttention(nn.Module):
         perm = (torch.arange(self.dim)[None, :] * h + torch.arange(h)[:, None]).reshape(-1)
         self.register_buffer("_perm", perm, persistent=False)
 
-    def fused_projection(self, x):
+    def fused_projection(self, x, chain=None):
         w = torch.cat([p.weight.squeeze(-1).index_select(0, self._perm) for p in self.proj], 0)
         b = torch.cat([p.bias.index_select(0, self._perm) for p in self.proj], 0)
-        qkv = ops.linear(x, w, b)
+        qkv = ops.linear(x, w, b, chain=chain, chain_last=True)
         return qkv.view(x.shape[0], x.shape[1], 3, self.h, self.dim)
 
 
@@ -137,12 +142,15 @@ class AttentionalPropagation(nn.Module):
         self.mlp = MLP([num_dim * 2, num_dim * 2, num_dim])
         nn.init.constant_(self.mlp[-1].bias, 0.0)
 
-    def forward(self, x, cross, halves):
-        """x [B',N,C] (stacked images when halves == 2); returns the residual delta."""
+    def forward(self, x, cross, halves, residual=False):
+        """x [B',N,C] (stacked images when halves == 2); returns the residual delta, or with ``residual`` the updated
+        x + delta (the addition rides in the last GEMM's epilogue, and the three gradients that meet in x -- residual,
+        MLP input, projection -- are summed in GEMM epilogues: ops.GradChain)."""
         b, n, d = x.shape
-        o = ops.attention_qkv(self.attn.fused_projection(x), cross=cross)
+        chain = ops.GradChain(3) if residual and x.requires_grad and torch.is_grad_enabled() else None
+        o = ops.attention_qkv(self.attn.fused_projection(x, chain), cross=cross)
         msg = _conv_cl(o.view(b, n, d), self.attn.merge, cols=self.attn._perm)
-        return _mlp_cl(self.mlp, x, halves, x2=msg)
+        return _mlp_cl(self.mlp, x, halves, x2=msg, res=x if residual else None, chain=chain)
 
     def forward_pair(self, x0, x1, cross):
         """Different keypoint counts: one projection per image, generic attention op."""
@@ -221,7 +229,7 @@ class SuperGlue(BaseModel):
             for layer, name in zip(self.gnn.layers, self.gnn.names):
                 if name not in ("self", "cross"):
                     raise ValueError(name)
-                x = x + layer(x, cross=(name == "cross"), halves=2)
+                x = layer(x, cross=(name == "cross"), halves=2, residual=True)
             md = _conv_cl(x, self.final_proj)
             md0, md1 = md[:b], md[b:]
         else:
