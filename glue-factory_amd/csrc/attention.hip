@@ -1149,16 +1149,22 @@ __global__ __launch_bounds__(256, 1) void head_bwd_bf16_kernel(HeadBwdParams p) 
     const float* gsp = p.gs + (int64_t)b * p.Ns;
 
     const int nt = (p.Ns + 63) / 64;
-    auto issue_tile = [&](int t, int stage) {
+    // part i of tile t's DMA: i < 4 the two pieces of sub-tile i, i == 4 the per-row vectors (waves 0 / 1 bring ns / gs,
+    // waves 2 / 3 the same into spare slots: equal vmcnt in every wave).  Tiles past the end re-fetch the last one.
+    auto issue_part = [&](int t, int stage, int i) {
         char* sb = smem + stage * HB_STAGE;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) fq_issue(othp + 64 * c, 256, t * 64, p.Ns, sb + c * FT_TILE, wave, lane);
-        // per-row vectors: waves 0 / 1 bring ns / gs, waves 2 / 3 the same into spare slots (equal vmcnt in every wave)
-        const float* src = (wave & 1) ? gsp : nsp;
-        dma4(src + min(t * 64 + lane, p.Ns - 1), sb + HB_TILE + (wave & 1) * 256 + (wave >> 1) * 512);
+        const int tc = min(t, nt - 1);
+        if (i < 4) {
+            fq_issue(othp + 64 * i, 256, tc * 64, p.Ns, sb + i * FT_TILE, wave, lane);
+        } else {
+            const float* src = (wave & 1) ? gsp : nsp;
+            dma4(src + min(tc * 64 + lane, p.Ns - 1), sb + HB_TILE + (wave & 1) * 256 + (wave >> 1) * 512);
+        }
     };
-    issue_tile(0, 0);
-    if (nt > 1) issue_tile(1, 1);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) issue_part(0, 0, i);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) issue_part(1, 1, i);
 
     bf16x8 of[16];                                     // owner row: B operand of S^T, k-step 4c + s
 #pragma unroll
@@ -1175,96 +1181,128 @@ __global__ __launch_bounds__(256, 1) void head_bwd_bf16_kernel(HeadBwdParams p) 
 
     int stage = 0;
     for (int t = 0; t < nt; ++t) {
-        if (t + 1 >= nt) wait_vm<0>();                            // tile t landed (this wave's pieces)
-        else wait_vm<9>();
+        wait_vm<9>();                                             // tile t landed (this wave's pieces; t + 1 in flight)
         __builtin_amdgcn_s_barrier();                             // ... everyone's; the stage of tile t-1 is free
         __builtin_amdgcn_sched_barrier(0);
-        if (t + 2 < nt) issue_tile(t + 2, stage == 0 ? 2 : stage - 1);
+        const int nstage = stage == 0 ? 2 : stage - 1;            // tile t + 2 goes there, piece by piece between MFMAs
         const unsigned so = stage * HB_STAGE;
         unsigned aR[4], aT[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) { aR[i] = ad.aR[i] + so; aT[i] = ad.aT[i] + so; }
         const unsigned aV = lds0 + so + HB_TILE + 16 * hi;        // ns of rows 8 g + 4 hi .. + 3 (gs: + 256 bytes)
         const int s0 = t * 64;
-        const bool ragged = s0 + 64 > p.Ns;
-
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            // ---- S^T[s][o] for 32 streamed rows: 16 k-steps, fragments requested 8 at a time
-            f32x16 sc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sc[r] = 0.f;
-            // (never more than 12 LDS requests in flight: the counter holds 15)
-            u32x4 vn[4], vg[4], ka[4], kc[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                vn[g] = kb ? lds_rd128<128>(aV + 32 * g) : lds_rd128<0>(aV + 32 * g);
-                vg[g] = kb ? lds_rd128<256 + 128>(aV + 32 * g) : lds_rd128<256>(aV + 32 * g);
+        if (s0 + 64 > p.Ns) {        // ragged last tile: the clamped duplicate rows become zero rows of oth (no contribution)
+            const int lim = p.Ns - s0;
+            for (int i = threadIdx.x; i < 4 * 64 * 8; i += 256) {
+                const int row = (i >> 3) & 63;
+                if (row >= lim) *reinterpret_cast<u32x4*>(smem + so + (i >> 9) * FT_TILE + row * 128 + (i & 7) * 16) = u32x4{0, 0, 0, 0};
             }
-#define GF_HB_RD(dst, c) _Pragma("unroll") for (int s = 0; s < 4; ++s) dst[s] = lds_rd128<(c) * FT_TILE>(aR[s] + kb * 4096);
-#define GF_HB_S(src, c) _Pragma("unroll") for (int s = 0; s < 4; ++s) { tie(src[s]); mma16(sc, as_frag(src[s]), of[4 * (c) + s]); }
-            GF_HB_RD(ka, 0)
-            wait_lgkm<4>();                                       // the row vectors
-            GF_HB_RD(kc, 1)
-            wait_lgkm<4>();
-            GF_HB_S(ka, 0)
-            GF_HB_RD(ka, 2)
-            wait_lgkm<4>();
-            GF_HB_S(kc, 1)
-            GF_HB_RD(kc, 3)
-            wait_lgkm<4>();
-            GF_HB_S(ka, 2)
-            wait_lgkm<0>();
-            GF_HB_S(kc, 3)
-#undef GF_HB_RD
-#undef GF_HB_S
+            __syncthreads();
+        }
 
-            // oth^T fragments of sub-tile 0 are requested before the exponentials
-            u32x2 va[2][2][2], vb[2][2][2];
-#define GF_HB_TR(dst, c) if (kb == 0) { GF_FQ_TR(dst, (c) * FT_TILE, 0, 0, 0) GF_FQ_TR(dst, (c) * FT_TILE, 0, 0, 1)   \
-                                        GF_FQ_TR(dst, (c) * FT_TILE, 0, 1, 0) GF_FQ_TR(dst, (c) * FT_TILE, 0, 1, 1) } \
-                         else         { GF_FQ_TR(dst, (c) * FT_TILE, 1, 0, 0) GF_FQ_TR(dst, (c) * FT_TILE, 1, 0, 1)   \
-                                        GF_FQ_TR(dst, (c) * FT_TILE, 1, 1, 0) GF_FQ_TR(dst, (c) * FT_TILE, 1, 1, 1) }
-            GF_HB_TR(va, 0)
-
-            // ---- dS (rows crow(r, hi) of this 32-row block)
+        // One wave per SIMD: the exponentials only overlap the matrix pipe if they sit BETWEEN MFMAs in program order.
+        // Schedule per tile: S(rows 0-31) | S(rows 32-63) with dS(rows 0-31) one element per MFMA gap |
+        // second product (rows 0-31) with dS(rows 32-63) in its gaps | second product (rows 32-63).
+        u32x4 vn[2][4], vg[2][4];
+        f32x16 sc0, sc1;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                tie(vn[g]); tie(vg[g]);
-                const f32x4 n4 = __builtin_bit_cast(f32x4, vn[g]), g4 = __builtin_bit_cast(f32x4, vg[g]);
+        for (int r = 0; r < 16; ++r) { sc0[r] = 0.f; sc1[r] = 0.f; }
+        auto elem = [&](f32x16& sc, const u32x4 (&n_)[4], const u32x4 (&g_)[4], int i) {
+            const f32x4 n4 = __builtin_bit_cast(f32x4, n_[i >> 2]), g4 = __builtin_bit_cast(f32x4, g_[i >> 2]);
+            const float x = sc[i];
+            sc[i] = fast_exp2((x - n4[i & 3]) * GF_LOG2E) * g4[i & 3] + fast_exp2(fmaf(x, GF_LOG2E, -no2)) * go;
+        };
+        u32x4 ka[4], kc[4];
+#define GF_HB_RD(dst, c, KB) _Pragma("unroll") for (int s = 0; s < 4; ++s) dst[s] = lds_rd128<(c) * FT_TILE + (KB) * 4096>(aR[s]);
+#define GF_HB_S(sc, src, c, SIDE) _Pragma("unroll") for (int s = 0; s < 4; ++s) { tie(src[s]); mma16(sc, as_frag(src[s]), of[4 * (c) + s]); SIDE(4 * (c) + s) }
+#define GF_HB_NONE(i)
+#define GF_HB_DMA(i) if ((i) % 3 == 0 && (i) / 3 < 5) issue_part(t + 2, nstage, (i) / 3);
+#define GF_HB_E0(i) elem(sc0, vn[0], vg[0], i);
+#define GF_HB_E1(i) elem(sc1, vn[1], vg[1], i);
+        // (never more than 12 LDS requests in flight: the counter holds 15)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float x = sc[4 * g + e];
-                    float v = fast_exp2((x - n4[e]) * GF_LOG2E) * g4[e] + fast_exp2(fmaf(x, GF_LOG2E, -no2)) * go;
-                    if (ragged && s0 + kb * 32 + 8 * g + 4 * hi + e >= p.Ns) v = 0.f;
-                    sc[4 * g + e] = v;
-                }
-            }
-            const bf16x8 p0 = cvt_frag(sc, 0), p1 = cvt_frag(sc, 1);
+        for (int g = 0; g < 4; ++g) { vn[0][g] = lds_rd128<0>(aV + 32 * g); vg[0][g] = lds_rd128<256>(aV + 32 * g); }
+        GF_HB_RD(ka, 0, 0)
+        wait_lgkm<4>();                                       // the row vectors of rows 0-31
+        GF_HB_RD(kc, 1, 0)
+        wait_lgkm<4>();
+        GF_HB_S(sc0, ka, 0, GF_HB_DMA)
+        GF_HB_RD(ka, 2, 0)
+        wait_lgkm<4>();
+        GF_HB_S(sc0, kc, 1, GF_HB_DMA)
+        GF_HB_RD(kc, 3, 0)
+        wait_lgkm<4>();
+        GF_HB_S(sc0, ka, 2, GF_HB_DMA)
+        GF_HB_RD(ka, 0, 1)
+        wait_lgkm<4>();
+        GF_HB_S(sc0, kc, 3, GF_HB_DMA)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { vn[1][g] = lds_rd128<128>(aV + 32 * g); vg[1][g] = lds_rd128<256 + 128>(aV + 32 * g); }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { tie(vn[0][g]); tie(vg[0][g]); }
+        wait_lgkm<8>();                                       // ka (rows 32-63, sub-tile 0); the vectors still in flight
+        GF_HB_RD(kc, 1, 1)
+        GF_HB_S(sc1, ka, 0, GF_HB_E0)
+        wait_lgkm<4>();                                       // the row vectors of rows 32-63
+        GF_HB_RD(ka, 2, 1)
+        wait_lgkm<4>();
+        GF_HB_S(sc1, kc, 1, GF_HB_E0)
+        GF_HB_RD(kc, 3, 1)
+        wait_lgkm<4>();
+        GF_HB_S(sc1, ka, 2, GF_HB_E0)
+        // oth^T fragments of sub-tile 0, rows 0-31, requested under the last S block
+        u32x2 va[2][2][2], vb[2][2][2];
+#define GF_HB_TR(dst, c, KB) GF_FQ_TR(dst, (c) * FT_TILE, KB, 0, 0) GF_FQ_TR(dst, (c) * FT_TILE, KB, 0, 1) \
+                             GF_FQ_TR(dst, (c) * FT_TILE, KB, 1, 0) GF_FQ_TR(dst, (c) * FT_TILE, KB, 1, 1)
+        GF_HB_TR(va, 0, 0)
+        wait_lgkm<8>();
+        GF_HB_S(sc1, kc, 3, GF_HB_E0)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { tie(vn[1][g]); tie(vg[1][g]); }
+        bf16x8 p0 = cvt_frag(sc0, 0), p1 = cvt_frag(sc0, 1);
 
-            // ---- dOwn^T[d][o] += oth^T[d][s] dS[s][o]: sub-tile c feeds d-tiles 2c, 2c + 1 for both 16-row k-steps
-#define GF_HB_MMA(src, c)                                                                                  \
-            _Pragma("unroll") for (int db = 0; db < 2; ++db) {                                             \
-                tie(src[0][db][0]); tie(src[0][db][1]); tie(src[1][db][0]); tie(src[1][db][1]);            \
-                mma16(acc[2 * (c) + db], as_frag(src[0][db][0], src[0][db][1]), p0);                       \
-                mma16(acc[2 * (c) + db], as_frag(src[1][db][0], src[1][db][1]), p1);                       \
-            }
-            wait_lgkm<0>();
-            GF_HB_TR(vb, 1)
-            GF_HB_MMA(va, 0)
-            wait_lgkm<0>();
-            GF_HB_TR(va, 2)
-            GF_HB_MMA(vb, 1)
-            wait_lgkm<0>();
-            GF_HB_TR(vb, 3)
-            GF_HB_MMA(va, 2)
-            wait_lgkm<0>();
-            GF_HB_MMA(vb, 3)
+        // ---- dOwn^T[d][o] += oth^T[d][s] dS[s][o]: sub-tile c feeds d-tiles 2c, 2c + 1 for both 16-row k-steps
+#define GF_HB_MMA(src, c, SIDE)                                                                            \
+        _Pragma("unroll") for (int db = 0; db < 2; ++db) {                                                 \
+            tie(src[0][db][0]); tie(src[0][db][1]); tie(src[1][db][0]); tie(src[1][db][1]);                \
+            mma16(acc[2 * (c) + db], as_frag(src[0][db][0], src[0][db][1]), p0); SIDE(4 * (c) + 2 * db)    \
+            mma16(acc[2 * (c) + db], as_frag(src[1][db][0], src[1][db][1]), p1); SIDE(4 * (c) + 2 * db + 1) \
+        }
+        wait_lgkm<0>();
+        GF_HB_TR(vb, 1, 0)
+        GF_HB_MMA(va, 0, GF_HB_E1)
+        wait_lgkm<0>();
+        GF_HB_TR(va, 2, 0)
+        GF_HB_MMA(vb, 1, GF_HB_E1)
+        wait_lgkm<0>();
+        GF_HB_TR(vb, 3, 0)
+        GF_HB_MMA(va, 2, GF_HB_E1)
+        wait_lgkm<0>();
+        GF_HB_TR(va, 0, 1)
+        GF_HB_MMA(vb, 3, GF_HB_E1)
+        p0 = cvt_frag(sc1, 0); p1 = cvt_frag(sc1, 1);
+        wait_lgkm<0>();
+        GF_HB_TR(vb, 1, 1)
+        GF_HB_MMA(va, 0, GF_HB_NONE)
+        wait_lgkm<0>();
+        GF_HB_TR(va, 2, 1)
+        GF_HB_MMA(vb, 1, GF_HB_NONE)
+        wait_lgkm<0>();
+        GF_HB_TR(vb, 3, 1)
+        GF_HB_MMA(va, 2, GF_HB_NONE)
+        wait_lgkm<0>();
+        GF_HB_MMA(vb, 3, GF_HB_NONE)
 #undef GF_HB_MMA
 #undef GF_HB_TR
-        }
+#undef GF_HB_RD
+#undef GF_HB_S
+#undef GF_HB_NONE
+#undef GF_HB_DMA
+#undef GF_HB_E0
+#undef GF_HB_E1
         stage = stage == 2 ? 0 : stage + 1;
     }
+    wait_vm<0>();                                                 // the re-fetched tail tiles
     if (orow < p.No) {
         bf16_t* dst = p.down + ((int64_t)b * p.No + orow) * 256;
 #pragma unroll
