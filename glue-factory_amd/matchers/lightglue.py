@@ -558,6 +558,12 @@ class LightGlue(nn.Module):
         layer_x = pred.get("_layer_desc")
         if layer_x is not None and self.training and "_final_argmax0" in pred:
             return self._loss_fused(pred, data, self._gt_sparse(data, fixed=True))
+        if (layer_x is None and self.training and torch.is_grad_enabled() and not rd0.requires_grad
+                and any(p.requires_grad for p in self.parameters())):
+            # the stacked training forward hands out DETACHED ref_descriptors next to the private differentiable list:
+            # a pred dict that was rebuilt / filtered without it would train on constants without any error
+            raise RuntimeError("LightGlue.loss: training-mode pred has detached ref_descriptors and no '_layer_desc' "
+                               "(pass the dict returned by forward unchanged, or keep its private keys)")
         gt = self._gt_sparse(data)
 
         def head(i):
