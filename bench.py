@@ -7,8 +7,9 @@
 under torchrun (RANK / WORLD_SIZE set) it just joins.
 
 One "step" (the headline, BASELINE.json configs[1], scope P of SURVEY.md §8d) = frozen SuperPoint forward on a
-batch of 2x32 synthetic 1024x1024 images resident in HBM (stock PyTorch-ROCm convolutions, as north_star
-prescribes, + the fused HIP tails) -> homography ground truth (gf_gt_nn) -> one full LightGlue train step
+batch of 2x32 synthetic 1024x1024 images resident in HBM (first block and the three 64-channel blocks as fused HIP
+kernels; library convolutions + fused HIP tails for the 128/256-channel blocks) -> homography ground truth
+(gf_gt_nn) -> one full LightGlue train step
 (forward, loss, backward, fused Adam) at B=32 pairs per GPU, N=2048 keypoints, d=256, L=9, bf16 compute.
 Data parallel over N GPUs is weak scaling (32 pairs per GPU) with DDP/RCCL gradient all-reduce.
 Rank 0 prints ONE JSON line (contract in the task statement) that also carries
@@ -490,8 +491,9 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "configs[1]: SuperPoint + LightGlue train step -- frozen SuperPoint-open forward on 2x32 "
-                               f"synthetic {IMG}x{IMG} images resident in HBM (stock PyTorch-ROCm convolutions + fused HIP "
-                               "tails), homography ground truth (gf_gt_nn), LightGlue fwd + loss + bwd + fused Adam",
+                               f"synthetic {IMG}x{IMG} images resident in HBM (first block and the 64-channel 3x3 blocks as fused HIP "
+                               "kernels, library convolutions + fused HIP tails for the 128/256-channel blocks), homography "
+                               "ground truth (gf_gt_nn), LightGlue fwd + loss + bwd + fused Adam",
                    "pairs_per_gpu": args.batch, "global_batch": args.batch * world, "keypoints": args.kpts,
                    "descriptor_dim": DIM, "layers": args.layers, "image_size": [IMG, IMG], "parallelism": f"dp{world}"},
         "extractor_ms": round(t_ext * 1e3, 2), "final_loss": round(p_loss, 4),
