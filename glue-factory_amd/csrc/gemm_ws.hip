@@ -88,6 +88,9 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_ws_kernel(GwParams p) {
     const int myblocks = (nblk - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // b, b + grid, ...
     const int total = myblocks * nslice;                    // slices this workgroup walks (the ring never restarts)
     if (myblocks <= 0) return;
+#ifdef GW_DELAY      // probe: odd workgroups start GW_DELAY x ~4 us late (are the phases of a round in lockstep?)
+    if (blockIdx.x & 1) for (int i = 0; i < GW_DELAY; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
 
     const T* wg = reinterpret_cast<const T*>(p.w);
     char* scr = smem + 2 * SLICE + wave * GW_SCRATCH;       // this wave's scratch
