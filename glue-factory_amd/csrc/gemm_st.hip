@@ -1,0 +1,215 @@
+// y = [x0 | x1] W^T + bias (+ residual), bf16, for the shapes that dominate the matcher blocks (K = 256 / 512, N a
+// multiple of 256, M a multiple of 64): the "weights stationary, activations streamed" counterpart of gemm_ws.hip.
+// Same reference lines (every nn.Linear forward and input-gradient GEMM of gluefactory/models/matchers/lightglue.py:
+// 131-221,271-290 and the Conv1d(k=1) layers of superglue.py:70-160 / gluestick.py:465-586).
+//
+// gemm_ws keeps a wave's 32 activation rows in registers and walks the weight through LDS; its workgroups live as
+// long as the kernel and every one of them is a serial chain (rows in -> fragments -> per weight slice: barrier, MFMAs,
+// accumulators out through LDS): counters show both the matrix and the vector pipe ~85-90 % idle at 3 TB/s.  Here
+//   * a workgroup is 8 waves and owns 256 output channels: wave w keeps the [32 x K] weight block of its 32 channels in
+//     REGISTERS (64 / 128 VGPRs) for the whole kernel;
+//   * the activation rows stream through a 3-stage LDS-DMA ring in 32 KiB tiles (64 rows at K = 256, 32 at K = 512),
+//     two tiles ahead of the MFMAs, 16-byte chunks XOR-swizzled by (row & 15) on the source side so that the B-operand
+//     ds_read_b128 (32 rows, one chunk) is conflict-free; every wave reads every row -- the same LDS traffic per MFMA as
+//     gemm_ws, but no staging registers, no per-slice barrier, one barrier per tile;
+//   * outputs are produced "swapped" (channel on the MFMA i axis = registers, row on j = lane): bias and residual are
+//     lane-local, a lane stores 4 consecutive channels (8 bytes) per instruction.  Loads (residual), LDS-DMA pieces
+//     and stores retire through ONE in-order counter on this part, so their program order is fixed by hand
+//     (inline asm) and every wait is a counted vmcnt: residual(t), DMA(t + 2), MFMAs(t), stores(t).
+#include <type_traits>
+#include "gf_common.h"
+#include "gf_amd.h"
+
+namespace {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void gs_lds_void;
+typedef const __attribute__((address_space(1))) void gs_glb_void;
+
+constexpr int GS_TILE = 32768;                // bytes of one activation tile
+constexpr int GS_NSTAGE = 3;
+
+struct GsParams {
+    const bf16_t* x0; const bf16_t* x1; const bf16_t* w; const float* bias; const bf16_t* res; bf16_t* y;
+    int M, N;
+    int64_t ld0, ld1, ldw, ldr, ldy;
+};
+
+template <int OFF> __device__ __forceinline__ u32x4 gs_rd128(unsigned a) {
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF) : "memory");
+    return v;
+}
+template <int N> __device__ __forceinline__ void gs_wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void gs_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <typename V> __device__ __forceinline__ void gs_tie(V& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ u32x2 gs_ld64(const void* p) {
+    u32x2 v;
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void gs_st64(void* p, u32x2 v) { asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(v) : "memory"); }
+
+// KF = K / 16 (16 or 32); TWO: the K columns come half from x0, half from x1; RES: + residual
+template <int KF, bool TWO, bool RES>
+__global__ __launch_bounds__(512, 2) void gemm_st_kernel(GsParams p) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    constexpr int K = 16 * KF, ROWB = 2 * K, CPR = ROWB / 16;     // bytes / 16-byte chunks of one activation row
+    constexpr int TR = GS_TILE / ROWB, NRB = TR / 32;             // rows, 32-row blocks per tile
+    constexpr int NR = RES ? 4 * NRB : 0, NS = 4 * NRB;           // residual loads / stores per tile and wave
+    const unsigned lds0 = (unsigned)(size_t)smem;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int ch0 = blockIdx.y * 256 + wave * 32;                 // this wave's 32 output channels
+    const int ntile = p.M / TR;
+    const int T = (ntile - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // my tiles: blockIdx.x + i gridDim.x
+    if (T <= 0) return;
+
+    // ---- weights (A operands): lane = channel ch0 + l31, k-step s = elements [16 s + 8 hi, + 8)
+    bf16x8 wf[KF];
+#pragma unroll
+    for (int s = 0; s < KF; ++s) wf[s] = *reinterpret_cast<const bf16x8*>(p.w + (int64_t)(ch0 + l31) * p.ldw + 16 * s + 8 * hi);
+    float bias16[16];                                             // channels ch0 + crow(r, hi)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bias16[r] = p.bias ? p.bias[ch0 + crow(r, hi)] : 0.f;
+    gs_wait_vm<0>();                                              // (compiler-issued loads above: nothing of them in flight below)
+
+    // ---- DMA of tile `ti` (clamped: the tail re-fetches the last tile, nobody reads it) into `stage`: 32 pieces of 1 KiB,
+    // four per wave; chunk position lin = 64 piece + lane of the tile is row lin / CPR, slot lin % CPR, and holds the
+    // row's logical chunk slot ^ (row & 15)
+    auto issue = [&](int i, int stage) {
+        const int ti = (int)blockIdx.x + min(i, T - 1) * (int)gridDim.x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int piece = 4 * wave + j;
+            const int lin = 64 * piece + lane;
+            const int row = lin / CPR, c = (lin % CPR) ^ (row & 15);
+            const int64_t grow = (int64_t)ti * TR + row;
+            const bf16_t* src = (TWO && c >= CPR / 2) ? p.x1 + grow * p.ld1 + (c - CPR / 2) * 8 : p.x0 + grow * p.ld0 + c * 8;
+            __builtin_amdgcn_global_load_lds((gs_glb_void*)src, (gs_lds_void*)(smem + stage * GS_TILE + piece * 1024), 16, 0, 0);
+        }
+    };
+    issue(0, 0);
+    issue(1, 1);
+
+    // B-operand read addresses: row 32 rb + l31 (rb as immediate), chunk (2 s + hi) ^ (l31 & 15); s = 8 sh + sl with
+    // sh as an immediate offset of 256 bytes (the swizzle only touches the low four chunk bits)
+    unsigned a0[8];
+#pragma unroll
+    for (int sl = 0; sl < 8; ++sl) a0[sl] = lds0 + (unsigned)(l31 * ROWB + (((2 * sl + hi) ^ (l31 & 15)) << 4));
+    // this lane's output / residual pointers: row l31 of a 32-row block, channels ch0 + 8 g + 4 hi .. + 3
+    const int64_t ycol = ch0 + 4 * hi;
+
+    for (int i = 0; i < T; ++i) {
+        const int stage = i % GS_NSTAGE;
+        const int64_t row0 = ((int64_t)blockIdx.x + (int64_t)i * gridDim.x) * TR;
+        // tile i landed?  in-order counter: behind its pieces sit stores(i-2), residual(i-1), DMA(i+1), stores(i-1)
+        if (i == 0) gs_wait_vm<4>();
+        else if (i == 1) gs_wait_vm<NR + 4 + NS>();
+        else gs_wait_vm<2 * NS + NR + 4>();
+        __builtin_amdgcn_s_barrier();                             // ... everyone's pieces; the stage of tile i-1 is free
+        __builtin_amdgcn_sched_barrier(0);
+        u32x2 rr[NRB][4];
+        if (RES) {
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) rr[rb][g] = gs_ld64(p.res + (row0 + 32 * rb + l31) * p.ldr + ycol + 8 * g);
+        }
+        issue(i + 2, (i + 2) % GS_NSTAGE);
+        unsigned a[8];
+#pragma unroll
+        for (int sl = 0; sl < 8; ++sl) a[sl] = a0[sl] + stage * GS_TILE;
+
+        f32x16 acc[NRB];
+        // fragments four at a time (group G = k-steps 4 G .. 4 G + 3), two groups in flight (the LDS counter holds 15)
+        u32x4 xa[4], xb[4];
+        auto rd = [&](u32x4 (&dst)[4], auto RB, auto G) {
+            constexpr int rb = decltype(RB)::value, g = decltype(G)::value;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dst[q] = gs_rd128<rb * 32 * ROWB + ((4 * g) / 8) * 256>(a[(4 * g + q) & 7]);
+        };
+        auto mma = [&](u32x4 (&src)[4], auto RB, auto G) {
+            constexpr int rb = decltype(RB)::value, g = decltype(G)::value;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                gs_tie(src[q]);
+                acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[4 * g + q], __builtin_bit_cast(bf16x8, src[q]), acc[rb], 0, 0, 0);
+            }
+        };
+        auto block = [&](auto RB) {
+            constexpr int rb = decltype(RB)::value, NG = KF / 4;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[rb][r] = bias16[r];
+            rd(xa, RB, std::integral_constant<int, 0>{});
+            rd(xb, RB, std::integral_constant<int, 1>{});
+            auto step = [&](u32x4 (&buf)[4], auto G) {
+                constexpr int g = decltype(G)::value;
+                if constexpr (g < NG) {
+                    if constexpr (g == NG - 1) gs_wait_lgkm<0>(); else gs_wait_lgkm<4>();
+                    mma(buf, RB, G);
+                    if constexpr (g + 2 < NG) rd(buf, RB, std::integral_constant<int, g + 2>{});
+                }
+            };
+            step(xa, std::integral_constant<int, 0>{}); step(xb, std::integral_constant<int, 1>{});
+            step(xa, std::integral_constant<int, 2>{}); step(xb, std::integral_constant<int, 3>{});
+            step(xa, std::integral_constant<int, 4>{}); step(xb, std::integral_constant<int, 5>{});
+            step(xa, std::integral_constant<int, 6>{}); step(xb, std::integral_constant<int, 7>{});
+        };
+        block(std::integral_constant<int, 0>{});
+        if constexpr (NRB > 1) block(std::integral_constant<int, 1>{});
+        // ---- epilogue: (+ residual), bf16, 8-byte stores; residual(i) sits in front of DMA(i+2) only
+        if (RES) gs_wait_vm<4>();
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) {
+            bf16_t* yp = p.y + (row0 + 32 * rb + l31) * p.ldy + ycol;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float v[4] = {acc[rb][4 * g], acc[rb][4 * g + 1], acc[rb][4 * g + 2], acc[rb][4 * g + 3]};
+                if (RES) {
+                    gs_tie(rr[rb][g]);
+                    const bf16x4 r4 = __builtin_bit_cast(bf16x4, rr[rb][g]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += (float)r4[e];
+                }
+                const bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+                gs_st64(yp + 8 * g, __builtin_bit_cast(u32x2, o));
+            }
+        }
+    }
+    gs_wait_vm<0>();                                              // the re-fetched tail tiles and the last stores
+}
+
+template <int KF, bool TWO, bool RES>
+int gs_launch(const GsParams& p, hipStream_t st) {
+    constexpr int TR = GS_TILE / (32 * KF);
+    const size_t lds = (size_t)GS_NSTAGE * GS_TILE;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_st_kernel<KF, TWO, RES>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    const int ntile = p.M / TR, ncg = p.N / 256;
+    int gx = 256 / ncg;                                       // one workgroup per CU over all channel groups
+    if (gx < 1) gx = 1;
+    if (gx > ntile) gx = ntile;
+    gemm_st_kernel<KF, TWO, RES><<<dim3(gx, ncg), dim3(512), lds, st>>>(p);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+// Internal (not part of the C ABI): called by gf_gemm first; GF_ERR_UNSUPPORTED = "use the register-resident kernel".
+int gf_gemm_stream_try(const void* x0, const void* x1, const void* w, const float* bias, const void* res, void* y,
+                       int M, int N, int K0, int K1, int64_t ld0, int64_t ld1, int64_t ldw, int64_t ldr, int64_t ldy,
+                       hipStream_t st) {
+    const int K = K0 + K1;
+    if ((K != 256 && K != 512) || N % 256 || M % 64 || (K1 && K1 != K0)) return GF_ERR_UNSUPPORTED;
+    GsParams p;
+    p.x0 = static_cast<const bf16_t*>(x0); p.x1 = static_cast<const bf16_t*>(x1); p.w = static_cast<const bf16_t*>(w);
+    p.bias = bias; p.res = static_cast<const bf16_t*>(res); p.y = static_cast<bf16_t*>(y);
+    p.M = M; p.N = N; p.ld0 = ld0; p.ld1 = ld1; p.ldw = ldw; p.ldr = ldr; p.ldy = ldy;
+#define GS_GO(KF) (K1 ? (res ? gs_launch<KF, true, true>(p, st) : gs_launch<KF, true, false>(p, st)) \
+                      : (res ? gs_launch<KF, false, true>(p, st) : gs_launch<KF, false, false>(p, st)))
+    return K == 256 ? GS_GO(16) : GS_GO(32);
+#undef GS_GO
+}

@@ -370,6 +370,11 @@ extern "C" int gf_gemm_trace(unsigned long long* host, int n) {
 }
 #endif
 
+// gemm_st.hip: the streamed-activation kernel for the large regular shapes (returns GF_ERR_UNSUPPORTED for the rest)
+int gf_gemm_stream_try(const void* x0, const void* x1, const void* w, const float* bias, const void* res, void* y,
+                       int M, int N, int K0, int K1, int64_t ld0, int64_t ld1, int64_t ldw, int64_t ldr, int64_t ldy,
+                       hipStream_t st);
+
 extern "C" int gf_gemm(const void* x0, const void* x1, const void* w, const float* bias, const void* res, void* y,
                        const float* cs, int rot_n, int M, int N, int K0, int K1,
                        int64_t ld0, int64_t ld1, int64_t ldw, int64_t ldr, int64_t ldy, int dtype, void* stream) {
@@ -384,6 +389,12 @@ extern "C" int gf_gemm(const void* x0, const void* x1, const void* w, const floa
     p.x0 = x0; p.x1 = x1; p.w = w; p.bias = bias; p.res = res; p.y = y; p.cs = cs; p.rot_n = cs ? rot_n : 0;
     p.M = M; p.N = N; p.K0 = K0; p.K1 = K1; p.ld0 = ld0; p.ld1 = ld1; p.ldw = ldw; p.ldr = ldr; p.ldy = ldy;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#ifndef GW_NO_STREAM
+    if (dtype == GF_BF16 && !cs) {
+        const int e = gf_gemm_stream_try(x0, x1, w, bias, res, y, M, N, K0, K1, ld0, ld1, ldw, ldr, ldy, st);
+        if (e != GF_ERR_UNSUPPORTED) return e;
+    }
+#endif
     if (dtype == GF_BF16) return K1 ? gw_dispatch<bf16_t, true>(p, K, st) : gw_dispatch<bf16_t, false>(p, K, st);
     return K1 ? gw_dispatch<float, true>(p, K, st) : gw_dispatch<float, false>(p, K, st);
 }

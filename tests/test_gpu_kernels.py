@@ -543,3 +543,41 @@ def test_head_bwd_fused(shape):
         sc = y.abs().max().item()
         err = (x.double() - y).abs().max().item() / sc
         assert err < 1.5e-2, f"{name}: max error {err:.3e} of the largest entry"
+
+
+@pytest.mark.parametrize("case", [(4096, 256, 256, False, False), (4096, 256, 256, False, True), (192, 512, 512, True, False),
+                                  (8192, 512, 512, True, True), (2048, 256, 512, False, True), (640, 768, 256, False, False),
+                                  (131072, 256, 256, False, True)])
+def test_gemm_streamed_kernel(case):
+    """The activation-streaming GEMM kernel behind gf_gemm (bf16, K in {256, 512}, N % 256 == 0, M % 64 == 0): one and
+    several tiles per workgroup, fewer tiles than workgroups, two sources, residual incl. y aliasing it, strided weight
+    rows, the benchmark's row count -- against fp64 on the same bf16 inputs, and against the register-resident kernel's
+    result for shapes both can run (M + 1 rows force that one)."""
+    from glue_factory_amd import lib as L_
+    from glue_factory_amd.ops import _p, _stream
+    M, N, K, two, with_res = case
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    x = torch.randn(M + 1, K, device="cuda", generator=g).to(torch.bfloat16)
+    wide = (torch.randn(N, K + 64, device="cuda", generator=g) / K ** 0.5).to(torch.bfloat16)
+    w = wide[:, 32:32 + K]
+    bias = torch.randn(N, device="cuda", generator=g)
+    res = torch.randn(M + 1, N, device="cuda", generator=g).to(torch.bfloat16) if with_res else None
+    lib = L_.load()
+
+    def run(rows, y):
+        if two:
+            x0, x1, k0, k1 = x[:, :K // 2], x[:, K // 2:], K // 2, K // 2
+        else:
+            x0, x1, k0, k1 = x, None, K, 0
+        L_.check(lib.gf_gemm(_p(x0), _p(x1), _p(w), _p(bias), _p(y if with_res else None), _p(y), None, 0, rows, N, k0, k1,
+                             x.stride(0), x.stride(0) if two else 0, w.stride(0), y.stride(0) if with_res else 0, y.stride(0),
+                             1, _stream()), "gf_gemm")
+        return y
+
+    ref = x.double() @ w.double().t() + bias.double()
+    if with_res:
+        ref = ref + res.double()
+    y_st = run(M, res.clone() if with_res else torch.full((M + 1, N), float("nan"), device="cuda", dtype=torch.bfloat16))
+    torch.testing.assert_close(y_st[:M].double(), ref[:M], rtol=2e-2, atol=3e-2)
+    y_ws = run(M + 1, res.clone() if with_res else torch.full((M + 1, N), float("nan"), device="cuda", dtype=torch.bfloat16))
+    assert (y_st[:M].float() - y_ws[:M].float()).abs().max().item() <= 0.0625      # same fp32 sums, one bf16 rounding each
