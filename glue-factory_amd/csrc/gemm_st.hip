@@ -13,7 +13,8 @@
 //     ds_read_b128 (32 rows, one chunk) is conflict-free; every wave reads every row -- the same LDS traffic per MFMA as
 //     gemm_ws, but no staging registers, no per-slice barrier, one barrier per tile;
 //   * outputs are produced "swapped" (channel on the MFMA i axis = registers, row on j = lane): bias and residual are
-//     lane-local, a lane stores 4 consecutive channels (8 bytes) per instruction.  Loads (residual), LDS-DMA pieces
+//     lane-local; a v_permlane32_swap pairs the two half-rows of a lane and its partner into 8 consecutive channels, so
+//     residual loads and stores are 16 bytes per lane.  Loads (residual), LDS-DMA pieces
 //     and stores retire through ONE in-order counter on this part, so their program order is fixed by hand
 //     (inline asm) and every wait is a counted vmcnt: residual(t), DMA(t + 2), MFMAs(t), stores(t).
 #include <type_traits>
@@ -44,12 +45,24 @@ template <int OFF> __device__ __forceinline__ u32x4 gs_rd128(unsigned a) {
 template <int N> __device__ __forceinline__ void gs_wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
 template <int N> __device__ __forceinline__ void gs_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 template <typename V> __device__ __forceinline__ void gs_tie(V& v) { asm volatile("" : "+v"(v)); }
-__device__ __forceinline__ u32x2 gs_ld64(const void* p) {
-    u32x2 v;
-    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+__device__ __forceinline__ u32x4 gs_ld128(const void* p) {
+    u32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
     return v;
 }
-__device__ __forceinline__ void gs_st64(void* p, u32x2 v) { asm volatile("global_store_dwordx2 %0, %1, off" ::"v"(p), "v"(v) : "memory"); }
+// (a store of more than 64 bits reads its data registers over several cycles: the wait states a compiler-issued store
+// would get are part of the asm, or the next VALU write to those registers clobbers lanes 12-15 of every row)
+__device__ __forceinline__ void gs_st128(void* p, u32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 2" ::"v"(p), "v"(v) : "memory");
+}
+// The accumulator layout gives a lane 4 consecutive channels of a row per register group g (8 g + 4 hi + e); its partner
+// lane ^ 32 holds the other 4 of that 8-channel group.  v_permlane32_swap trades the upper half's copy of group g0 for
+// the lower half's copy of group g1: afterwards lanes 0-31 hold the 8 channels of g0, lanes 32-63 those of g1, in
+// ascending order {a, b} -- 16-byte instead of 8-byte global accesses.  The same swap undoes it.
+__device__ __forceinline__ void gs_swap(unsigned& a, unsigned& b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    a = r[0]; b = r[1];
+}
 
 // KF = K / 16 (16 or 32); TWO: the K columns come half from x0, half from x1; RES: + residual
 template <int KF, bool TWO, bool RES>
@@ -57,7 +70,7 @@ __global__ __launch_bounds__(512, 2) void gemm_st_kernel(GsParams p) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     constexpr int K = 16 * KF, ROWB = 2 * K, CPR = ROWB / 16;     // bytes / 16-byte chunks of one activation row
     constexpr int TR = GS_TILE / ROWB, NRB = TR / 32;             // rows, 32-row blocks per tile
-    constexpr int NR = RES ? 4 * NRB : 0, NS = 4 * NRB;           // residual loads / stores per tile and wave
+    constexpr int NR = RES ? 2 * NRB : 0, NS = 2 * NRB;           // residual loads / stores (16 bytes) per tile and wave
     const unsigned lds0 = (unsigned)(size_t)smem;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
@@ -98,8 +111,8 @@ __global__ __launch_bounds__(512, 2) void gemm_st_kernel(GsParams p) {
     unsigned a0[8];
 #pragma unroll
     for (int sl = 0; sl < 8; ++sl) a0[sl] = lds0 + (unsigned)(l31 * ROWB + (((2 * sl + hi) ^ (l31 & 15)) << 4));
-    // this lane's output / residual pointers: row l31 of a 32-row block, channels ch0 + 8 g + 4 hi .. + 3
-    const int64_t ycol = ch0 + 4 * hi;
+    // this lane's output / residual accesses: row l31 of a 32-row block, the 8 channels of group 2 j + hi (j = 0, 1)
+    const int64_t ycol = ch0 + 8 * hi;
 
     for (int i = 0; i < T; ++i) {
         const int stage = i % GS_NSTAGE;
@@ -110,12 +123,12 @@ __global__ __launch_bounds__(512, 2) void gemm_st_kernel(GsParams p) {
         else gs_wait_vm<2 * NS + NR + 4>();
         __builtin_amdgcn_s_barrier();                             // ... everyone's pieces; the stage of tile i-1 is free
         __builtin_amdgcn_sched_barrier(0);
-        u32x2 rr[NRB][4];
+        u32x4 rr[NRB][2];
         if (RES) {
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) rr[rb][g] = gs_ld64(p.res + (row0 + 32 * rb + l31) * p.ldr + ycol + 8 * g);
+                for (int j = 0; j < 2; ++j) rr[rb][j] = gs_ld128(p.res + (row0 + 32 * rb + l31) * p.ldr + ycol + 16 * j);
         }
         issue(i + 2, (i + 2) % GS_NSTAGE);
         unsigned a[8];
@@ -159,22 +172,32 @@ __global__ __launch_bounds__(512, 2) void gemm_st_kernel(GsParams p) {
         };
         block(std::integral_constant<int, 0>{});
         if constexpr (NRB > 1) block(std::integral_constant<int, 1>{});
-        // ---- epilogue: (+ residual), bf16, 8-byte stores; residual(i) sits in front of DMA(i+2) only
+        // ---- epilogue: (+ residual), bf16, 16-byte stores; residual(i) sits in front of DMA(i+2) only
         if (RES) gs_wait_vm<4>();
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb) {
             bf16_t* yp = p.y + (row0 + 32 * rb + l31) * p.ldy + ycol;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float v[4] = {acc[rb][4 * g], acc[rb][4 * g + 1], acc[rb][4 * g + 2], acc[rb][4 * g + 3]};
-                if (RES) {
-                    gs_tie(rr[rb][g]);
-                    const bf16x4 r4 = __builtin_bit_cast(bf16x4, rr[rb][g]);
+            for (int j = 0; j < 2; ++j) {                         // register groups g0 = 2 j, g1 = 2 j + 1
+                float v[2][4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += (float)r4[e];
+                for (int e = 0; e < 4; ++e) { v[0][e] = acc[rb][8 * j + e]; v[1][e] = acc[rb][8 * j + 4 + e]; }
+                if (RES) {
+                    gs_tie(rr[rb][j]);
+                    unsigned a0_ = rr[rb][j][0], a1_ = rr[rb][j][1], b0_ = rr[rb][j][2], b1_ = rr[rb][j][3];
+                    gs_swap(a0_, b0_);                            // back to "4 channels of g0 / 4 of g1 per lane"
+                    gs_swap(a1_, b1_);
+                    const bf16x4 r0 = __builtin_bit_cast(bf16x4, u32x2{a0_, a1_}), r1 = __builtin_bit_cast(bf16x4, u32x2{b0_, b1_});
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[0][e] += (float)r0[e]; v[1][e] += (float)r1[e]; }
                 }
-                const bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-                gs_st64(yp + 8 * g, __builtin_bit_cast(u32x2, o));
+                const bf16x4 o0 = {(bf16_t)v[0][0], (bf16_t)v[0][1], (bf16_t)v[0][2], (bf16_t)v[0][3]};
+                const bf16x4 o1 = {(bf16_t)v[1][0], (bf16_t)v[1][1], (bf16_t)v[1][2], (bf16_t)v[1][3]};
+                const u32x2 p0 = __builtin_bit_cast(u32x2, o0), p1 = __builtin_bit_cast(u32x2, o1);
+                unsigned q0 = p0[0], q1 = p0[1], q2 = p1[0], q3 = p1[1];
+                gs_swap(q0, q2);
+                gs_swap(q1, q3);
+                gs_st128(yp + 16 * j, u32x4{q0, q1, q2, q3});
             }
         }
     }
