@@ -29,7 +29,13 @@ typedef __attribute__((address_space(3))) void gs_lds_void;
 typedef const __attribute__((address_space(1))) void gs_glb_void;
 
 constexpr int GS_TILE = 32768;                // bytes of one activation tile
-constexpr int GS_NSTAGE = 3;
+#ifndef GS_NSTAGE_
+#define GS_NSTAGE_ 3                         // ring depth (probe builds: 2 = two workgroups per CU, 4 = three tiles ahead)
+#endif
+#ifndef GS_WGS
+#define GS_WGS 256                           // resident workgroups the grid is sized for
+#endif
+constexpr int GS_NSTAGE = GS_NSTAGE_, GS_PD = GS_NSTAGE - 1;   // stages, prefetch distance in tiles
 
 struct GsParams {
     const bf16_t* x0; const bf16_t* x1; const bf16_t* w; const float* bias; const bf16_t* res; bf16_t* y;
@@ -103,8 +109,8 @@ __global__ __launch_bounds__(512, 2) void gemm_st_kernel(GsParams p) {
             __builtin_amdgcn_global_load_lds((gs_glb_void*)src, (gs_lds_void*)(smem + stage * GS_TILE + piece * 1024), 16, 0, 0);
         }
     };
-    issue(0, 0);
-    issue(1, 1);
+#pragma unroll
+    for (int t = 0; t < GS_PD; ++t) issue(t, t);
 
     // B-operand read addresses: row 32 rb + l31 (rb as immediate), chunk (2 s + hi) ^ (l31 & 15); s = 8 sh + sl with
     // sh as an immediate offset of 256 bytes (the swizzle only touches the low four chunk bits)
@@ -118,9 +124,13 @@ __global__ __launch_bounds__(512, 2) void gemm_st_kernel(GsParams p) {
         const int stage = i % GS_NSTAGE;
         const int64_t row0 = ((int64_t)blockIdx.x + (int64_t)i * gridDim.x) * TR;
         // tile i landed?  in-order counter: behind its pieces sit stores(i-2), residual(i-1), DMA(i+1), stores(i-1)
-        if (i == 0) gs_wait_vm<4>();
-        else if (i == 1) gs_wait_vm<NR + 4 + NS>();
-        else gs_wait_vm<2 * NS + NR + 4>();
+        // (tile i < PD came with the prologue: PD-1-i later prologue tiles and i whole tiles of traffic sit behind it;
+        //  steady state: stores(i-PD) and PD-1 whole tiles)
+        constexpr int PER = NR + 4 + NS;
+        if (i >= GS_PD) gs_wait_vm<NS + (GS_PD - 1) * PER>();
+        else if (i == 0) gs_wait_vm<(GS_PD - 1) * 4>();
+        else if (i == 1) gs_wait_vm<(GS_PD > 1 ? (GS_PD - 2) * 4 + PER : 0)>();
+        else gs_wait_vm<(GS_PD > 2 ? (GS_PD - 3) * 4 + 2 * PER : 0)>();
         __builtin_amdgcn_s_barrier();                             // ... everyone's pieces; the stage of tile i-1 is free
         __builtin_amdgcn_sched_barrier(0);
         u32x4 rr[NRB][2];
@@ -130,7 +140,7 @@ __global__ __launch_bounds__(512, 2) void gemm_st_kernel(GsParams p) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) rr[rb][j] = gs_ld128(p.res + (row0 + 32 * rb + l31) * p.ldr + ycol + 16 * j);
         }
-        issue(i + 2, (i + 2) % GS_NSTAGE);
+        issue(i + GS_PD, (i + GS_PD) % GS_NSTAGE);
         unsigned a[8];
 #pragma unroll
         for (int sl = 0; sl < 8; ++sl) a[sl] = a0[sl] + stage * GS_TILE;
@@ -212,7 +222,7 @@ int gs_launch(const GsParams& p, hipStream_t st) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     const int ntile = p.M / TR, ncg = p.N / 256;
-    int gx = 256 / ncg;                                       // one workgroup per CU over all channel groups
+    int gx = GS_WGS / ncg;                                    // one workgroup per CU over all channel groups
     if (gx < 1) gx = 1;
     if (gx > ntile) gx = ntile;
     gemm_st_kernel<KF, TWO, RES><<<dim3(gx, ncg), dim3(512), lds, st>>>(p);
