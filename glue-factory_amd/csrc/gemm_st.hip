@@ -39,6 +39,7 @@ constexpr int GS_NSTAGE = GS_NSTAGE_, GS_PD = GS_NSTAGE - 1;   // stages, prefet
 
 struct GsParams {
     const bf16_t* x0; const bf16_t* x1; const bf16_t* w; const float* bias; const bf16_t* res; bf16_t* y;
+    const float* cs;          // [M, 64] (cos, sin) per channel pair of a 64-wide head (ROT kernels)
     int M, N;
     int64_t ld0, ld1, ldw, ldr, ldy;
 };
@@ -70,13 +71,14 @@ __device__ __forceinline__ void gs_swap(unsigned& a, unsigned& b) {
     a = r[0]; b = r[1];
 }
 
-// KF = K / 16 (16 or 32); TWO: the K columns come half from x0, half from x1; RES: + residual
-template <int KF, bool TWO, bool RES>
+// KF = K / 16 (16 or 32); TWO: the K columns come half from x0, half from x1; RES: + residual; ROT: rotary epilogue
+// (lightglue.py:42-49,159-160) on every channel of the launch, head dim 64
+template <int KF, bool TWO, bool RES, bool ROT>
 __global__ __launch_bounds__(512, 2) void gemm_st_kernel(GsParams p) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     constexpr int K = 16 * KF, ROWB = 2 * K, CPR = ROWB / 16;     // bytes / 16-byte chunks of one activation row
     constexpr int TR = GS_TILE / ROWB, NRB = TR / 32;             // rows, 32-row blocks per tile
-    constexpr int NR = RES ? 2 * NRB : 0, NS = 2 * NRB;           // residual loads / stores (16 bytes) per tile and wave
+    constexpr int NR = (RES ? 2 * NRB : 0) + (ROT ? 4 * NRB : 0), NS = 2 * NRB;   // residual + (cos, sin) loads / stores per tile and wave
     const unsigned lds0 = (unsigned)(size_t)smem;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
@@ -140,6 +142,14 @@ __global__ __launch_bounds__(512, 2) void gemm_st_kernel(GsParams p) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) rr[rb][j] = gs_ld128(p.res + (row0 + 32 * rb + l31) * p.ldr + ycol + 16 * j);
         }
+        u32x4 cc[NRB][4];                                          // (cos, sin) of this lane's channel pairs, per register group
+        if (ROT) {
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    cc[rb][g] = gs_ld128(p.cs + (row0 + 32 * rb + l31) * 64 + (wave & 1) * 32 + 8 * g + 4 * hi);
+        }
         issue(i + GS_PD, (i + GS_PD) % GS_NSTAGE);
         unsigned a[8];
 #pragma unroll
@@ -183,7 +193,7 @@ __global__ __launch_bounds__(512, 2) void gemm_st_kernel(GsParams p) {
         block(std::integral_constant<int, 0>{});
         if constexpr (NRB > 1) block(std::integral_constant<int, 1>{});
         // ---- epilogue: (+ residual), bf16, 16-byte stores; residual(i) sits in front of DMA(i+2) only
-        if (RES) gs_wait_vm<4>();
+        if (RES || ROT) gs_wait_vm<4>();
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb) {
             bf16_t* yp = p.y + (row0 + 32 * rb + l31) * p.ldy + ycol;
@@ -192,6 +202,16 @@ __global__ __launch_bounds__(512, 2) void gemm_st_kernel(GsParams p) {
                 float v[2][4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { v[0][e] = acc[rb][8 * j + e]; v[1][e] = acc[rb][8 * j + 4 + e]; }
+                if (ROT) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        gs_tie(cc[rb][2 * j + t]);
+                        const f32x4 c = __builtin_bit_cast(f32x4, cc[rb][2 * j + t]);
+                        const float o0 = v[t][0] * c[0] - v[t][1] * c[1], o1 = v[t][1] * c[0] + v[t][0] * c[1];
+                        const float o2 = v[t][2] * c[2] - v[t][3] * c[3], o3 = v[t][3] * c[2] + v[t][2] * c[3];
+                        v[t][0] = o0; v[t][1] = o1; v[t][2] = o2; v[t][3] = o3;
+                    }
+                }
                 if (RES) {
                     gs_tie(rr[rb][j]);
                     unsigned a0_ = rr[rb][j][0], a1_ = rr[rb][j][1], b0_ = rr[rb][j][2], b1_ = rr[rb][j][3];
@@ -214,18 +234,18 @@ __global__ __launch_bounds__(512, 2) void gemm_st_kernel(GsParams p) {
     gs_wait_vm<0>();                                              // the re-fetched tail tiles and the last stores
 }
 
-template <int KF, bool TWO, bool RES>
+template <int KF, bool TWO, bool RES, bool ROT = false>
 int gs_launch(const GsParams& p, hipStream_t st) {
     constexpr int TR = GS_TILE / (32 * KF);
     const size_t lds = (size_t)GS_NSTAGE * GS_TILE;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_st_kernel<KF, TWO, RES>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_st_kernel<KF, TWO, RES, ROT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     const int ntile = p.M / TR, ncg = p.N / 256;
     int gx = GS_WGS / ncg;                                    // one workgroup per CU over all channel groups
     if (gx < 1) gx = 1;
     if (gx > ntile) gx = ntile;
-    gemm_st_kernel<KF, TWO, RES><<<dim3(gx, ncg), dim3(512), lds, st>>>(p);
+    gemm_st_kernel<KF, TWO, RES, ROT><<<dim3(gx, ncg), dim3(512), lds, st>>>(p);
     return (int)hipGetLastError();
 }
 
@@ -233,14 +253,23 @@ int gs_launch(const GsParams& p, hipStream_t st) {
 
 // Internal (not part of the C ABI): called by gf_gemm first; GF_ERR_UNSUPPORTED = "use the register-resident kernel".
 int gf_gemm_stream_try(const void* x0, const void* x1, const void* w, const float* bias, const void* res, void* y,
-                       int M, int N, int K0, int K1, int64_t ld0, int64_t ld1, int64_t ldw, int64_t ldr, int64_t ldy,
-                       hipStream_t st) {
+                       const float* cs, int rot_n, int M, int N, int K0, int K1, int64_t ld0, int64_t ld1, int64_t ldw,
+                       int64_t ldr, int64_t ldy, hipStream_t st) {
     const int K = K0 + K1;
     if ((K != 256 && K != 512) || N % 256 || M % 64 || (K1 && K1 != K0)) return GF_ERR_UNSUPPORTED;
+    if (cs && (rot_n % 256 || rot_n <= 0 || rot_n > N || res || K1)) return GF_ERR_UNSUPPORTED;
     GsParams p;
     p.x0 = static_cast<const bf16_t*>(x0); p.x1 = static_cast<const bf16_t*>(x1); p.w = static_cast<const bf16_t*>(w);
-    p.bias = bias; p.res = static_cast<const bf16_t*>(res); p.y = static_cast<bf16_t*>(y);
+    p.bias = bias; p.res = static_cast<const bf16_t*>(res); p.y = static_cast<bf16_t*>(y); p.cs = cs;
     p.M = M; p.N = N; p.ld0 = ld0; p.ld1 = ld1; p.ldw = ldw; p.ldr = ldr; p.ldy = ldy;
+    if (cs) {       // rotated channel groups first, the rest (the v third of a fused qkv projection) as a plain launch
+        p.N = rot_n;
+        if (int e = K == 256 ? gs_launch<16, false, false, true>(p, st) : gs_launch<32, false, false, true>(p, st)) return e;
+        if (N == rot_n) return 0;
+        p.N = N - rot_n; p.w += (int64_t)rot_n * ldw; p.y += rot_n; p.cs = nullptr;
+        if (p.bias) p.bias += rot_n;
+        return K == 256 ? gs_launch<16, false, false>(p, st) : gs_launch<32, false, false>(p, st);
+    }
 #define GS_GO(KF) (K1 ? (res ? gs_launch<KF, true, true>(p, st) : gs_launch<KF, true, false>(p, st)) \
                       : (res ? gs_launch<KF, false, true>(p, st) : gs_launch<KF, false, false>(p, st)))
     return K == 256 ? GS_GO(16) : GS_GO(32);

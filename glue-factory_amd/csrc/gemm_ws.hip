@@ -372,8 +372,8 @@ extern "C" int gf_gemm_trace(unsigned long long* host, int n) {
 
 // gemm_st.hip: the streamed-activation kernel for the large regular shapes (returns GF_ERR_UNSUPPORTED for the rest)
 int gf_gemm_stream_try(const void* x0, const void* x1, const void* w, const float* bias, const void* res, void* y,
-                       int M, int N, int K0, int K1, int64_t ld0, int64_t ld1, int64_t ldw, int64_t ldr, int64_t ldy,
-                       hipStream_t st);
+                       const float* cs, int rot_n, int M, int N, int K0, int K1, int64_t ld0, int64_t ld1, int64_t ldw,
+                       int64_t ldr, int64_t ldy, hipStream_t st);
 
 extern "C" int gf_gemm(const void* x0, const void* x1, const void* w, const float* bias, const void* res, void* y,
                        const float* cs, int rot_n, int M, int N, int K0, int K1,
@@ -390,8 +390,8 @@ extern "C" int gf_gemm(const void* x0, const void* x1, const void* w, const floa
     p.M = M; p.N = N; p.K0 = K0; p.K1 = K1; p.ld0 = ld0; p.ld1 = ld1; p.ldw = ldw; p.ldr = ldr; p.ldy = ldy;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #ifndef GW_NO_STREAM
-    if (dtype == GF_BF16 && !cs) {
-        const int e = gf_gemm_stream_try(x0, x1, w, bias, res, y, M, N, K0, K1, ld0, ld1, ldw, ldr, ldy, st);
+    if (dtype == GF_BF16) {
+        const int e = gf_gemm_stream_try(x0, x1, w, bias, res, y, cs, rot_n, M, N, K0, K1, ld0, ld1, ldw, ldr, ldy, st);
         if (e != GF_ERR_UNSUPPORTED) return e;
     }
 #endif

@@ -581,3 +581,34 @@ def test_gemm_streamed_kernel(case):
     torch.testing.assert_close(y_st[:M].double(), ref[:M], rtol=2e-2, atol=3e-2)
     y_ws = run(M + 1, res.clone() if with_res else torch.full((M + 1, N), float("nan"), device="cuda", dtype=torch.bfloat16))
     assert (y_st[:M].float() - y_ws[:M].float()).abs().max().item() <= 0.0625      # same fp32 sums, one bf16 rounding each
+
+
+@pytest.mark.parametrize("M,N,K,rot_n", [(4096, 768, 256, 512), (128, 512, 512, 512), (131072, 768, 256, 512)])
+def test_gemm_streamed_kernel_rotary(M, N, K, rot_n):
+    """Rotary epilogue of the activation-streaming GEMM (the fused Wqkv projection of lightglue.py:159-160: channels
+    [0, rot_n) rotated pairwise by the per-token (cos, sin) table, the rest plain) vs fp64 and vs the register-resident
+    kernel (M + 1 rows force that one)."""
+    from glue_factory_amd import lib as L_
+    from glue_factory_amd.ops import _p, _stream
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    x = torch.randn(M + 1, K, device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).to(torch.bfloat16)
+    bias = torch.randn(N, device="cuda", generator=g)
+    th = torch.rand(M + 1, 32, device="cuda", generator=g) * 6.28
+    cs = torch.stack((torch.cos(th), torch.sin(th)), -1).flatten(-2).contiguous()      # [M+1, 64] (cos, sin) per pair
+    lib = L_.load()
+
+    def run(rows):
+        y = torch.full((M + 1, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+        L_.check(lib.gf_gemm(_p(x), None, _p(w), _p(bias), None, _p(y), _p(cs), rot_n, rows, N, K, 0, K, 0, K, 0, N, 1, _stream()),
+                 "gf_gemm")
+        return y
+
+    lin = x.double() @ w.double().t() + bias.double()
+    r = lin[:, :rot_n].reshape(M + 1, rot_n // 64, 32, 2)
+    c, s_ = cs.double()[:, 0::2][:, None, :], cs.double()[:, 1::2][:, None, :]
+    rot = torch.stack((r[..., 0] * c - r[..., 1] * s_, r[..., 1] * c + r[..., 0] * s_), -1).reshape(M + 1, rot_n)
+    ref = torch.cat([rot, lin[:, rot_n:]], 1)
+    y_st, y_ws = run(M), run(M + 1)
+    torch.testing.assert_close(y_st[:M].double(), ref[:M], rtol=2e-2, atol=3e-2)
+    assert (y_st[:M].float() - y_ws[:M].float()).abs().max().item() <= 0.0625
