@@ -336,6 +336,96 @@ def gen_lightglue_config(name, batch, n, n_layers, seed, size, stride=61):
           "metrics", {k: v.tolist() for k, v in me.items()})
 
 
+def _grad_digest(out, named_grads, sample=2048):
+    """norm of every parameter gradient + a strided sample of <= `sample` entries (the bf16 tests bound the relative
+    error of the sample, the fp32 tests hold the norm and the sample to the reference)."""
+    for k, g in named_grads:
+        out["gradnorm." + k] = np.array([float(g.double().norm())])
+        flat = g.detach().flatten()
+        st = max(1, flat.numel() // sample)
+        out["gradsample." + k] = flat[::st][:sample].numpy()
+
+
+def _la_digest(out, la, stride, prefix="train."):
+    la = la.detach()
+    out[prefix + "la_sample"] = la.flatten(1)[:, ::stride].numpy()
+    out[prefix + "la_rowsum"] = la.double().sum(2).float().numpy()
+    out[prefix + "la_colsum"] = la.double().sum(1).float().numpy()
+    out[prefix + "rowmax"] = la[:, :-1, :-1].max(2).values.numpy()
+
+
+def gen_superglue_config(name, batch, n, iters, seed, stride=997):
+    """BASELINE configs[3] through the REFERENCE SuperGlue itself: N=2048 keypoints per image, the full 18-layer
+    GNN, 100 Sinkhorn iterations (B=1: the reference keeps ~10 GB of autograd state for the unrolled Sinkhorn).
+    Compact storage as for lightglue_n2048_l9: inputs / weights regenerated from the seed by the test."""
+    from gluefactory_nonfree.superglue import SuperGlue
+    from oracle import superglue_oracle as sgo
+
+    params = sgo.init_params(256, gnn_layers=18, seed=seed)
+    data = make_pairs(batch, n, dim=256, size=(1024, 1024), seed=seed + 1)
+    data["view0"]["image"] = torch.zeros(batch, 1, 1024, 1024)
+    data["view1"]["image"] = torch.zeros(batch, 1, 1024, 1024)
+    model = SuperGlue({"weights": None, "num_sinkhorn_iterations": iters})
+    res = model.load_state_dict(params, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    out = {}
+    model.eval()
+    with torch.no_grad():
+        pe = model(data)
+    out.update(_np({k: pe[k] for k in ("matches0", "matches1", "matching_scores0")}, "eval."))
+    _la_digest(out, pe["log_assignment"], stride, "eval.")
+    model.train()
+    pred = model(data)
+    losses = model.loss(pred, {**pred, **data})
+    losses["total"].mean().backward()
+    _la_digest(out, pred["log_assignment"], stride)
+    out["train.cost_sample"] = pred["sinkhorn_cost"].detach().flatten(1)[:, ::stride].numpy()
+    out.update(_np({k: pred[k] for k in ("matches0", "matches1", "matching_scores0")}, "train."))
+    out.update(_np({k: v for k, v in losses.items() if torch.is_tensor(v)}, "loss."))
+    _grad_digest(out, [(k, p.grad) for k, p in model.named_parameters()])
+    out["param_checksum"] = np.array([float(sum(v.double().abs().sum() for v in params.values()))])
+    out["data_checksum"] = _data_checksum(data)
+    out["meta"] = np.array([batch, n, 18, iters, seed, stride])
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+    print(name, "loss", losses["total"].tolist(), "matches", (pred["matches0"] > -1).sum(1).tolist())
+
+
+def gen_gluestick_config(name, batch, n_kpts, n_lines, seed, stride=997):
+    """BASELINE configs[4] through the REFERENCE GlueStick: 2048 keypoints + 512 lines (1024 junctions -> 3072 tokens
+    per image), default 9 x (self, cross) GNN with the line layers, B=1.  Compact storage."""
+    from gluefactory.models.matchers.gluestick import GlueStick
+    from glue_factory_amd.synthetic import make_point_line_pairs
+    from oracle import gluestick_oracle as gso
+
+    gnn = ["self", "cross"] * 9
+    params = gso.init_params(256, gnn_layers=len(gnn), inter=None, seed=seed)
+    data = make_point_line_pairs(batch, n_kpts, n_lines, dim=256, size=(1024, 1024), seed=seed + 1)
+    model = GlueStick({"weights": None})
+    res = model.load_state_dict(params, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    out = {}
+    model.eval()
+    with torch.no_grad():
+        pe = model(data)
+    out.update(_np({k: pe[k] for k in ("matches0", "matching_scores0", "line_matches0", "line_matching_scores0")}, "eval."))
+    model.train()
+    pred = model(data)
+    losses, _ = model.loss(pred, {**pred, **data})
+    losses["total"].mean().backward()
+    _la_digest(out, pred["log_assignment"], stride)
+    _la_digest(out, pred["line_log_assignment"], 97, "train.line_")
+    out["train.raw_line_scores_sample"] = pred["raw_line_scores"].detach().flatten(1)[:, ::97].numpy()
+    out.update(_np({k: pred[k] for k in ("matches0", "matching_scores0", "line_matches0", "line_matching_scores0")}, "train."))
+    out.update(_np({k: v for k, v in losses.items() if torch.is_tensor(v)}, "loss."))
+    _grad_digest(out, [(k, p.grad) for k, p in model.named_parameters() if p.grad is not None])
+    out["param_checksum"] = np.array([float(sum(v.double().abs().sum() for v in params.values()))])
+    out["data_checksum"] = _data_checksum(data)
+    out["meta"] = np.array([batch, n_kpts, n_lines, len(gnn), seed, stride])
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+    print(name, "loss", losses["total"].tolist(), "matches", (pred["matches0"] > -1).sum(1).tolist(),
+          "line matches", (pred["line_matches0"] > -1).sum(1).tolist())
+
+
 def gen_metrics(name, seed):
     """matcher_metrics of the reference (models/utils/metrics.py:4-50) on seeded match / ground-truth vectors
     with every label class present: correct and wrong matches, unmatched (-1) and ignored (-2) ground truth."""
@@ -406,6 +496,8 @@ def main():
                                                                 size=(1024, 1024), stride=997),
             "lightglue_adaptive": lambda: gen_lightglue_adaptive("lightglue_adaptive", 160, 200, 3, seed=107),
             "metrics": lambda: gen_metrics("metrics", seed=109),
+            "superglue_config4": lambda: gen_superglue_config("superglue_config4", 1, 2048, 100, seed=113),
+            "gluestick_config5": lambda: gen_gluestick_config("gluestick_config5", 1, 2048, 512, seed=127),
             "gluestick_lineattn": lambda: gen_gluestick("gluestick_lineattn", batch=2, n_kpts=36, n_lines=14,
                                                         gnn=["self", "cross"] * 2, inter=[0], seed=43, line_attention=True),
         }
@@ -426,6 +518,8 @@ def main():
     gen_lightglue_config("lightglue_n2048_l9", 1, 2048, 9, seed=103, size=(1024, 1024), stride=997)
     gen_lightglue_adaptive("lightglue_adaptive", 160, 200, 3, seed=107)
     gen_metrics("metrics", seed=109)
+    gen_superglue_config("superglue_config4", 1, 2048, 100, seed=113)
+    gen_gluestick_config("gluestick_config5", 1, 2048, 512, seed=127)
     gen_gluestick("gluestick_lineattn", batch=2, n_kpts=36, n_lines=14, gnn=["self", "cross"] * 2, inter=[0], seed=43,
                   line_attention=True)
 

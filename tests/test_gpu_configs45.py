@@ -1,0 +1,130 @@
+"""HIP-vs-reference parity AT BASELINE configs[3] and configs[4]: SuperGlue with N=2048 keypoints, the full 18-layer
+GNN and 100 Sinkhorn iterations, and GlueStick with 2048 keypoints + 512 lines (3072 tokens per image), B=1, whole
+train step (forward + loss + backward) -- in fp32 against the reference-generated compact goldens at north_star's
+1e-4, and in bf16 (the dtype bench.py times for `other_configs`) with stated, measured bounds incl. per-tensor
+gradient error.  Goldens: tests/golden/superglue_config4.npz, gluestick_config5.npz (oracle/gen_golden.py)."""
+import numpy as np
+import pytest
+import torch
+
+from config_golden import (check_la_digest, grad_digest_errors, gs_config_inputs, la_digest_error, matches_agreement,
+                           sg_config_inputs, significant_grads)
+
+pytestmark = pytest.mark.gpu
+
+# ---- stated bf16 bounds: about 2x what was measured on MI355X (round 3; the measured numbers are printed) ----
+SG_BF16 = {"la_max": 1.0, "la_p99": 0.3, "la_mean": 0.08, "loss_rel": 2e-2, "grad_rel": 0.10}
+GS_BF16 = {"la_max": 1.0, "la_p99": 0.3, "la_mean": 0.08, "loss_rel": 2e-2, "grad_rel": 0.10}
+
+
+def _cuda(d):
+    from glue_factory_amd.synthetic import to_device
+    return to_device(d, "cuda")
+
+
+def _sg_step(bf16):
+    from glue_factory_amd.matchers.superglue import SuperGlue
+    z, params, data, nl, iters = sg_config_inputs()
+    model = SuperGlue({"num_sinkhorn_iterations": iters})
+    res = model.load_state_dict(params, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    model = model.cuda().train()
+    cdata = _cuda(data)
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16):
+        pred = model(cdata)
+        losses, _ = model.loss(pred, {**pred, **cdata})
+    losses["total"].mean().backward()
+    grads = {k: p.grad for k, p in model.named_parameters()}
+    assert all(g is not None for g in grads.values())
+    return z, pred, losses, grads
+
+
+def _gs_step(bf16):
+    from glue_factory_amd.matchers.gluestick import GlueStick
+    z, params, data, nl = gs_config_inputs()
+    model = GlueStick({})
+    res = model.load_state_dict(params, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    model = model.cuda().train()
+    cdata = _cuda(data)
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16):
+        pred = model(cdata)
+        losses, _ = model.loss(pred, {**pred, **cdata})
+    losses["total"].mean().backward()
+    grads = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+    return z, pred, losses, grads
+
+
+def _check_losses(z, losses, tol):
+    for k in [k[5:] for k in z if k.startswith("loss.")]:
+        np.testing.assert_allclose(losses[k].detach().float().cpu().numpy(), z["loss." + k], rtol=tol, atol=tol, err_msg=k)
+
+
+def _fp32_grads(z, grads, norm_tol, sample_tol):
+    errs = significant_grads(grad_digest_errors(z, grads))
+    worst_n = max((e[0], k) for k, e in errs.items())
+    worst_s = max((e[1], k) for k, e in errs.items())
+    print("worst gradient-norm error", worst_n, "worst gradient-sample error", worst_s)
+    assert worst_n[0] <= norm_tol, worst_n
+    assert worst_s[0] <= sample_tol, worst_s
+
+
+def _bf16_report(tag, z, la_items, losses, grads, bounds):
+    for name, la, stride, prefix in la_items:
+        mx, p99, mean = la_digest_error(z, la, stride, prefix)
+        print(f"{tag} bf16 {name}: max|d| {mx:.4f}  p99 {p99:.4f}  mean {mean:.4f}")
+        assert mx <= bounds["la_max"] and p99 <= bounds["la_p99"] and mean <= bounds["la_mean"], (name, mx, p99, mean)
+    worst_loss = 0.0
+    for k in [k[5:] for k in z if k.startswith("loss.")]:
+        r = z["loss." + k]
+        got = losses[k].detach().float().cpu().numpy()
+        rel = float(np.max(np.abs(got - r) / np.maximum(np.abs(r), 1e-3)))
+        worst_loss = max(worst_loss, rel)
+    big = significant_grads(grad_digest_errors(z, grads))   # (without the analytically-zero gradients)
+    rels = sorted(e[1] for e in big.values())
+    worst = max((e[1], k) for k, e in big.items())
+    print(f"{tag} bf16: worst loss entry rel {worst_loss:.2e}; per-tensor gradient-sample error: worst {worst}, "
+          f"median {rels[len(rels) // 2]:.4f}, tensors {len(rels)}")
+    assert worst_loss <= bounds["loss_rel"], worst_loss
+    assert worst[0] <= bounds["grad_rel"], worst
+
+
+def test_superglue_config4_fp32_train_step_vs_reference():
+    z, pred, losses, grads = _sg_step(bf16=False)
+    stride = int(z["meta"][5])
+    check_la_digest(z, pred["log_assignment"], stride, tol=1e-4)
+    np.testing.assert_allclose(pred["sinkhorn_cost"].detach().cpu().flatten(1)[:, ::stride].numpy(), z["train.cost_sample"],
+                               rtol=1e-4, atol=1e-4)
+    agree = matches_agreement(pred["matches0"], z["train.matches0"])
+    print("superglue config4 fp32: matches0 agreement", agree)
+    assert agree >= 0.999
+    _check_losses(z, losses, 1e-4)
+    _fp32_grads(z, grads, norm_tol=3e-3, sample_tol=1e-2)
+
+
+def test_superglue_config4_bf16_train_step_bounds():
+    z, pred, losses, grads = _sg_step(bf16=True)
+    _bf16_report("superglue config4", z, [("log_assignment", pred["log_assignment"], int(z["meta"][5]), "train.")],
+                 losses, grads, SG_BF16)
+
+
+def test_gluestick_config5_fp32_train_step_vs_reference():
+    z, pred, losses, grads = _gs_step(bf16=False)
+    stride = int(z["meta"][5])
+    check_la_digest(z, pred["log_assignment"], stride, tol=1e-4)
+    check_la_digest(z, pred["line_log_assignment"], 97, prefix="train.line_", tol=1e-4)
+    np.testing.assert_allclose(pred["raw_line_scores"].detach().cpu().flatten(1)[:, ::97].numpy(),
+                               z["train.raw_line_scores_sample"], rtol=1e-4, atol=1e-4)
+    for k in ("matches0", "line_matches0"):
+        agree = matches_agreement(pred[k], z["train." + k])
+        print("gluestick config5 fp32:", k, "agreement", agree)
+        assert agree >= 0.999
+    _check_losses(z, losses, 1e-4)
+    _fp32_grads(z, grads, norm_tol=5e-3, sample_tol=1e-2)
+
+
+def test_gluestick_config5_bf16_train_step_bounds():
+    z, pred, losses, grads = _gs_step(bf16=True)
+    _bf16_report("gluestick config5", z,
+                 [("log_assignment", pred["log_assignment"], int(z["meta"][5]), "train."),
+                  ("line_log_assignment", pred["line_log_assignment"], 97, "train.line_")], losses, grads, GS_BF16)
