@@ -14,30 +14,12 @@
 // key-order on the V^T fragments (no LDS round trip, no permutes).
 #include "gf_common.h"
 #include "gf_amd.h"
+#include "attn_common.h"
+
+using namespace gfattn;
 
 namespace {
 
-struct AttnParams {
-    const void* q; const void* k; const void* v; void* o;
-    const void* dout; void* dq; void* dk; void* dv;
-    float* lse; float* delta;
-    int B, H, Nq, Nk;
-    int64_t sqb, sqn, sqh, skb, skn, skh, svb, svn, svh, sob, son, soh;
-    // gradients: dq/dout use the o-like strides given below
-    int64_t sdob, sdon, sdoh, sdqb, sdqn, sdqh, sdkb, sdkn, sdkh, sdvb, sdvn, sdvh;
-    float scale;
-};
-
-template <typename T, int HD> struct Lay {
-    static constexpr int VEC = 16 / sizeof(T);   // elements per 16-byte chunk
-    static constexpr int CPR = HD / VEC;         // chunks per row
-    static constexpr int LDR = HD + VEC;         // row-major LDS stride (+16 B: conflict-free b128)
-    static constexpr int LDT = 64 + 8;           // transposed LDS stride (64 rows of the tile + 16 B pad)
-    static constexpr int ROWMAJOR = 64 * LDR;    // elements
-    static constexpr int TRANSP = HD * LDT;      // elements
-};
-
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // Position of tile row r inside a transposed LDS row: bits 2 and 3 of r are swapped so that the 8
 // rows a lane needs for one k-step of the second MFMA — {16t + 4hi + e, 16t + 8 + 4hi + e}, e<4, the
@@ -96,17 +78,6 @@ __device__ __forceinline__ void mma_transposed(f32x16 (&acc)[HD / 32], const T* 
             mma32(acc[db], ld_frag8(ldsT + d * L::LDT + tswz(d, i0 + 16 * t + 8 * hi)), pf);
         }
     }
-}
-
-// write acc^T: lane owns row (rowptr), acc[db][r] is column db*32 + crow(r,hi)
-template <typename T, int HD>
-__device__ __forceinline__ void store_row(T* rowptr, const f32x16 (&acc)[HD / 32], float mul, int hi) {
-#pragma unroll
-    for (int db = 0; db < HD / 32; ++db)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-            st4(rowptr + db * 32 + 8 * g + 4 * hi, acc[db][4 * g] * mul, acc[db][4 * g + 1] * mul,
-                acc[db][4 * g + 2] * mul, acc[db][4 * g + 3] * mul);
 }
 
 // ===========================================================================================
@@ -389,8 +360,17 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dq_kerne
         d += xhalf(d);
         delta[j] = d;
         const int64_t stat = ((int64_t)b * p.H + h) * p.Nq + qld;
-        if (qrow0 + 32 * j < p.Nq && hi == 0) p.delta[stat] = d;
         lse2[j] = p.lse[stat] * GF_LOG2E;
+        if (qrow0 + 32 * j < p.Nq && hi == 0) {
+            if constexpr (sizeof(T) == 2) {      // what attn_bwd_dkv_bf16_kernel starts its accumulators from (attention_bwd3.hip)
+                float p2_, rr_;
+                split_scale(p.scale, p2_, rr_);
+                p.delta[stat] = -lse2[j] / rr_;
+                p.delta[(int64_t)p.B * p.H * p.Nq + stat] = -d;
+            } else {
+                p.delta[stat] = d;
+            }
+        }
     }
     const float c = p.scale * GF_LOG2E;
 
@@ -633,65 +613,10 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dkv_kern
     }
 }
 
-// ===========================================================================================
-// bf16 fast path: LDS-DMA staging + hardware-transposed LDS reads
-// ===========================================================================================
-// Tiles are 64 rows x 128 B, row-major and UNPADDED in LDS (a `global_load_lds_dwordx4` writes
-// 64 lanes x 16 B contiguously, so there is no room for padding): instead the 16-byte chunk index of
-// row r is XORed with fswz(r).  Conflict-free for both access patterns used below:
-//   * ds_read_b128 of one chunk per row, rows = the lanes of a 16-lane service group;
-//   * ds_read_b64_tr_b16 of a 4-row x 32-column block per 32 lanes (the operand of the second MFMA,
-//     read TRANSPOSED straight from the row-major tile: no transposed copy, no VALU transposition).
-// The DMA writes LDS asynchronously (tracked by vmcnt): a 3-stage ring keeps two tiles in flight and
-// needs ONE raw s_barrier per tile.  Every LDS read is inline asm with hand-placed s_waitcnt, since
-// the compiler would otherwise drain vmcnt (= the prefetch) in front of each read.
-constexpr int FT_TILE = 8192;              // bytes of one 64 x 64 bf16 tile
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-typedef __attribute__((address_space(3))) void lds_void;
-typedef const __attribute__((address_space(1))) void glb_void;
-
-__device__ __forceinline__ int fswz(int row) {
-    const int x = (row >> 1) & 7;
-    return ((x & 1) << 2) | (x >> 1);
-}
-__device__ __forceinline__ void dma16(const void* g, char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((glb_void*)g, (lds_void*)lds_wave_base, 16, 0, 0);
-}
-__device__ __forceinline__ void dma4(const void* g, char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((glb_void*)g, (lds_void*)lds_wave_base, 4, 0, 0);
-}
-template <int OFF> __device__ __forceinline__ u32x4 lds_rd128(unsigned a) {
-    u32x4 v;
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF) : "memory");
-    return v;
-}
-template <int OFF> __device__ __forceinline__ u32x2 lds_rdtr(unsigned a) {
-    u32x2 v;
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF) : "memory");
-    return v;
-}
-template <int N> __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
-template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-// the asm reads are invisible to the compiler's waitcnt bookkeeping: a tie after the wait orders every use
-template <typename V> __device__ __forceinline__ void tie(V& v) { asm volatile("" : "+v"(v)); }
-__device__ __forceinline__ bf16x8 as_frag(u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
-__device__ __forceinline__ bf16x8 as_frag(u32x2 lo, u32x2 hi) {
-    u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
-    return __builtin_bit_cast(bf16x8, v);
-}
-__device__ __forceinline__ bf16x8 cvt_frag(const f32x16& c, int t) {
-    bf16x8 f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) f[e] = (bf16_t)c[8 * t + e];
-    return f;
-}
-__device__ __forceinline__ void mma16(f32x16& acc, bf16x8 a, bf16x8 b) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
-}
-
-// dK / dV: one workgroup per 128 keys (32 per wave, K and V fragments in registers), Q / dO / lse / delta
-// tiles of 64 query rows streamed through the ring.  -lse/scale and -delta are the INITIAL VALUES of the
-// S and dP accumulators, so P = exp2(c * acc) and dS = P * acc need no subtraction.
+// dK / dV: one workgroup per 128 keys (32 per wave, K and V fragments in registers; K carries the exact power-of-two
+// part p2 of scale * log2(e) = p2 * rr), Q / dO tiles of 64 query rows and the two per-row vectors the dQ kernel wrote
+// (stat[0] = -lse * log2(e) / rr, stat[1] = -delta) streamed through the ring.  The vectors are the INITIAL VALUES of
+// the S and dP accumulators -- they land there straight from LDS -- so P = exp2(rr * acc) and dS = P * acc.
 constexpr int DKV_STATS = 2 * FT_TILE;                 // per wave: 16 lse | 16 delta | duplicates (256 B)
 constexpr int DKV_STAGE = 2 * FT_TILE + 1024;
 constexpr int DKV_NSTAGE = 3;
@@ -699,7 +624,7 @@ constexpr int DKV_NSTAGE = 3;
 template <int QB, typename Mid>
 __device__ __forceinline__ void dkv_half_tile(f32x16 (&dk)[2], f32x16 (&dv)[2], const bf16x8 (&kf)[4],
                                               const bf16x8 (&vf)[4], const unsigned (&aR)[4],
-                                              const unsigned (&aT)[4], unsigned aS, float c, float rscale,
+                                              const unsigned (&aT)[4], unsigned aS, float c,
                                               int hi, int nvalid, Mid&& mid) {
     f32x4 l4[4], d4[4];
 #define GF_ST(g) l4[g] = __builtin_bit_cast(f32x4, lds_rd128<(2 * QB + (g >> 1)) * 256 + 32 * (g & 1)>(aS)); \
@@ -712,13 +637,13 @@ __device__ __forceinline__ void dkv_half_tile(f32x16 (&dk)[2], f32x16 (&dv)[2], 
     wait_lgkm<4>();
     f32x16 sa, dp;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        tie(l4[g]);
+    for (int g = 0; g < 4; ++g) {                                   // the per-row vectors ARE the initial values (stored
+        tie(l4[g]);                                                 // negated and in the exponent's units by the dQ kernel)
         tie(d4[g]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            sa[4 * g + e] = -l4[g][e] * rscale;
-            dp[4 * g + e] = -d4[g][e];
+            sa[4 * g + e] = l4[g][e];
+            dp[4 * g + e] = d4[g][e];
         }
     }
 #pragma unroll
@@ -789,6 +714,11 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void attn_bwd_dkv_bf16_kernel(Attn
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, hi = lane >> 5, s16 = lane & 15, half = (lane >> 4) & 1;
+#ifdef GF_DKV_PRIO
+    // static priority asymmetry between the waves that share a SIMD (probe knob; see DESIGN.md "convoy")
+    if (NW == 8) { if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(GF_DKV_PRIO); }
+    else if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_setprio(GF_DKV_PRIO);
+#endif
     const int krow = kb_ * KPB + wave * 32 + l31;
     const int kld = min(krow, p.Nk - 1);
 
@@ -796,8 +726,8 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void attn_bwd_dkv_bf16_kernel(Attn
     const bf16_t* kp = reinterpret_cast<const bf16_t*>(p.k) + b * p.skb + h * p.skh;
     const bf16_t* vp = reinterpret_cast<const bf16_t*>(p.v) + b * p.svb + h * p.svh;
     const bf16_t* dop = reinterpret_cast<const bf16_t*>(p.dout) + b * p.sdob + h * p.sdoh;
-    const float* lsep = p.lse + ((int64_t)b * p.H + h) * p.Nq;
-    const float* delp = p.delta + ((int64_t)b * p.H + h) * p.Nq;
+    const float* lsep = p.delta + ((int64_t)b * p.H + h) * p.Nq;                       // stat[0]
+    const float* delp = lsep + (int64_t)p.B * p.H * p.Nq;                               // stat[1]
 
     // ---- DMA descriptors: chunk (2 wave + i) * 64 + lane of a tile -> row, swizzled source column
     int drow[PPW], dcol[PPW];
@@ -843,13 +773,14 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void attn_bwd_dkv_bf16_kernel(Attn
     issue_tile(0, 0);
     if (nt > 1) issue_tile(1, 1);
 
+    float p2, c;                                                   // c: the non-power-of-two rest rr of scale * log2(e)
+    split_scale(p.scale, p2, c);
     bf16x8 kf[4], vf[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        kf[s] = *reinterpret_cast<const bf16x8*>(kp + (int64_t)kld * p.skn + 16 * s + 8 * hi);
+        kf[s] = scale_frag(*reinterpret_cast<const bf16x8*>(kp + (int64_t)kld * p.skn + 16 * s + 8 * hi), p2);
         vf[s] = *reinterpret_cast<const bf16x8*>(vp + (int64_t)kld * p.svn + 16 * s + 8 * hi);
     }
-    const float c = p.scale * GF_LOG2E, rscale = 1.f / p.scale;
 
     f32x16 dk[2], dv[2];
 #pragma unroll
@@ -887,9 +818,9 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void attn_bwd_dkv_bf16_kernel(Attn
         const int nvalid = p.Nq - t * 64;
         const int nstage = stage == 0 ? 2 : stage - 1;
         const bool more = t + 2 < nt;
-        dkv_half_tile<0>(dk, dv, kf, vf, aR, aT, bS + so, c, rscale, hi, nvalid,
+        dkv_half_tile<0>(dk, dv, kf, vf, aR, aT, bS + so, c, hi, nvalid,
                          [&] { if (more) issue_part(0, t + 2, nstage); });
-        dkv_half_tile<1>(dk, dv, kf, vf, aR, aT, bS + so, c, rscale, hi, nvalid,
+        dkv_half_tile<1>(dk, dv, kf, vf, aR, aT, bS + so, c, hi, nvalid,
                          [&] { if (more) issue_part(1, t + 2, nstage); });
         stage = stage == 2 ? 0 : stage + 1;
     }
@@ -901,48 +832,6 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void attn_bwd_dkv_bf16_kernel(Attn
     }
 }
 
-// ===========================================================================================
-// bf16 forward and dQ on the same staging scheme as the dK/dV kernel above
-// ===========================================================================================
-// K and V tiles (64 keys x 128 B, row-major, chunk-swizzled by fswz) arrive by LDS-DMA into a 3-stage ring; the
-// score MFMAs read K rows with ds_read_b128, the second product reads V^T (forward) or K^T (dQ) straight from the
-// row-major tile with ds_read_b64_tr_b16 -- no transposed copy, no staging registers, no bank conflicts (the
-// register-staged kernels spent 36-43 % of their LDS cycles on conflicts of the transposed-tile stores).
-// One wave owns 64 query rows (two 32-row blocks: every K / V fragment feeds two MFMAs), 4 waves per workgroup.
-constexpr int FQ_STAGE = 2 * FT_TILE;          // K tile | V tile
-constexpr int FQ_NSTAGE = 3;
-
-struct FqAddr { unsigned aR[4], aT[4]; };      // per-lane LDS read addresses of stage 0 (see attn_bwd_dkv_bf16_kernel)
-
-__device__ __forceinline__ FqAddr fq_addresses(unsigned lds0, int lane) {
-    const int l31 = lane & 31, hi = lane >> 5, s16 = lane & 15, half = (lane >> 4) & 1;
-    FqAddr a;
-    const unsigned rb = l31 * 128 + 16 * (hi ^ fswz(l31));
-#pragma unroll
-    for (int s = 0; s < 4; ++s) a.aR[s] = lds0 + (rb ^ (32 * s));
-    const int bq = s16 >> 3;
-    const unsigned tb = (4 * hi + (s16 >> 2)) * 128 + 8 * (s16 & 1) + 16 * ((2 * half + ((s16 & 3) >> 1)) ^ (4 * bq + hi));
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int db = 0; db < 2; ++db) a.aT[2 * u + db] = lds0 + (tb ^ (32 * u) ^ (64 * db));
-    return a;
-}
-
-// DMA of one 64-row tile of a [rows, 64] bf16 matrix (row stride ld): wave w moves pieces 2w, 2w+1 (8 rows each)
-__device__ __forceinline__ void fq_issue(const bf16_t* base, int64_t ld, int row0, int nmax, char* dst, int wave, int lane) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int piece = 2 * wave + i;
-        const int r = piece * 8 + (lane >> 3);
-        const int col = ((lane & 7) ^ fswz(r)) * 8;
-        dma16(base + (int64_t)min(row0 + r, nmax - 1) * ld + col, dst + piece * 1024);
-    }
-}
-
-// transposed operand [t][db] of the 32-row block KB of the tile at byte offset BASE (rows 16t + 4hi + {0..3} and + 8)
-#define GF_FQ_TR(dst, BASE, KB, t, db) dst[t][db][0] = lds_rdtr<BASE + KB * 4096 + t * 2048>(aT[db]); \
-                                       dst[t][db][1] = lds_rdtr<BASE + KB * 4096 + t * 2048 + 1024>(aT[2 + db]);
 
 __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -1330,6 +1219,14 @@ template <typename K> int set_lds(K kern, size_t bytes) {
 
 template <typename T> int launch_fwd(const AttnParams& p, hipStream_t st) {
     int total = ((p.Nq + 255) / 256) * p.H * p.B;
+#if !defined(GF_ATTN_FWD_V1) && !defined(GF_ATTN_FWD_V2)
+    if constexpr (sizeof(T) == 2) {
+        // buffer descriptors address rows with 32-bit byte offsets
+        if (kvdma_ok(p.Nk, p.skn) && kvdma_ok(p.Nk, p.svn)) {
+            return launch_fwd3_bf16(p, st);
+        }
+    }
+#endif
 #ifndef GF_ATTN_FWD_V1
     if constexpr (sizeof(T) == 2) {
         const size_t l2 = FQ_NSTAGE * FQ_STAGE;
@@ -1346,14 +1243,27 @@ template <typename T> int launch_fwd(const AttnParams& p, hipStream_t st) {
 template <typename T> int launch_bwd(const AttnParams& p, hipStream_t st) {
     int total = ((p.Nq + 255) / 256) * p.H * p.B;
     size_t lds = dq_lds<T, 64>();
-    if (int e = set_lds(attn_bwd_dq_kernel<T, 64>, lds)) return e;
-#ifndef GF_PROBE_SKIP_DQ
-    attn_bwd_dq_kernel<T, 64><<<dim3(total), dim3(256), lds, st>>>(p);
-    if (int e = (int)hipGetLastError()) return e;
+    bool dq_done = false;
+#if !defined(GF_ATTN_DQ_V2)
+    if constexpr (sizeof(T) == 2) {
+        if (kvdma_ok(p.Nk, p.skn) && kvdma_ok(p.Nk, p.svn)) {
+            if (int e = launch_dq3_bf16(p, st)) return e;
+            dq_done = true;
+        }
+    }
 #endif
+    if (!dq_done) {
+        if (int e = set_lds(attn_bwd_dq_kernel<T, 64>, lds)) return e;
+        attn_bwd_dq_kernel<T, 64><<<dim3(total), dim3(256), lds, st>>>(p);
+        if (int e = (int)hipGetLastError()) return e;
+    }
     total = ((p.Nk + 127) / 128) * p.H * p.B;
     if constexpr (sizeof(T) == 2) {
+#ifdef GF_DKV_NW
+        constexpr int NW = GF_DKV_NW;
+#else
         constexpr int NW = 4;                       // 8 waves sharing one Q/dO stream measured 7 % slower
+#endif
         total = ((p.Nk + 32 * NW - 1) / (32 * NW)) * p.H * p.B;
         lds = DKV_NSTAGE * DKV_STAGE;
         if (int e = set_lds(attn_bwd_dkv_bf16_kernel<NW>, lds)) return e;

@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgf_amd.so")
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 1
+ABI_VERSION = 2      # == GF_AMD_ABI_VERSION in include/gf_amd.h (bumped with every signature / workspace change)
 
 _c = ctypes
 _P, _I, _F, _L = _c.c_void_p, _c.c_int, _c.c_float, _c.c_int64

@@ -71,7 +71,7 @@ def attn_bwd_raw(q, k, v, o, do, lse, dq, dk, dv, scale):
     Nk = k.shape[1]
     if do.stride(3) != 1:
         do = do.contiguous()
-    delta = torch.empty_like(lse)
+    delta = lse.new_empty((2,) + tuple(lse.shape))      # scratch: the two per-row vectors the dQ kernel hands to dK/dV
     _lib.check(_lib.load().gf_attn_bwd(_p(q), _p(k), _p(v), _p(o), _p(do), _p(lse), _p(delta),
                                        _p(dq), _p(dk), _p(dv), B, H, Nq, Nk, D,
                                        _s3(q), _s3(k), _s3(v), _s3(o), _s3(do), _s3(dq), _s3(dk),

@@ -35,7 +35,8 @@ extern "C" {
 #define GF_ERR_ALIGN (-3)
 #define GF_ERR_DTYPE (-4)
 
-/* ABI version; bumped on any signature change. */
+/* ABI version; bumped on any signature or workspace-size change (2: gf_attn_bwd's delta workspace doubled). */
+#define GF_AMD_ABI_VERSION 2
 int gf_abi_version(void);
 
 /* ---- multi-head attention over keypoints --------------------------------------------------
@@ -51,8 +52,9 @@ int gf_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse
                 const int64_t* v_strides, const int64_t* o_strides,
                 float scale, int dtype, void* stream);
 
-/* Backward of gf_attn_fwd (what autograd derives from the lines above).  delta [B,H,Nq] is
- * workspace (rowsum(dout * o)), written by the call. */
+/* Backward of gf_attn_fwd (what autograd derives from the lines above).  delta is WORKSPACE of 2*B*H*Nq floats,
+ * written by the call: the two per-row vectors the dQ kernel hands to the dK/dV kernel (fp32: delta = rowsum(dout * o)
+ * in the first plane; bf16: -lse in the exponent's units and -delta, the initial values of its accumulators). */
 int gf_attn_bwd(const void* q, const void* k, const void* v, const void* o,
                 const void* dout, const float* lse, float* delta,
                 void* dq, void* dk, void* dv,

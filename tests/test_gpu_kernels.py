@@ -64,6 +64,40 @@ def test_attention_strided_views_and_spike():
     torch.testing.assert_close(o.cpu().double(), ref, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("case", ["random2048", "late_spike", "ramp", "ramp_steep", "huge_logits", "ragged_tail", "first_key_dominates"])
+def test_attention_bf16_forward_reference_cases(case):
+    """The bf16 forward keeps a REFERENCE m instead of a running max (csrc/attention_fwd3.hip): scores leave the MFMA as
+    exp2 arguments relative to m, and a tile is redone conventionally when its row sum exceeds 2^16.  Cases that walk
+    every branch: maxima that creep up below the threshold (P >> 1 without a redo), that jump across it late, logits
+    far outside exp's range, a ragged last tile, a first key that dominates (everything after underflows)."""
+    B, H, D = 2, 2, 64
+    N = {"random2048": 2048, "ragged_tail": 333}.get(case, 512)
+    g = torch.Generator().manual_seed(11)
+    q, k, v = (torch.randn(B, N, H, D, generator=g, dtype=torch.float64) for _ in range(3))
+    pos = torch.arange(N, dtype=torch.float64)[None, :, None, None]
+    if case == "late_spike":
+        k[:, 450] *= 12.0
+        k[:, 200] *= 5.0
+    elif case == "ramp":            # logit scale grows slowly with the key index: the row maximum rises in every tile
+        k = k * (1 + 1.5 * pos / N)
+    elif case == "ramp_steep":      # ... and fast enough to cross the 2^16 limit several times
+        k = k * (1 + 12.0 * pos / N)
+    elif case == "huge_logits":
+        q = q * 6.0
+        k = k * 6.0
+    elif case == "first_key_dominates":
+        k[:, 0] = q[:, 7] * 40.0
+    qd, kd, vd = (t.to(DEV, torch.bfloat16) for t in (q, k, v))
+    ref, lse_ref = _attn_ref(*(t.double().cpu() for t in (qd, kd, vd)), D ** -0.5)
+    o, lse = ops.attn_fwd_raw(qd, kd, vd, D ** -0.5)
+    assert torch.isfinite(o.float()).all() and torch.isfinite(lse).all()
+    # P is rounded to bf16 (2^-9 relative), O is stored as bf16: errors scale with |v| ~ 4
+    torch.testing.assert_close(o.double().cpu(), ref, rtol=2e-2, atol=3e-2)
+    # lse: the bf16 rounding of q * scale * log2(e) moves a logit by up to 2^-9 of its magnitude
+    smax = (torch.einsum("bqhd,bkhd->bhqk", qd.double().cpu(), kd.double().cpu()) * D ** -0.5).abs().amax(-1)
+    assert ((lse.double().cpu() - lse_ref).abs() <= 2e-2 + 6e-3 * smax).all(), (lse.double().cpu() - lse_ref).abs().max()
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_self_attention_rotary(dtype):
     B, N, H, D = 2, 96, 4, 64

@@ -9,7 +9,7 @@ qkv = torch.randn(B2, N, 3, H, D, device="cuda", dtype=torch.bfloat16, generator
 do = torch.randn(B2, N, H, D, device="cuda", dtype=torch.bfloat16, generator=g)
 q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
 o = torch.empty(B2, N, H, D, device="cuda", dtype=torch.bfloat16)
-lse = torch.empty(B2, H, N, device="cuda"); delta = torch.empty_like(lse)
+lse = torch.empty(B2, H, N, device="cuda"); delta = torch.empty(2, B2, H, N, device="cuda")
 dqkv = torch.empty_like(qkv)
 stream = torch.cuda.current_stream().cuda_stream
 def timeit(fn, iters=20):
