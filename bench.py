@@ -300,8 +300,9 @@ def cpu_baseline(n, layers):
     what = ("gluefactory.models.matchers.lightglue.LightGlue (the reference module, oracle/_ref)" if kind == "reference"
             else "the torch-CPU oracle port")
     return {"value": round(1.0 / dt, 4), "unit": "image-pairs/s", "cores": cores, "kind": kind,
-            "sample": f"B=1 pair, N={n}, L={layers}, fp32, 1 warm + {reps} timed full train steps "
-                      f"({dt:.2f} s/step) of {what} on {cores} of {avail} host threads"}
+            "sample": f"B=1 pair, N={n}, L={layers}, fp32, 1 warm + {reps} timed train steps = forward + loss + backward "
+                      f"(NO optimiser step, `checkpointed: false`, no extractor) ({dt:.2f} s/step) of {what} on {cores} of "
+                      f"{avail} host threads"}
 
 
 # ------------------------------------------------------------------------------------------- model setup

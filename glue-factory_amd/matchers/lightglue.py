@@ -102,7 +102,7 @@ class SelfBlock(nn.Module):
         bias = self.Wqkv.bias.index_select(0, self._perm)
         # x feeds the projection, the FFN input and the residual: one gradient chain, closed by the projection
         chain = ops.GradChain(3) if x.requires_grad and torch.is_grad_enabled() else None
-        if ops.gemm_takes(d, 3 * d, x.dtype):     # q, k leave the GEMM already rotated (rotary epilogue)
+        if self.head_dim == 64 and ops.gemm_takes(d, 3 * d, x.dtype):     # q, k leave the GEMM already rotated (rotary epilogue: 64-wide heads)
             qkv = ops.linear(x, w, bias, rotary_cs=cs, rot_n=2 * d, chain=chain, chain_last=True)
             qkv = qkv.view(b, n, 3, self.heads, self.head_dim)
             ctx = ops.self_attention_rotary(qkv, theta, cs, pre_rotated=True)      # [b,n,H,hd]

@@ -1182,6 +1182,12 @@ def line_graph(idx, n):
     _chk(idx)
     idx = idx.contiguous()
     B, E = idx.shape
+    if E > 4096 or n > 8192:
+        raise NotImplementedError(f"gf_line_csr keeps one image's junction graph in LDS: E={E} endpoints (max 4096), "
+                                  f"n={n} junctions (max 8192)")
+    # a junction index outside [0, n) would corrupt LDS in the kernels below; the torch gather they replace raises too
+    # (device-side assert: no host synchronisation)
+    torch._assert_async(((idx >= 0) & (idx < n)).all())
     order = torch.empty((B, E), dtype=torch.int32, device=idx.device)
     seg = torch.empty((B, n + 1), dtype=torch.int32, device=idx.device)
     _lib.check(_lib.load().gf_line_csr(_p(idx), _p(order), _p(seg), B, E, n, _stream()), "gf_line_csr")

@@ -71,7 +71,11 @@ def stack_twoviews(data, indices=PAIRS):
 
 
 def unstack_twoviews(data, batch, indices=PAIRS):
-    return {idx: {k: _slice(v, i * batch, (i + 1) * batch) for k, v in data.items()} for i, idx in enumerate(indices)}
+    """Per-pair views of a stacked prediction.  Private entries of a matcher (keys starting with ``_``: e.g. LightGlue's
+    per-layer descriptor list and image-stacked head state for its fused loss) are NOT per-pair batched and are left
+    out: the stacked prediction itself is kept for the loss (``TripletPipeline._forward``)."""
+    public = {k: v for k, v in data.items() if not k.startswith("_")}
+    return {idx: {k: _slice(v, i * batch, (i + 1) * batch) for k, v in public.items()} for i, idx in enumerate(indices)}
 
 
 def _batch_size(data):
@@ -104,7 +108,9 @@ class TripletPipeline(TwoViewPipeline):
         if self.conf.batch_triplets:
             batch = _batch_size(data["view1"])
             m_pred = self._stages(stack_twoviews(pred), stack_twoviews(data))
-            pred = {**pred, **unstack_twoviews(m_pred, batch)}
+            # the loss runs on the stacked matcher output itself: slicing and re-stacking would tear the matcher's
+            # private, not-per-pair entries apart (LightGlue: 6 of 9 layers, half of the image-stacked head state)
+            pred = {**pred, **unstack_twoviews(m_pred, batch), "_stacked": m_pred}
         else:
             for idx in PAIRS:
                 pred[idx] = self._stages(get_twoview(pred, idx), get_twoview(data, idx))
@@ -114,7 +120,8 @@ class TripletPipeline(TwoViewPipeline):
         if not has_triplet(data):
             return super().loss(pred, data)
         if self.conf.batch_triplets:
-            return super().loss(stack_twoviews(pred), stack_twoviews(data))
+            stacked = pred["_stacked"] if "_stacked" in pred else stack_twoviews(pred)
+            return super().loss(stacked, stack_twoviews(data))
         losses, metrics = {}, {}
         for idx in PAIRS:
             li, mi = super().loss(pred[idx], get_twoview(data, idx))

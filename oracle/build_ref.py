@@ -1,8 +1,7 @@
 """Recipe for oracle/_ref: the REFERENCE's own matcher modules as byte-compiled, sourceless Python.
 
 TEST / BENCH INFRASTRUCTURE ONLY.  The reference is Python, so "building" it means compiling the module
-closure of ``gluefactory.models.matchers.lightglue`` (+ the SuperGlue / GlueStick matchers and the two-view
-pipeline) from the sources WHERE THEY LIE under /root/reference into ``oracle/_ref/**.pyc`` -- outputs only; no
+closure of ``gluefactory.models.matchers.lightglue`` from the sources WHERE THEY LIE under /root/reference into ``oracle/_ref/**.pyc`` -- outputs only; no
 reference source is copied into the repository, and ``oracle/_ref/`` is git-ignored (it travels to the GPU box with
 the snapshot, like the built libgf_amd.so).  Consumers: ``bench.py``'s ``cpu_baseline`` leg, which times the
 reference's LightGlue train step on the GPU box's host cores (``"kind": "reference"``), and nothing else.
@@ -10,6 +9,7 @@ reference's LightGlue train step on the GPU box's host cores (``"kind": "referen
     python oracle/build_ref.py        # needs /root/reference (build container); no-op message otherwise
 """
 import importlib
+import importlib.util
 import os
 import py_compile
 import shutil
@@ -19,10 +19,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REF = "/root/reference"
 OUT = os.path.join(HERE, "_ref")
 STUBS = os.path.join(HERE, "stubs")          # omegaconf / kornia stand-ins (ours, tracked)
+# Only what bench.py's cpu_baseline times: the LightGlue matcher and its losses.  (gluefactory_nonfree -- SuperGlue, under
+# its own non-commercial licence -- is NOT bundled; SuperGlue / GlueStick goldens come from oracle/gen_golden.py, which
+# imports the reference in place.)
 TARGETS = ["gluefactory.models.matchers.lightglue", "gluefactory.models.utils.losses",
-           "gluefactory.models.utils.metrics", "gluefactory_nonfree.superglue",
-           "gluefactory.models.matchers.gluestick", "gluefactory.models.two_view_pipeline",
-           "gluefactory.models.base_model", "gluefactory.models"]
+           "gluefactory.models.utils.metrics", "gluefactory.models.base_model", "gluefactory.models"]
 
 
 def build(verbose=True):
@@ -51,7 +52,8 @@ def build(verbose=True):
         os.makedirs(os.path.dirname(dst), exist_ok=True)
         py_compile.compile(src, cfile=dst, dfile=rel, doraise=True, optimize=0)
     with open(os.path.join(OUT, "MANIFEST.txt"), "w") as f:
-        f.write("byte-compiled from /root/reference by oracle/build_ref.py with python %s\n" % sys.version.split()[0])
+        f.write("byte-compiled from /root/reference by oracle/build_ref.py with python %s magic %s\n"
+                % (sys.version.split()[0], importlib.util.MAGIC_NUMBER.hex()))
         f.write("\n".join(os.path.relpath(s, REF) for s in files) + "\n")
     if verbose:
         print(f"oracle/_ref: {len(files)} reference modules byte-compiled")
@@ -59,9 +61,14 @@ def build(verbose=True):
 
 
 def import_reference():
-    """Put oracle/_ref (+ the stand-ins) on sys.path; returns False when it has not been built."""
-    if not os.path.exists(os.path.join(OUT, "gluefactory", "models", "matchers", "lightglue.pyc")):
+    """Put oracle/_ref (+ the stand-ins) on sys.path; returns False when it has not been built or was byte-compiled by
+    another Python (sourceless .pyc files only load under the interpreter version that wrote them)."""
+    pyc = os.path.join(OUT, "gluefactory", "models", "matchers", "lightglue.pyc")
+    if not os.path.exists(pyc):
         return False
+    with open(pyc, "rb") as f:
+        if f.read(4) != importlib.util.MAGIC_NUMBER:
+            return False
     for p in (OUT, STUBS):
         if p not in sys.path:
             sys.path.insert(0, p)

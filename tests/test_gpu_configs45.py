@@ -14,7 +14,9 @@ pytestmark = pytest.mark.gpu
 
 # ---- stated bf16 bounds: about 2x what was measured on MI355X (round 3; the measured numbers are printed) ----
 SG_BF16 = {"la_max": 1.0, "la_p99": 0.3, "la_mean": 0.08, "loss_rel": 2e-2, "grad_rel": 0.10}
-GS_BF16 = {"la_max": 1.0, "la_p99": 0.3, "la_mean": 0.08, "loss_rel": 2e-2, "grad_rel": 0.10}
+# GlueStick measured: log_assignment max 0.40 / p99 0.22 / mean 0.044, lines 0.41 / 0.20 / 0.055, worst loss entry 4.2e-3,
+# per-tensor gradient error median 7.4 %, worst 20 % (lenc.encoder.4.bias, a 256-vector in front of the 18-layer GNN)
+GS_BF16 = {"la_max": 0.8, "la_p99": 0.4, "la_mean": 0.09, "loss_rel": 1e-2, "grad_rel": 0.35}
 
 
 def _cuda(d):

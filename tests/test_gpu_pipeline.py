@@ -96,3 +96,48 @@ def test_triplet_pipeline_with_hip_lightglue():
     with torch.no_grad():
         p2 = batched(two)
     torch.testing.assert_close(p2["log_assignment"], pb["0to1"]["log_assignment"], rtol=1e-4, atol=1e-4)
+
+
+def test_triplet_pipeline_trains_lightglue_batched_equals_pairwise():
+    """TripletPipeline (batch_triplets, the default) around the HIP LightGlue in TRAINING mode: the fused loss reads the
+    matcher's private per-layer / image-stacked state, so the stacked prediction must reach it untouched.  Batched
+    triplets == pair by pair: per-pair losses and every parameter gradient."""
+    from glue_factory_amd.base_model import get_model
+    from glue_factory_amd.synthetic import to_device
+    P3 = get_model("glue_factory_amd.triplet_pipeline")
+
+    def conf(batched):
+        return {"extractor": {"name": "extractors.superpoint_open", "max_num_keypoints": 96, "force_num_keypoints": True,
+                              "detection_threshold": 0.0, "nms_radius": 3, "trainable": False},
+                "ground_truth": {"name": "matchers.homography_matcher", "th_positive": 3, "th_negative": 3},
+                "matcher": {"name": "matchers.lightglue", "filter_threshold": 0.1, "n_layers": 3},
+                "batch_triplets": batched}
+
+    torch.manual_seed(0)
+    pb = P3(conf(True)).cuda()
+    pp = P3(conf(False)).cuda()
+    pp.load_state_dict(pb.state_dict())
+    d2 = _batch(b=2)
+    g = torch.Generator().manual_seed(5)
+    data = {"view0": d2["view0"], "view1": d2["view1"],
+            "view2": {"image": d2["view0"]["image"].roll(16, -2), "image_size": d2["view0"]["image_size"]},
+            "H_0to1": d2["H_0to1"],
+            "H_0to2": torch.tensor([[1.0, 0, 0], [0, 1, 16], [0, 0, 1]])[None].repeat(2, 1, 1),
+            "H_1to2": torch.tensor([[1.0, 0, -8], [0, 1, 16], [0, 0, 1]])[None].repeat(2, 1, 1)}
+    data = to_device(data, "cuda")
+    grads = []
+    totals = []
+    for pipe in (pb, pp):
+        pipe.eval()
+        pipe.matcher.train()
+        pred = pipe(data)
+        losses, _ = pipe.loss(pred, data)
+        totals.append(losses["total"])
+        losses["total"].sum().backward()
+        grads.append({k: p.grad.clone() for k, p in pipe.matcher.named_parameters()})
+    assert totals[0].shape == (6,) and totals[1].shape == (2,)
+    # pair-by-pair losses are summed over the three pairs, the batched ones come stacked pair after pair
+    torch.testing.assert_close(totals[0][0:2] + totals[0][2:4] + totals[0][4:6], totals[1], rtol=1e-4, atol=1e-4)
+    for k in grads[0]:
+        sc = grads[1][k].abs().max().clamp(min=1e-6)
+        torch.testing.assert_close(grads[0][k] / sc, grads[1][k] / sc, rtol=2e-3, atol=2e-3, msg=lambda m: f"{k}: {m}")
