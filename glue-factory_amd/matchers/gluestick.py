@@ -87,12 +87,11 @@ class LineLayer(nn.Module):
             self.proj_node = nn.Conv1d(feature_dim, feature_dim, kernel_size=1)
             self.proj_neigh = nn.Conv1d(2 * feature_dim, feature_dim, kernel_size=1)
 
-    def _attention(self, msg, ldesc, junc_idx):
+    def _attention(self, msg, ldesc, junc_idx, graph):
         """Per-endpoint weights: softmax over the endpoints that share a junction of <proj_node(x_j), proj_neigh([x_other,
         enc])> / sqrt(D), with the reference's global max shift and its epsilon (gluestick.py:623-639)."""
         d = self.dim
-        query = _conv_cl(ldesc, self.proj_node).float()
-        query = query.gather(1, junc_idx[..., None].expand(-1, -1, d))
+        query = ops.rows_gather(_conv_cl(ldesc, self.proj_node).float(), junc_idx, *graph)
         key = _conv_cl(msg[..., d:].contiguous(), self.proj_neigh).float()
         prob = (query * key).sum(-1) / d ** 0.5
         prob = torch.exp(prob - prob.max())
@@ -106,7 +105,7 @@ class LineLayer(nn.Module):
         msg = ops.line_gather(ldesc, line_enc.to(ldesc.dtype), junc_idx, order, seg)
         upd = _mlp_cl(self.mlp, msg, halves)
         if self.line_attention:
-            upd = upd * self._attention(msg, ldesc, junc_idx)[..., None].to(upd.dtype)
+            upd = upd * self._attention(msg, ldesc, junc_idx, graph)[..., None].to(upd.dtype)
         return ops.line_aggregate(ldesc, upd, junc_idx, order, seg, mean=not self.line_attention)
 
 
@@ -119,19 +118,6 @@ class AttentionalGNN(nn.Module):
         self.layers = nn.ModuleList([GNNLayer(feature_dim, t) for t in layer_types])
         self.line_layers = nn.ModuleList([LineLayer(feature_dim, line_attention)
                                           for _ in range(len(layer_types) // 2)])
-
-
-def log_double_softmax_dense(scores, bin_score):
-    """gluestick.py:772-783 on a small dense matrix (line head), stock torch."""
-    b, m, n = scores.shape
-    beta = bin_score.to(scores).reshape(1, 1, 1)
-    r = torch.logsumexp(torch.cat([scores, beta.expand(b, m, 1)], 2), 2)
-    c = torch.logsumexp(torch.cat([scores, beta.expand(b, 1, n)], 1), 1)
-    out = scores.new_zeros(b, m + 1, n + 1)
-    out[:, :m, :n] = scores - 0.5 * (r[:, :, None] + c[:, None, :])
-    out[:, :m, n] = beta.reshape(1, 1) - r
-    out[:, m, :n] = beta.reshape(1, 1) - c
-    return out
 
 
 class GlueStick(BaseModel):
@@ -208,16 +194,16 @@ class GlueStick(BaseModel):
         r, c = torch.logaddexp(r_raw, beta), torch.logaddexp(c_raw, beta)
         return ops.assign_write(md0, md1, -0.5 * r, -0.5 * c, beta - r, beta - c, alpha=1.0, corner=0.0)
 
-    def _line_head(self, ld0, ld1, idx0, idx1, proj):
+    def _line_head(self, ld0, ld1, idx0, idx1, graph0, graph1, proj):
+        """gluestick.py:336-376: endpoint descriptors -> final_line_proj -> endpoint scores -> line scores (max over the
+        two endpoint pairings) -> bin-augmented double softmax.  The projection runs on the gathered endpoint rows only
+        (a 1x1 convolution commutes with the row gather); every [B, lines, lines] pass is a HIP kernel
+        (csrc/line_head.hip, gf_bgemm)."""
         d = self.conf.descriptor_dim
-        m0, m1 = _conv_cl(ld0, proj).float(), _conv_cl(ld1, proj).float()
-        s = torch.bmm(m0, m1.transpose(1, 2)) / d ** 0.5
-        s = s.gather(2, idx1[:, None, :].expand(-1, s.shape[1], -1))
-        s = s.gather(1, idx0[:, :, None].expand(-1, -1, s.shape[2]))
-        b = s.shape[0]
-        s = s.reshape(b, idx0.shape[1] // 2, 2, idx1.shape[1] // 2, 2)
-        raw = 0.5 * torch.maximum(s[:, :, 0, :, 0] + s[:, :, 1, :, 1], s[:, :, 0, :, 1] + s[:, :, 1, :, 0])
-        scores = log_double_softmax_dense(raw, self.line_bin_score.float())
+        g0 = _conv_cl(ops.rows_gather(ld0, idx0, *graph0), proj)
+        g1 = _conv_cl(ops.rows_gather(ld1, idx1, *graph1), proj)
+        raw = ops.line_pair_scores(g0, g1, d ** -0.5)
+        scores = ops.dense_log_double_softmax(raw, self.line_bin_score)
         return (scores, *self._filter(scores), raw)
 
     # ------------------------------------------------------------------ forward
@@ -294,11 +280,12 @@ class GlueStick(BaseModel):
         pred.update({"log_assignment": kp_scores, "matches0": m0, "matches1": m1,
                      "matching_scores0": ms0, "matching_scores1": ms1})
         if have_lines:
-            ls, lm0, lm1, lms0, lms1, raw = self._line_head(d0[:, :2 * nl0], d1[:, :2 * nl1], idx0, idx1,
-                                                            self.final_line_proj)
+            # junction graphs of the two images (the gather's backward is a segment sum over them)
+            gr0, gr1 = (tuple(t[:b] for t in graphs[0]), tuple(t[b:] for t in graphs[0])) if stacked else (graphs[0], graphs[1])
+            ls, lm0, lm1, lms0, lms1, raw = self._line_head(d0, d1, idx0, idx1, gr0, gr1, self.final_line_proj)
             for layer_id in (inter or []):
                 e0, e1 = split(inter_desc[layer_id])
-                li, a0, a1, s0, s1, _ = self._line_head(e0[:, :2 * nl0], e1[:, :2 * nl1], idx0, idx1,
+                li, a0, a1, s0, s1, _ = self._line_head(e0, e1, idx0, idx1, gr0, gr1,
                                                         self.inter_line_proj[self.layer2idx[layer_id]])
                 pred.update({f"line_{layer_id}_log_assignment": li, f"line_{layer_id}_matches0": a0,
                              f"line_{layer_id}_matches1": a1, f"line_{layer_id}_matching_scores0": s0,

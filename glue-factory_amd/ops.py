@@ -664,10 +664,25 @@ def rows_argmax(a, b, colbias=None, alpha=1.0):
     return vmax, arg
 
 
+def bgemm(a, b, out=None, alpha=1.0):
+    """out[bt] = alpha * a[bt] @ b[bt] for 3-d a [B,M,K], b [B,K,N] with ARBITRARY strides (transposed views cost
+    nothing); fp32 operands on the exact-fp32 MFMA.  No autograd (callers own their backward)."""
+    _chk(a, b)
+    assert a.dim() == 3 and b.dim() == 3 and a.shape[0] == b.shape[0] and a.shape[2] == b.shape[1] and a.dtype == b.dtype
+    B, M, K = a.shape
+    N = b.shape[2]
+    if out is None:
+        out = torch.empty((B, M, N), dtype=a.dtype, device=a.device)
+    st = lambda t: _lib.strides(t.stride(0), t.stride(1), t.stride(2))  # noqa: E731
+    _lib.check(_lib.load().gf_bgemm(_p(a), _p(b), _p(out), B, M, N, K, st(a), st(b), st(out), float(alpha), _dt(a),
+                                    _stream()), "gf_bgemm")
+    return out
+
+
 def _head_bwd(a, b, r, c, gr, gc, da, db):
     """da = dS b, db = dS^T a for dS = P_row * gr + P_col * gc (module docstring of _DualLSE), written into the given
     buffers.  bf16 / D = 256: the fused gf_head_bwd (no dS tensor); otherwise dS is written once and two batched
-    products follow."""
+    products (gf_bgemm) follow."""
     B, M, D = a.shape
     N = b.shape[1]
     if a.dtype == torch.bfloat16 and D == 256 and da.is_contiguous() and db.is_contiguous():
@@ -677,8 +692,8 @@ def _head_bwd(a, b, r, c, gr, gc, da, db):
     dS = torch.empty((B, M, N), dtype=a.dtype, device=a.device)
     _lib.check(_lib.load().gf_dual_softmax_bwd(_p(a), _p(b), _p(r), _p(c), _p(gr), _p(gc), None, 0,
                                                0.0, _p(dS), B, M, N, D, _dt(a), _stream()), "gf_dual_softmax_bwd")
-    torch.bmm(dS, b, out=da)
-    torch.bmm(dS.transpose(1, 2), a, out=db)
+    bgemm(dS, b, out=da)                       # exact-fp32 MFMA in the fp32 parity mode: no library product on the path
+    bgemm(dS.transpose(1, 2), a, out=db)
 
 
 class _DualLSE(torch.autograd.Function):
@@ -851,8 +866,8 @@ class _AssignWrite(torch.autograd.Function):
         a, b = ctx.saved_tensors
         core = G[:, :-1, :-1]
         g = (ctx.alpha * core).to(a.dtype)
-        da = torch.bmm(g, b)
-        db = torch.bmm(g.transpose(1, 2), a)
+        da = bgemm(g.contiguous(), b)
+        db = bgemm(g.transpose(1, 2), a)
         d = ctx.dts
         gcorner = None
         if ctx.corner_shape is not None:
@@ -1260,3 +1275,115 @@ def line_gather(x, enc, idx, order, seg):
 
 def line_aggregate(x, upd, idx, order, seg, mean=True):
     return _LineAggregate.apply(x, upd, idx, order, seg, mean)
+
+
+# ------------------------------------------------------------------------------ GlueStick line head (dense scores)
+class _RowsGather(torch.autograd.Function):
+    """out[b,e,:] = x[b, idx[b,e], :]; backward: deterministic segment sum over the junction graph (order, seg)."""
+
+    @staticmethod
+    def forward(ctx, x, idx, order, seg):
+        _chk(x, idx)
+        x = x.contiguous()
+        B, N, D = x.shape
+        E = idx.shape[1]
+        out = torch.empty((B, E, D), dtype=x.dtype, device=x.device)
+        _lib.check(_lib.load().gf_rows_gather(_p(x), _p(idx), _p(out), B, E, N, D, _dt(x), _stream()), "gf_rows_gather")
+        ctx.save_for_backward(order, seg)
+        ctx.n = N
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        order, seg = ctx.saved_tensors
+        g = g.contiguous()
+        B, E, D = g.shape
+        return _segsum(g, None, order, seg, None, B, E, ctx.n, D, 0), None, None, None
+
+
+def rows_gather(x, idx, order, seg):
+    return _RowsGather.apply(x, idx.contiguous(), order, seg)
+
+
+class _LinePairScores(torch.autograd.Function):
+    """raw[a,c] = scale/2 * max(S[2a,2c] + S[2a+1,2c+1], S[2a,2c+1] + S[2a+1,2c]) with S = g0 g1^T the endpoint
+    scores (gluestick.py:345-354), fp32.  S is kept for the backward (16 MB per pair at 512 lines); the gradient
+    reaches g0 / g1 through two gf_bgemm products."""
+
+    @staticmethod
+    def forward(ctx, g0, g1, scale):
+        g0, g1 = g0.float().contiguous(), g1.float().contiguous()
+        B, E0, D = g0.shape
+        E1 = g1.shape[1]
+        S = bgemm(g0, g1.transpose(1, 2), alpha=scale)
+        raw = torch.empty((B, E0 // 2, E1 // 2), dtype=torch.float32, device=g0.device)
+        _lib.check(_lib.load().gf_line_pair_scores(_p(S), None, _p(raw), B, E0 // 2, E1 // 2, 0, _stream()),
+                   "gf_line_pair_scores")
+        ctx.save_for_backward(g0, g1, S)
+        ctx.scale = scale
+        return raw
+
+    @staticmethod
+    def backward(ctx, draw):
+        g0, g1, S = ctx.saved_tensors
+        B, E0, _ = g0.shape
+        E1 = g1.shape[1]
+        dS = torch.empty_like(S)
+        draw = draw.contiguous()
+        _lib.check(_lib.load().gf_line_pair_scores(_p(S), _p(draw), _p(dS), B, E0 // 2, E1 // 2, 1, _stream()),
+                   "gf_line_pair_scores")
+        return bgemm(dS, g1, alpha=ctx.scale), bgemm(dS.transpose(1, 2), g0, alpha=ctx.scale), None
+
+
+def line_pair_scores(g0, g1, scale):
+    return _LinePairScores.apply(g0, g1, scale)
+
+
+def _dense_rowcol(z, M, N, mode):
+    B = z.shape[0]
+    rows = torch.empty((B, M), dtype=torch.float32, device=z.device)
+    cols = torch.empty((B, N), dtype=torch.float32, device=z.device)
+    _lib.check(_lib.load().gf_dense_rowcol(_p(z), z.stride(0), z.stride(1), _p(rows), _p(cols), B, M, N, mode, _stream()),
+               "gf_dense_rowcol")
+    return rows, cols
+
+
+class _DenseLogDoubleSoftmax(torch.autograd.Function):
+    """gluestick.py:772-783 on a dense fp32 [B,M,N] score matrix with a learnable bin score beta:
+    out[:, :M, :N] = raw - (r_i + c_j) / 2, out[:, :M, N] = beta - r_i, out[:, M, :N] = beta - c_j, out[:, M, N] = 0 with
+    r_i = log(sum_j exp raw_ij + exp beta), c_j likewise over rows.  The [B,M,N] passes are HIP kernels
+    (csrc/line_head.hip); the [B,M] / [B,N] vector algebra stays in torch."""
+
+    @staticmethod
+    def forward(ctx, raw, beta):
+        _chk(raw)
+        raw = raw.float().contiguous()
+        B, M, N = raw.shape
+        beta = beta.float().reshape(())
+        r0, c0 = _dense_rowcol(raw, M, N, 0)
+        r, c = torch.logaddexp(r0, beta), torch.logaddexp(c0, beta)
+        out = torch.empty((B, M + 1, N + 1), dtype=torch.float32, device=raw.device)
+        rb, cb, br, bc = (-0.5 * r).contiguous(), (-0.5 * c).contiguous(), (beta - r).contiguous(), (beta - c).contiguous()
+        _lib.check(_lib.load().gf_dense_assign(_p(raw), _p(rb), _p(cb), _p(br), _p(bc), 0.0, _p(out),
+                                               B, M, N, _stream()), "gf_dense_assign")
+        ctx.save_for_backward(raw, r, c, beta)
+        return out
+
+    @staticmethod
+    def backward(ctx, G):
+        raw, r, c, beta = ctx.saved_tensors
+        B, M, N = raw.shape
+        G = G.float().contiguous()
+        gs_r, gs_c = _dense_rowcol(G, M, N, 1)                    # sums of the core block of G ([B,M+1,N+1] view strides)
+        A = 0.5 * gs_r + G[:, :M, N]                              # gradient arriving at -r_i
+        Bv = 0.5 * gs_c + G[:, M, :N]                             # ... at -c_j
+        draw = torch.empty_like(raw)
+        A, Bv = A.contiguous(), Bv.contiguous()      # (named: a temporary's storage could be reused before the launch reads it)
+        _lib.check(_lib.load().gf_dense_assign_bwd(_p(raw), _p(r), _p(c), _p(A), _p(Bv), _p(G),
+                                                   _p(draw), B, M, N, _stream()), "gf_dense_assign_bwd")
+        dbeta = (G[:, :M, N] - A * torch.exp(beta - r)).sum() + (G[:, M, :N] - Bv * torch.exp(beta - c)).sum()
+        return draw, dbeta
+
+
+def dense_log_double_softmax(raw, beta):
+    return _DenseLogDoubleSoftmax.apply(raw, beta)

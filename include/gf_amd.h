@@ -35,8 +35,8 @@ extern "C" {
 #define GF_ERR_ALIGN (-3)
 #define GF_ERR_DTYPE (-4)
 
-/* ABI version; bumped on any signature or workspace-size change (2: gf_attn_bwd's delta workspace doubled). */
-#define GF_AMD_ABI_VERSION 2
+/* ABI version; bumped on any signature or workspace-size change (2: gf_attn_bwd's delta workspace doubled; 3: line head + gf_bgemm). */
+#define GF_AMD_ABI_VERSION 3
 int gf_abi_version(void);
 
 /* ---- multi-head attention over keypoints --------------------------------------------------
@@ -168,6 +168,32 @@ int gf_line_segsum(const void* s0, int64_t ld0, const void* s1, int64_t ld1, con
                    const void* base, void* out, int B, int E, int N, int D, int mode, int dtype, void* stream);
 int gf_line_expand(const void* g, const int64_t* idx, const int* seg, void* d, int B, int E, int N, int D,
                    int mode, int dtype, void* stream);
+
+/* ---- GlueStick line-matching head on dense score matrices (gluestick.py:336-376, :772-783; csrc/line_head.hip) ----
+ * gf_rows_gather:      out [B,E,D] = x[b, idx[b,e], :] (x [B,N,D]; endpoint descriptors; backward = gf_line_segsum).
+ * gf_line_pair_scores: backward == 0: out = raw [B,M,N], raw[a,c] = 1/2 max(S[2a,2c] + S[2a+1,2c+1], S[2a,2c+1] +
+ *                      S[2a+1,2c]) for the endpoint scores S [B,2M,2N] (:349-354); backward != 0: out = dS [B,2M,2N]
+ *                      for draw [B,M,N] (the winning pairing, recomputed from S, receives 1/2 draw).
+ * gf_dense_rowcol:     rows [B,M] / cols [B,N] (either may be NULL) of the [B,M,N] fp32 view z (batch stride, row stride
+ *                      ld in elements): mode 0 log-sum-exp (the normalisers of :772-783 before the bin), mode 1 sum.
+ * gf_dense_assign:     out [B,M+1,N+1] = [[raw + row_bias_i + col_bias_j, bin_row_i], [bin_col_j, corner]].
+ * gf_dense_assign_bwd: draw = G[:, :M, :N] - exp(raw - r_i) A_i - exp(raw - c_j) Bv_j  (G [B,M+1,N+1]). */
+int gf_rows_gather(const void* x, const int64_t* idx, void* out, int B, int E, int N, int D, int dtype, void* stream);
+int gf_line_pair_scores(const float* S, const float* draw, float* out, int B, int M, int N, int backward, void* stream);
+int gf_dense_rowcol(const float* z, int64_t batch_stride, int64_t ld, float* rows, float* cols, int B, int M, int N,
+                    int mode, void* stream);
+int gf_dense_assign(const float* raw, const float* row_bias, const float* col_bias, const float* bin_row,
+                    const float* bin_col, float corner, float* out, int B, int M, int N, void* stream);
+int gf_dense_assign_bwd(const float* raw, const float* r, const float* c, const float* A, const float* Bv,
+                        const float* G, float* draw, int B, int M, int N, void* stream);
+
+/* ---- small batched GEMM with arbitrary element strides (csrc/bgemm.hip): C[b,i,j] = alpha sum_k A[b,i,k] B[b,k,j],
+ * strides {batch, row, column} of A [M,K], B [K,N], C [M,N]; fp32 operands use the exact-fp32 MFMA.  The products of
+ * two ACTIVATION tensors outside the fused kernels: the line head's endpoint scores and their gradients
+ * (gluestick.py:345-347), the fp32 parity mode of the assignment-head backward (lightglue.py:256-290 autograd). */
+int gf_bgemm(const void* a, const void* b, void* c, int batch, int M, int N, int K,
+             const int64_t* a_strides, const int64_t* b_strides, const int64_t* c_strides,
+             float alpha, int dtype, void* stream);
 
 /* ---- weight-streaming GEMM of the tall-and-skinny linear layers (default path of every nn.Linear / Conv1d(k=1)
  * forward and, with the transposed weight, of every input-gradient GEMM: lightglue.py:131-221,271-290,

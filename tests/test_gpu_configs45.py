@@ -13,7 +13,9 @@ from config_golden import (check_la_digest, grad_digest_errors, gs_config_inputs
 pytestmark = pytest.mark.gpu
 
 # ---- stated bf16 bounds: about 2x what was measured on MI355X (round 3; the measured numbers are printed) ----
-SG_BF16 = {"la_max": 1.0, "la_p99": 0.3, "la_mean": 0.08, "loss_rel": 2e-2, "grad_rel": 0.10}
+# SuperGlue measured: log_assignment max 0.32 / p99 0.136 / mean 0.027, worst loss entry 3.8e-4, per-tensor gradient error
+# median 2.9 %, worst 9.5 % (gnn.layers.0.attn.proj.0.bias: the query bias, whose gradient is a sum of cancelling terms)
+SG_BF16 = {"la_max": 0.65, "la_p99": 0.28, "la_mean": 0.055, "loss_rel": 2e-3, "grad_rel": 0.20}
 # GlueStick measured: log_assignment max 0.40 / p99 0.22 / mean 0.044, lines 0.41 / 0.20 / 0.055, worst loss entry 4.2e-3,
 # per-tensor gradient error median 7.4 %, worst 20 % (lenc.encoder.4.bias, a 256-vector in front of the 18-layer GNN)
 GS_BF16 = {"la_max": 0.8, "la_p99": 0.4, "la_mean": 0.09, "loss_rel": 1e-2, "grad_rel": 0.35}
@@ -101,7 +103,7 @@ def test_superglue_config4_fp32_train_step_vs_reference():
     print("superglue config4 fp32: matches0 agreement", agree)
     assert agree >= 0.999
     _check_losses(z, losses, 1e-4)
-    _fp32_grads(z, grads, norm_tol=3e-3, sample_tol=1e-2)
+    _fp32_grads(z, grads, norm_tol=1e-3, sample_tol=4e-3)        # measured 3.1e-4 / 1.0e-3
 
 
 def test_superglue_config4_bf16_train_step_bounds():
@@ -122,7 +124,7 @@ def test_gluestick_config5_fp32_train_step_vs_reference():
         print("gluestick config5 fp32:", k, "agreement", agree)
         assert agree >= 0.999
     _check_losses(z, losses, 1e-4)
-    _fp32_grads(z, grads, norm_tol=5e-3, sample_tol=1e-2)
+    _fp32_grads(z, grads, norm_tol=1e-3, sample_tol=4e-3)        # measured 1.3e-4 / 7.3e-4
 
 
 def test_gluestick_config5_bf16_train_step_bounds():

@@ -646,3 +646,68 @@ def test_gemm_streamed_kernel_rotary(M, N, K, rot_n):
     y_st, y_ws = run(M), run(M + 1)
     torch.testing.assert_close(y_st[:M].double(), ref[:M], rtol=2e-2, atol=3e-2)
     assert (y_st[:M].float() - y_ws[:M].float()).abs().max().item() <= 0.0625
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,M,N,K", [(2, 64, 64, 256), (3, 100, 37, 50), (1, 1024, 1024, 256), (2, 5, 300, 7)])
+def test_bgemm_strided_operands(dtype, B, M, N, K):
+    """gf_bgemm: C = alpha A B for plain, transposed and sliced views (no copies); fp32 on the exact-fp32 MFMA."""
+    g = torch.Generator().manual_seed(B + M + N + K)
+    a = torch.randn(B, M, K, generator=g).to(DEV, dtype)
+    bt = torch.randn(B, N, K + 3, generator=g).to(DEV, dtype)[:, :, 1:K + 1]       # B^T stored [N, K] inside a wider buffer
+    at = torch.randn(B, K, M, generator=g).to(DEV, dtype)                           # A^T stored [K, M]
+    tol = dict(rtol=1e-5, atol=1e-5 * K ** 0.5) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2 * K ** 0.5)
+    for A, Bm in ((a, bt.transpose(1, 2)), (at.transpose(1, 2), bt.transpose(1, 2))):
+        out = ops.bgemm(A, Bm, alpha=0.5)
+        ref = 0.5 * torch.matmul(A.double().cpu(), Bm.double().cpu())
+        torch.testing.assert_close(out.double().cpu(), ref, **tol)
+    # "NN" with a transposed left operand written into a strided output slice
+    big = torch.zeros(B, M + 2, N + 5, device=DEV, dtype=dtype)
+    ops.bgemm(at.transpose(1, 2), bt.transpose(1, 2), out=big[:, 1:M + 1, 2:N + 2])
+    torch.testing.assert_close(big[:, 1:M + 1, 2:N + 2].double().cpu(), torch.matmul(at.transpose(1, 2).double().cpu(), bt.transpose(1, 2).double().cpu()), **tol)
+    assert float(big[:, 0].abs().max()) == 0 and float(big[:, :, :2].abs().max()) == 0
+
+
+@pytest.mark.parametrize("B,L0,L1,N0,N1", [(2, 12, 9, 40, 33), (1, 512, 512, 1200, 1100), (2, 1, 3, 8, 8)])
+def test_line_head_kernels_vs_torch_autograd(B, L0, L1, N0, N1):
+    """GlueStick line head (gluestick.py:336-376, :772-783): gather + endpoint scores + pairing max + bin-augmented
+    double softmax through the HIP kernels vs the stock-torch formulation in fp64, forward and every gradient."""
+    D = 256
+    g = torch.Generator().manual_seed(L0 + L1)
+    x0 = torch.randn(B, N0, D, generator=g, dtype=torch.float64) * 0.3
+    x1 = torch.randn(B, N1, D, generator=g, dtype=torch.float64) * 0.3
+    idx0 = torch.randint(0, min(N0, 2 * L0), (B, 2 * L0), generator=g)
+    idx1 = torch.randint(0, min(N1, 2 * L1), (B, 2 * L1), generator=g)
+    beta = torch.tensor(0.7, dtype=torch.float64)
+    Gup = torch.randn(B, L0 + 1, L1 + 1, generator=g, dtype=torch.float64)
+
+    def reference(x0, x1, beta):
+        g0 = x0.gather(1, idx0[..., None].expand(-1, -1, D))
+        g1 = x1.gather(1, idx1[..., None].expand(-1, -1, D))
+        s = torch.bmm(g0, g1.transpose(1, 2)) / D ** 0.5
+        s = s.reshape(B, L0, 2, L1, 2)
+        raw = 0.5 * torch.maximum(s[:, :, 0, :, 0] + s[:, :, 1, :, 1], s[:, :, 0, :, 1] + s[:, :, 1, :, 0])
+        r = torch.logsumexp(torch.cat([raw, beta.expand(B, L0, 1)], 2), 2)
+        c = torch.logsumexp(torch.cat([raw, beta.expand(B, 1, L1)], 1), 1)
+        out = raw.new_zeros(B, L0 + 1, L1 + 1)
+        out[:, :L0, :L1] = raw - 0.5 * (r[:, :, None] + c[:, None, :])
+        out[:, :L0, L1] = beta - r
+        out[:, L0, :L1] = beta - c
+        return raw, out
+
+    xr0, xr1, br = x0.clone().requires_grad_(True), x1.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    raw_ref, out_ref = reference(xr0, xr1, br)
+    (out_ref * Gup).sum().backward()
+
+    xd0, xd1 = x0.float().to(DEV).requires_grad_(True), x1.float().to(DEV).requires_grad_(True)
+    bd = beta.float().to(DEV).requires_grad_(True)
+    i0, i1 = idx0.to(DEV), idx1.to(DEV)
+    gr0, gr1 = ops.line_graph(i0, N0), ops.line_graph(i1, N1)
+    raw = ops.line_pair_scores(ops.rows_gather(xd0, i0, *gr0), ops.rows_gather(xd1, i1, *gr1), D ** -0.5)
+    out = ops.dense_log_double_softmax(raw, bd)
+    (out * Gup.float().to(DEV)).sum().backward()
+    torch.testing.assert_close(raw.detach().double().cpu(), raw_ref.detach(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(out.detach().double().cpu(), out_ref.detach(), rtol=1e-5, atol=2e-5)
+    for name, a, r in (("dx0", xd0.grad, xr0.grad), ("dx1", xd1.grad, xr1.grad), ("dbeta", bd.grad, br.grad)):
+        sc = max(float(r.abs().max()), 1e-6)
+        torch.testing.assert_close(a.double().cpu() / sc, r / sc, rtol=1e-4, atol=1e-4, msg=lambda m: f"{name}: {m}")
