@@ -85,6 +85,7 @@ def parse():
     ap.add_argument("--sinkhorn-iters", type=int, default=100)
     ap.add_argument("--no-graph", action="store_true", help="launch the step kernel by kernel instead of replaying a hipGraph")
     ap.add_argument("--matcher-only", action="store_true", help="skip the extractor: scope M becomes the only line")
+    ap.add_argument("--dp-graph", action="store_true", help="N > 1: capture the multi-rank step (bucketed RCCL all-reduces included) as a hipGraph")
     return ap.parse_args()
 
 
@@ -329,9 +330,12 @@ def make_stepper(args, model, local, allow_graph=True):
     from glue_factory_amd.train_step import TrainStep
     import torch.distributed as dist_
     single = not (dist_.is_available() and dist_.is_initialized() and dist_.get_world_size() > 1)
-    graph = single and allow_graph and not args.no_graph
+    # one process: the whole matcher step is captured once and replayed as a hipGraph (TrainStep(graph=True)).  Several
+    # ranks: the bucket reducer's collectives are capturable on RCCL, but that path has never run on hardware (1-GPU
+    # test boxes), so the multi-rank capture is opt-in (--dp-graph) and the default launches the step kernel by kernel
+    # with the bucketed all-reduces overlapped from autograd hooks.
+    graph = (single or args.dp_graph) and allow_graph and not args.no_graph
     opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True, capturable=graph)
-    # one process: the whole matcher step is captured once and replayed as a hipGraph (TrainStep(graph=True))
     return TrainStep(model, opt, amp_dtype=torch.bfloat16 if args.dtype == "bf16" else None, device_ids=[local],
                      graph=graph)
 

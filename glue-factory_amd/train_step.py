@@ -2,13 +2,21 @@
 
 Mirrors the semantics of the reference hot loop (gluefactory/train.py:465-517): zero_grad,
 autocast forward, ``loss_fn(pred, data)``, mean of ``losses["total"]``, cross-rank agreement on
-whether the loss is differentiable (all_reduce PRODUCT, train.py:482-488), backward (DDP bucketed
-gradient all-reduce over RCCL/xGMI overlapped with the backward), optional gradient clipping,
-optimizer step (optionally the whole step as ONE hipGraph replay: ``graph=True``); a NaN / non-finite loss (train.py:477-480) or gradient norm skips the update.  On the GPU path
-the skip decision never touches the host: the cross-rank flag is a device tensor handed to the fused optimiser as
-``found_inf``.  Image pairs are independent, so the batch shards across ranks with no
-data-path collective; the only collectives are the gradient all-reduce, the 4-byte flag and the
+whether the loss is differentiable (all_reduce PRODUCT, train.py:482-488), backward (bucketed gradient all-reduce
+over RCCL/xGMI overlapped with the backward), optional gradient clipping, optimizer step (optionally the whole step
+as ONE hipGraph replay: ``graph=True``); a NaN / non-finite loss (train.py:477-480) or gradient norm skips the
+update.  On the GPU path the skip decision never touches the host: the cross-rank flag is a device value handed to
+the fused optimiser as ``found_inf``.  Image pairs are independent, so the batch shards across ranks with no
+data-path collective; the only collectives are the gradient buckets (the skip flag rides in the last one) and the
 logging reduce (train.py:525-531).
+
+Gradient reduction (``reducer="buckets"``, the default for world size > 1): ``GradBuckets`` below -- plain
+``dist.all_reduce`` calls on slices of ONE flat fp32 buffer, issued from autograd's post-accumulate hooks the moment a
+bucket's last gradient exists (buckets follow the backward: assignment / confidence heads first, so their reduce
+runs under the transformer backward), on the process group's own stream.  Unlike DistributedDataParallel's C++ reducer
+this is a fixed sequence of kernels and collectives with no host decisions, i.e. it can be CAPTURED: with the
+``nccl`` (= RCCL) backend ``graph=True`` replays the multi-rank step -- collectives included -- as one hipGraph.
+``reducer="ddp"`` keeps the stock wrapper (never captured) for comparison.
 
 The same code runs on CPU with the ``gloo`` backend for tests (any module with the
 forward/loss interface), and on GPUs with ``nccl`` (= RCCL on ROCm).
@@ -69,19 +77,92 @@ def shard_batch(data, rank, world_size, batch_size=None):
     return data
 
 
+class GradBuckets:
+    """Bucketed data-parallel gradient averaging without DistributedDataParallel.
+
+    * one flat fp32 buffer holds every gradient (+ ``extra`` scalar slots at its end: the step's skip flag);
+    * parameters are assigned to buckets of <= ``cap_mb`` in REVERSE registration order (~ the order the backward
+      produces them: heads and confidence classifiers first, the first transformer layer and the input projection
+      last);
+    * a post-accumulate-grad hook per parameter counts arrivals; when a bucket is complete its gradients are gathered
+      into the flat slice by one multi-tensor copy and ``dist.all_reduce(slice, async_op=True)`` is issued -- always in
+      bucket order, so every rank issues the same sequence of collectives whatever order its autograd engine ran in;
+    * ``finish()`` issues whatever is left (parameters that received no gradient contribute zeros), waits for the
+      collectives (a stream dependency on NCCL/RCCL, not a host sync) and re-points ``p.grad`` at the flat views.
+    The loss is pre-divided by the world size, so SUM yields DDP's average."""
+
+    def __init__(self, params, cap_mb=16, extra=1, group=None):
+        self.params = [p for p in params if p.requires_grad]
+        self.group = group
+        dev = self.params[0].device
+        order = list(reversed(self.params))
+        total = sum(p.numel() for p in order)
+        self.flat = torch.zeros(total + extra, dtype=torch.float32, device=dev)
+        self.extra = self.flat[total:]
+        cap = max(1, int(cap_mb * (1 << 20)) // 4)
+        self.buckets, self.views, self.bucket_of = [], {}, {}
+        lo = off = 0
+        cur = []
+        for p in order:
+            if cur and off - lo + p.numel() > cap:
+                self.buckets.append((lo, off, cur))
+                lo, cur = off, []
+            self.views[p] = self.flat[off:off + p.numel()].view_as(p)
+            self.bucket_of[p] = len(self.buckets)
+            cur.append(p)
+            off += p.numel()
+        self.buckets.append((lo, off + extra, cur))           # the last bucket carries the extra slots
+        self._hooks = [p.register_post_accumulate_grad_hook(self._arrived) for p in self.params]
+        self._count, self._next, self._work = [0] * len(self.buckets), 0, []
+        self._active = False
+
+    def start(self):
+        self._count, self._next, self._work = [0] * len(self.buckets), 0, []
+        self._active = True
+
+    def _arrived(self, p):
+        if not self._active:
+            return
+        b = self.bucket_of[p]
+        self._count[b] += 1
+        while self._next < len(self.buckets) and self._count[self._next] == len(self.buckets[self._next][2]):
+            self._launch(self._next)
+            self._next += 1
+
+    def _launch(self, b):
+        lo, hi, ps = self.buckets[b]
+        have = [p for p in ps if p.grad is not None]
+        if len(have) != len(ps):
+            self.flat[lo:hi - (self.extra.numel() if b == len(self.buckets) - 1 else 0)].zero_()
+        if have:
+            torch._foreach_copy_([self.views[p] for p in have], [p.grad for p in have])
+        self._work.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        while self._next < len(self.buckets):      # parameters without a gradient this step: reduced as zeros
+            self._launch(self._next)
+            self._next += 1
+        for w in self._work:
+            w.wait()
+        for p in self.params:
+            p.grad = self.views[p]
+        self._active = False
+
+
 class TrainStep:
     """step(data) -> dict of detached per-sample losses; one optimiser update per call."""
 
     def __init__(self, model, optimizer, amp_dtype=None, clip_grad=None, device_ids=None,
-                 bucket_cap_mb=16, find_unused_parameters=False, check_grads=True, graph=False, graph_warmup=2):
+                 bucket_cap_mb=16, find_unused_parameters=False, check_grads=True, graph=False, graph_warmup=2,
+                 reducer="buckets"):
         self.model = model
         self.optimizer = optimizer
         self.amp_dtype = amp_dtype
         self.clip_grad = clip_grad
         self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         self.fwd_model = model
+        self.buckets = None
         if self.distributed:
-            from torch.nn.parallel import DistributedDataParallel as DDP
             # train.py:338: BatchNorm layers (SuperGlue / GlueStick MLPs) use global-batch statistics;
             # ops.batch_norm_act all-reduces its sums when it sees a SyncBatchNorm module.
             if any(isinstance(m, torch.nn.modules.batchnorm._BatchNorm) for m in model.modules()):
@@ -90,9 +171,13 @@ class TrainStep:
             # assignment/confidence heads (first gradients of the backward) start while the
             # transformer backward is still running; loss() is called on the bare module (as the
             # reference binds loss_fn before wrapping, train.py:334-339).
-            self.fwd_model = DDP(model, device_ids=device_ids, bucket_cap_mb=bucket_cap_mb,
-                                 gradient_as_bucket_view=True,
-                                 find_unused_parameters=find_unused_parameters)
+            if reducer == "ddp":
+                from torch.nn.parallel import DistributedDataParallel as DDP
+                self.fwd_model = DDP(model, device_ids=device_ids, bucket_cap_mb=bucket_cap_mb,
+                                     gradient_as_bucket_view=True,
+                                     find_unused_parameters=find_unused_parameters)
+            else:
+                self.buckets = GradBuckets(model.parameters(), cap_mb=bucket_cap_mb, extra=1)
         p = next(model.parameters())
         self.device_type = p.device.type
         self.check_grads = check_grads
@@ -105,7 +190,10 @@ class TrainStep:
         # were observed to be dropped from some replays on ROCm 7.2 when eager work is queued between replays (see
         # csrc/gf_common.h gf_zero_f32), so the launchers never call hipMemsetAsync / hipMemcpyAsync.  The first ``graph_warmup`` calls run eagerly, the next
         # one is captured and replayed; a batch of different shapes is run eagerly and re-captured.
-        self.graph = bool(graph) and self.device_type == "cuda" and not self.distributed
+        # Multi-rank: only with the bucket reducer on NCCL/RCCL (its collectives are stream-ordered and capturable; DDP's
+        # reducer and gloo are not).
+        capturable_dp = (not self.distributed) or (self.buckets is not None and dist.get_backend() == "nccl")
+        self.graph = bool(graph) and self.device_type == "cuda" and capturable_dp
         self.graph_warmup = graph_warmup
         self._calls = 0
         self._g = None            # (shape signature, CUDAGraph, static inputs, static outputs)
@@ -164,11 +252,20 @@ class TrainStep:
         bad = (~torch.isfinite(loss.detach())).float().reshape(())
         if not loss.requires_grad:
             bad = bad + 1.0
-            # keep the autograd graph (and DDP's hooks) alive with an exactly-zero contribution
+            # keep the autograd graph (and the reduction hooks) alive with an exactly-zero contribution
             loss = loss.detach() + sum((p.sum() * 0.0 for p in self.model.parameters() if p.requires_grad))
-        if self.distributed:
-            dist.all_reduce(bad, op=dist.ReduceOp.MAX)
-        loss.backward()
+        if self.buckets is not None:
+            # the flag rides in the last gradient bucket (SUM over ranks > 0 <=> bad on some rank): no collective of its
+            # own and nothing on the critical path in front of the backward
+            self.buckets.start()
+            self.buckets.extra.copy_(bad.reshape(1))
+            (loss / dist.get_world_size()).backward()
+            self.buckets.finish()
+            bad = (self.buckets.extra[0] > 0).float()
+        else:
+            if self.distributed:
+                dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+            loss.backward()
         if self.clip_grad is not None:
             gn = torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.clip_grad)   # no host sync
             bad = torch.maximum(bad, (~torch.isfinite(gn)).float().reshape(()).to(bad.device))

@@ -36,13 +36,16 @@ def _batch(n=8):
             "view0": {"image_size": torch.ones(n, 2)}}
 
 
-def _worker(rank, world, lock, out):
+def _worker(rank, world, lock, out, reducer):
     torch.set_num_threads(1)
     init_distributed("gloo", init_method="file://" + lock, rank=rank, world_size=world)
     model = Toy()
     opt = torch.optim.SGD(model.parameters(), lr=0.1)
-    step = TrainStep(model, opt)
-    assert step.distributed
+    # tiny buckets: the two linears land in different buckets, the skip flag rides in the last one
+    step = TrainStep(model, opt, reducer=reducer, bucket_cap_mb=1e-4)
+    assert step.distributed and (step.buckets is not None) == (reducer == "buckets")
+    if reducer == "buckets":
+        assert len(step.buckets.buckets) >= 2
     data = shard_batch(_batch(), rank, world)
     assert data["x"].shape[0] == 4 and data["view0"]["image_size"].shape[0] == 4
     losses = step(data)
@@ -58,10 +61,16 @@ def _worker(rank, world, lock, out):
     torch.distributed.destroy_process_group()
 
 
-def test_two_rank_gloo_equals_single_process():
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("reducer", ["buckets", "ddp"])
+def test_two_rank_gloo_equals_single_process(reducer):
+    """Both gradient reducers -- the capturable bucket reducer (default) and stock DistributedDataParallel -- give the
+    single-process result on the concatenated batch."""
     with tempfile.TemporaryDirectory() as d:
         lock, out = os.path.join(d, "distributed_lock"), os.path.join(d, "out.pt")
-        mp.spawn(_worker, args=(2, lock, out), nprocs=2, join=True)
+        mp.spawn(_worker, args=(2, lock, out, reducer), nprocs=2, join=True)
         got = torch.load(out)
     model = Toy()
     opt = torch.optim.SGD(model.parameters(), lr=0.1)

@@ -1,7 +1,8 @@
-"""The real HIP LightGlue under DistributedDataParallel: two processes share cuda:0 and talk over gloo
-(one MI355X is all the test box has; RCCL refuses two ranks on one device), with the reference's file://
-rendezvous.  Everything of the N>1 path except the RCCL transport itself runs here: DDP bucket hooks on our
-custom autograd nodes, the per-step precast cache under DDP, the do_backward agreement, the fused loss.
+"""The real HIP LightGlue data-parallel: two processes share cuda:0 and talk over gloo (one MI355X is all the test
+box has; RCCL refuses two ranks on one device), with the reference's file:// rendezvous.  Everything of the N>1 path
+except the RCCL transport itself runs here, for BOTH gradient reducers: the capturable bucket reducer (GradBuckets:
+post-accumulate hooks on our custom autograd nodes, flat fp32 buckets, the skip flag in the last bucket) and stock
+DistributedDataParallel; the per-step precast cache, the do_backward agreement, the fused loss.
 After one SGD step on the sharded batch the weights must equal a single-process step on the whole batch."""
 import os
 import tempfile
@@ -25,14 +26,16 @@ def _model_and_data():
     return model, data
 
 
-def _worker(rank, world, lock, out):
+def _worker(rank, world, lock, out, reducer):
     from glue_factory_amd.train_step import TrainStep, init_distributed, reduce_losses, shard_batch
     torch.cuda.set_device(0)
     init_distributed("gloo", init_method="file://" + lock, rank=rank, world_size=world)
     model, data = _model_and_data()
     opt = torch.optim.SGD(model.parameters(), lr=0.05)
-    step = TrainStep(model, opt, amp_dtype=None, device_ids=[0])
-    assert step.distributed
+    step = TrainStep(model, opt, amp_dtype=None, device_ids=[0], reducer=reducer, bucket_cap_mb=4)
+    assert step.distributed and (step.buckets is not None) == (reducer == "buckets")
+    if reducer == "buckets":
+        assert len(step.buckets.buckets) >= 3 and not step.graph      # (gloo is not capturable; nccl would be)
     losses = step(shard_batch(data, rank, world))
     red = reduce_losses(losses)
     torch.cuda.synchronize()
@@ -42,11 +45,12 @@ def _worker(rank, world, lock, out):
     torch.distributed.destroy_process_group()
 
 
-def test_two_rank_ddp_step_equals_single_process():
+@pytest.mark.parametrize("reducer", ["buckets", "ddp"])
+def test_two_rank_ddp_step_equals_single_process(reducer):
     from glue_factory_amd.train_step import TrainStep, reduce_losses
     with tempfile.TemporaryDirectory() as d:
         lock, out = os.path.join(d, "distributed_lock"), os.path.join(d, "out.pt")
-        mp.spawn(_worker, args=(2, lock, out), nprocs=2, join=True)
+        mp.spawn(_worker, args=(2, lock, out, reducer), nprocs=2, join=True)
         got = torch.load(out)
     model, data = _model_and_data()
     opt = torch.optim.SGD(model.parameters(), lr=0.05)

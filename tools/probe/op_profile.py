@@ -16,3 +16,12 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_sh
     step(data)
     torch.cuda.synchronize()
 print(prof.key_averages(group_by_input_shape=True).table(sort_by="count", row_limit=70, max_name_column_width=40, max_shapes_column_width=70))
+# second view: aten operators that launch device work, by device time (what the "elementwise sweep" has to remove)
+rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.key.startswith("aten::") and e.self_device_time_total > 0]
+rows.sort(key=lambda e: -e.self_device_time_total)
+print("\n== aten operators with device time, one train step ==")
+tot = 0.0
+for e in rows[:60]:
+    tot += e.self_device_time_total
+    print(f"{e.self_device_time_total / 1e3:8.3f} ms  x{e.count:4d}  {e.key:28s} {str(e.input_shapes)[:110]}")
+print(f"total aten device time {sum(e.self_device_time_total for e in rows) / 1e3:.3f} ms in {sum(e.count for e in rows)} calls")
