@@ -396,8 +396,8 @@ def other_config(args, name, local):
     """BASELINE.json configs[3] / configs[4]: matcher train step of SuperGlue / GlueStick, inputs resident in HBM."""
     from glue_factory_amd.synthetic import to_device
     model, cpu_data = build_matcher(args, 0, name)
-    # launched kernel by kernel: their losses index the ground truth with nonzero() (a host read), which a capture forbids
-    stepper = make_stepper(args, model, local, allow_graph=False)
+    # captured like the LightGlue step: their losses gather the positives through the fixed-length col0 vectors
+    stepper = make_stepper(args, model, local, allow_graph=True)
     data = to_device(cpu_data, "cuda")
     steps = min(args.steps, 10)
     dt, loss = timed_steps(lambda: stepper(data)["total"].mean(), min(args.warmup, 3), steps,
@@ -456,7 +456,7 @@ def main():
         torch.cuda.synchronize()
 
     model, cpu_data = build_matcher(args, rank, args.model)
-    stepper = make_stepper(args, model, local, allow_graph=args.model == "lightglue")   # the others' losses read nonzero()
+    stepper = make_stepper(args, model, local, allow_graph=True)
     data = to_device(cpu_data, "cuda")
 
     def matcher_step():

@@ -306,14 +306,12 @@ class GlueStick(BaseModel):
         suffix = "" if layer == -1 else f"{layer}_"
         weight = 1.0 if layer == -1 else self.conf.loss.inter_supervision[self.layer2idx[layer]]
         la = pred[prefix + suffix + "log_assignment"]
-        bi, ii, ji = data["gt_" + prefix + "assignment"].nonzero(as_tuple=True)
-        bsz = la.shape[0]
         neg0 = (data["gt_" + prefix + "matches0"] == -1).float()
         neg1 = (data["gt_" + prefix + "matches1"] == -1).float()
-        zeros = torch.zeros(bsz, device=la.device)
-        num_pos = zeros.index_add(0, bi, torch.ones_like(bi, dtype=torch.float32)).clamp(min=1.0)
+        pos_sum, num_pos = ops.nll_positive_terms(la, data, prefix)     # fixed-length gather when the col0 vector is there
+        num_pos = num_pos.clamp(min=1.0)
         num_neg = (neg0.sum(1) + neg1.sum(1)).clamp(min=1.0)
-        nll_pos = -zeros.index_add(0, bi, la[bi, ii, ji]) / num_pos
+        nll_pos = -pos_sum / num_pos
         nll_neg = -((la[:, :-1, -1] * neg0).sum(1) + (la[:, -1, :-1] * neg1).sum(1)) / num_neg
         bal = self.conf.loss.nll_balancing
         nll = bal * nll_pos + (1 - bal) * nll_neg

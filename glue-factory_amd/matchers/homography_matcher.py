@@ -41,7 +41,10 @@ class HomographyMatcher(BaseModel):
             data["lines0"], data["lines1"], data["valid_lines0"], data["valid_lines1"],
             data["view0"]["image"].shape, data["view1"]["image"].shape, data["H_0to1"],
             c.n_line_sampled_pts, c.line_perp_dist_th, c.overlap_th, c.min_visibility_th)
-        return {"line_matches0": fwd, "line_matches1": bwd, "line_assignment": assignment}
+        # (ours) the single positive column of every row, -1 if none: lets the matcher losses gather their positive terms
+        # with a fixed-length index instead of scanning the dense matrix (ops.nll_positive_terms)
+        col0 = fwd.clamp(min=-1) if fwd.numel() else fwd
+        return {"line_matches0": fwd, "line_matches1": bwd, "line_assignment": assignment, "line_assignment_col0": col0}
 
     def _forward(self, data):
         out = self._label_points(data) if self.conf.use_points else {}

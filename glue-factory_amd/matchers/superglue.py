@@ -259,14 +259,12 @@ class SuperGlue(BaseModel):
 
     def loss(self, pred, data):
         la = pred["log_assignment"]
-        bi, ii, ji = data["gt_assignment"].nonzero(as_tuple=True)
-        bsz = la.shape[0]
         neg0 = (data["gt_matches0"] == -1).float()
         neg1 = (data["gt_matches1"] == -1).float()
-        num_pos = torch.zeros(bsz, device=la.device).index_add_(0, bi, torch.ones_like(bi, dtype=torch.float32))
+        pos_sum, num_pos = ops.nll_positive_terms(la, data)       # fixed-length gather when gt_assignment_col0 is there
         num_pos = num_pos.clamp(min=1.0)
         num_neg = (neg0.sum(1) + neg1.sum(1)).clamp(min=1.0)
-        nll_pos = -torch.zeros(bsz, device=la.device).index_add_(0, bi, la[bi, ii, ji]) / num_pos
+        nll_pos = -pos_sum / num_pos
         nll_neg = -((la[:, :-1, -1] * neg0).sum(1) + (la[:, -1, :-1] * neg1).sum(1)) / num_neg
         bal = self.conf.loss.nll_balancing
         nll = bal * nll_pos + (1 - bal) * nll_neg

@@ -1387,3 +1387,21 @@ class _DenseLogDoubleSoftmax(torch.autograd.Function):
 
 def dense_log_double_softmax(raw, beta):
     return _DenseLogDoubleSoftmax.apply(raw, beta)
+
+
+# ------------------------------------------------------------------------------ sparse positives of the NLL losses
+def nll_positive_terms(la, data, prefix=""):
+    """(sum over the positives of la[b,i,j], number of positives) per pair, for the NLL of superglue.py:322-352 and
+    gluestick.py:378-414 (weights = gt_assignment).  When the ground-truth producer supplied
+    ``gt_<prefix>assignment_col0`` (the single positive column of each row, -1 if none: ours do) the terms are one
+    fixed-length gather -- no scan of the dense matrix, no host synchronisation, capturable in a hipGraph; otherwise
+    the dense matrix is scanned with nonzero() (same numbers, one host read)."""
+    bsz = la.shape[0]
+    col0 = data.get("gt_" + prefix + "assignment_col0")
+    if col0 is not None:
+        valid = col0 >= 0
+        picked = la[:, :-1, :].gather(2, col0.clamp(min=0).long()[..., None]).squeeze(-1)
+        return (picked * valid.to(picked.dtype)).sum(1), valid.sum(1).float()
+    bi, ii, ji = data["gt_" + prefix + "assignment"].nonzero(as_tuple=True)
+    zeros = torch.zeros(bsz, device=la.device)
+    return zeros.index_add(0, bi, la[bi, ii, ji]), zeros.index_add(0, bi, torch.ones_like(bi, dtype=torch.float32))

@@ -131,5 +131,6 @@ def make_point_line_pairs(batch, n_kpts, n_lines, dim=256, size=(1024, 1024), se
                  "line_scores1": torch.rand(batch, n_lines, generator=g)})
     gt = gt_matches_from_homography(data["keypoints0"], data["keypoints1"], H, pos_th=3.0, neg_th=3.0)
     data.update({"gt_assignment": gt["assignment"], "gt_assignment_col0": gt["assignment_col0"], "gt_matches0": gt["matches0"], "gt_matches1": gt["matches1"],
-                 "gt_line_assignment": gt_la, "gt_line_matches0": gt_l0, "gt_line_matches1": gt_l1})
+                 "gt_line_assignment": gt_la, "gt_line_assignment_col0": gt_l0.clone(),
+                 "gt_line_matches0": gt_l0, "gt_line_matches1": gt_l1})
     return data

@@ -87,3 +87,28 @@ def test_gluestick_unequal_counts_and_bf16():
     err = (pb["log_assignment"].cpu() - ref["log_assignment"]).abs().max().item()
     print("gluestick bf16 max|dlog_assignment| =", err)
     assert err < 0.5
+
+
+def test_gluestick_train_step_hipgraph_replay_equals_eager():
+    """GlueStick (points + lines, HIP line layers and line head) captured as one hipGraph: replay == eager."""
+    from glue_factory_amd.matchers.gluestick import GlueStick
+    from glue_factory_amd.synthetic import make_point_line_pairs, to_device
+    from glue_factory_amd.train_step import TrainStep
+    from oracle import gluestick_oracle as gso
+    params = gso.init_params(256, gnn_layers=4, seed=9)
+    batches = [to_device(make_point_line_pairs(2, 96, 24, dim=256, size=(640, 480), seed=50 + i), "cuda") for i in range(5)]
+    assert "gt_line_assignment_col0" in batches[0]
+    results = []
+    for use_graph in (False, True):
+        model = GlueStick({"GNN_layers": ["self", "cross"] * 2})
+        model.load_state_dict(params)
+        model = model.cuda().train()
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True, capturable=True)
+        step = TrainStep(model, opt, amp_dtype=torch.bfloat16, graph=use_graph, graph_warmup=2)
+        losses = [step(b)["total"].clone() for b in batches]
+        assert (step._g is not None) == use_graph
+        results.append((losses, {k: p.detach().clone() for k, p in model.named_parameters()}))
+    for i, (a, b) in enumerate(zip(results[0][0], results[1][0])):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5, msg=lambda m: f"step {i}: {m}")
+    for k in results[0][1]:
+        torch.testing.assert_close(results[0][1][k], results[1][1][k], rtol=1e-5, atol=1e-6, msg=lambda m: f"{k}: {m}")

@@ -124,3 +124,36 @@ def test_superglue_unequal_counts_and_bf16():
     err = (pb["log_assignment"].cpu() - ref["log_assignment"]).abs().max().item()
     print("superglue bf16 max|dlog_assignment| =", err)
     assert err < 0.5
+
+
+def test_superglue_train_step_hipgraph_replay_equals_eager():
+    """SuperGlue's loss gathers its positives through gt_assignment_col0 (no nonzero() scan, no host read), so the
+    whole step captures: replay == kernel-by-kernel on changing batches, and fixed-length == dense-scan losses."""
+    from glue_factory_amd import ops
+    from glue_factory_amd.matchers.superglue import SuperGlue
+    from glue_factory_amd.synthetic import make_pairs, to_device
+    from glue_factory_amd.train_step import TrainStep
+    from oracle import superglue_oracle as sgo
+    params = sgo.init_params(256, gnn_layers=4, seed=3)
+    batches = [to_device(make_pairs(2, 192, dim=256, size=(640, 480), seed=40 + i), "cuda") for i in range(5)]
+    results = []
+    for use_graph in (False, True):
+        model = SuperGlue({"GNN_layers": ["self", "cross"] * 2, "num_sinkhorn_iterations": 10})
+        model.load_state_dict(params)
+        model = model.cuda().train()
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True, capturable=True)
+        step = TrainStep(model, opt, amp_dtype=torch.bfloat16, graph=use_graph, graph_warmup=2)
+        losses = [step(b)["total"].clone() for b in batches]
+        assert (step._g is not None) == use_graph
+        results.append((losses, {k: p.detach().clone() for k, p in model.named_parameters()}))
+    for i, (a, b) in enumerate(zip(results[0][0], results[1][0])):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5, msg=lambda m: f"step {i}: {m}")
+    for k in results[0][1]:
+        torch.testing.assert_close(results[0][1][k], results[1][1][k], rtol=1e-5, atol=1e-6, msg=lambda m: f"{k}: {m}")
+    # the fixed-length positives are the dense matrix's
+    d = batches[0]
+    la = torch.randn(2, 193, 193, device="cuda")
+    s1, n1 = ops.nll_positive_terms(la, d)
+    s2, n2 = ops.nll_positive_terms(la, {k: v for k, v in d.items() if k != "gt_assignment_col0"})
+    torch.testing.assert_close(s1, s2, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(n1, n2)
