@@ -1,0 +1,156 @@
+// Small per-step utility kernels that replace swarms of tiny stock-torch launches in the train step
+// (tools/probe/op_profile.py: 486 aten launches, 4.6 ms of the 55 ms LightGlue step before this file):
+//   gf_multi_cast_transpose  ONE launch per step converts every fp32 master parameter into the compute dtype AND writes
+//                            the transposed copy W^T of every matrix (the "weight" of the input-gradient GEMM
+//                            dx = dy W) -- instead of one multi-tensor cast plus ~107 transposing copies per step;
+//   gf_colsum_f32            deterministic column sums of an [R, C] fp32 matrix of per-block partials (LayerNorm
+//                            gamma / beta gradients: 36 reductions of [2048, 512] per step, 16 us each in torch);
+//   gf_small_dw              dW[o, k] = sum_m dy[m, o] x[m, k] for a tall dy [M, O] and a FEW input columns (K <= 4):
+//                            the gradient of the Fourier positional encoding's Wr (lightglue.py:52-65; M = 131072,
+//                            O = 32, K = 2), which the library ran as a 0.4 ms skinny GEMM.
+#include "gf_common.h"
+#include "gf_amd.h"
+
+namespace {
+
+struct CastEntry {            // one parameter: src fp32 [rows, cols] row-major
+    const float* src;
+    void* dst;                // compute-dtype copy (may be NULL when only the transpose is wanted)
+    void* dst_t;              // [cols, rows] transposed copy (NULL for vectors)
+    int rows, cols;
+    int tile0;                // first 32 x 32 tile of this tensor in the launch
+    int tiles_x;              // tiles per row of tiles (cols direction)
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void multi_cast_transpose_kernel(const CastEntry* __restrict__ tab, int n) {
+    __shared__ float tile[32][33];
+    // binary search: last entry with tile0 <= blockIdx.x
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tab[mid].tile0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const CastEntry e = tab[lo];
+    const int t = blockIdx.x - e.tile0;
+    const int r0 = (t / e.tiles_x) * 32, c0 = (t % e.tiles_x) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;         // 32 x 8 threads
+    T* dst = static_cast<T*>(e.dst);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + 8 * i, c = c0 + tx;
+        float v = 0.f;
+        if (r < e.rows && c < e.cols) {
+            v = e.src[(size_t)r * e.cols + c];
+            if (dst) dst[(size_t)r * e.cols + c] = from_f32<T>(v);
+        }
+        tile[ty + 8 * i][tx] = v;
+    }
+    if (!e.dst_t) return;
+    __syncthreads();
+    T* dt = static_cast<T*>(e.dst_t);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, r = r0 + tx;
+        if (r < e.rows && c < e.cols) dt[(size_t)c * e.rows + r] = from_f32<T>(tile[tx][ty + 8 * i]);
+    }
+}
+
+constexpr int CS_CHUNKS = 32;
+// stage 1: block (column group of 64, row chunk) -> part2[chunk][c]; stage 2: sum of the CS_CHUNKS rows
+__global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ x, float* __restrict__ part2, int R, int C) {
+    __shared__ float sm[4][64];
+    x += (size_t)blockIdx.z * R * C;
+    part2 += (size_t)blockIdx.z * CS_CHUNKS * C;
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+    const int per = (R + CS_CHUNKS - 1) / CS_CHUNKS, r0 = blockIdx.y * per, r1 = min(R, r0 + per);
+    float s = 0.f;
+    if (c < C)
+        for (int r = r0 + w; r < r1; r += 4) s += x[(size_t)r * C + c];
+    sm[w][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (w == 0 && c < C) part2[(size_t)blockIdx.y * C + c] = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+}
+__global__ void colsum_stage2(const float* __restrict__ part2, float* __restrict__ out, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    part2 += (size_t)blockIdx.y * CS_CHUNKS * C;
+    out += (size_t)blockIdx.y * C;
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < CS_CHUNKS; ++k) s += part2[(size_t)k * C + c];
+    out[c] = s;
+}
+
+constexpr int SDW_BLOCKS = 256;
+// thread = (row slot g, output o); K <= 4 columns of x per row; partial sums per block, then colsum_stage-like finish
+template <int K>
+__global__ __launch_bounds__(256) void small_dw_stage1(const float* __restrict__ dy, const float* __restrict__ x,
+                                                       float* __restrict__ part, int M, int O) {
+    extern __shared__ float sm[];                       // [G][O * K]
+    const int G = 256 / O, g = threadIdx.x / O, o = threadIdx.x % O;
+    float acc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[k] = 0.f;
+    if (g < G) {
+        for (int m = blockIdx.x * G + g; m < M; m += SDW_BLOCKS * G) {
+            const float d = dy[(size_t)m * O + o];
+#pragma unroll
+            for (int k = 0; k < K; ++k) acc[k] += d * x[(size_t)m * K + k];
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) sm[(g * O + o) * K + k] = acc[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < O * K) {
+        float s = 0.f;
+        for (int gg = 0; gg < G; ++gg) s += sm[gg * O * K + threadIdx.x];
+        part[(size_t)blockIdx.x * O * K + threadIdx.x] = s;
+    }
+}
+__global__ void small_dw_stage2(const float* __restrict__ part, float* __restrict__ dw, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int b = 0; b < SDW_BLOCKS; ++b) s += part[(size_t)b * n + i];
+    dw[i] = s;
+}
+
+}  // namespace
+
+extern "C" int gf_multi_cast_transpose(const void* table, int n_entries, int total_tiles, int dtype, void* stream) {
+    if (n_entries <= 0 || total_tiles <= 0) return GF_ERR_SHAPE;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const CastEntry* tab = static_cast<const CastEntry*>(table);
+    if (dtype == GF_BF16) multi_cast_transpose_kernel<bf16_t><<<dim3(total_tiles), dim3(256), 0, st>>>(tab, n_entries);
+    else if (dtype == GF_F32) multi_cast_transpose_kernel<float><<<dim3(total_tiles), dim3(256), 0, st>>>(tab, n_entries);
+    else return GF_ERR_DTYPE;
+    return (int)hipGetLastError();
+}
+extern "C" int gf_cast_entry_bytes(void) { return (int)sizeof(CastEntry); }
+
+extern "C" int gf_colsum_f32(const float* x, float* ws, float* out, int G, int R, int C, void* stream) {
+    if (G <= 0 || R <= 0 || C <= 0) return GF_ERR_SHAPE;
+    if (G > 65535) return GF_ERR_UNSUPPORTED;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    colsum_stage1<<<dim3((C + 63) / 64, CS_CHUNKS, G), dim3(256), 0, st>>>(x, ws, R, C);
+    colsum_stage2<<<dim3((C + 255) / 256, G), dim3(256), 0, st>>>(ws, out, C);
+    return (int)hipGetLastError();
+}
+extern "C" int gf_colsum_ws_floats(int G, int C) { return G * CS_CHUNKS * C; }
+
+extern "C" int gf_small_dw(const float* dy, const float* x, float* ws, float* dw, int M, int O, int K, void* stream) {
+    if (M <= 0 || O <= 0 || K <= 0) return GF_ERR_SHAPE;
+    if (O > 256 || K > 4 || O * K > 256) return GF_ERR_UNSUPPORTED;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const size_t lds = (size_t)(256 / O) * O * K * sizeof(float);
+    switch (K) {
+        case 1: small_dw_stage1<1><<<dim3(SDW_BLOCKS), dim3(256), lds, st>>>(dy, x, ws, M, O); break;
+        case 2: small_dw_stage1<2><<<dim3(SDW_BLOCKS), dim3(256), lds, st>>>(dy, x, ws, M, O); break;
+        case 3: small_dw_stage1<3><<<dim3(SDW_BLOCKS), dim3(256), lds, st>>>(dy, x, ws, M, O); break;
+        default: small_dw_stage1<4><<<dim3(SDW_BLOCKS), dim3(256), lds, st>>>(dy, x, ws, M, O); break;
+    }
+    small_dw_stage2<<<dim3((O * K + 255) / 256), dim3(256), 0, st>>>(ws, dw, O * K);
+    return (int)hipGetLastError();
+}
+extern "C" int gf_small_dw_ws_floats(int O, int K) { return SDW_BLOCKS * O * K; }

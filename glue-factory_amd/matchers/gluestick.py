@@ -223,6 +223,7 @@ class GlueStick(BaseModel):
             raise RuntimeError("glue_factory_amd.GlueStick runs on the MI355X HIP path only (no CPU fallback)")
         T = torch.bfloat16 if (self.conf.mp or torch.is_autocast_enabled()) else torch.float32
         with torch.autocast(device_type="cuda", enabled=False):
+            ops.precast(list(self.parameters()), T, key=id(self))   # one launch: compute-dtype + transposed weights
             return self._forward_impl(data, T)
 
     def _forward_impl(self, data, T):

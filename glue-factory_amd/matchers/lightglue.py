@@ -55,7 +55,8 @@ class _PosEnc(nn.Module):
         nn.init.normal_(self.Wr.weight.data, mean=0.0, std=1.0)
 
     def forward(self, kpts):
-        theta = F.linear(kpts, self.Wr.weight.float())            # [B,N,hd/2] fp32
+        w = self.Wr.weight.float()
+        theta = ops.small_linear(kpts, w) if kpts.is_cuda else F.linear(kpts, w)     # [B,N,hd/2] fp32
         with torch.no_grad():
             cs = torch.stack((torch.cos(theta), torch.sin(theta)), -1).flatten(-2).contiguous()
         return theta, cs

@@ -210,6 +210,7 @@ class SuperGlue(BaseModel):
             raise RuntimeError("glue_factory_amd.SuperGlue runs on the MI355X HIP path only (no CPU fallback)")
         T = torch.bfloat16 if (self.conf.mp or torch.is_autocast_enabled()) else torch.float32
         with torch.autocast(device_type="cuda", enabled=False):
+            ops.precast(list(self.parameters()), T, key=id(self))   # one launch: compute-dtype + transposed weights
             return self._forward_impl(data, T)
 
     def _forward_impl(self, data, T):

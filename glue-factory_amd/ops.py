@@ -220,36 +220,69 @@ def cross_attention_stacked(p):
 # layer per step.  precast() converts a whole parameter list with one multi-tensor copy into a flat buffer
 # and _lp() serves the views made by the precast() of the CURRENT forward.
 _LP_CACHE = {}        # id(param) -> (param._version, dtype, view)
+_LP_PTR = {}          # (data_ptr, numel) of a parameter -> the same record (serves reshaped views of it)
+_LP_T = {}            # data_ptr of a compute-dtype weight -> (its transposed copy [K,N], weakref(param), dtype)
 _LP_FLAT = {}         # (key, dtype) -> (flat buffer, [views], [params])
 
 
 def precast(params, dtype, key="default"):
-    params = [p_ for p_ in params if p_.dtype != dtype and p_.is_cuda]
-    if not params:
+    """One launch per forward: every fp32 master parameter -> the compute dtype (flat buffer, served by _lp()), and the
+    transposed copy W^T of every matrix (served by _wt_t(): the weight of the input-gradient GEMM dx = dy W), by
+    gf_multi_cast_transpose.  Always re-done: a fused / capturable optimiser step, ``param.data = ...`` or a replayed
+    hipGraph change the values without bumping the version counter (measured: stale bf16 weights in an eval forward
+    after fused Adam steps), so skipping it "when nothing moved" is not safe."""
+    params = [p_ for p_ in params if p_.is_cuda and p_.dtype == torch.float32]
+    if not params or dtype not in (torch.bfloat16, torch.float32):
         return
     slot = _LP_FLAT.get((key, dtype))
-    if slot is None or len(slot[2]) != len(params) or any(a is not b for a, b in zip(slot[2], params)):
-        sizes = [(p_.numel() + 7) // 8 * 8 for p_ in params]        # 16-byte aligned bf16 views
-        flat = torch.empty(sum(sizes), dtype=dtype, device=params[0].device)
-        views, off = [], 0
+    if slot is None or len(slot["params"]) != len(params) or any(a is not b for a, b in zip(slot["params"], params)):
+        import struct
+        cast = dtype != torch.float32
+        sizes = [(p_.numel() + 7) // 8 * 8 for p_ in params]        # 16-byte aligned views
+        flat = torch.empty(sum(sizes) if cast else 0, dtype=dtype, device=params[0].device)
+        mats = [p_ for p_ in params if p_.dim() >= 2]
+        flat_t = torch.empty(sum((p_.numel() + 7) // 8 * 8 for p_ in mats), dtype=dtype, device=params[0].device)
+        views, tviews, rec, off, toff, tile0 = [], {}, b"", 0, 0, 0
         for p_, sz in zip(params, sizes):
-            views.append(flat[off:off + p_.numel()].view(p_.shape))
+            v = flat[off:off + p_.numel()].view(p_.shape) if cast else p_
             off += sz
-        slot = (flat, views, params)
+            views.append(v)
+            rows = p_.shape[0] if p_.dim() >= 2 else 1
+            cols = p_.numel() // rows
+            vt = None
+            if p_.dim() >= 2:
+                vt = flat_t[toff:toff + p_.numel()].view(cols, rows)
+                toff += (p_.numel() + 7) // 8 * 8
+                tviews[id(p_)] = vt
+            elif not cast:
+                continue                                       # fp32 vector: nothing to do
+            tx = (cols + 31) // 32
+            rec += struct.pack("<QQQiiii", p_.data_ptr(), v.data_ptr() if cast else 0, 0 if vt is None else vt.data_ptr(),
+                               rows, cols, tile0, tx)
+            tile0 += tx * ((rows + 31) // 32)
+        assert len(rec) % _lib.load().gf_cast_entry_bytes() == 0
+        table = torch.frombuffer(bytearray(rec), dtype=torch.uint8).to(params[0].device) if rec else None
+        slot = {"flat": flat, "flat_t": flat_t, "views": views, "tviews": tviews, "params": params, "table": table,
+                "n": len(rec) // 40, "tiles": tile0}
         _LP_FLAT[(key, dtype)] = slot
-    # Always re-cast: one multi-tensor copy (~20 us for 12 M parameters).  Skipping it when no ``_version`` moved is
-    # NOT safe -- a fused / capturable optimiser step, ``param.data = ...`` or a replayed hipGraph change the values
-    # without bumping the version counter (measured: stale bf16 weights in an eval forward after fused Adam steps).
-    with torch.no_grad():
-        torch._foreach_copy_(slot[1], [p_.detach() for p_ in params])
-    for p_, v in zip(params, slot[1]):
-        _LP_CACHE[id(p_)] = (p_._version, dtype, v, weakref.ref(p_))
+    if slot["table"] is not None:
+        _lib.check(_lib.load().gf_multi_cast_transpose(_p(slot["table"]), slot["n"], slot["tiles"], BF16 if dtype == torch.bfloat16 else F32, _stream()),
+                   "gf_multi_cast_transpose")
+    for p_, v in zip(params, slot["views"]):
+        if v is not p_:
+            _LP_CACHE[id(p_)] = (p_._version, dtype, v, weakref.ref(p_))
+            _LP_PTR[(p_.data_ptr(), p_.numel())] = (p_._version, dtype, v, weakref.ref(p_))   # views (conv weight.squeeze(-1))
+        vt = slot["tviews"].get(id(p_))
+        if vt is not None:
+            _LP_T[v.data_ptr()] = (vt, weakref.ref(p_), dtype)
 
 
 def invalidate_precast():
     """Forget the per-parameter cache entries (the flat buffers stay): needed when parameters change without a
     version bump, e.g. after a captured optimiser step is replayed from a hipGraph."""
     _LP_CACHE.clear()
+    _LP_PTR.clear()
+    _LP_T.clear()
 
 
 def _lp(t, dtype):
@@ -259,6 +292,10 @@ def _lp(t, dtype):
     hit = _LP_CACHE.get(id(t))
     if hit is not None and hit[3]() is t and hit[0] == t._version and hit[1] == dtype:
         return hit[2]
+    if t.is_contiguous():          # a reshaped view of a precast parameter (e.g. a Conv1d weight without its kernel axis)
+        hit = _LP_PTR.get((t.data_ptr(), t.numel()))
+        if hit is not None and hit[3]() is not None and hit[0] == t._version and hit[1] == dtype:
+            return hit[2].view(t.shape)
     return t.to(dtype)
 
 
@@ -367,9 +404,17 @@ def _linear_fwd(x2, wt, bias, res2=None, out=None, cs=None, rot_n=0):
     return gemm(x2, wt, bias, res2, out, cs=cs, rot_n=rot_n)
 
 
-def _wt_t(wt):
-    """[N,K] compute-dtype weight -> contiguous [K,N] (the "weight" of the input-gradient GEMM dx = dy W)."""
-    return wt.t().contiguous()
+def _wt_t(wt, k0=None, k1=None):
+    """Columns [k0, k1) of the [N,K] compute-dtype weight, transposed and contiguous ([k1-k0, N]: the "weight" of the
+    input-gradient GEMM dx = dy W).  Served from this forward's precast() when there is one (no kernel), else copied."""
+    hit = _LP_T.get(wt.data_ptr())
+    n = wt.shape[0]
+    kk = wt.numel() // n
+    if hit is not None and hit[1]() is not None and hit[2] == wt.dtype and hit[0].shape == (kk, n):
+        wt_t = hit[0]
+        return wt_t if k0 is None else wt_t[k0:k1]
+    w2 = wt.reshape(n, kk)
+    return (w2 if k0 is None else w2[:, k0:k1]).t().contiguous()
 
 
 class GradChain:
@@ -524,10 +569,10 @@ class _LinearCat(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             ch = ctx.chain1
             if ch is None:
-                dx1 = gemm(dy2, _wt_t(wt[:, :k1])).view(x1.shape)
+                dx1 = gemm(dy2, _wt_t(wt, 0, k1)).view(x1.shape)
             else:                                   # a middle link: the parked residual gradient rides in the epilogue
-                ch.park(gemm(dy2, _wt_t(wt[:, :k1]), res2=ch.acc))
-        dx2 = gemm(dy2, _wt_t(wt[:, k1:])).view(x2.shape) if ctx.needs_input_grad[1] else None
+                ch.park(gemm(dy2, _wt_t(wt, 0, k1), res2=ch.acc))
+        dx2 = gemm(dy2, _wt_t(wt, k1, wt.shape[1])).view(x2.shape) if ctx.needs_input_grad[1] else None
         dw = db = None
         if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
             a = x1.reshape(-1, k1)
@@ -619,11 +664,51 @@ class _LnGelu(torch.autograd.Function):
         L = _lib.load()
         nblk = L.gf_ln_gelu_nblk(R)
         dx = torch.empty_like(x2)
-        dgp = torch.empty((nblk, C), dtype=torch.float32, device=x2.device)
-        dbp = torch.empty((nblk, C), dtype=torch.float32, device=x2.device)
+        part = torch.empty((2, nblk, C), dtype=torch.float32, device=x2.device)        # per-block dgamma | dbeta partials
         _lib.check(L.gf_ln_gelu_bwd(_p(x2), _p(g32), _p(b32), _p(mean), _p(rstd), _p(dy2), _p(dx),
-                                    _p(dgp), _p(dbp), R, C, _dt(x2), _stream()), "gf_ln_gelu_bwd")
-        return (dx.view(ctx.shape), dgp.sum(0).to(ctx.pdtypes[0]), dbp.sum(0).to(ctx.pdtypes[1]), None)
+                                    _p(part[0]), _p(part[1]), R, C, _dt(x2), _stream()), "gf_ln_gelu_bwd")
+        sums = colsum(part)                                                             # one deterministic reduction
+        return (dx.view(ctx.shape), sums[0].to(ctx.pdtypes[0]), sums[1].to(ctx.pdtypes[1]), None)
+
+
+def colsum(x):
+    """out[g, c] = sum_r x[g, r, c] for contiguous fp32 x [G, R, C] (deterministic two-stage reduction)."""
+    _chk(x)
+    G, R, C = x.shape
+    L = _lib.load()
+    ws = torch.empty(L.gf_colsum_ws_floats(G, C), dtype=torch.float32, device=x.device)
+    out = torch.empty((G, C), dtype=torch.float32, device=x.device)
+    _lib.check(L.gf_colsum_f32(_p(x), _p(ws), _p(out), G, R, C, _stream()), "gf_colsum_f32")
+    return out
+
+
+class _SmallLinear(torch.autograd.Function):
+    """theta = x W^T for a tall fp32 x [M, K] with K <= 4 input columns (the Fourier positional encoding's Wr,
+    lightglue.py:52-65): the forward is the stock product (tiny), the weight gradient a dedicated reduction
+    (gf_small_dw) instead of a skinny library GEMM over M = 131072 rows."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return torch.nn.functional.linear(x, w)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        O, K = w.shape
+        g2, x2 = g.reshape(-1, O).float().contiguous(), x.reshape(-1, K).float().contiguous()
+        dx = g @ w if ctx.needs_input_grad[0] else None
+        L = _lib.load()
+        if not g2.is_cuda or K > 4 or O * K > 256:
+            return dx, (g2.t() @ x2).to(w.dtype)
+        ws = torch.empty(L.gf_small_dw_ws_floats(O, K), dtype=torch.float32, device=g2.device)
+        dw = torch.empty((O, K), dtype=torch.float32, device=g2.device)
+        _lib.check(L.gf_small_dw(_p(g2), _p(x2), _p(ws), _p(dw), g2.shape[0], O, K, _stream()), "gf_small_dw")
+        return dx, dw.to(w.dtype)
+
+
+def small_linear(x, w):
+    return _SmallLinear.apply(x, w)
 
 
 def ln_gelu(x, gamma, beta, eps=1e-5):

@@ -35,8 +35,8 @@ extern "C" {
 #define GF_ERR_ALIGN (-3)
 #define GF_ERR_DTYPE (-4)
 
-/* ABI version; bumped on any signature or workspace-size change (2: gf_attn_bwd's delta workspace doubled; 3: line head + gf_bgemm). */
-#define GF_AMD_ABI_VERSION 3
+/* ABI version; bumped on any signature or workspace-size change (2: gf_attn_bwd's delta workspace doubled; 3: line head + gf_bgemm; 4: smallops). */
+#define GF_AMD_ABI_VERSION 4
 int gf_abi_version(void);
 
 /* ---- multi-head attention over keypoints --------------------------------------------------
@@ -186,6 +186,22 @@ int gf_dense_assign(const float* raw, const float* row_bias, const float* col_bi
                     const float* bin_col, float corner, float* out, int B, int M, int N, void* stream);
 int gf_dense_assign_bwd(const float* raw, const float* r, const float* c, const float* A, const float* Bv,
                         const float* G, float* draw, int B, int M, int N, void* stream);
+
+/* ---- per-step utility kernels (csrc/smallops.hip) ---------------------------------------------------------------
+ * gf_multi_cast_transpose: ONE launch converts every fp32 master parameter of a model into the compute dtype and writes
+ *   the transposed copy of every matrix (the weight of the input-gradient GEMM dx = dy W).  `table` is a DEVICE array of
+ *   n_entries records {const float* src; void* dst; void* dst_t; int rows, cols, tile0, tiles_x;} (gf_cast_entry_bytes()
+ *   each; dst or dst_t may be NULL), tile0 = running count of the 32 x 32 tiles of the preceding entries, tiles_x =
+ *   ceil(cols / 32); total_tiles = the grid.
+ * gf_colsum_f32: out[g, c] = sum_r x[g, r, c] for fp32 x [G, R, C], deterministic (ws: gf_colsum_ws_floats(G, C) floats).
+ * gf_small_dw:   dw[o, k] = sum_m dy[m, o] x[m, k], fp32, dy [M, O], x [M, K], K <= 4, O * K <= 256 (the gradient of
+ *   lightglue.py:52-65 posenc.Wr); ws: gf_small_dw_ws_floats(O, K) floats. */
+int gf_multi_cast_transpose(const void* table, int n_entries, int total_tiles, int dtype, void* stream);
+int gf_cast_entry_bytes(void);
+int gf_colsum_f32(const float* x, float* ws, float* out, int G, int R, int C, void* stream);
+int gf_colsum_ws_floats(int G, int C);
+int gf_small_dw(const float* dy, const float* x, float* ws, float* dw, int M, int O, int K, void* stream);
+int gf_small_dw_ws_floats(int O, int K);
 
 /* ---- small batched GEMM with arbitrary element strides (csrc/bgemm.hip): C[b,i,j] = alpha sum_k A[b,i,k] B[b,k,j],
  * strides {batch, row, column} of A [M,K], B [K,N], C [M,N]; fp32 operands use the exact-fp32 MFMA.  The products of
