@@ -104,14 +104,34 @@ def time_kernel(fn, iters=10, warm=2):
     return ev0.elapsed_time(ev1) / iters * 1e-3
 
 
-def _traffic(key):
-    """Measured HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 (gfx950 half count) + WRITE_SIZE; collected by
-    tools/collect_pmc.sh over `bench.py --roofline-only`, summarised into profiles/roofline_traffic.json)."""
+def _traffic_table():
     try:
         with open(TRAFFIC_FILE) as f:
-            return json.load(f).get(key, {}).get("hbm_bytes_per_launch")
+            return json.load(f)
     except (OSError, ValueError):
-        return None
+        return {}
+
+
+def _traffic(key):
+    """Measured HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 (gfx950 half count) + WRITE_SIZE; collected by
+    tools/collect_pmc.sh over `bench.py --roofline-only`, summarised into profiles/roofline_traffic.json).  NOT
+    measured in this run: `traffic_source` in the JSON line names the collection it comes from."""
+    return _traffic_table().get(key, {}).get("hbm_bytes_per_launch")
+
+
+def _lib_sha():
+    import hashlib
+    try:
+        with open(os.path.join(ROOT, "glue-factory_amd", "libgf_amd.so"), "rb") as f:
+            return hashlib.sha1(f.read()).hexdigest()[:12]
+    except OSError:
+        return "missing"
+
+
+def _traffic_source():
+    t = _traffic_table()
+    src = t.get("source", "none") if t else "none (profiles/roofline_traffic.json missing)"
+    return f"{src}; this run: libgf_amd.so sha1 {_lib_sha()}"
 
 
 def roofline_attention(batch, n, dtype):
@@ -132,11 +152,12 @@ def roofline_attention(batch, n, dtype):
     f_bwd = 2.5 * f_fwd
     ach = f_bwd / t_bwd / 1e12
     return {
-        "bound": "mfma", "kernel": "gf_attn_bwd (attention backward kernels of one launch)",
+        "bound": "mfma", "kernel": "gf_attn_bwd (attn_dq3_bf16_kernel + attn_bwd_dkv_bf16_kernel of one launch)",
         "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": _traffic("gf_attn_bwd"),
         "launch_ms": round(t_bwd * 1e3, 4), "algorithmic_flop_per_launch": f_bwd,
-        "fwd_kernel": {"kernel": "attn_fwd_kernel", "launch_ms": round(t_fwd * 1e3, 4),
+        "traffic_source": _traffic_source(),
+        "fwd_kernel": {"kernel": "attn_fwd3_bf16_kernel", "launch_ms": round(t_fwd * 1e3, 4),
                        "achieved": round(f_fwd / t_fwd / 1e12, 2),
                        "frac": round(f_fwd / t_fwd / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
                        "traffic": _traffic("attn_fwd_kernel")},
@@ -168,27 +189,77 @@ def roofline_hbm(batch, n, dtype, sinkhorn_iters=100):
     vh = torch.empty((sinkhorn_iters, batch, n + 1), device="cuda")
     st = torch.cuda.current_stream().cuda_stream
     t = time_kernel(lambda: lib.gf_sinkhorn_fwd(Z.data_ptr(), o.data_ptr(), uh.data_ptr(), vh.data_ptr(), ws.data_ptr(),
-                                                batch, n, n, sinkhorn_iters, st), iters=3, warm=1)
+                                                batch, n, n, sinkhorn_iters, st), iters=10, warm=2)
     byt = 2.0 * batch * (n + 1) * (n + 1) * 4.0 * sinkhorn_iters
     out["sinkhorn_fwd"] = {"bound": "hbm", "kernel": f"gf_sinkhorn_fwd ({sinkhorn_iters} iterations, B={batch})",
                            "achieved": round(byt / t / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(byt / t / 1e9 / HBM_PEAK_GBS, 4), "traffic": _traffic("gf_sinkhorn_fwd"),
+                           "frac": round(byt / t / 1e9 / HBM_PEAK_GBS, 4),
+                           "frac_one_sweep": round(byt / 2 / t / 1e9 / HBM_PEAK_GBS, 4),
+                           "traffic": _traffic("gf_sinkhorn_fwd"),
                            "launch_ms": round(t * 1e3, 3), "algorithmic_bytes_per_launch": byt}
-    note = ("algorithmic bytes follow SURVEY 8(d): two sweeps of the couplings per iteration (the reference's row LSE, then "
-            "column LSE).  The kernel makes ONE sweep per iteration (row and column sums share one exp), so frac can "
-            "exceed 1; against its own one-sweep minimum the fraction is frac/2, and `traffic` (PMC) is what reached HBM "
-            "(the rest of each sweep hits the 256 MiB MALL)")
+    note = ("accounting, not measurement: `frac` prices SURVEY 8(d)'s TWO sweeps of the couplings per iteration (the "
+            "reference's row LSE, then column LSE) although the kernel needs and makes ONE (row and column sums share one "
+            "exp), so it can exceed 1; `frac_one_sweep` is the fraction of the 8 TB/s peak against the kernel's own "
+            "one-sweep minimum, and `traffic` (PMC) is what reached HBM (the rest of each sweep hits the 256 MiB MALL)")
     out["sinkhorn_fwd"]["note"] = note
     G = torch.randn_like(Z)
     gZ = torch.empty_like(Z)
     gr, gc = G.sum(2).contiguous(), G.sum(1).contiguous()
     t = time_kernel(lambda: lib.gf_sinkhorn_bwd(Z.data_ptr(), G.data_ptr(), gr.data_ptr(), gc.data_ptr(), uh.data_ptr(),
                                                 vh.data_ptr(), gZ.data_ptr(), ws.data_ptr(), batch, n, n,
-                                                sinkhorn_iters, st), iters=3, warm=1)
+                                                sinkhorn_iters, st), iters=10, warm=2)
     out["sinkhorn_bwd"] = {"bound": "hbm", "kernel": f"gf_sinkhorn_bwd ({sinkhorn_iters} iterations, B={batch})",
                            "achieved": round(byt / t / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(byt / t / 1e9 / HBM_PEAK_GBS, 4), "traffic": _traffic("gf_sinkhorn_bwd"),
+                           "frac": round(byt / t / 1e9 / HBM_PEAK_GBS, 4),
+                           "frac_one_sweep": round(byt / 2 / t / 1e9 / HBM_PEAK_GBS, 4),
+                           "traffic": _traffic("gf_sinkhorn_bwd"),
                            "launch_ms": round(t * 1e3, 3), "algorithmic_bytes_per_launch": byt, "note": note}
+    return out
+
+
+def roofline_extra(batch, n, dtype):
+    """The two next-largest own kernels of the headline step: the streamed-activation GEMM (HBM-bound: x read + y
+    write, weights stationary in registers) at the step's most frequent shape, and the fused 64-channel 3x3
+    convolution block of the extractor (MFMA-bound implicit GEMM)."""
+    from glue_factory_amd import lib as L_
+    from glue_factory_amd import ops
+    lib = L_.load()
+    out = {}
+    M = 2 * batch * n
+    g = torch.Generator(device="cuda").manual_seed(0)
+    x = torch.randn(M, 256, device="cuda", dtype=dtype, generator=g)
+    w = torch.randn(256, 256, device="cuda", dtype=dtype, generator=g) * 0.05
+    b = torch.zeros(256, device="cuda")
+    y = torch.empty(M, 256, device="cuda", dtype=dtype)
+    t = time_kernel(lambda: ops.gemm(x, w, b, None, y), iters=20)
+    byt = 2.0 * M * (256 + 256) + 2.0 * 256 * 256
+    out["gemm_st"] = {"bound": "hbm", "kernel": "gemm_st_kernel (gf_gemm, M=131072, 256 <- 256, bf16)",
+                      "achieved": round(byt / t / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                      "frac": round(byt / t / 1e9 / HBM_PEAK_GBS, 4), "traffic": _traffic("gemm_st_kernel"),
+                      "launch_ms": round(t * 1e3, 4), "algorithmic_bytes_per_launch": byt}
+    if dtype == torch.bfloat16:
+        nimg, hh, ww = 2 * batch, IMG, IMG
+        xi = torch.randn(nimg, hh, ww, 64, device="cuda", dtype=dtype, generator=g)
+        wc = (torch.randn(9, 64, 64, device="cuda", generator=g) * 0.05).to(dtype)       # [tap][c_out][c_in]
+        v = torch.zeros(64, device="cuda")
+        one = torch.ones(64, device="cuda")
+        yo = torch.empty(nimg, hh, ww, 64, device="cuda", dtype=dtype)
+        st = torch.cuda.current_stream().cuda_stream
+
+        def conv():
+            rc = lib.gf_conv3x3_c64(xi.data_ptr(), wc.data_ptr(), v.data_ptr(), one.data_ptr(), v.data_ptr(), yo.data_ptr(),
+                                    nimg, hh, ww, 1, 0, 1, st)          # relu, no pool, GF_BF16
+            if rc != 0:
+                raise RuntimeError(f"gf_conv3x3_c64 rc={rc}")
+        try:
+            t = time_kernel(conv, iters=5)
+            fl = 2.0 * 64 * 576 * nimg * hh * ww
+            out["conv3x3_c64"] = {"bound": "mfma", "kernel": f"conv3x3_c64_kernel ({nimg} x {hh} x {ww} x 64, conv + bias + ReLU + BN)",
+                                  "achieved": round(fl / t / 1e12, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": round(fl / t / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": _traffic("conv3x3_c64_kernel"),
+                                  "launch_ms": round(t * 1e3, 3), "algorithmic_flop_per_launch": fl}
+        except Exception as e:      # noqa: BLE001  (an extra entry must never cost the headline line)
+            out["conv3x3_c64"] = {"error": str(e)[:200]}
     return out
 
 
@@ -435,7 +506,8 @@ def main():
     if args.roofline_only:
         torch.cuda.set_device(0)
         out = {"roofline": roofline_attention(args.batch, args.kpts, dtype),
-               "roofline_hbm": roofline_hbm(args.batch, args.kpts, dtype, args.sinkhorn_iters)}
+               "roofline_hbm": roofline_hbm(args.batch, args.kpts, dtype, args.sinkhorn_iters),
+               "roofline_extra": roofline_extra(args.batch, args.kpts, dtype)}
         print(json.dumps(out))
         return
     from glue_factory_amd import lib
@@ -509,6 +581,7 @@ def main():
             try:
                 out["roofline"] = roofline_attention(args.batch, args.kpts, dtype)
                 out["roofline_hbm"] = roofline_hbm(args.batch, args.kpts, dtype, args.sinkhorn_iters)
+                out["roofline_extra"] = roofline_extra(args.batch, args.kpts, dtype)
             except Exception as e:   # a secondary measurement must never cost the headline line
                 out.setdefault("roofline", {"error": f"{type(e).__name__}: {e}"})
         if not args.no_other_configs:

@@ -15,7 +15,7 @@ import sys
 
 tag, root = sys.argv[1], sys.argv[2]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KEEP = ("attn_", "assign_write", "sk_", "skf_", "sinkhorn")
+KEEP = ("attn_", "assign_write", "sk_", "skf_", "sinkhorn", "gemm_st", "conv3x3_c64")
 agg = collections.defaultdict(lambda: [0.0, 0])
 for f in glob.glob(os.path.join(root, "pmc*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
@@ -73,7 +73,8 @@ def group(subs, launches_from, half=()):
             "formula": "FETCH_SIZE*1024*2 + WRITE_SIZE*1024 (gfx950 correction, MI355X_MICROARCH.md HBM section)"}
 
 
-out = {"gf_attn_bwd": group(["attn_bwd"], "attn_bwd_dq"), "attn_fwd_kernel": group(["attn_fwd"], "attn_fwd"),
+out = {"gf_attn_bwd": group(["attn_bwd", "attn_dq3"], "attn_dq3"), "attn_fwd_kernel": group(["attn_fwd"], "attn_fwd"),
+       "gemm_st_kernel": group(["gemm_st"], "gemm_st"), "conv3x3_c64_kernel": group(["conv3x3_c64"], "conv3x3_c64"),
        "assign_write_kernel": group(["assign_write"], "assign_write"),
        # N <= 2304: the register-resident "skf_" kernels (one launch = prescale + T iterations + final pass)
        "gf_sinkhorn_fwd": group(["sk_rows_fwd", "sk_cols_fwd", "sk_final_fwd", "sk_fwd", "skf_fwd_iter", "skf_cols_fwd"],
@@ -81,6 +82,11 @@ out = {"gf_attn_bwd": group(["attn_bwd"], "attn_bwd_dq"), "attn_fwd_kernel": gro
        "gf_sinkhorn_bwd": group(["sk_rows_bwd", "sk_cols_bwd", "sk_final_bwd", "sk_bwd", "skf_bwd_iter", "skf_cols_bwd",
                                  "skf_bwd_prep", "skf_factors", "skf_final_bwd"], "skf_final_bwd", half=["skf_prescale"])}
 out = {k: v for k, v in out.items() if v}
-out["source"] = f"tools/collect_pmc.sh {tag}: rocprofv3 --pmc passes over `bench.py --roofline-only`"
+import hashlib
+try:      # (no git on the GPU box: the build is identified by the library it measured)
+    build = "libgf_amd.so sha1 " + hashlib.sha1(open(os.path.join(ROOT, "glue-factory_amd", "libgf_amd.so"), "rb").read()).hexdigest()[:12]
+except OSError:
+    build = "unknown"
+out["source"] = f"tools/collect_pmc.sh {tag} (build {build}): rocprofv3 --pmc passes over `bench.py --roofline-only`"
 json.dump(out, open(os.path.join(ROOT, "profiles", "roofline_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))

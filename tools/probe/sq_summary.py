@@ -5,7 +5,7 @@ agg = collections.defaultdict(lambda: [0.0, 0])
 for f in glob.glob(root + "/pass*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         n = r["Kernel_Name"]
-        k = "fwd" if "attn_fwd" in n else "dq" if "bwd_dq" in n else "dkv" if "bwd_dkv" in n else None
+        k = "fwd" if "attn_fwd" in n else "dq" if ("bwd_dq" in n or "attn_dq3" in n) else "dkv" if "bwd_dkv" in n else None
         if k:
             a = agg[(k, r["Counter_Name"])]; a[0] += float(r["Counter_Value"]); a[1] += 1
 ks = sorted({k for k, _ in agg}); cs = sorted({c for _, c in agg})
