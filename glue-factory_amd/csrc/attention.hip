@@ -363,9 +363,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dq_kerne
         lse2[j] = p.lse[stat] * GF_LOG2E;
         if (qrow0 + 32 * j < p.Nq && hi == 0) {
             if constexpr (sizeof(T) == 2) {      // what attn_bwd_dkv_bf16_kernel starts its accumulators from (attention_bwd3.hip)
-                float p2_, rr_;
-                split_scale(p.scale, p2_, rr_);
-                p.delta[stat] = -lse2[j] / rr_;
+                p.delta[stat] = -lse2[j] / p.rr;
                 p.delta[(int64_t)p.B * p.H * p.Nq + stat] = -d;
             } else {
                 p.delta[stat] = d;
@@ -621,7 +619,7 @@ constexpr int DKV_STATS = 2 * FT_TILE;                 // per wave: 16 lse | 16 
 constexpr int DKV_STAGE = 2 * FT_TILE + 1024;
 constexpr int DKV_NSTAGE = 3;
 
-template <int QB, typename Mid>
+template <int QB, bool PRE, typename Mid>
 __device__ __forceinline__ void dkv_half_tile(f32x16 (&dk)[2], f32x16 (&dv)[2], const bf16x8 (&kf)[4],
                                               const bf16x8 (&vf)[4], const unsigned (&aR)[4],
                                               const unsigned (&aT)[4], unsigned aS, float c,
@@ -670,7 +668,7 @@ __device__ __forceinline__ void dkv_half_tile(f32x16 (&dk)[2], f32x16 (&dv)[2], 
     mid();                                                      // DMA issue rides in the VALU gap
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const float pr = fast_exp2(sa[r] * c);
+        const float pr = fast_exp2(PRE ? sa[r] : sa[r] * c);
         sa[r] = pr;
         dp[r] = pr * dp[r];                                     // dS overwrites dP
     }
@@ -701,7 +699,7 @@ __device__ __forceinline__ void dkv_half_tile(f32x16 (&dk)[2], f32x16 (&dv)[2], 
     }
 }
 
-template <int NW>   // waves per workgroup (32 keys each): the Q/dO stream is shared by all of them
+template <int NW, bool PRE>   // NW waves per workgroup (32 keys each) share the Q/dO stream; PRE: rr == 1, no multiply per score
 __global__ __launch_bounds__(64 * NW, 8 / NW) void attn_bwd_dkv_bf16_kernel(AttnParams p) {
     constexpr int KPB = 32 * NW, PPW = 8 / NW;    // keys per block, 1-KiB DMA pieces per wave and matrix
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -773,12 +771,12 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void attn_bwd_dkv_bf16_kernel(Attn
     issue_tile(0, 0);
     if (nt > 1) issue_tile(1, 1);
 
-    float p2, c;                                                   // c: the non-power-of-two rest rr of scale * log2(e)
-    split_scale(p.scale, p2, c);
+    const float p2 = p.p2, c = PRE ? 1.f : p.rr;                   // c: the non-power-of-two rest rr of scale * log2(e)
     bf16x8 kf[4], vf[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        kf[s] = scale_frag(*reinterpret_cast<const bf16x8*>(kp + (int64_t)kld * p.skn + 16 * s + 8 * hi), p2);
+        kf[s] = *reinterpret_cast<const bf16x8*>(kp + (int64_t)kld * p.skn + 16 * s + 8 * hi);
+        if (p2 != 1.f) kf[s] = scale_frag(kf[s], p2);
         vf[s] = *reinterpret_cast<const bf16x8*>(vp + (int64_t)kld * p.svn + 16 * s + 8 * hi);
     }
 
@@ -818,9 +816,9 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void attn_bwd_dkv_bf16_kernel(Attn
         const int nvalid = p.Nq - t * 64;
         const int nstage = stage == 0 ? 2 : stage - 1;
         const bool more = t + 2 < nt;
-        dkv_half_tile<0>(dk, dv, kf, vf, aR, aT, bS + so, c, hi, nvalid,
+        dkv_half_tile<0, PRE>(dk, dv, kf, vf, aR, aT, bS + so, c, hi, nvalid,
                          [&] { if (more) issue_part(0, t + 2, nstage); });
-        dkv_half_tile<1>(dk, dv, kf, vf, aR, aT, bS + so, c, hi, nvalid,
+        dkv_half_tile<1, PRE>(dk, dv, kf, vf, aR, aT, bS + so, c, hi, nvalid,
                          [&] { if (more) issue_part(1, t + 2, nstage); });
         stage = stage == 2 ? 0 : stage + 1;
     }
@@ -1266,8 +1264,10 @@ template <typename T> int launch_bwd(const AttnParams& p, hipStream_t st) {
 #endif
         total = ((p.Nk + 32 * NW - 1) / (32 * NW)) * p.H * p.B;
         lds = DKV_NSTAGE * DKV_STAGE;
-        if (int e = set_lds(attn_bwd_dkv_bf16_kernel<NW>, lds)) return e;
-        attn_bwd_dkv_bf16_kernel<NW><<<dim3(total), dim3(64 * NW), lds, st>>>(p);
+        if (int e = set_lds(attn_bwd_dkv_bf16_kernel<NW, false>, lds)) return e;
+        if (int e = set_lds(attn_bwd_dkv_bf16_kernel<NW, true>, lds)) return e;
+        if (p.rr == 1.f) attn_bwd_dkv_bf16_kernel<NW, true><<<dim3(total), dim3(64 * NW), lds, st>>>(p);
+        else attn_bwd_dkv_bf16_kernel<NW, false><<<dim3(total), dim3(64 * NW), lds, st>>>(p);
         return (int)hipGetLastError();
     }
     lds = dkv_lds<T, 64>();
@@ -1298,6 +1298,7 @@ extern "C" int gf_attn_fwd(const void* q, const void* k, const void* v, void* o,
     AttnParams p = {};
     p.q = q; p.k = k; p.v = v; p.o = o; p.lse = lse;
     p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk; p.scale = scale;
+    host_split_scale(scale, p.p2, p.rr);
     p.sqb = q_strides[0]; p.sqn = q_strides[1]; p.sqh = q_strides[2];
     p.skb = k_strides[0]; p.skn = k_strides[1]; p.skh = k_strides[2];
     p.svb = v_strides[0]; p.svn = v_strides[1]; p.svh = v_strides[2];
@@ -1328,6 +1329,7 @@ extern "C" int gf_attn_bwd(const void* q, const void* k, const void* v, const vo
     p.q = q; p.k = k; p.v = v; p.o = const_cast<void*>(o); p.dout = dout;
     p.lse = const_cast<float*>(lse); p.delta = delta; p.dq = dq; p.dk = dk; p.dv = dv;
     p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk; p.scale = scale;
+    host_split_scale(scale, p.p2, p.rr);
     p.sqb = q_strides[0]; p.sqn = q_strides[1]; p.sqh = q_strides[2];
     p.skb = k_strides[0]; p.skn = k_strides[1]; p.skh = k_strides[2];
     p.svb = v_strides[0]; p.svn = v_strides[1]; p.svh = v_strides[2];

@@ -26,6 +26,7 @@ namespace {
 #define DQ3_WPS 2          // workgroups per CU = waves per SIMD
 #endif
 
+template <bool PRE>      // PRE: rr == 1 (operands pre-multiplied by the caller): no multiply in front of exp2
 __global__ __launch_bounds__(256, DQ3_WPS) void attn_dq3_bf16_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const unsigned lds0 = (unsigned)(size_t)smem;
@@ -53,8 +54,7 @@ __global__ __launch_bounds__(256, DQ3_WPS) void attn_dq3_bf16_kernel(AttnParams 
     dma.issue(0, smem + wave * 1024);
     if (nt > 1) dma.issue(1, smem + FQ_STAGE + wave * 1024);
 
-    float p2, rr;
-    split_scale(p.scale, p2, rr);
+    const float p2 = p.p2, rr = PRE ? 1.f : p.rr;
     bf16x8 qf[4], dof[4];
     float delta = 0.f;
 #pragma unroll
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256, DQ3_WPS) void attn_dq3_bf16_kernel(AttnParams 
         const bf16x8 o8 = *reinterpret_cast<const bf16x8*>(op + (int64_t)qld * p.son + 16 * s + 8 * hi);
 #pragma unroll
         for (int e = 0; e < 8; ++e) delta += (float)o8[e] * (float)dof[s][e];
-        qf[s] = scale_frag(q8, p2);
+        qf[s] = p2 != 1.f ? scale_frag(q8, p2) : q8;
     }
     delta += xhalf(delta);
     const int64_t stat = ((int64_t)b * p.H + h) * p.Nq + qld;
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256, DQ3_WPS) void attn_dq3_bf16_kernel(AttnParams 
         _Pragma("unroll") for (int i = 0; i < 4; ++i) tie(va[i]);                                                   \
         dp = mma16c(as_frag(va[0]), dof[0], ndb);                            /* dP^T[key][q] - delta */             \
         _Pragma("unroll") for (int i = 1; i < 4; ++i) mma16(dp, as_frag(va[i]), dof[i]);                            \
-        _Pragma("unroll") for (int r = 0; r < 16; ++r) s[r] = fast_exp2(s[r] * rr) * dp[r];      /* dS */           \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) s[r] = fast_exp2(PRE ? s[r] : s[r] * rr) * dp[r];      /* dS */           \
         if (ragged) {                                                        /* keys past Nk contribute nothing */   \
             _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                          \
                 if (t * 64 + KB * 32 + crow(r, hi) >= p.Nk) s[r] = 0.f;                                             \
@@ -143,12 +143,16 @@ int launch_dq3_bf16(const AttnParams& p, hipStream_t st) {
     const size_t lds = FQ_NSTAGE * FQ_STAGE;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_dq3_bf16_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_dq3_bf16_kernel<false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_dq3_bf16_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    attn_dq3_bf16_kernel<<<dim3(total), dim3(256), lds, st>>>(p);
+    if (p.rr == 1.f) attn_dq3_bf16_kernel<true><<<dim3(total), dim3(256), lds, st>>>(p);
+    else attn_dq3_bf16_kernel<false><<<dim3(total), dim3(256), lds, st>>>(p);
     return (int)hipGetLastError();
 }
 

@@ -80,6 +80,7 @@ __device__ __forceinline__ void fw3_scores(f32x16 (&sc)[2], const unsigned (&aR)
 #endif
 }
 
+template <bool PRE>      // PRE: rr == 1 (operands pre-multiplied by the caller): no multiply in front of exp2
 __device__ __forceinline__ void fw3_tile(bool force_slow, int kv0, int Nk, const unsigned (&aR)[4], const unsigned (&aT)[4],
                                          const bf16x8 (&qf)[4], f32x16 (&o)[2], f32x16& negm, float& m, float& lsum, int hi, float rr) {
     constexpr int VB = FT_TILE;
@@ -95,7 +96,7 @@ __device__ __forceinline__ void fw3_tile(bool force_slow, int kv0, int Nk, const
 #if FW3_ABL & 8
                 const float e = sc[kb][r] * rr;
 #else
-                const float e = fast_exp2(sc[kb][r] * rr);
+                const float e = fast_exp2(PRE ? sc[kb][r] : sc[kb][r] * rr);
 #endif
                 sc[kb][r] = e;
                 ps[kb] += e;
@@ -185,6 +186,7 @@ __device__ __forceinline__ void fw3_tile(bool force_slow, int kv0, int Nk, const
 #endif
 }
 
+template <bool PRE>
 __global__ __launch_bounds__(256, FW3_WPS) void attn_fwd3_bf16_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const unsigned lds0 = (unsigned)(size_t)smem;
@@ -211,12 +213,13 @@ __global__ __launch_bounds__(256, FW3_WPS) void attn_fwd3_bf16_kernel(AttnParams
     dma.issue(0, smem + wave * 1024);
     if (nt > 1) dma.issue(1, smem + FQ_STAGE + wave * 1024);
 
-    float p2, rr;
-    split_scale(p.scale, p2, rr);
+    const float p2 = p.p2, rr = PRE ? 1.f : p.rr;
     bf16x8 qf[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
-        qf[s] = scale_frag(*reinterpret_cast<const bf16x8*>(qp + (int64_t)min(qrow, p.Nq - 1) * p.sqn + 16 * s + 8 * hi), p2);
+    for (int s = 0; s < 4; ++s) {
+        qf[s] = *reinterpret_cast<const bf16x8*>(qp + (int64_t)min(qrow, p.Nq - 1) * p.sqn + 16 * s + 8 * hi);
+        if (p2 != 1.f) qf[s] = scale_frag(qf[s], p2);
+    }
 
     f32x16 o[2], negm;
 #pragma unroll
@@ -242,7 +245,7 @@ __global__ __launch_bounds__(256, FW3_WPS) void attn_fwd3_bf16_kernel(AttnParams
 #if !(FW3_ABL & 64)
         if (t + 2 < nt) dma.issue(t + 2, smem + (stage == 0 ? 2 : stage - 1) * FQ_STAGE + wave * 1024);
 #endif
-        fw3_tile(t == 0 || t * 64 + 64 > p.Nk, t * 64, p.Nk, aR, aT, qf, o, negm, m, lsum, hi, rr);
+        fw3_tile<PRE>(t == 0 || t * 64 + 64 > p.Nk, t * 64, p.Nk, aR, aT, qf, o, negm, m, lsum, hi, rr);
         const int step = stage == 2 ? -2 * FQ_STAGE : FQ_STAGE;      // ring: per-lane read addresses follow the stage
 #pragma unroll
         for (int i = 0; i < 4; ++i) { aR[i] += step; aT[i] += step; }
@@ -264,12 +267,16 @@ int launch_fwd3_bf16(const AttnParams& p, hipStream_t st) {
     const size_t lds = FQ_NSTAGE * FQ_STAGE;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd3_bf16_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd3_bf16_kernel<false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd3_bf16_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    attn_fwd3_bf16_kernel<<<dim3(total), dim3(256), lds, st>>>(p);
+    if (p.rr == 1.f) attn_fwd3_bf16_kernel<true><<<dim3(total), dim3(256), lds, st>>>(p);
+    else attn_fwd3_bf16_kernel<false><<<dim3(total), dim3(256), lds, st>>>(p);
     return (int)hipGetLastError();
 }
 

@@ -3,6 +3,7 @@
 // so that both translation units can include it.
 #pragma once
 #include "gf_common.h"
+#include <cmath>
 
 namespace gfattn {
 
@@ -15,6 +16,8 @@ struct AttnParams {
     // gradients: dq/dout use the o-like strides given below
     int64_t sdob, sdon, sdoh, sdqb, sdqn, sdqh, sdkb, sdkn, sdkh, sdvb, sdvn, sdvh;
     float scale;
+    float p2, rr;     // scale * log2(e) = p2 * rr, p2 a power of two, rr in [1, 2) (host_split_scale); rr == 1 exactly when the
+                      // caller pre-multiplied its operands (scale = ln 2): the kernels then skip the multiply per score
 };
 
 template <typename T, int HD> struct Lay {
@@ -181,11 +184,18 @@ struct KvDma {
 inline bool kvdma_ok(int64_t rows, int64_t ld) { return rows * ld < (1 << 29); }
 
 // scale * log2(e) = p2 * rr with p2 a power of two and rr in [1, 2): an operand takes p2 (exact in bf16), the exponent
-// argument the rest (multiplying by the whole factor would round the operand a second time)
-__device__ __forceinline__ void split_scale(float scale, float& p2, float& rr) {
-    const float c = scale * GF_LOG2E;
-    p2 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, c) & 0x7f800000u);
-    rr = c / p2;
+// argument the rest (multiplying by the whole factor would round the operand a second time).  Computed on the host in
+// double precision and snapped: a caller that pre-multiplies its operands by scale * log2(e) (in the fp32 epilogue of the
+// producing GEMM: ONE rounding) passes scale = ln 2, for which rr must come out as exactly 1.
+inline void host_split_scale(float scale, float& p2, float& rr) {
+    const double c = (double)scale * 1.4426950408889634074;
+    int e;
+    double m = std::frexp(c, &e);                      // c = m * 2^e, m in [0.5, 1)
+    m *= 2.0; e -= 1;                                  // m in [1, 2)
+    if (m - 1.0 < 1e-6) m = 1.0;
+    if (2.0 - m < 2e-6) { m = 1.0; e += 1; }
+    p2 = (float)std::ldexp(1.0, e);
+    rr = (float)m;
 }
 __device__ __forceinline__ bf16x8 scale_frag(bf16x8 v, float p2) {
     bf16x8 r;

@@ -96,20 +96,25 @@ class SelfBlock(nn.Module):
         perm = (torch.arange(h)[None, :, None] * (3 * c) + torch.arange(c)[None, None, :] * 3
                 + torch.arange(3)[:, None, None]).reshape(-1)
         self.register_buffer("_perm", perm, persistent=False)
+        # head_dim^-1/2 * log2(e) is folded into the q rows of the projection (fp32, before the GEMM's single rounding): the
+        # attention kernels then read their scores as exp2 arguments (ops.attn_premul)
+        rs = torch.ones(3 * dim)
+        rs[:dim] = ops.attn_premul(self.head_dim)
+        self.register_buffer("_rowscale", rs, persistent=False)
 
     def forward(self, x, theta, cs):
         b, n, d = x.shape
-        w = self.Wqkv.weight.index_select(0, self._perm)
-        bias = self.Wqkv.bias.index_select(0, self._perm)
+        w = self.Wqkv.weight.index_select(0, self._perm) * self._rowscale[:, None]
+        bias = self.Wqkv.bias.index_select(0, self._perm) * self._rowscale
         # x feeds the projection, the FFN input and the residual: one gradient chain, closed by the projection
         chain = ops.GradChain(3) if x.requires_grad and torch.is_grad_enabled() else None
         if self.head_dim == 64 and ops.gemm_takes(d, 3 * d, x.dtype):     # q, k leave the GEMM already rotated (rotary epilogue: 64-wide heads)
             qkv = ops.linear(x, w, bias, rotary_cs=cs, rot_n=2 * d, chain=chain, chain_last=True)
             qkv = qkv.view(b, n, 3, self.heads, self.head_dim)
-            ctx = ops.self_attention_rotary(qkv, theta, cs, pre_rotated=True)      # [b,n,H,hd]
+            ctx = ops.self_attention_rotary(qkv, theta, cs, pre_rotated=True, scale=ops.LN2)      # [b,n,H,hd]
         else:
             qkv = ops.linear(x, w, bias, chain=chain, chain_last=True).view(b, n, 3, self.heads, self.head_dim)
-            ctx = ops.self_attention_rotary(qkv, theta, cs)
+            ctx = ops.self_attention_rotary(qkv, theta, cs, scale=ops.LN2)
         msg = _lin(ctx.view(b, n, d), self.out_proj)
         return _ffn(self.ffn, x, msg, chain)
 
@@ -124,19 +129,21 @@ class CrossBlock(nn.Module):
         self.ffn = _ffn_modules(dim)
 
     def _proj(self, x, chain=None):
-        w = torch.cat([self.to_qk.weight, self.to_v.weight], 0)
-        bias = torch.cat([self.to_qk.bias, self.to_v.bias], 0)
+        # sqrt(head_dim^-1/2 * log2(e)) on BOTH images' qk (each is query in one direction and key in the other)
+        sq = ops.attn_premul(self.head_dim) ** 0.5
+        w = torch.cat([self.to_qk.weight * sq, self.to_v.weight], 0)
+        bias = torch.cat([self.to_qk.bias * sq, self.to_v.bias], 0)
         return ops.linear(x, w, bias, chain=chain, chain_last=True).view(x.shape[0], x.shape[1], 2, self.heads, self.head_dim)
 
     def forward_stacked(self, x, out=None):
         """x [2B,N,C]: image 0 in the first half of the batch, image 1 in the second."""
         b2, n, d = x.shape
         chain = ops.GradChain(3) if x.requires_grad and torch.is_grad_enabled() else None
-        m = ops.cross_attention_stacked(self._proj(x, chain))
+        m = ops.cross_attention_stacked(self._proj(x, chain), scale=ops.LN2)
         return _ffn(self.ffn, x, _lin(m.view(b2, n, d), self.to_out), chain, out)
 
     def forward(self, x0, x1):
-        m0, m1 = ops.cross_attention(self._proj(x0), self._proj(x1))
+        m0, m1 = ops.cross_attention(self._proj(x0), self._proj(x1), scale=ops.LN2)
         m0 = _lin(m0.view(x0.shape), self.to_out)
         m1 = _lin(m1.view(x1.shape), self.to_out)
         return _ffn(self.ffn, x0, m0), _ffn(self.ffn, x1, m1)

@@ -110,14 +110,15 @@ class _SelfAttentionRotary(torch.autograd.Function):
     they carry the gradient to posenc.Wr); cs [B,N,D] = interleaved (cos, sin) of theta."""
 
     @staticmethod
-    def forward(ctx, qkv, theta, cs, pre_rotated=False):
+    def forward(ctx, qkv, theta, cs, pre_rotated=False, scale=None):
         _chk(qkv, cs)
         B, N, three, H, D = qkv.shape
         assert three == 3 and qkv.is_contiguous() and cs.is_contiguous() and cs.dtype == torch.float32
         L = _lib.load()
         if not pre_rotated:      # else: q and k left the Wqkv GEMM already rotated (gf_gemm's rotary epilogue)
             _lib.check(L.gf_rotary_qk(_p(qkv), _p(cs), B, N, H, D, 0, _dt(qkv), _stream()), "gf_rotary_qk")
-        o, lse = attn_fwd_raw(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], D ** -0.5)
+        ctx.scale = D ** -0.5 if scale is None else scale
+        o, lse = attn_fwd_raw(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], ctx.scale)
         ctx.save_for_backward(qkv, cs, o, lse)
         ctx.theta_dtype = theta.dtype
         return o
@@ -128,15 +129,25 @@ class _SelfAttentionRotary(torch.autograd.Function):
         B, N, _, H, D = qkv.shape
         dqkv = torch.empty_like(qkv)
         attn_bwd_raw(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], o, do, lse,
-                     dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2], D ** -0.5)
+                     dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2], ctx.scale)
         dtheta = torch.empty((B, N, D // 2), dtype=torch.float32, device=qkv.device)
         _lib.check(_lib.load().gf_rotary_qk_bwd(_p(dqkv), _p(qkv), _p(cs), _p(dtheta), B, N, H, D,
                                                 _dt(qkv), _stream()), "gf_rotary_qk_bwd")
-        return dqkv, dtheta.to(ctx.theta_dtype), None, None
+        return dqkv, dtheta.to(ctx.theta_dtype), None, None, None
 
 
-def self_attention_rotary(qkv, theta, cs, pre_rotated=False):
-    return _SelfAttentionRotary.apply(qkv, theta, cs, pre_rotated)
+LN2 = 0.6931471805599453
+# "Pre-multiplied operands": a caller that folds head_dim^-1/2 * log2(e) into the projection that PRODUCES q (one rounding,
+# in the GEMM's fp32 epilogue) passes scale = LN2, i.e. softmax(ln2 * q'.k) = 2^(q'.k) / sum: the kernels then take the
+# scores straight from the matrix pipe as exp2 arguments (no multiply per score; csrc/attn_common.h host_split_scale).
+def attn_premul(head_dim):
+    """The factor to fold into q (self attention) -- or its square root into both operands (cross attention, where the
+    same tensor is query in one direction and key in the other) -- when calling the attention ops with scale=LN2."""
+    return head_dim ** -0.5 * 1.4426950408889634
+
+
+def self_attention_rotary(qkv, theta, cs, pre_rotated=False, scale=None):
+    return _SelfAttentionRotary.apply(qkv, theta, cs, pre_rotated, scale)
 
 
 class _CrossAttention(torch.autograd.Function):
@@ -146,10 +157,11 @@ class _CrossAttention(torch.autograd.Function):
     m0 = softmax(qk0 qk1^T / sqrt(D)) v1,  m1 = softmax(qk1 qk0^T / sqrt(D)) v0."""
 
     @staticmethod
-    def forward(ctx, p0, p1):
+    def forward(ctx, p0, p1, scale=None):
         D = p0.shape[-1]
-        m0, lse0 = attn_fwd_raw(p0[:, :, 0], p1[:, :, 0], p1[:, :, 1], D ** -0.5)
-        m1, lse1 = attn_fwd_raw(p1[:, :, 0], p0[:, :, 0], p0[:, :, 1], D ** -0.5)
+        sc = ctx.scale = D ** -0.5 if scale is None else scale
+        m0, lse0 = attn_fwd_raw(p0[:, :, 0], p1[:, :, 0], p1[:, :, 1], sc)
+        m1, lse1 = attn_fwd_raw(p1[:, :, 0], p0[:, :, 0], p0[:, :, 1], sc)
         ctx.save_for_backward(p0, p1, m0, m1, lse0, lse1)
         return m0, m1
 
@@ -162,13 +174,13 @@ class _CrossAttention(torch.autograd.Function):
         tk0, tk1 = tk0.contiguous(), tk1.contiguous()
         # direction 0->1: q = qk0, k = qk1, v = v1
         attn_bwd_raw(p0[:, :, 0], p1[:, :, 0], p1[:, :, 1], m0, dm0, lse0,
-                     d0[:, :, 0], tk1, d1[:, :, 1], D ** -0.5)
+                     d0[:, :, 0], tk1, d1[:, :, 1], ctx.scale)
         # direction 1->0: q = qk1, k = qk0, v = v0
         attn_bwd_raw(p1[:, :, 0], p0[:, :, 0], p0[:, :, 1], m1, dm1, lse1,
-                     d1[:, :, 0], tk0, d0[:, :, 1], D ** -0.5)
+                     d1[:, :, 0], tk0, d0[:, :, 1], ctx.scale)
         d0[:, :, 0] += tk0
         d1[:, :, 0] += tk1
-        return d0, d1
+        return d0, d1, None
 
 
 class _CrossAttentionStacked(torch.autograd.Function):
@@ -177,14 +189,15 @@ class _CrossAttentionStacked(torch.autograd.Function):
     the following to_out GEMM runs once over both images without a concat."""
 
     @staticmethod
-    def forward(ctx, p):
+    def forward(ctx, p, scale=None):
         B2, N, _, H, D = p.shape
         B = B2 // 2
+        sc = ctx.scale = D ** -0.5 if scale is None else scale
         m = torch.empty((B2, N, H, D), dtype=p.dtype, device=p.device)
         lse = torch.empty((B2, H, N), dtype=torch.float32, device=p.device)
         p0, p1 = p[:B], p[B:]
-        attn_fwd_raw(p0[:, :, 0], p1[:, :, 0], p1[:, :, 1], D ** -0.5, out=m[:B], lse=lse[:B])
-        attn_fwd_raw(p1[:, :, 0], p0[:, :, 0], p0[:, :, 1], D ** -0.5, out=m[B:], lse=lse[B:])
+        attn_fwd_raw(p0[:, :, 0], p1[:, :, 0], p1[:, :, 1], sc, out=m[:B], lse=lse[:B])
+        attn_fwd_raw(p1[:, :, 0], p0[:, :, 0], p0[:, :, 1], sc, out=m[B:], lse=lse[B:])
         ctx.save_for_backward(p, m, lse)
         return m
 
@@ -199,19 +212,19 @@ class _CrossAttentionStacked(torch.autograd.Function):
         tk = torch.empty((B2, N, H, D), dtype=p.dtype, device=p.device)
         p0, p1, d0, d1 = p[:B], p[B:], d[:B], d[B:]
         attn_bwd_raw(p0[:, :, 0], p1[:, :, 0], p1[:, :, 1], m[:B], dm[:B], lse[:B],
-                     d0[:, :, 0], tk[B:], d1[:, :, 1], D ** -0.5)
+                     d0[:, :, 0], tk[B:], d1[:, :, 1], ctx.scale)
         attn_bwd_raw(p1[:, :, 0], p0[:, :, 0], p0[:, :, 1], m[B:], dm[B:], lse[B:],
-                     d1[:, :, 0], tk[:B], d0[:, :, 1], D ** -0.5)
+                     d1[:, :, 0], tk[:B], d0[:, :, 1], ctx.scale)
         d[:, :, 0] += tk
-        return d
+        return d, None
 
 
-def cross_attention(p0, p1):
-    return _CrossAttention.apply(p0, p1)
+def cross_attention(p0, p1, scale=None):
+    return _CrossAttention.apply(p0, p1, scale)
 
 
-def cross_attention_stacked(p):
-    return _CrossAttentionStacked.apply(p)
+def cross_attention_stacked(p, scale=None):
+    return _CrossAttentionStacked.apply(p, scale)
 
 
 # ------------------------------------------------------------------------------ linear layer

@@ -64,6 +64,33 @@ def test_attention_strided_views_and_spike():
     torch.testing.assert_close(o.cpu().double(), ref, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("B,H,Nq,Nk", [(2, 4, 256, 256), (1, 2, 100, 333)])
+def test_attention_premultiplied_operands(B, H, Nq, Nk):
+    """scale = ln 2 with head_dim^-1/2 * log2(e) already folded into q (ops.attn_premul: what LightGlue's projections do):
+    the bf16 kernels take the no-multiply instantiations (rr == 1).  Forward, lse and all three gradients vs fp64 on the
+    SAME pre-multiplied bf16 operands; and the result equals plain attention on the un-multiplied q up to q's rounding."""
+    D = 64
+    g = torch.Generator().manual_seed(Nq + Nk)
+    q, k, v, do = (torch.randn(B, n, H, D, generator=g, dtype=torch.float64) for n in (Nq, Nk, Nk, Nq))
+    c = ops.attn_premul(D)
+    qd = (q * c).to(DEV, torch.bfloat16)
+    kd, vd, dod = (t.to(DEV, torch.bfloat16) for t in (k, v, do))
+    qr, kr, vr = (t.double().cpu().requires_grad_(True) for t in (qd, kd, vd))
+    oref, lse_ref = _attn_ref(qr, kr, vr, ops.LN2)
+    (oref * dod.cpu().double()).sum().backward()
+    qd, kd, vd = (t.requires_grad_(True) for t in (qd, kd, vd))
+    o = ops.attention(qd, kd, vd, scale=ops.LN2)
+    (o * dod).sum().backward()
+    torch.testing.assert_close(o.detach().cpu().double(), oref.detach(), rtol=2e-2, atol=2e-2)
+    for name, a, b in (("dq", qd.grad, qr.grad), ("dk", kd.grad, kr.grad), ("dv", vd.grad, vr.grad)):
+        sc = max(b.abs().max().item(), 1e-2)
+        torch.testing.assert_close(a.cpu().double() / sc, b / sc, rtol=3e-2, atol=3e-2, msg=lambda m: f"{name}: {m}")
+    _, lse = ops.attn_fwd_raw(qd.detach(), kd.detach(), vd.detach(), ops.LN2)
+    torch.testing.assert_close(lse.cpu().double(), lse_ref.detach(), rtol=1e-4, atol=2e-2)
+    plain = ops.attention(q.to(DEV, torch.bfloat16), kd.detach(), vd.detach())
+    torch.testing.assert_close(o.detach().float(), plain.float(), rtol=5e-2, atol=5e-2)
+
+
 @pytest.mark.parametrize("case", ["random2048", "late_spike", "ramp", "ramp_steep", "huge_logits", "ragged_tail", "first_key_dominates"])
 def test_attention_bf16_forward_reference_cases(case):
     """The bf16 forward keeps a REFERENCE m instead of a running max (csrc/attention_fwd3.hip): scores leave the MFMA as

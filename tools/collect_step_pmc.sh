@@ -8,7 +8,9 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/steppmc_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-CMD="python $REPO/bench.py --steps 2 --warmup 1 --no-graph --no-roofline --no-other-configs --no-cpu-baseline"
+MODEL=${2:-lightglue}
+EXTRA=""; [ "$MODEL" != lightglue ] && EXTRA="--model $MODEL"
+CMD="python $REPO/bench.py --steps 2 --warmup 1 --no-graph --no-roofline --no-other-configs --no-cpu-baseline $EXTRA"
 cd /tmp
 i=0
 for C in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES" \

@@ -23,18 +23,21 @@ def timeit(fn, iters=20):
         b.record(); torch.cuda.synchronize()
         best = min(best, a.elapsed_time(b) / iters)
     return best
-for path in sys.argv[1:]:
+# an argument "lib.so@ln2" times the pre-multiplied-operand instantiations (scale = ln 2: no multiply per score)
+for arg in sys.argv[1:]:
+    path, _, mode = arg.partition("@")
+    SC = 0.6931471805599453 if mode == "ln2" else D ** -0.5
     lib = ctypes.CDLL(path)
     lib.gf_attn_fwd.argtypes = [P, P, P, P, P, I, I, I, I, I, S, S, S, S, F, I, P]
     lib.gf_attn_bwd.argtypes = [P] * 10 + [I] * 5 + [S] * 8 + [F, I, P]
     def fwd():
         rc = lib.gf_attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), lse.data_ptr(), B2, H, N, N, D,
-                             st(q), st(k), st(v), st(o), D ** -0.5, 1, stream)
+                             st(q), st(k), st(v), st(o), SC, 1, stream)
         assert rc == 0, rc
     def bwd():
         rc = lib.gf_attn_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), lse.data_ptr(),
                              delta.data_ptr(), dqkv[:, :, 0].data_ptr(), dqkv[:, :, 1].data_ptr(), dqkv[:, :, 2].data_ptr(),
-                             B2, H, N, N, D, st(q), st(k), st(v), st(o), st(do), st(q), st(k), st(v), D ** -0.5, 1, stream)
+                             B2, H, N, N, D, st(q), st(k), st(v), st(o), st(do), st(q), st(k), st(v), SC, 1, stream)
         assert rc == 0, rc
     fwd()
-    print(f"{path}: fwd {timeit(fwd)*1e3:.1f} us   bwd {timeit(bwd)*1e3:.1f} us", flush=True)
+    print(f"{arg}: fwd {timeit(fwd)*1e3:.1f} us   bwd {timeit(bwd)*1e3:.1f} us", flush=True)
