@@ -186,7 +186,10 @@ __device__ __forceinline__ void fw3_tile(bool force_slow, int kv0, int Nk, const
 #endif
 }
 
-template <bool PRE>
+// EVEN: Nk % 64 == 0 -- no ragged tile, so the loop carries no tile-dependent branches: tile 0 (always conventional) is
+// peeled, tiles past the end re-fetch the last one (unconditional DMA, constant wait count).  Every instruction of the
+// loop costs an issue slot: the scalar bookkeeping of the general loop is ~25 of them per tile.
+template <bool PRE, bool EVEN>
 __global__ __launch_bounds__(256, FW3_WPS) void attn_fwd3_bf16_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const unsigned lds0 = (unsigned)(size_t)smem;
@@ -210,8 +213,13 @@ __global__ __launch_bounds__(256, FW3_WPS) void attn_fwd3_bf16_kernel(AttnParams
     KvDma dma;
     dma.init(kp, vp, p.skn, p.svn, p.Nk, wave, lane);
     const int nt = (p.Nk + 63) / 64;
-    dma.issue(0, smem + wave * 1024);
-    if (nt > 1) dma.issue(1, smem + FQ_STAGE + wave * 1024);
+    if (EVEN) {
+        dma.issue_full(0, smem + wave * 1024);
+        dma.issue_full(min(1, nt - 1), smem + FQ_STAGE + wave * 1024);
+    } else {
+        dma.issue(0, smem + wave * 1024);
+        if (nt > 1) dma.issue(1, smem + FQ_STAGE + wave * 1024);
+    }
 
     const float p2 = p.p2, rr = PRE ? 1.f : p.rr;
     bf16x8 qf[4];
@@ -236,6 +244,29 @@ __global__ __launch_bounds__(256, FW3_WPS) void attn_fwd3_bf16_kernel(AttnParams
 #pragma unroll
     for (int i = 0; i < 4; ++i) { aR[i] = ad.aR[i]; aT[i] = ad.aT[i]; }
     int stage = 0;
+    if (EVEN) {
+        char* const wbase = smem + wave * 1024;
+        wait_vm<4>();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        dma.issue_full(min(2, nt - 1), wbase + 2 * FQ_STAGE);
+        fw3_tile<PRE>(true, 0, p.Nk, aR, aT, qf, o, negm, m, lsum, hi, rr);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { aR[i] += FQ_STAGE; aT[i] += FQ_STAGE; }
+        stage = 1;
+        for (int t = 1; t < nt; ++t) {
+            wait_vm<4>();                                                // tile t landed (this wave's pieces)
+            __builtin_amdgcn_s_barrier();                                // ... everyone's; the stage of tile t-1 is free
+            __builtin_amdgcn_sched_barrier(0);
+            dma.issue_full(min(t + 2, nt - 1), wbase + (stage == 0 ? 2 : stage - 1) * FQ_STAGE);
+            fw3_tile<PRE>(false, t * 64, p.Nk, aR, aT, qf, o, negm, m, lsum, hi, rr);
+            const int step = stage == 2 ? -2 * FQ_STAGE : FQ_STAGE;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { aR[i] += step; aT[i] += step; }
+            stage = stage == 2 ? 0 : stage + 1;
+        }
+        wait_vm<0>();                                                    // the re-fetched tail tiles
+    } else {
     for (int t = 0; t < nt; ++t) {
 #if !(FW3_ABL & 1)
         if (t + 1 >= nt) wait_vm<0>(); else wait_vm<4>();            // tile t landed (this wave's pieces)
@@ -250,6 +281,7 @@ __global__ __launch_bounds__(256, FW3_WPS) void attn_fwd3_bf16_kernel(AttnParams
 #pragma unroll
         for (int i = 0; i < 4; ++i) { aR[i] += step; aT[i] += step; }
         stage = stage == 2 ? 0 : stage + 1;
+    }
     }
     const float l = lsum + xhalf(lsum);
     if (qrow < p.Nq) {
@@ -267,16 +299,26 @@ int launch_fwd3_bf16(const AttnParams& p, hipStream_t st) {
     const size_t lds = FQ_NSTAGE * FQ_STAGE;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd3_bf16_kernel<false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd3_bf16_kernel<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
+        const void* ks[4] = {reinterpret_cast<const void*>(attn_fwd3_bf16_kernel<false, false>),
+                             reinterpret_cast<const void*>(attn_fwd3_bf16_kernel<false, true>),
+                             reinterpret_cast<const void*>(attn_fwd3_bf16_kernel<true, false>),
+                             reinterpret_cast<const void*>(attn_fwd3_bf16_kernel<true, true>)};
+        for (const void* k : ks) {
+            hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+        }
         attr_set = true;
     }
-    if (p.rr == 1.f) attn_fwd3_bf16_kernel<true><<<dim3(total), dim3(256), lds, st>>>(p);
-    else attn_fwd3_bf16_kernel<false><<<dim3(total), dim3(256), lds, st>>>(p);
+#ifdef FW3_NO_EVEN
+    const bool pre = p.rr == 1.f, even = false;
+#else
+    const bool pre = p.rr == 1.f, even = p.Nk % 64 == 0;
+#endif
+    const dim3 g(total), b(256);
+    if (pre && even) attn_fwd3_bf16_kernel<true, true><<<g, b, lds, st>>>(p);
+    else if (pre) attn_fwd3_bf16_kernel<true, false><<<g, b, lds, st>>>(p);
+    else if (even) attn_fwd3_bf16_kernel<false, true><<<g, b, lds, st>>>(p);
+    else attn_fwd3_bf16_kernel<false, false><<<g, b, lds, st>>>(p);
     return (int)hipGetLastError();
 }
 

@@ -159,7 +159,15 @@ struct KvDma {
         col = ((lane & 7) ^ fswz(r8)) * 16;
         vk = r8 * skn2 + col; vv = r8 * svn2 + col;
     }
-    // tile `t` into the stage whose first byte (for this wave: + wave * 1024) is `dst`
+    // a FULL tile `t` (t * 64 + 64 <= Nk) into the stage whose first byte (for this wave: + wave * 1024) is `dst`
+    __device__ __forceinline__ void issue_full(int t, char* dst) const {
+        const int sk = t * 64 * skn2, sv = t * 64 * svn2;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_void*)dst, 16, vk, sk, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_void*)(dst + 4096), 16, vk, sk + 32 * skn2, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_void*)(dst + FT_TILE), 16, vv, sv, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_void*)(dst + FT_TILE + 4096), 16, vv, sv + 32 * svn2, 0, 0);
+    }
+    // any tile (the last one may be ragged)
     __device__ __forceinline__ void issue(int t, char* dst) const {
         const int sk = t * 64 * skn2, sv = t * 64 * svn2;
         if (t * 64 + 64 <= Nk) {

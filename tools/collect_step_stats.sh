@@ -17,5 +17,5 @@ cd /tmp
 timeout 900 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o stats --output-format csv -- $CMD > "$OUT/stats.log" 2>&1 || echo "stats pass failed"
 cd "$REPO"
 f=$(find "$OUT/stats" -name "*kernel_stats.csv" | head -1)
-if [ -n "$f" ]; then cp "$f" "profiles/${TAG}_${MODEL}_step_kernel_stats.csv"; head -12 "$f" | cut -c1-150; else echo "no kernel_stats.csv"; tail -5 "$OUT/stats.log"; fi
+if [ -n "$f" ]; then cp "$f" "profiles/${TAG}_${MODEL}_step_kernel_stats.csv"; mkdir -p gpurun_out/profiles; cp "$f" "gpurun_out/profiles/${TAG}_${MODEL}_step_kernel_stats.csv"; head -12 "$f" | cut -c1-150; else echo "no kernel_stats.csv"; tail -5 "$OUT/stats.log"; fi
 tail -1 "$OUT/stats.log" | cut -c1-400
