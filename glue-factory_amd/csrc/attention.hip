@@ -448,7 +448,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dq_kerne
         const int qrow = qrow0 + 32 * j;
         if (qrow < p.Nq) {
             T* dqp = reinterpret_cast<T*>(p.dq) + b * p.sdqb + h * p.sdqh + (int64_t)qrow * p.sdqn;
-            store_row<T, HD>(dqp, dq[j], p.scale, hi);
+            if (p.flags & GF_ATTN_ACC_DQ) add_row<HD>(dqp, dq[j], p.scale, hi); else store_row<T, HD>(dqp, dq[j], p.scale, hi);
         }
     }
 }
@@ -606,7 +606,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dkv_kern
     if (krow < p.Nk) {
         T* dkp = reinterpret_cast<T*>(p.dk) + b * p.sdkb + h * p.sdkh + (int64_t)krow * p.sdkn;
         T* dvp = reinterpret_cast<T*>(p.dv) + b * p.sdvb + h * p.sdvh + (int64_t)krow * p.sdvn;
-        store_row<T, HD>(dkp, dk, p.scale, hi);
+        if (p.flags & GF_ATTN_ACC_DK) add_row<HD>(dkp, dk, p.scale, hi); else store_row<T, HD>(dkp, dk, p.scale, hi);
         store_row<T, HD>(dvp, dv, 1.f, hi);
     }
 }
@@ -825,7 +825,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void attn_bwd_dkv_bf16_kernel(Attn
     if (krow < p.Nk) {
         bf16_t* dkp = reinterpret_cast<bf16_t*>(p.dk) + b * p.sdkb + h * p.sdkh + (int64_t)krow * p.sdkn;
         bf16_t* dvp = reinterpret_cast<bf16_t*>(p.dv) + b * p.sdvb + h * p.sdvh + (int64_t)krow * p.sdvn;
-        store_row<bf16_t, 64>(dkp, dk, p.scale, hi);
+        if (p.flags & GF_ATTN_ACC_DK) add_row<64>(dkp, dk, p.scale, hi); else store_row<bf16_t, 64>(dkp, dk, p.scale, hi);
         store_row<bf16_t, 64>(dvp, dv, 1.f, hi);
     }
 }
@@ -1318,7 +1318,21 @@ extern "C" int gf_attn_bwd(const void* q, const void* k, const void* v, const vo
                            const int64_t* do_strides, const int64_t* dq_strides,
                            const int64_t* dk_strides, const int64_t* dv_strides,
                            float scale, int dtype, void* stream) {
+    return gf_attn_bwd_acc(q, k, v, o, dout, lse, delta, dq, dk, dv, B, H, Nq, Nk, D, q_strides, k_strides, v_strides, o_strides,
+                           do_strides, dq_strides, dk_strides, dv_strides, scale, dtype, 0, stream);
+}
+
+extern "C" int gf_attn_bwd_acc(const void* q, const void* k, const void* v, const void* o,
+                               const void* dout, const float* lse, float* delta,
+                               void* dq, void* dk, void* dv,
+                               int B, int H, int Nq, int Nk, int D,
+                               const int64_t* q_strides, const int64_t* k_strides,
+                               const int64_t* v_strides, const int64_t* o_strides,
+                               const int64_t* do_strides, const int64_t* dq_strides,
+                               const int64_t* dk_strides, const int64_t* dv_strides,
+                               float scale, int dtype, int flags, void* stream) {
     if (D != 64) return GF_ERR_UNSUPPORTED;
+    if (flags & ~3) return GF_ERR_UNSUPPORTED;
     if (B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0) return GF_ERR_SHAPE;
     const int align = dtype == GF_BF16 ? 8 : 4;
     const int64_t* all[8] = {q_strides, k_strides, v_strides, o_strides,
@@ -1330,6 +1344,7 @@ extern "C" int gf_attn_bwd(const void* q, const void* k, const void* v, const vo
     p.lse = const_cast<float*>(lse); p.delta = delta; p.dq = dq; p.dk = dk; p.dv = dv;
     p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk; p.scale = scale;
     host_split_scale(scale, p.p2, p.rr);
+    p.flags = flags;
     p.sqb = q_strides[0]; p.sqn = q_strides[1]; p.sqh = q_strides[2];
     p.skb = k_strides[0]; p.skn = k_strides[1]; p.skh = k_strides[2];
     p.svb = v_strides[0]; p.svn = v_strides[1]; p.svh = v_strides[2];

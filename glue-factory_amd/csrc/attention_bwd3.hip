@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256, DQ3_WPS) void attn_dq3_bf16_kernel(AttnParams 
     }
     if (qrow < p.Nq) {
         bf16_t* dqp = reinterpret_cast<bf16_t*>(p.dq) + b * p.sdqb + h * p.sdqh + (int64_t)qrow * p.sdqn;
-        store_row<bf16_t, 64>(dqp, dq, p.scale, hi);
+        if (p.flags & GF_ATTN_ACC_DQ) add_row<64>(dqp, dq, p.scale, hi); else store_row<bf16_t, 64>(dqp, dq, p.scale, hi);
     }
 }
 

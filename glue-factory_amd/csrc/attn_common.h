@@ -7,6 +7,8 @@
 
 namespace gfattn {
 
+enum { GF_ATTN_ACC_DQ = 1, GF_ATTN_ACC_DK = 2 };
+
 struct AttnParams {
     const void* q; const void* k; const void* v; void* o;
     const void* dout; void* dq; void* dk; void* dv;
@@ -16,6 +18,7 @@ struct AttnParams {
     // gradients: dq/dout use the o-like strides given below
     int64_t sdob, sdon, sdoh, sdqb, sdqn, sdqh, sdkb, sdkn, sdkh, sdvb, sdvn, sdvh;
     float scale;
+    int flags;        // GF_ATTN_ACC_DQ / GF_ATTN_ACC_DK: add to what dq / dk hold instead of overwriting (gf_attn_bwd_acc)
     float p2, rr;     // scale * log2(e) = p2 * rr, p2 a power of two, rr in [1, 2) (host_split_scale); rr == 1 exactly when the
                       // caller pre-multiplied its operands (scale = ln 2): the kernels then skip the multiply per score
 };
@@ -30,6 +33,32 @@ template <typename T, int HD> struct Lay {
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// acc^T added to what the row already holds (fp32 sum, one rounding)
+template <int HD>
+__device__ __forceinline__ void add_row(float* rowptr, const f32x16 (&acc)[HD / 32], float mul, int hi) {
+#pragma unroll
+    for (int db = 0; db < HD / 32; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float* p = rowptr + db * 32 + 8 * g + 4 * hi;
+            const f32x4 old = *reinterpret_cast<const f32x4*>(p);
+            st4(p, old[0] + acc[db][4 * g] * mul, old[1] + acc[db][4 * g + 1] * mul, old[2] + acc[db][4 * g + 2] * mul,
+                old[3] + acc[db][4 * g + 3] * mul);
+        }
+}
+template <int HD>
+__device__ __forceinline__ void add_row(bf16_t* rowptr, const f32x16 (&acc)[HD / 32], float mul, int hi) {
+#pragma unroll
+    for (int db = 0; db < HD / 32; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            bf16_t* p = rowptr + db * 32 + 8 * g + 4 * hi;
+            const bf16x4 old = *reinterpret_cast<const bf16x4*>(p);
+            st4(p, (float)old[0] + acc[db][4 * g] * mul, (float)old[1] + acc[db][4 * g + 1] * mul,
+                (float)old[2] + acc[db][4 * g + 2] * mul, (float)old[3] + acc[db][4 * g + 3] * mul);
+        }
+}
 
 // write acc^T: lane owns row (rowptr), acc[db][r] is column db*32 + crow(r,hi)
 template <typename T, int HD>

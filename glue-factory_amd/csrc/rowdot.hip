@@ -34,6 +34,7 @@ __global__ __launch_bounds__(256) void rowdot_fwd_kernel(const T* __restrict__ x
 template <typename T, bool WITH_DX>
 __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const T* __restrict__ x, const float* __restrict__ dz,
                                                          const float* __restrict__ w, T* __restrict__ dx,
+                                                         const T* __restrict__ base,
                                                          float* __restrict__ part, int64_t M, int C) {
     constexpr int VEC = 16 / sizeof(T);
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -47,12 +48,13 @@ __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const T* __restrict__ x
     if (rl < rows_per_iter) {
         for (int64_t r = (int64_t)blockIdx.x * rows_per_iter + rl; r < M; r += (int64_t)gridDim.x * rows_per_iter) {
             const float g = dz[r];
-            union { u32x4 u; T e[VEC]; } v, o;
+            union { u32x4 u; T e[VEC]; } v, o, bs;
             v.u = *reinterpret_cast<const u32x4*>(x + r * C + cc * VEC);
+            if (WITH_DX && base) bs.u = *reinterpret_cast<const u32x4*>(base + r * C + cc * VEC);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
                 acc[e] += g * to_f32(v.e[e]);
-                if (WITH_DX) o.e[e] = from_f32<T>(g * wv[e]);
+                if (WITH_DX) o.e[e] = from_f32<T>(base ? to_f32(bs.e[e]) + g * wv[e] : g * wv[e]);
             }
             if (WITH_DX) *reinterpret_cast<u32x4*>(dx + r * C + cc * VEC) = o.u;
             if (cc == 0) bsum += g;
@@ -102,7 +104,7 @@ extern "C" int gf_rowdot_fwd(const void* x, const float* w, float bias, float* z
     return (int)hipGetLastError();
 }
 
-extern "C" int gf_rowdot_bwd(const void* x, const float* dz, const float* w, void* dx, float* part,
+extern "C" int gf_rowdot_bwd(const void* x, const float* dz, const float* w, void* dx, const void* base, float* part,
                              int M, int C, int dtype, void* stream) {
     if (M <= 0 || C <= 0) return GF_ERR_SHAPE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -110,13 +112,13 @@ extern "C" int gf_rowdot_bwd(const void* x, const float* dz, const float* w, voi
     if (dtype == GF_F32) {
         if (int e = rd_check<float>(C)) return e;
         size_t lds = 256 * 5 * sizeof(float);
-        if (dx) rowdot_bwd_kernel<float, true><<<nb, 256, lds, st>>>(reinterpret_cast<const float*>(x), dz, w, reinterpret_cast<float*>(dx), part, M, C);
-        else rowdot_bwd_kernel<float, false><<<nb, 256, lds, st>>>(reinterpret_cast<const float*>(x), dz, w, nullptr, part, M, C);
+        if (dx) rowdot_bwd_kernel<float, true><<<nb, 256, lds, st>>>(reinterpret_cast<const float*>(x), dz, w, reinterpret_cast<float*>(dx), reinterpret_cast<const float*>(base), part, M, C);
+        else rowdot_bwd_kernel<float, false><<<nb, 256, lds, st>>>(reinterpret_cast<const float*>(x), dz, w, nullptr, nullptr, part, M, C);
     } else if (dtype == GF_BF16) {
         if (int e = rd_check<bf16_t>(C)) return e;
         size_t lds = 256 * 9 * sizeof(float);
-        if (dx) rowdot_bwd_kernel<bf16_t, true><<<nb, 256, lds, st>>>(reinterpret_cast<const bf16_t*>(x), dz, w, reinterpret_cast<bf16_t*>(dx), part, M, C);
-        else rowdot_bwd_kernel<bf16_t, false><<<nb, 256, lds, st>>>(reinterpret_cast<const bf16_t*>(x), dz, w, nullptr, part, M, C);
+        if (dx) rowdot_bwd_kernel<bf16_t, true><<<nb, 256, lds, st>>>(reinterpret_cast<const bf16_t*>(x), dz, w, reinterpret_cast<bf16_t*>(dx), reinterpret_cast<const bf16_t*>(base), part, M, C);
+        else rowdot_bwd_kernel<bf16_t, false><<<nb, 256, lds, st>>>(reinterpret_cast<const bf16_t*>(x), dz, w, nullptr, nullptr, part, M, C);
     } else return GF_ERR_DTYPE;
     return (int)hipGetLastError();
 }

@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgf_amd.so")
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 4      # == GF_AMD_ABI_VERSION in include/gf_amd.h (bumped with every signature / workspace change)
+ABI_VERSION = 5      # == GF_AMD_ABI_VERSION in include/gf_amd.h (bumped with every signature / workspace change)
 
 _c = ctypes
 _P, _I, _F, _L = _c.c_void_p, _c.c_int, _c.c_float, _c.c_int64
@@ -22,6 +22,8 @@ SIGNATURES = {
     "gf_attn_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _S, _S, _S, _S, _F, _I, _P],
     "gf_attn_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I,
                     _S, _S, _S, _S, _S, _S, _S, _S, _F, _I, _P],
+    "gf_attn_bwd_acc": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I,
+                        _S, _S, _S, _S, _S, _S, _S, _S, _F, _I, _I, _P],
     "gf_rows_lse": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "gf_rows_argmax": [_P, _P, _P, _F, _P, _P, _I, _I, _I, _I, _I, _P],
     "gf_assign_write": [_P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _I, _I, _I, _I, _I, _P],
@@ -65,7 +67,7 @@ SIGNATURES = {
     "gf_sample_descriptors": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "gf_rowdot_nblk": [_I],
     "gf_rowdot_fwd": [_P, _P, _F, _P, _I, _I, _I, _P],
-    "gf_rowdot_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "gf_rowdot_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "gf_rows_lse_argmax": [_P, _P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "gf_lg_loss_fwd": [_P] * 9 + [_L] + [_P] * 13 + [_I, _I, _I, _I, _I, _P],
     "gf_lg_loss_bwd_tokens": [_P] * 11 + [_L] + [_P] * 7 + [_I, _I, _I, _P],

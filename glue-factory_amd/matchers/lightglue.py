@@ -102,12 +102,14 @@ class SelfBlock(nn.Module):
         rs[:dim] = ops.attn_premul(self.head_dim)
         self.register_buffer("_rowscale", rs, persistent=False)
 
-    def forward(self, x, theta, cs):
+    def forward(self, x, theta, cs, chain=None):
         b, n, d = x.shape
         w = self.Wqkv.weight.index_select(0, self._perm) * self._rowscale[:, None]
         bias = self.Wqkv.bias.index_select(0, self._perm) * self._rowscale
-        # x feeds the projection, the FFN input and the residual: one gradient chain, closed by the projection
-        chain = ops.GradChain(3) if x.requires_grad and torch.is_grad_enabled() else None
+        # x feeds the projection, the FFN input and the residual: one gradient chain, closed by the projection (a chain
+        # handed in by the caller may already carry optional contributions: the loss heads of the previous layer's output)
+        if chain is None:
+            chain = ops.GradChain(3) if x.requires_grad and torch.is_grad_enabled() else None
         if self.head_dim == 64 and ops.gemm_takes(d, 3 * d, x.dtype):     # q, k leave the GEMM already rotated (rotary epilogue: 64-wide heads)
             qkv = ops.linear(x, w, bias, rotary_cs=cs, rot_n=2 * d, chain=chain, chain_last=True)
             qkv = qkv.view(b, n, 3, self.heads, self.head_dim)
@@ -178,12 +180,16 @@ class MatchAssignment(nn.Module):
                 "lz0": F.logsigmoid(z0), "lz1": F.logsigmoid(z1),
                 "bin0": F.logsigmoid(-z0), "bin1": F.logsigmoid(-z1)}
 
-    def stats_stacked(self, x, b):
+    def stats_stacked(self, x, b, chain=None, closing=False):
         """Same as ``stats`` on the batch-stacked descriptors x [2B,N,D] (image 0 first): one GEMM for both
-        images and gradients that stay stacked (no slice / zero-fill / add nodes in the autograd graph)."""
+        images and gradients that stay stacked (no slice / zero-fill / add nodes in the autograd graph).
+        ``chain``: GradChain of x.  closing=True (last layer: these two heads are x's only consumers): the matchability
+        head parks its rank-1 gradient, the projection's input-gradient GEMM adds it in its epilogue and returns the
+        total.  closing=False: both park, uncounted, into the chain of the NEXT block (see LightGlue._loss_fused)."""
         s = self.dim ** -0.25
-        md = ops.linear(x, self.final_proj.weight * s, self.final_proj.bias * s)
-        z = _lin(x, self.matchability).squeeze(-1).float()
+        md = ops.linear(x, self.final_proj.weight * s, self.final_proj.bias * s, chain=chain,
+                        chain_last=True if closing else "extra")
+        z = ops.rowdot(x, self.matchability.weight, self.matchability.bias, chain=chain, counted=closing).float()
         r, c = ops.dual_lse_stacked(md)
         lz, lnz = F.logsigmoid(z), F.logsigmoid(-z)
         return {"md": md, "z": z, "md0": md[:b], "md1": md[b:], "r": r, "c": c,
@@ -336,8 +342,14 @@ class LightGlue(nn.Module):
             # layer's last GEMM, so the public ref_descriptors are views of it (no stack of L copies)
             lbuf = torch.empty((conf.n_layers, 2 * b, m, x.shape[-1]), dtype=x.dtype, device=x.device) \
                 if self.training and x.is_cuda else None
+            # gradient chains: chains[i] collects every gradient of the tensor ENTERING layer i (= layer i-1's output):
+            # the self block's three consumers and, optionally, that output's loss heads (added in _loss_fused)
+            grad = torch.is_grad_enabled() and self.training and x.is_cuda
+            chains = []
             for i, layer in enumerate(self.transformers):
-                x = layer.self_attn(x, theta, cs)
+                ch = ops.GradChain(3) if grad and x.requires_grad else None
+                chains.append(ch)
+                x = layer.self_attn(x, theta, cs, chain=ch)
                 x = layer.cross_attn.forward_stacked(x, out=None if lbuf is None else lbuf[i])
                 if self.training or i == conf.n_layers - 1:
                     layer_x.append(x)
@@ -358,7 +370,8 @@ class LightGlue(nn.Module):
                     all1.append(desc1)
 
         if stacked:
-            head = self.log_assignment[conf.n_layers - 1].stats_stacked(x, b)
+            fch = ops.GradChain(2) if grad and x.requires_grad else None      # the last output feeds only its two heads
+            head = self.log_assignment[conf.n_layers - 1].stats_stacked(x, b, chain=fch, closing=True)
         else:
             head = self.log_assignment[conf.n_layers - 1].stats(desc0, desc1)
         # the `row_norm` statistic of the loss (lightglue.py:602) is accumulated while the matrix is written
@@ -372,7 +385,8 @@ class LightGlue(nn.Module):
                 rd0, rd1 = lbuf.detach()[:, :b].transpose(0, 1), lbuf.detach()[:, b:].transpose(0, 1)   # [B, L, N, C] views
             else:
                 rd0, rd1 = torch.stack(all0, 1), torch.stack(all1, 1)
-            extra = {"_layer_desc": layer_x, "_final_head": head, "_row_norm": expsum / (scores.shape[1] - 1)}
+            extra = {"_layer_desc": layer_x, "_final_head": head, "_row_norm": expsum / (scores.shape[1] - 1),
+                     "_layer_chain": chains[1:] + [None]}        # chain of layer_x[i] = the one entering layer i + 1
         else:
             rd0, rd1 = torch.stack(all0, 1), torch.stack(all1, 1)
             extra = {}
@@ -533,9 +547,11 @@ class LightGlue(nn.Module):
             if fh is not None:           # the forward pass already projected the last layer
                 md, z, rc = fh["md"], fh["z"], (fh["r"], fh["c"])
             else:
+                # the gradients of x from these two heads ride in the next block's chain (GEMM / row-dot epilogues)
+                ch = pred["_layer_chain"][i] if "_layer_chain" in pred else None
                 s = la.dim ** -0.25
-                md = ops.linear(x, la.final_proj.weight * s, la.final_proj.bias * s)
-                z = _lin(x, la.matchability).squeeze(-1)
+                md = ops.linear(x, la.final_proj.weight * s, la.final_proj.bias * s, chain=ch, chain_last="extra")
+                z = ops.rowdot(x, la.matchability.weight, la.matchability.bias, chain=ch, counted=False)
                 rc = None
             t = self.token_confidence[i].logits(x) if i < L - 1 else None
             accs.append(ops.lg_layer_loss(md, z, t, rc, gt["pos"], gt["neg0"], gt["neg1"], fin0, fin1))

@@ -66,16 +66,17 @@ def attn_fwd_raw(q, k, v, scale, out=None, lse=None):
     return o, lse
 
 
-def attn_bwd_raw(q, k, v, o, do, lse, dq, dk, dv, scale):
+def attn_bwd_raw(q, k, v, o, do, lse, dq, dk, dv, scale, acc_dq=False, acc_dk=False):
     B, Nq, H, D = q.shape
     Nk = k.shape[1]
     if do.stride(3) != 1:
         do = do.contiguous()
     delta = lse.new_empty((2,) + tuple(lse.shape))      # scratch: the two per-row vectors the dQ kernel hands to dK/dV
-    _lib.check(_lib.load().gf_attn_bwd(_p(q), _p(k), _p(v), _p(o), _p(do), _p(lse), _p(delta),
+    _lib.check(_lib.load().gf_attn_bwd_acc(_p(q), _p(k), _p(v), _p(o), _p(do), _p(lse), _p(delta),
                                        _p(dq), _p(dk), _p(dv), B, H, Nq, Nk, D,
                                        _s3(q), _s3(k), _s3(v), _s3(o), _s3(do), _s3(dq), _s3(dk),
-                                       _s3(dv), float(scale), _dt(q), _stream()), "gf_attn_bwd")
+                                       _s3(dv), float(scale), _dt(q), int(acc_dq) | 2 * int(acc_dk), _stream()),
+               "gf_attn_bwd_acc")
 
 
 class _Attention(torch.autograd.Function):
@@ -170,16 +171,12 @@ class _CrossAttention(torch.autograd.Function):
         p0, p1, m0, m1, lse0, lse1 = ctx.saved_tensors
         D = p0.shape[-1]
         d0, d1 = torch.empty_like(p0), torch.empty_like(p1)
-        tk0, tk1 = torch.empty_like(p0[:, :, 0]), torch.empty_like(p1[:, :, 0])
-        tk0, tk1 = tk0.contiguous(), tk1.contiguous()
-        # direction 0->1: q = qk0, k = qk1, v = v1
+        # direction 0->1: q = qk0, k = qk1, v = v1: writes d qk0 (as query) and d qk1 (as key)
         attn_bwd_raw(p0[:, :, 0], p1[:, :, 0], p1[:, :, 1], m0, dm0, lse0,
-                     d0[:, :, 0], tk1, d1[:, :, 1], ctx.scale)
-        # direction 1->0: q = qk1, k = qk0, v = v0
+                     d0[:, :, 0], d1[:, :, 0], d1[:, :, 1], ctx.scale)
+        # direction 1->0: q = qk1, k = qk0, v = v0: ADDS d qk1 (as query) and d qk0 (as key) in the kernels' epilogues
         attn_bwd_raw(p1[:, :, 0], p0[:, :, 0], p0[:, :, 1], m1, dm1, lse1,
-                     d1[:, :, 0], tk0, d0[:, :, 1], ctx.scale)
-        d0[:, :, 0] += tk0
-        d1[:, :, 0] += tk1
+                     d1[:, :, 0], d0[:, :, 0], d0[:, :, 1], ctx.scale, acc_dq=True, acc_dk=True)
         return d0, d1, None
 
 
@@ -209,13 +206,12 @@ class _CrossAttentionStacked(torch.autograd.Function):
         if not dm.is_contiguous():
             dm = dm.contiguous()
         d = torch.empty_like(p)
-        tk = torch.empty((B2, N, H, D), dtype=p.dtype, device=p.device)
         p0, p1, d0, d1 = p[:B], p[B:], d[:B], d[B:]
         attn_bwd_raw(p0[:, :, 0], p1[:, :, 0], p1[:, :, 1], m[:B], dm[:B], lse[:B],
-                     d0[:, :, 0], tk[B:], d1[:, :, 1], ctx.scale)
+                     d0[:, :, 0], d1[:, :, 0], d1[:, :, 1], ctx.scale)
+        # the second direction adds its query / key gradients to the first one's in the kernels' epilogues
         attn_bwd_raw(p1[:, :, 0], p0[:, :, 0], p0[:, :, 1], m[B:], dm[B:], lse[B:],
-                     d1[:, :, 0], tk[:B], d0[:, :, 1], ctx.scale)
-        d[:, :, 0] += tk
+                     d1[:, :, 0], d0[:, :, 0], d0[:, :, 1], ctx.scale, acc_dq=True, acc_dk=True)
         return d, None
 
 
@@ -437,19 +433,24 @@ class GradChain:
     gradient; the last one's input-gradient GEMM adds the parked sum in its residual epilogue and returns the total.
     The last consumer must be the one whose backward runs last -- true by data dependence for the transformer blocks
     (the projection's gradient needs the attention backward, which needs the FFN's) and checked by the counter."""
-    __slots__ = ("acc", "got", "expected")
+    __slots__ = ("acc", "got", "expected", "closed")
 
     def __init__(self, consumers):
-        self.acc, self.got, self.expected = None, 0, consumers - 1
+        self.acc, self.got, self.expected, self.closed = None, 0, consumers - 1, False
 
-    def park(self, g):
+    def park(self, g, counted=True):
+        """counted=False: an OPTIONAL contribution (the per-layer loss heads of LightGlue, which exist only when the
+        fused loss is evaluated and whose backward always runs before the blocks': they were created later)."""
+        if self.closed:
+            raise RuntimeError("GradChain: a contribution arrived after the last consumer closed the chain (it would be lost)")
         self.acc = g
-        self.got += 1
+        if counted:
+            self.got += 1
 
     def take(self):
         if self.got != self.expected:
             raise RuntimeError(f"GradChain: {self.got} of {self.expected} contributions arrived before the last consumer")
-        acc, self.acc, self.got = self.acc, None, 0
+        acc, self.acc, self.got, self.closed = self.acc, None, 0, True
         return acc
 
 
@@ -495,16 +496,19 @@ class _Linear(torch.autograd.Function):
         dx = dw = db = None
         dres = dy if ctx.has_res and ctx.needs_input_grad[3] else None
         if dres is not None and ctx.res_chain is not None:       # first link of the residual tensor's chain
-            ctx.res_chain.park(_flat2(dres, nout))
+            d2 = _flat2(dres, nout)
+            if ctx.res_chain.acc is not None:      # optional contributions got here first (the previous output's loss heads)
+                d2 = d2 + ctx.res_chain.acc
+            ctx.res_chain.park(d2)
             dres = None
         if ctx.needs_input_grad[0]:
             ch = ctx.chain
             if ch is None:
                 dx = gemm(dy2, _wt_t(wt)).view(x.shape)
-            elif ctx.chain_last:
+            elif ctx.chain_last is True:
                 dx = gemm(dy2, _wt_t(wt), res2=ch.take()).view(x.shape)
-            else:
-                ch.park(gemm(dy2, _wt_t(wt), res2=ch.acc))
+            else:                                       # chain_last == "extra": an optional, uncounted contribution
+                ch.park(gemm(dy2, _wt_t(wt), res2=ch.acc), counted=ctx.chain_last != "extra")
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             x2 = x.reshape(-1, k)
             if not x2.is_contiguous():
@@ -608,7 +612,8 @@ class _RowDot(torch.autograd.Function):
     """z = x w^T + b for a single output channel (w [1,C], b [1]); returns fp32 [..]."""
 
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, chain=None, counted=True):
+        ctx.chain, ctx.counted = chain, counted
         C = x.shape[-1]
         x2 = x.reshape(-1, C)
         if not x2.is_contiguous():
@@ -632,18 +637,27 @@ class _RowDot(torch.autograd.Function):
         L = _lib.load()
         dz = dz.reshape(-1).float().contiguous()
         dx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
+        ch = ctx.chain if dx is not None else None
+        base = None if ch is None else ch.acc           # the chain's running sum rides in this kernel (dx = base + dz w)
         part = torch.empty((L.gf_rowdot_nblk(M), C + 1), dtype=torch.float32, device=x2.device)
-        _lib.check(L.gf_rowdot_bwd(_p(x2), _p(dz), _p(w32), _p(dx), _p(part), M, C, _dt(x2), _stream()),
+        _lib.check(L.gf_rowdot_bwd(_p(x2), _p(dz), _p(w32), _p(dx), _p(base), _p(part), M, C, _dt(x2), _stream()),
                    "gf_rowdot_bwd")
         s = part.sum(0)
         dw = s[:C].reshape(wshape).to(wdt)
         db = None if bdt is None else s[C:].to(bdt)
-        return (None if dx is None else dx.view(xshape)), dw, db
+        if ch is not None:
+            ch.park(dx, counted=ctx.counted)
+            dx = None
+        return (None if dx is None else dx.view(xshape)), dw, db, None, None
 
 
-def rowdot(x, w, b=None):
+def rowdot(x, w, b=None, chain=None, counted=True):
+    """``chain``: GradChain of x -- the input gradient is parked there (added to the chain's running sum inside the
+    kernel) instead of being returned."""
     _chk(x)
-    return _RowDot.apply(x, w, b)
+    if not x.requires_grad:
+        chain = None
+    return _RowDot.apply(x, w, b, chain, counted)
 
 
 # ------------------------------------------------------------------------------ LN + GELU

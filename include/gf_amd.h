@@ -35,8 +35,8 @@ extern "C" {
 #define GF_ERR_ALIGN (-3)
 #define GF_ERR_DTYPE (-4)
 
-/* ABI version; bumped on any signature or workspace-size change (2: gf_attn_bwd's delta workspace doubled; 3: line head + gf_bgemm; 4: smallops). */
-#define GF_AMD_ABI_VERSION 4
+/* ABI version; bumped on any signature or workspace-size change (2: gf_attn_bwd's delta workspace doubled; 3: line head + gf_bgemm; 4: smallops; 5: gf_attn_bwd_acc). */
+#define GF_AMD_ABI_VERSION 5
 int gf_abi_version(void);
 
 /* ---- multi-head attention over keypoints --------------------------------------------------
@@ -64,6 +64,18 @@ int gf_attn_bwd(const void* q, const void* k, const void* v, const void* o,
                 const int64_t* do_strides, const int64_t* dq_strides,
                 const int64_t* dk_strides, const int64_t* dv_strides,
                 float scale, int dtype, void* stream);
+/* The same with accumulation: flags bit 0 (1): dq += instead of dq =; bit 1 (2): dk += (fp32 sum of the stored value and
+ * the new gradient, one rounding).  Bidirectional cross attention (lightglue.py:203-216) uses one tensor as query in one
+ * direction and as key in the other: the second direction's backward adds straight into the first one's results. */
+int gf_attn_bwd_acc(const void* q, const void* k, const void* v, const void* o,
+                    const void* dout, const float* lse, float* delta,
+                    void* dq, void* dk, void* dv,
+                    int B, int H, int Nq, int Nk, int D,
+                    const int64_t* q_strides, const int64_t* k_strides,
+                    const int64_t* v_strides, const int64_t* o_strides,
+                    const int64_t* do_strides, const int64_t* dq_strides,
+                    const int64_t* dk_strides, const int64_t* dv_strides,
+                    float scale, int dtype, int flags, void* stream);
 
 /* ---- assignment head: double softmax with dustbins ------------------------------------------
  * S = a b^T with a [B,M,D], b [B,N,D] (the final_proj outputs, already scaled by D^-1/4),
@@ -305,11 +317,12 @@ int gf_sample_descriptors(const void* map, const float* kpts, float* out, int B,
 
 /* ---- single-output linear heads z[m] = x[m,:] . w + b (matchability / token-confidence logits,
  * lightglue.py:71,275-276,285-286).  x [M,C] in `dtype`, w [C] fp32, z/dz [M] fp32.
- * gf_rowdot_bwd writes dx = dz * w when dx != NULL (pass NULL for a detached input) and per-block
+ * gf_rowdot_bwd writes dx = dz * w (+ base, when base != NULL: the running sum of a gradient chain; dx may alias base)
+ * when dx != NULL (pass NULL for a detached input) and per-block
  * partials part [gf_rowdot_nblk(M)][C+1] whose column sums are (dw[0..C), db). */
 int gf_rowdot_nblk(int M);
 int gf_rowdot_fwd(const void* x, const float* w, float bias, float* z, int M, int C, int dtype, void* stream);
-int gf_rowdot_bwd(const void* x, const float* dz, const float* w, void* dx, float* part,
+int gf_rowdot_bwd(const void* x, const float* dz, const float* w, void* dx, const void* base, float* part,
                   int M, int C, int dtype, void* stream);
 
 /* ---- fused deep-supervision loss of one LightGlue layer (lightglue.py:598-657 `loss`,
