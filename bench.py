@@ -142,12 +142,13 @@ def roofline_attention(batch, n, dtype):
     g = torch.Generator(device="cuda").manual_seed(0)
     qkv = torch.randn(B2, n, 3, H, D, device="cuda", dtype=dtype, generator=g)
     do = torch.randn(B2, n, H, D, device="cuda", dtype=dtype, generator=g)
-    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
-    o, lse = ops.attn_fwd_raw(q, k, v, D ** -0.5)
+    qkv[:, :, 0] *= D ** -0.5 / ops.LN2            # the step's own mode: head_dim^-1/2 * log2(e) folded into the q rows of
+    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]     # Wqkv (matchers/lightglue.py), the kernels run at scale = ln 2
+    o, lse = ops.attn_fwd_raw(q, k, v, ops.LN2)
     dqkv = torch.empty_like(qkv)
-    t_fwd = time_kernel(lambda: ops.attn_fwd_raw(q, k, v, D ** -0.5, out=o, lse=lse))
+    t_fwd = time_kernel(lambda: ops.attn_fwd_raw(q, k, v, ops.LN2, out=o, lse=lse))
     t_bwd = time_kernel(lambda: ops.attn_bwd_raw(q, k, v, o, do, lse, dqkv[:, :, 0], dqkv[:, :, 1],
-                                                 dqkv[:, :, 2], D ** -0.5))
+                                                 dqkv[:, :, 2], ops.LN2))
     f_fwd = 4.0 * n * n * D * B2 * H
     f_bwd = 2.5 * f_fwd
     ach = f_bwd / t_bwd / 1e12
@@ -238,6 +239,16 @@ def roofline_extra(batch, n, dtype):
                       "frac": round(byt / t / 1e9 / HBM_PEAK_GBS, 4), "traffic": _traffic("gemm_st_kernel"),
                       "launch_ms": round(t * 1e3, 4), "algorithmic_bytes_per_launch": byt}
     if dtype == torch.bfloat16:
+        # calibration, not a product kernel: what the vendor library's plain bf16 GEMM reaches on THIS box in THIS process
+        # (the part clocks down under sustained MFMA load; DESIGN.md section 5 reads the attention fractions against it)
+        ga = torch.randn(8192, 8192, device="cuda", dtype=dtype, generator=g)
+        gb = torch.randn(8192, 8192, device="cuda", dtype=dtype, generator=g)
+        gc = torch.empty(8192, 8192, device="cuda", dtype=dtype)
+        t = time_kernel(lambda: torch.matmul(ga, gb, out=gc), iters=10, warm=3)
+        out["library_gemm_calibration"] = {"kernel": "hipBLASLt bf16 GEMM 8192^3 via torch.matmul (not on the product path)",
+                                           "achieved": round(2.0 * 8192 ** 3 / t / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
+                                           "unit": "TFLOP/s", "frac": round(2.0 * 8192 ** 3 / t / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)}
+        del ga, gb, gc
         nimg, hh, ww = 2 * batch, IMG, IMG
         xi = torch.randn(nimg, hh, ww, 64, device="cuda", dtype=dtype, generator=g)
         wc = (torch.randn(9, 64, 64, device="cuda", generator=g) * 0.05).to(dtype)       # [tap][c_out][c_in]

@@ -23,9 +23,16 @@ def timeit(fn, iters=20):
         b.record(); torch.cuda.synchronize()
         best = min(best, a.elapsed_time(b) / iters)
     return best
+# "+zero" after the mode (lib.so@ln2+zero) times the same launches on all-zero operands: same instruction stream, no
+# data toggling -- separates issue limits from the power limit
 # an argument "lib.so@ln2" times the pre-multiplied-operand instantiations (scale = ln 2: no multiply per score)
 for arg in sys.argv[1:]:
     path, _, mode = arg.partition("@")
+    mode, _, data = mode.partition("+")
+    if data == "zero":
+        qkv.zero_(); do.zero_()
+    elif data == "small":
+        qkv.mul_(1e-3); do.mul_(1e-3)
     SC = 0.6931471805599453 if mode == "ln2" else D ** -0.5
     lib = ctypes.CDLL(path)
     lib.gf_attn_fwd.argtypes = [P, P, P, P, P, I, I, I, I, I, S, S, S, S, F, I, P]
@@ -41,3 +48,10 @@ for arg in sys.argv[1:]:
         assert rc == 0, rc
     fwd()
     print(f"{arg}: fwd {timeit(fwd)*1e3:.1f} us   bwd {timeit(bwd)*1e3:.1f} us", flush=True)
+ga = torch.randn(8192, 8192, device="cuda", dtype=torch.bfloat16); gb = torch.randn(8192, 8192, device="cuda", dtype=torch.bfloat16)
+gc = torch.empty_like(ga)
+t = timeit(lambda: torch.matmul(ga, gb, out=gc), iters=10)
+print(f"hipBLASLt 8192^3 bf16 random: {t*1e3:.0f} us = {2*8192**3/t/1e9:.0f} TFLOP/s")
+ga.zero_(); gb.zero_()
+t = timeit(lambda: torch.matmul(ga, gb, out=gc), iters=10)
+print(f"hipBLASLt 8192^3 bf16 zeros : {t*1e3:.0f} us = {2*8192**3/t/1e9:.0f} TFLOP/s")
