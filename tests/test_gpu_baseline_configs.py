@@ -22,10 +22,11 @@ from oracle import lightglue_oracle as lgo  # noqa: E402
 # ---- stated bf16 bounds (bf16 has an 8-bit mantissa: eps = 3.9e-3; errors accumulate over L layers) ----
 # measured on MI355X (round 2): config 1: max|dLA| 0.066, mean 0.0096, worst loss entry 1.5e-3, worst per-tensor gradient
 # error 1.4 % (median 0.5 %); N=2048/L=9: 0.19, 0.026, 2.9e-3, 1.8 % (median 0.7 %).  Bounds = about 2x that.
-BF16_LA_MAX = {"lightglue_config1": 0.12, "lightglue_n2048_l9": 0.3}      # max |d log_assignment|
-BF16_LA_MEAN = {"lightglue_config1": 0.02, "lightglue_n2048_l9": 0.05}     # mean |d log_assignment|
+BF16_LA_MAX = {"lightglue_config1": 0.09, "lightglue_n2048_l9": 0.25}     # max |d log_assignment| (measured 0.054 / 0.161)
+BF16_LA_MEAN = {"lightglue_config1": 0.015, "lightglue_n2048_l9": 0.04}    # mean |d log_assignment| (0.0083 / 0.023)
+BF16_LA_P99 = {"lightglue_config1": 0.045, "lightglue_n2048_l9": 0.12}     # 99th percentile (0.027 / 0.075)
 BF16_LOSS_REL = 5e-3                                                        # every loss entry, relative
-BF16_GRAD_REL = {"lightglue_config1": 0.03, "lightglue_n2048_l9": 0.04}    # ||g - g_ref|| / ||g_ref|| per tensor
+BF16_GRAD_REL = {"lightglue_config1": 0.025, "lightglue_n2048_l9": 0.035}  # ||g - g_ref|| / ||g_ref|| per tensor (0.014 / 0.025)
 
 
 def _model(params, L, **kw):
@@ -101,10 +102,12 @@ def test_bf16_train_step_on_baseline_config(name):
     rels = {k: _rel(grads[k], grads_o[k]) for k in grads_o}
     k_w = max(rels, key=rels.get)
     srt = sorted(rels.values())
-    print(f"{name} bf16: |d log_assignment| max {err.max():.4f} mean {err.mean():.5f}; loss rel err "
+    sample = err.flatten()[:: max(1, err.numel() // 2_000_000)]                 # quantile() takes at most 16 M entries
+    p99 = float(torch.quantile(sample.detach(), 0.99))
+    print(f"{name} bf16: |d log_assignment| max {err.max():.4f} p99 {p99:.4f} mean {err.mean():.5f}; loss rel err "
           f"{ {k: round(v, 5) for k, v in lrel.items()} }; per-tensor relative gradient error max {rels[k_w]:.4f} "
           f"({k_w}) p90 {srt[int(0.9 * len(srt))]:.4f} median {srt[len(srt) // 2]:.4f}")
-    assert err.max() < BF16_LA_MAX[name] and err.mean() < BF16_LA_MEAN[name]
+    assert err.max() < BF16_LA_MAX[name] and err.mean() < BF16_LA_MEAN[name] and p99 < BF16_LA_P99[name]
     for k, v in lrel.items():
         if k in ("num_matchable", "num_unmatchable"):
             assert v == 0.0
@@ -116,7 +119,18 @@ def test_bf16_train_step_on_baseline_config(name):
     top2 = la.topk(2, dim=-1).values
     clear = (top2[..., 0] - top2[..., 1]) > 4 * BF16_LA_MAX[name]
     hip_arg = pred["log_assignment"][:, :-1, :-1].argmax(-1).cpu()
+    n_rows, n_clear = clear.numel(), int(clear.sum())
+    n_diff_all = int((hip_arg != la.argmax(-1)).sum())
+    print(f"{name} bf16: row arg-max compared on {n_clear} of {n_rows} rows (margin > {4 * BF16_LA_MAX[name]:.2f}; "
+          f"{n_rows - n_clear} excluded as near-ties); rows whose arg-max differs over ALL rows: {n_diff_all}")
     assert torch.equal(hip_arg[clear], la.argmax(-1)[clear])
+    # (random weights: almost every row of these goldens is a near-tie, so the clear-margin set is small; the statement that
+    # covers ALL rows is the one below) wherever the decisions differ, the reference itself rates the two candidates within
+    # twice the log-assignment bound of each other
+    gap = la.max(-1).values - la.gather(-1, hip_arg[..., None])[..., 0]
+    print(f"{name} bf16: largest reference gap between its own and our row arg-max: {float(gap.max()):.4f}")
+    assert float(gap.max()) <= 2 * BF16_LA_MAX[name]
+    assert n_diff_all <= 0.06 * n_rows, f"{n_diff_all} of {n_rows} row decisions differ"
 
 
 @pytest.mark.parametrize("name", ["lightglue_config1", "lightglue_n2048_l9"])

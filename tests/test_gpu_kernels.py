@@ -581,8 +581,9 @@ def test_line_message_passing_kernels(dtype, mean):
 def test_head_bwd_fused(shape):
     """gf_head_bwd (assignment-head backward without the dS tensor: da = dS b, db = dS^T a with
     dS = exp(S - r) gr + exp(S - c) gc, lightglue.py:256-290 autograd) vs an fp64 restatement on the same bf16 inputs;
-    ragged row / column counts, a single column, the benchmark size.  Tolerance: bf16 rounding of dS (2^-9 relative per
-    entry) and of the outputs, relative to the largest output entry."""
+    ragged row / column counts, a single column, the benchmark size.  Tolerance: the kernel's own rounding model, entry by
+    entry (one bf16 rounding of dS, fp32 accumulation, one bf16 rounding of the output), and 2 u = 7.8e-3 of the largest entry
+    (was 1.5e-2; measured 2.5e-3 ... 4.5e-3, worst error / bound 0.23 ... 0.88)."""
     from glue_factory_amd import lib as L_
     B, M, N = shape
     g = torch.Generator(device="cuda").manual_seed(M + N)
@@ -600,10 +601,18 @@ def test_head_bwd_fused(shape):
     L_.check(L_.load().gf_head_bwd(a.data_ptr(), b.data_ptr(), r32.data_ptr(), c32.data_ptr(),
                                    gr.data_ptr(), gc.data_ptr(), da.data_ptr(), db.data_ptr(), B, M, N, 256, 1,
                                    torch.cuda.current_stream().cuda_stream), "gf_head_bwd")
-    for name, x, y in (("da", da, da_ref), ("db", db, db_ref)):
-        sc = y.abs().max().item()
-        err = (x.double() - y).abs().max().item() / sc
-        assert err < 1.5e-2, f"{name}: max error {err:.3e} of the largest entry"
+    # rounding model of the kernel, entry by entry: dS is rounded to bf16 once (unit roundoff u = 2^-8: 8 significant
+    # bits; fp32 before), the products accumulate in fp32, the output is rounded to bf16 once:
+    #     |x - y| <= u (|y| + (|dS| |b|))   (+ 5 % for the second-order terms)
+    u = 2.0 ** -8
+    bound_a = 1.05 * u * (da_ref.abs() + torch.bmm(dS.abs(), b.double().abs()))
+    bound_b = 1.05 * u * (db_ref.abs() + torch.bmm(dS.abs().transpose(1, 2), a.double().abs()))
+    for name, x, y, bd in (("da", da, da_ref, bound_a), ("db", db, db_ref, bound_b)):
+        ratio = ((x.double() - y).abs() / (bd + 1e-9 * y.abs().max())).max().item()
+        rel = (x.double() - y).abs().max().item() / y.abs().max().item()
+        print(f"head_bwd {shape} {name}: worst |error| / rounding bound = {ratio:.3f}, max error {rel:.2e} of the largest entry")
+        assert ratio <= 1.0, f"{name}: error {ratio:.3f} x the bf16 rounding bound"
+        assert rel < 2 * u, f"{name}: max error {rel:.3e} of the largest entry"
 
 
 @pytest.mark.parametrize("case", [(4096, 256, 256, False, False), (4096, 256, 256, False, True), (192, 512, 512, True, False),
