@@ -131,8 +131,27 @@ struct HeadParams {
     load_owner<T, D>(of, ownp + (int64_t)old_ * D, hi);                                           \
     (void)split;
 
+// Running (max, argmax) of one lane.  A lane visits its streamed rows in ASCENDING index order (tiles ascend, and inside a
+// tile the offset 32 kb + 8 g + e ascends with (kb, g, e); + 4 hi is fixed per lane), so a strict > keeps the lowest index
+// of a tie: one compare + two selects per score, the offset an inline constant; the tile's winner meets the running one
+// once per tile, and the full tie rule is only needed where the two half-wave partners meet.
+struct TileArg {
+    float v; int off;
+    __device__ __forceinline__ void reset() { v = -INFINITY; off = 0; }
+    __device__ __forceinline__ void see(float x, int off_const) {
+        const bool gt = x > v;
+        v = gt ? x : v;
+        off = gt ? off_const : off;
+    }
+    __device__ __forceinline__ void merge(int s0, int hi, float& best, int& bidx) const {
+        const bool gt = v > best;
+        best = gt ? v : best;
+        bidx = gt ? s0 + 4 * hi + off : bidx;
+    }
+};
+
 // lse[b, owner] = log sum_s exp(own . oth_s + sbias_s)
-template <typename T, int D>
+template <typename T, int D, bool HAS_BIAS>
 __global__ __launch_bounds__(256) void rows_lse_kernel(HeadParams p) {
     GF_HEAD_PROLOGUE(T, D)
     float m = GF_NEG_BIG, lsum = 0.f;
@@ -142,32 +161,42 @@ __global__ __launch_bounds__(256) void rows_lse_kernel(HeadParams p) {
         v0 = si < p.Ns ? x : -INFINITY;
         v1 = 0.f;
     };
-    auto body = [&](const T* tile, const float* vec0, const float*, int) {
+    auto body = [&](const T* tile, const float* vec0, const float*, int s0) {
         f32x16 s[2];
         float mx = GF_NEG_BIG;
+        // without a bias (LightGlue's double softmax) the scores stay RAW: the maximum is taken on them and log2(e) and the
+        // shift ride in the fma in front of exp2 -- max3, fma, exp2, add = 3.5 instructions per score instead of 5
+        const bool plain = !HAS_BIAS && s0 + 64 <= p.Ns;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
             mma_tile<T, D>(s[kb], tile, kb * 32, of, l31, hi);
+            if (plain) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 b4 = *reinterpret_cast<const f32x4*>(vec0 + kb * 32 + 8 * g + 4 * hi);
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+            } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float x = s[kb][4 * g + e] * GF_LOG2E + b4[e];
-                    s[kb][4 * g + e] = x;
-                    mx = fmaxf(mx, x);
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 b4 = *reinterpret_cast<const f32x4*>(vec0 + kb * 32 + 8 * g + 4 * hi);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float x = s[kb][4 * g + e] * GF_LOG2E + b4[e];
+                        s[kb][4 * g + e] = x;
+                        mx = fmaxf(mx, x);
+                    }
                 }
             }
         }
+        if (plain) mx *= GF_LOG2E;
         mx = fmaxf(mx, xhalf(mx));
         const float mnew = fmaxf(m, mx);
         float ps = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) ps += fast_exp2(s[kb][r] - mnew);
+            for (int r = 0; r < 16; ++r)
+                ps += plain ? fast_exp2(fmaf(s[kb][r], GF_LOG2E, -mnew)) : fast_exp2(s[kb][r] - mnew);
         lsum = lsum * fast_exp2(m - mnew) + ps;
         m = mnew;
     };
@@ -189,6 +218,8 @@ __global__ __launch_bounds__(256) void rows_argmax_kernel(HeadParams p) {
         v1 = 0.f;
     };
     auto body = [&](const T* tile, const float* vec0, const float*, int s0) {
+        TileArg ta;
+        ta.reset();
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             f32x16 s;
@@ -200,12 +231,11 @@ __global__ __launch_bounds__(256) void rows_argmax_kernel(HeadParams p) {
                 f32x4 b4 = *reinterpret_cast<const f32x4*>(vec0 + kb * 32 + 8 * g + 4 * hi);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float x = p.alpha * s[4 * g + e] + b4[e];
-                    int idx = s0 + kb * 32 + 8 * g + 4 * hi + e;
-                    if (x > best || (x == best && idx < bidx)) { best = x; bidx = idx; }
+                    ta.see(p.alpha * s[4 * g + e] + b4[e], kb * 32 + 8 * g + e);
                 }
             }
         }
+        ta.merge(s0, hi, best, bidx);
     };
     stream_tiles<T, D>(tiles, vecs, othp, 0, p.Ns, p.Ns, bias, body);
     float ob_ = xhalf(best);
@@ -222,7 +252,7 @@ __global__ __launch_bounds__(256) void rows_argmax_kernel(HeadParams p) {
 //   max / argmax over s of alpha * own . oth_s + logsigmoid(g0_s) - g1_s   (-> f0, i0)
 // (g0 = matchability logits of the streamed side, g1 = its normaliser from the previous pass.)
 template <typename T, int D, bool WITH_LSE>
-__global__ __launch_bounds__(256) void rows_lse_argmax_kernel(HeadParams p) {
+__global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void rows_lse_argmax_kernel(HeadParams p) {     // bf16: two waves per SIMD
     GF_HEAD_PROLOGUE(T, D)
     float m = GF_NEG_BIG, lsum = 0.f;
     float best = -INFINITY;
@@ -239,6 +269,8 @@ __global__ __launch_bounds__(256) void rows_lse_argmax_kernel(HeadParams p) {
     auto body = [&](const T* tile, const float* vec0, const float* vec1, int s0) {
         f32x16 s[2];
         float mx = GF_NEG_BIG;
+        TileArg ta;
+        ta.reset();
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
@@ -250,17 +282,12 @@ __global__ __launch_bounds__(256) void rows_lse_argmax_kernel(HeadParams p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float raw = s[kb][4 * g + e];
-                    const float x = p.alpha * raw + b4[e];
-                    const int idx = s0 + kb * 32 + 8 * g + 4 * hi + e;
-                    if (x > best || (x == best && idx < bidx)) { best = x; bidx = idx; }
-                    if (WITH_LSE) {
-                        const float y = raw * GF_LOG2E;
-                        s[kb][4 * g + e] = y;
-                        mx = fmaxf(mx, y);
-                    }
+                    ta.see(p.alpha * raw + b4[e], kb * 32 + 8 * g + e);
+                    if (WITH_LSE) mx = fmaxf(mx, raw);            // the lse works on the RAW scores (see rows_lse_kernel)
                 }
             }
         }
+        ta.merge(s0, hi, best, bidx);
         if (WITH_LSE) {
             if (s0 + 64 > p.Ns) {                                 // ragged last tile
                 mx = GF_NEG_BIG;
@@ -276,13 +303,14 @@ __global__ __launch_bounds__(256) void rows_lse_argmax_kernel(HeadParams p) {
                         }
                     }
             }
+            mx *= GF_LOG2E;
             mx = fmaxf(mx, xhalf(mx));
             const float mnew = fmaxf(m, mx);
             float ps = 0.f;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) ps += fast_exp2(s[kb][r] - mnew);
+                for (int r = 0; r < 16; ++r) ps += fast_exp2(fmaf(s[kb][r], GF_LOG2E, -mnew));
             lsum = lsum * fast_exp2(m - mnew) + ps;
             m = mnew;
         }
@@ -314,6 +342,8 @@ __global__ __launch_bounds__(256) void assign_write_kernel(HeadParams p) {
     };
     float esum = 0.f;       // sum of exp(out) over this lane's entries (rows < Ns, all columns): the "row_norm" statistic
     auto body = [&](const T* tile, const float* vec0, const float*, int s0) {
+        TileArg ta;
+        ta.reset();
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             f32x16 s;
@@ -447,7 +477,15 @@ template <typename T, int D> int launch_td(int which, const HeadParams& p, hipSt
         return (int)hipGetLastError();                              \
     }
     switch (which) {
-        case K_LSE: GF_LAUNCH(rows_lse_kernel)
+        case K_LSE:
+            if (p.sbias) {
+                if (int e = set_lds(rows_lse_kernel<T, D, true>, lds)) return e;
+                rows_lse_kernel<T, D, true><<<dim3(total), dim3(256), lds, st>>>(p);
+            } else {
+                if (int e = set_lds(rows_lse_kernel<T, D, false>, lds)) return e;
+                rows_lse_kernel<T, D, false><<<dim3(total), dim3(256), lds, st>>>(p);
+            }
+            return (int)hipGetLastError();
         case K_ARGMAX: GF_LAUNCH(rows_argmax_kernel)
         case K_WRITE: GF_LAUNCH(assign_write_kernel)
         case K_BWD: GF_LAUNCH(dual_softmax_bwd_kernel)
