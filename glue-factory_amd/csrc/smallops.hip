@@ -3,6 +3,9 @@
 //   gf_multi_cast_transpose  ONE launch per step converts every fp32 master parameter into the compute dtype AND writes
 //                            the transposed copy W^T of every matrix (the "weight" of the input-gradient GEMM
 //                            dx = dy W) -- instead of one multi-tensor cast plus ~107 transposing copies per step;
+//                            derived weights (a projection's rows gathered / scaled / stacked from several parameters,
+//                            e.g. LightGlue's Wqkv in kernel order with the softmax scale folded into its q rows) are
+//                            entries of the same table; gf_weight_grad_map sends their gradient back to the sources;
 //   gf_colsum_f32            deterministic column sums of an [R, C] fp32 matrix of per-block partials (LayerNorm
 //                            gamma / beta gradients: 36 reductions of [2048, 512] per step, 16 us each in torch);
 //   gf_small_dw              dW[o, k] = sum_m dy[m, o] x[m, k] for a tall dy [M, O] and a FEW input columns (K <= 4):
@@ -13,14 +16,22 @@
 
 namespace {
 
-struct CastEntry {            // one parameter: src fp32 [rows, cols] row-major
+struct CastEntry {            // one parameter (or one row block of a DERIVED weight): src fp32 [src rows, cols] row-major
     const float* src;
-    void* dst;                // compute-dtype copy (may be NULL when only the transpose is wanted)
-    void* dst_t;              // [cols, rows] transposed copy (NULL for vectors)
+    void* dst;                // compute-dtype copy [rows, cols] (may be NULL when only the transpose is wanted)
+    void* dst_t;              // transposed copy: element (r, c) at dst_t[c * ldt + r] (NULL for vectors)
     int rows, cols;
     int tile0;                // first 32 x 32 tile of this tensor in the launch
     int tiles_x;              // tiles per row of tiles (cols direction)
+    // derived weights (the matcher's prepared projections: row gather, per-row / scalar scale, row blocks of one output)
+    const int* perm;          // dst row r reads src row perm[r] (NULL: r)
+    const float* rscale;      // dst row r is scaled by rscale[r] (NULL: 1)
+    float scale;              // ... and by this scalar, all in fp32 before the single rounding
+    int ldt;                  // leading dimension of dst_t (rows of the WHOLE output when this is one block of it)
+    int flags;                // bit 0: dst is fp32 whatever the launch's dtype (biases stay fp32 for the GEMM epilogues)
+    int pad_;
 };
+static_assert(sizeof(CastEntry) == 72, "host table layout (ops.precast)");
 
 template <typename T>
 __global__ __launch_bounds__(256) void multi_cast_transpose_kernel(const CastEntry* __restrict__ tab, int n) {
@@ -36,13 +47,19 @@ __global__ __launch_bounds__(256) void multi_cast_transpose_kernel(const CastEnt
     const int r0 = (t / e.tiles_x) * 32, c0 = (t % e.tiles_x) * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;         // 32 x 8 threads
     T* dst = static_cast<T*>(e.dst);
+    float* dst32 = static_cast<float*>(e.dst);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = r0 + ty + 8 * i, c = c0 + tx;
         float v = 0.f;
         if (r < e.rows && c < e.cols) {
-            v = e.src[(size_t)r * e.cols + c];
-            if (dst) dst[(size_t)r * e.cols + c] = from_f32<T>(v);
+            const int sr = e.perm ? e.perm[r] : r;
+            v = e.src[(size_t)sr * e.cols + c] * e.scale;
+            if (e.rscale) v *= e.rscale[r];
+            if (e.dst) {
+                if (e.flags & 1) dst32[(size_t)r * e.cols + c] = v;
+                else dst[(size_t)r * e.cols + c] = from_f32<T>(v);
+            }
         }
         tile[ty + 8 * i][tx] = v;
     }
@@ -52,7 +69,21 @@ __global__ __launch_bounds__(256) void multi_cast_transpose_kernel(const CastEnt
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = c0 + ty + 8 * i, r = r0 + tx;
-        if (r < e.rows && c < e.cols) dt[(size_t)c * e.rows + r] = from_f32<T>(tile[tx][ty + 8 * i]);
+        if (r < e.rows && c < e.cols) dt[(size_t)c * e.ldt + r] = from_f32<T>(tile[tx][ty + 8 * i]);
+    }
+}
+
+// gradient of a derived-weight row block back to its source parameter: out[perm[r]][c] = g[r][c] * rscale[r] * scale
+// (perm a bijection onto the source rows: a scatter without accumulation)
+__global__ __launch_bounds__(256) void weight_grad_map_kernel(const float* __restrict__ g, float* __restrict__ out,
+                                                              const int* __restrict__ perm, const float* __restrict__ rscale,
+                                                              float scale, int rows, int cols) {
+    const size_t total = (size_t)rows * cols;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int r = (int)(i / cols), c = (int)(i - (size_t)r * cols);
+        float v = g[i] * scale;
+        if (rscale) v *= rscale[r];
+        out[(size_t)(perm ? perm[r] : r) * cols + c] = v;
     }
 }
 
@@ -128,6 +159,15 @@ extern "C" int gf_multi_cast_transpose(const void* table, int n_entries, int tot
     return (int)hipGetLastError();
 }
 extern "C" int gf_cast_entry_bytes(void) { return (int)sizeof(CastEntry); }
+
+extern "C" int gf_weight_grad_map(const float* g, float* out, const int* perm, const float* rscale, float scale,
+                                  int rows, int cols, void* stream) {
+    if (rows <= 0 || cols <= 0) return GF_ERR_SHAPE;
+    const size_t total = (size_t)rows * cols;
+    const int nb = (int)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256);
+    weight_grad_map_kernel<<<dim3(nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(g, out, perm, rscale, scale, rows, cols);
+    return (int)hipGetLastError();
+}
 
 extern "C" int gf_colsum_f32(const float* x, float* ws, float* out, int G, int R, int C, void* stream) {
     if (G <= 0 || R <= 0 || C <= 0) return GF_ERR_SHAPE;

@@ -102,10 +102,24 @@ class SelfBlock(nn.Module):
         rs[:dim] = ops.attn_premul(self.head_dim)
         self.register_buffer("_rowscale", rs, persistent=False)
 
+    _pc = None      # (precast key, name): set by the owning model, see LightGlue._derived_specs
+
+    def derived_specs(self, name):
+        """Row gather + q-row scale of the projection as entries of the model's per-step precast launch (ops.precast)."""
+        return [(name + ".w", [(self.Wqkv.weight, self._perm, self._rowscale, 1.0)]),
+                (name + ".b", [(self.Wqkv.bias, self._perm, self._rowscale, 1.0)])]
+
+    def _prepared(self, dtype):
+        if self._pc is not None:
+            w = ops.derived_weight(self._pc[0], dtype, self._pc[1] + ".w", self.Wqkv.weight)
+            if w is not None:
+                return w, ops.derived_weight(self._pc[0], dtype, self._pc[1] + ".b", self.Wqkv.bias)
+        return (self.Wqkv.weight.index_select(0, self._perm) * self._rowscale[:, None],
+                self.Wqkv.bias.index_select(0, self._perm) * self._rowscale)
+
     def forward(self, x, theta, cs, chain=None):
         b, n, d = x.shape
-        w = self.Wqkv.weight.index_select(0, self._perm) * self._rowscale[:, None]
-        bias = self.Wqkv.bias.index_select(0, self._perm) * self._rowscale
+        w, bias = self._prepared(x.dtype)
         # x feeds the projection, the FFN input and the residual: one gradient chain, closed by the projection (a chain
         # handed in by the caller may already carry optional contributions: the loss heads of the previous layer's output)
         if chain is None:
@@ -130,11 +144,24 @@ class CrossBlock(nn.Module):
         self.to_out = nn.Linear(dim, dim, bias=True)
         self.ffn = _ffn_modules(dim)
 
+    _pc = None
+
+    def derived_specs(self, name):
+        sq = ops.attn_premul(self.head_dim) ** 0.5
+        return [(name + ".w", [(self.to_qk.weight, None, None, sq), (self.to_v.weight, None, None, 1.0)]),
+                (name + ".b", [(self.to_qk.bias, None, None, sq), (self.to_v.bias, None, None, 1.0)])]
+
     def _proj(self, x, chain=None):
         # sqrt(head_dim^-1/2 * log2(e)) on BOTH images' qk (each is query in one direction and key in the other)
-        sq = ops.attn_premul(self.head_dim) ** 0.5
-        w = torch.cat([self.to_qk.weight * sq, self.to_v.weight], 0)
-        bias = torch.cat([self.to_qk.bias * sq, self.to_v.bias], 0)
+        w = None
+        if self._pc is not None:
+            w = ops.derived_weight(self._pc[0], x.dtype, self._pc[1] + ".w", self.to_qk.weight, self.to_v.weight)
+        if w is not None:
+            bias = ops.derived_weight(self._pc[0], x.dtype, self._pc[1] + ".b", self.to_qk.bias, self.to_v.bias)
+        else:
+            sq = ops.attn_premul(self.head_dim) ** 0.5
+            w = torch.cat([self.to_qk.weight * sq, self.to_v.weight], 0)
+            bias = torch.cat([self.to_qk.bias * sq, self.to_v.bias], 0)
         return ops.linear(x, w, bias, chain=chain, chain_last=True).view(x.shape[0], x.shape[1], 2, self.heads, self.head_dim)
 
     def forward_stacked(self, x, out=None):
@@ -280,6 +307,14 @@ class LightGlue(nn.Module):
         self.load_state_dict(sd, strict=False)
 
     # ------------------------------------------------------------------ forward
+    def _derived_specs(self):
+        specs = []
+        for i, layer in enumerate(self.transformers):
+            for blk, nm in ((layer.self_attn, f"self{i}"), (layer.cross_attn, f"cross{i}")):
+                blk._pc = (id(self), nm)
+                specs += blk.derived_specs(nm)
+        return specs
+
     def _compute_dtype(self):
         if self.conf.mp or torch.is_autocast_enabled():
             return torch.bfloat16
@@ -293,7 +328,9 @@ class LightGlue(nn.Module):
                                "(move the batch to the GPU; there is no CPU fallback)")
         T = self._compute_dtype()  # read the autocast state before switching it off
         if T != torch.float32:
-            ops.precast(list(self.parameters()), T, key=id(self))   # one multi-tensor cast per step
+            # one launch per step: every parameter in the compute dtype (+ transposed copies) AND the blocks' prepared
+            # projections (row order / softmax scale folded in)
+            ops.precast(list(self.parameters()), T, key=id(self), derived=self._derived_specs())
         with torch.autocast(device_type="cuda", enabled=False):
             return self._forward(data, T)
 

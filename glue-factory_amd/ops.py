@@ -234,45 +234,94 @@ _LP_T = {}            # data_ptr of a compute-dtype weight -> (its transposed co
 _LP_FLAT = {}         # (key, dtype) -> (flat buffer, [views], [params])
 
 
-def precast(params, dtype, key="default"):
+def precast(params, dtype, key="default", derived=None):
     """One launch per forward: every fp32 master parameter -> the compute dtype (flat buffer, served by _lp()), and the
     transposed copy W^T of every matrix (served by _wt_t(): the weight of the input-gradient GEMM dx = dy W), by
     gf_multi_cast_transpose.  Always re-done: a fused / capturable optimiser step, ``param.data = ...`` or a replayed
     hipGraph change the values without bumping the version counter (measured: stale bf16 weights in an eval forward
-    after fused Adam steps), so skipping it "when nothing moved" is not safe."""
+    after fused Adam steps), so skipping it "when nothing moved" is not safe.
+
+    derived: [(name, [(src_param, perm | None, rscale | None, scale), ...]), ...] -- prepared weights built from row blocks
+    of parameters (rows gathered by the int32 vector `perm`, scaled per row by the fp32 vector `rscale` and by the float
+    `scale`, in fp32 before the single rounding), written by the SAME launch: matrices in the compute dtype with their
+    transposed copy, vectors (biases) in fp32.  derived_weight(key, name) hands them to the linears."""
     params = [p_ for p_ in params if p_.is_cuda and p_.dtype == torch.float32]
     if not params or dtype not in (torch.bfloat16, torch.float32):
         return
+    derived = derived or []
+    assert not derived or dtype != torch.float32, "derived weights are a compute-dtype (cast) feature"
+    dkey = tuple((name, tuple(id(b_[0]) for b_ in blocks)) for name, blocks in derived)
     slot = _LP_FLAT.get((key, dtype))
-    if slot is None or len(slot["params"]) != len(params) or any(a is not b for a, b in zip(slot["params"], params)):
+    if (slot is None or len(slot["params"]) != len(params) or any(a is not b for a, b in zip(slot["params"], params))
+            or slot["dkey"] != dkey):
         import struct
         cast = dtype != torch.float32
-        sizes = [(p_.numel() + 7) // 8 * 8 for p_ in params]        # 16-byte aligned views
-        flat = torch.empty(sum(sizes) if cast else 0, dtype=dtype, device=params[0].device)
+        dev = params[0].device
+        al = lambda n_: (n_ + 7) // 8 * 8                      # noqa: E731  (16-byte aligned views)
+        sizes = [al(p_.numel()) for p_ in params]
+        dmat = [(name, blocks) for name, blocks in derived if blocks[0][0].dim() >= 2]
+        dvec = [(name, blocks) for name, blocks in derived if blocks[0][0].dim() < 2]
+        dsize = lambda blocks: sum(b_[0].numel() for b_ in blocks)   # noqa: E731
+        flat = torch.empty((sum(sizes) if cast else 0) + sum(al(dsize(bl)) for _, bl in dmat), dtype=dtype, device=dev)
         mats = [p_ for p_ in params if p_.dim() >= 2]
-        flat_t = torch.empty(sum((p_.numel() + 7) // 8 * 8 for p_ in mats), dtype=dtype, device=params[0].device)
+        flat_t = torch.empty(sum(al(p_.numel()) for p_ in mats) + sum(al(dsize(bl)) for _, bl in dmat), dtype=dtype, device=dev)
+        flat32 = torch.empty(sum(al(dsize(bl)) for _, bl in dvec), dtype=torch.float32, device=dev)
         views, tviews, rec, off, toff, tile0 = [], {}, b"", 0, 0, 0
+
+        def entry(src, dst, dst_t, rows, cols, perm=None, rscale=None, scale=1.0, ldt=None, flags=0):
+            nonlocal rec, tile0
+            tx = (cols + 31) // 32
+            rec += struct.pack("<QQQiiiiQQfiii", src, dst, dst_t, rows, cols, tile0, tx, 0 if perm is None else perm.data_ptr(),
+                               0 if rscale is None else rscale.data_ptr(), float(scale), rows if ldt is None else ldt, flags, 0)
+            tile0 += tx * ((rows + 31) // 32)
+
         for p_, sz in zip(params, sizes):
             v = flat[off:off + p_.numel()].view(p_.shape) if cast else p_
-            off += sz
+            off += sz if cast else 0
             views.append(v)
             rows = p_.shape[0] if p_.dim() >= 2 else 1
             cols = p_.numel() // rows
             vt = None
             if p_.dim() >= 2:
                 vt = flat_t[toff:toff + p_.numel()].view(cols, rows)
-                toff += (p_.numel() + 7) // 8 * 8
+                toff += al(p_.numel())
                 tviews[id(p_)] = vt
             elif not cast:
                 continue                                       # fp32 vector: nothing to do
-            tx = (cols + 31) // 32
-            rec += struct.pack("<QQQiiii", p_.data_ptr(), v.data_ptr() if cast else 0, 0 if vt is None else vt.data_ptr(),
-                               rows, cols, tile0, tx)
-            tile0 += tx * ((rows + 31) // 32)
-        assert len(rec) % _lib.load().gf_cast_entry_bytes() == 0
-        table = torch.frombuffer(bytearray(rec), dtype=torch.uint8).to(params[0].device) if rec else None
-        slot = {"flat": flat, "flat_t": flat_t, "views": views, "tviews": tviews, "params": params, "table": table,
-                "n": len(rec) // 40, "tiles": tile0}
+            entry(p_.data_ptr(), v.data_ptr() if cast else 0, 0 if vt is None else vt.data_ptr(), rows, cols)
+        dslot, off32, keep = {}, 0, []
+        for name, blocks in derived:
+            mat = blocks[0][0].dim() >= 2
+            cols = blocks[0][0].shape[1] if mat else 1
+            rows_all = sum(b_[0].shape[0] for b_ in blocks)
+            if mat:
+                v = flat[off:off + rows_all * cols].view(rows_all, cols)
+                vt = flat_t[toff:toff + rows_all * cols].view(cols, rows_all)
+                off += al(rows_all * cols)
+                toff += al(rows_all * cols)
+                handle = torch.empty((rows_all, cols), dtype=torch.float32, device=dev)    # never written: _lp() maps it to v
+            else:
+                v = flat32[off32:off32 + rows_all]
+                off32 += al(rows_all)
+                vt, handle = None, v
+            r0, meta = 0, []
+            for src, perm, rscale, scale in blocks:
+                assert src.is_contiguous() and src.dtype == torch.float32 and (src.shape[1] if mat else 1) == cols
+                rows = src.shape[0]
+                perm = None if perm is None else perm.to(device=dev, dtype=torch.int32).contiguous()
+                rscale = None if rscale is None else rscale.to(device=dev, dtype=torch.float32).contiguous()
+                keep += [perm, rscale]
+                esz = v.element_size()
+                entry(src.data_ptr(), v.data_ptr() + r0 * cols * esz, 0 if vt is None else vt.data_ptr() + r0 * vt.element_size(),
+                      rows, cols, perm, rscale, scale, rows_all, 0 if mat else 1)
+                meta.append((r0, rows, perm, rscale, float(scale)))
+                r0 += rows
+            dslot[name] = {"view": v, "view_t": vt, "handle": handle, "meta": meta, "cols": cols}
+        esz = _lib.load().gf_cast_entry_bytes()
+        assert len(rec) % esz == 0 and esz == 72
+        table = torch.frombuffer(bytearray(rec), dtype=torch.uint8).to(dev) if rec else None
+        slot = {"flat": flat, "flat_t": flat_t, "flat32": flat32, "views": views, "tviews": tviews, "params": params, "table": table,
+                "n": len(rec) // esz, "tiles": tile0, "dkey": dkey, "derived": dslot, "keep": keep}
         _LP_FLAT[(key, dtype)] = slot
     if slot["table"] is not None:
         _lib.check(_lib.load().gf_multi_cast_transpose(_p(slot["table"]), slot["n"], slot["tiles"], BF16 if dtype == torch.bfloat16 else F32, _stream()),
@@ -284,6 +333,54 @@ def precast(params, dtype, key="default"):
         vt = slot["tviews"].get(id(p_))
         if vt is not None:
             _LP_T[v.data_ptr()] = (vt, weakref.ref(p_), dtype)
+    for d in slot["derived"].values():
+        h, v = d["handle"], d["view"]
+        if d["view_t"] is not None:             # matrices: the fp32 handle stands for the compute-dtype view
+            _LP_PTR[(h.data_ptr(), h.numel())] = (h._version, dtype, v, weakref.ref(h))
+            _LP_T[v.data_ptr()] = (d["view_t"], weakref.ref(h), dtype)
+
+
+class _DerivedWeight(torch.autograd.Function):
+    """The autograd face of a derived weight (precast(derived=...)): forward hands out the prepared tensor -- for a matrix
+    an fp32 HANDLE that _lp() / _wt_t() resolve to the compute-dtype copy and its transpose written by this forward's
+    precast launch, for a vector the fp32 values themselves --, backward sends the gradient of each row block back to its
+    source parameter (gf_weight_grad_map: un-gather, scales)."""
+
+    @staticmethod
+    def forward(ctx, d, *srcs):
+        ctx.d = d
+        return d["handle"].view(d["handle"].shape)          # a fresh alias: the cached tensor keeps no autograd state
+
+    @staticmethod
+    def backward(ctx, g):
+        d = ctx.d
+        g = g.float().contiguous()
+        outs = []
+        for i, (r0, rows, perm, rscale, scale) in enumerate(d["meta"]):
+            if not ctx.needs_input_grad[1 + i]:
+                outs.append(None)
+                continue
+            gi = g[r0:r0 + rows]
+            if perm is None and rscale is None and scale == 1.0:
+                outs.append(gi if d["view_t"] is not None else gi.reshape(rows))
+                continue
+            out = torch.empty((rows, d["cols"]) if d["view_t"] is not None else (rows,), dtype=torch.float32, device=g.device)
+            _lib.check(_lib.load().gf_weight_grad_map(_p(gi), _p(out), None if perm is None else _p(perm),
+                                                      None if rscale is None else _p(rscale), scale, rows, d["cols"], _stream()),
+                       "gf_weight_grad_map")
+            outs.append(out)
+        return (None, *outs)
+
+
+def derived_weight(key, dtype, name, *srcs):
+    """The prepared weight `name` of this forward's precast(key=..., derived=...) launch, differentiable w.r.t. the source
+    parameters of its row blocks (passed again here, in block order, so autograd sees them), or None when this forward
+    did not precast it (fp32 parity mode: the caller builds the weight with torch ops)."""
+    slot = _LP_FLAT.get((key, dtype))
+    d = None if slot is None else slot["derived"].get(name)
+    if d is None:
+        return None
+    return _DerivedWeight.apply(d, *srcs)
 
 
 def invalidate_precast():
