@@ -194,11 +194,25 @@ class MatchAssignment(nn.Module):
         self.matchability = nn.Linear(dim, 1, bias=True)
         self.final_proj = nn.Linear(dim, dim, bias=True)
 
+    _pc = None      # (precast key, name): set by the owning model, see LightGlue._derived_specs
+
+    def derived_specs(self, name):
+        s = self.dim ** -0.25
+        return [(name + ".w", [(self.final_proj.weight, None, None, s)]), (name + ".b", [(self.final_proj.bias, None, None, s)])]
+
+    def scaled_proj(self, dtype):
+        """final_proj with dim^-1/4 folded in (lightglue.py:271-274): from this forward's precast launch, else by torch ops."""
+        if self._pc is not None:
+            w = ops.derived_weight(self._pc[0], dtype, self._pc[1] + ".w", self.final_proj.weight)
+            if w is not None:
+                return w, ops.derived_weight(self._pc[0], dtype, self._pc[1] + ".b", self.final_proj.bias)
+        s = self.dim ** -0.25
+        return self.final_proj.weight * s, self.final_proj.bias * s
+
     def stats(self, d0, d1):
         """Everything the log assignment is made of, without the matrix:
         A_ij = 2 md0_i.md1_j - r_i - c_j + lz0_i + lz1_j,  A_i,n = bin0_i,  A_m,j = bin1_j."""
-        s = self.dim ** -0.25
-        w, bias = self.final_proj.weight * s, self.final_proj.bias * s
+        w, bias = self.scaled_proj(d0.dtype)
         md0, md1 = ops.linear(d0, w, bias), ops.linear(d1, w, bias)
         z0 = _lin(d0, self.matchability).squeeze(-1).float()
         z1 = _lin(d1, self.matchability).squeeze(-1).float()
@@ -213,9 +227,8 @@ class MatchAssignment(nn.Module):
         ``chain``: GradChain of x.  closing=True (last layer: these two heads are x's only consumers): the matchability
         head parks its rank-1 gradient, the projection's input-gradient GEMM adds it in its epilogue and returns the
         total.  closing=False: both park, uncounted, into the chain of the NEXT block (see LightGlue._loss_fused)."""
-        s = self.dim ** -0.25
-        md = ops.linear(x, self.final_proj.weight * s, self.final_proj.bias * s, chain=chain,
-                        chain_last=True if closing else "extra")
+        w, bias = self.scaled_proj(x.dtype)
+        md = ops.linear(x, w, bias, chain=chain, chain_last=True if closing else "extra")
         z = ops.rowdot(x, self.matchability.weight, self.matchability.bias, chain=chain, counted=closing).float()
         r, c = ops.dual_lse_stacked(md)
         lz, lnz = F.logsigmoid(z), F.logsigmoid(-z)
@@ -313,6 +326,9 @@ class LightGlue(nn.Module):
             for blk, nm in ((layer.self_attn, f"self{i}"), (layer.cross_attn, f"cross{i}")):
                 blk._pc = (id(self), nm)
                 specs += blk.derived_specs(nm)
+        for i, la in enumerate(self.log_assignment):
+            la._pc = (id(self), f"head{i}")
+            specs += la.derived_specs(f"head{i}")
         return specs
 
     def _compute_dtype(self):
@@ -586,8 +602,8 @@ class LightGlue(nn.Module):
             else:
                 # the gradients of x from these two heads ride in the next block's chain (GEMM / row-dot epilogues)
                 ch = pred["_layer_chain"][i] if "_layer_chain" in pred else None
-                s = la.dim ** -0.25
-                md = ops.linear(x, la.final_proj.weight * s, la.final_proj.bias * s, chain=ch, chain_last="extra")
+                w, bias = la.scaled_proj(x.dtype)
+                md = ops.linear(x, w, bias, chain=ch, chain_last="extra")
                 z = ops.rowdot(x, la.matchability.weight, la.matchability.bias, chain=ch, counted=False)
                 rc = None
             t = self.token_confidence[i].logits(x) if i < L - 1 else None
