@@ -3,7 +3,7 @@
 //   * VGGBlock = Conv2d -> ReLU -> BatchNorm2d(eval) [-> MaxPool2d(2,2)]  (:37-75, :98-111)
 //       one pass over the channels-last activation instead of bias-add, clamp, batch-norm and pool passes;
 //   * simple_nms (:19-34): five 2r+1 max-pools and a dozen elementwise passes over the [B,H,W] score map
-//       become one kernel working on an LDS tile with a 5r halo.
+//       become one kernel working on a register tile (64 columns x 48 + 10r rows per wave) with a 5r halo.
 #include "gf_common.h"
 #include "gf_amd.h"
 
@@ -86,10 +86,8 @@ __global__ __launch_bounds__(256) void bias_act_bn_pool_kernel(const T* __restri
 // ---- fused simple_nms ----------------------------------------------------------------------------
 // out = where(M, s, 0) with  M0 = (s == P(s));  twice: supp = P(M) > 0, ss = where(supp, 0, s),
 // M |= (ss == P(ss)) & ~supp;  P = max over the (2r+1)^2 window clipped to the image.
-// A workgroup produces a TS x TS output tile from a (TS + 10r)^2 input tile held in LDS (three float planes
-// and two byte masks: 151 KB at r = 4); every pooling is separable (row pass into a scratch plane, column
-// pass back) with register windows.  Pixels outside the image are -inf for the
-// score pools and "no maximum" for the mask pools, which is what clipping the window means.
+// Every pooling is separable; pixels outside the image are -inf for the score pools and "no maximum" for the mask
+// pools, which is what clipping the window means.
 // ---- first VGG block on a 1-channel image ---------------------------------------------------------------------
 // backbone.0.0 (superpoint_open.py:98-100: Conv2d(1, C, 3, padding=1) -> ReLU -> BatchNorm2d(eval)) is not
 // GEMM-shaped -- 9 multiply-adds per output value -- but its OUTPUT is the largest tensor of the extractor
@@ -156,122 +154,179 @@ __global__ __launch_bounds__(256) void conv1_fused_kernel(const T* __restrict__ 
     }
 }
 
-#ifndef NMS_THREADS_V
-#define NMS_THREADS_V 1024
+// ---- register-resident NMS ------------------------------------------------------------------------------------------
+// (Round 2's kernel kept five planes of a (64 + 10 R)^2 tile in 124 KB of LDS -- one workgroup per CU, ~20 barriers per
+// tile -- and ran at 1/4 of its own LDS-bandwidth bound: 1.46 ms on 64 x 1024^2; this one 0.52 ms.)  A WAVE owns a strip of 64 image columns (lane = column)
+// and a tile of NR = NMS_RT + 10 R rows of it in REGISTERS (sc[NR]): a (2R+1)^2 max-pool is a horizontal pass over lanes
+// (window maximum by doubling: m2, m4, .. by __shfl_down, then two shifted copies) and a vertical pass over the register
+// array (the same doubling, compile-time indices, in place); the two pools of the 0/1 masks are bit operations on a
+// 128-bit row mask per lane (dilation = ORs of shifts, across lanes ORs of shuffles: ~40 instructions for the whole tile
+// instead of 9 per pixel).  Every pool invalidates R more columns / rows at each side: after the 5 pools of simple_nms
+// (superpoint_open.py:19-34) the inner 64 - 10 R columns and NMS_RT rows are exact, ties included (plain float ==).
+// No LDS, no barriers; waves are independent.
+#ifndef NMS_RT_V
+#define NMS_RT_V 48             // 48 rows + 30 halo rows at R = 3: 216 VGPRs (R = 4: 247) -> two waves per SIMD;
+#endif                          // 64 needs 308 (one wave: 0.73 ms instead of 0.52 on 64 x 1024^2), 32 wastes half the rows on halo
+#ifndef NMS_WPS
+#define NMS_WPS 2
 #endif
-constexpr int NMS_TS = 64, NMS_SEG = 8;
-// The tile's three fp32 planes fill most of a CU's LDS (one workgroup per CU), so the workgroup itself has to bring
-// the waves that hide the LDS latency: 16 waves (4 per SIMD) instead of 4 measured 3.8 -> 1.x ms on 64 x 1024^2.
-constexpr int NMS_THREADS = NMS_THREADS_V;
+constexpr int NMS_RT = NMS_RT_V;           // output rows per wave tile
 
-// 1-D running maximum of radius R over `n` lines of length `len`: each work item produces NMS_SEG consecutive
-// outputs of one line from NMS_SEG + 2R inputs held in registers (1.75 LDS reads per output at R = 3
-// instead of 2R + 1).  ALONG_X: lines are rows (stride 1 inside a line), else columns (stride TW).
-template <int R, int TW, bool ALONG_X>
-__device__ __forceinline__ void max1d(const float* __restrict__ src, float* __restrict__ dst) {
-    constexpr int NSEG = (TW + NMS_SEG - 1) / NMS_SEG;
-    for (int it = threadIdx.x; it < NSEG * TW; it += NMS_THREADS) {
-        // consecutive work items walk the direction that is contiguous in LDS (conflict-free)
-        const int line = ALONG_X ? it / NSEG : it % TW;
-        const int seg = ALONG_X ? it % NSEG : it / TW;
-        const int p0 = seg * NMS_SEG;
-        float v[NMS_SEG + 2 * R];
+struct RowMask {                           // one bit per tile row of this lane's column
+    unsigned long long lo, hi;
+    __device__ __forceinline__ RowMask shl(int k) const { return {lo << k, (hi << k) | (lo >> (64 - k))}; }
+    __device__ __forceinline__ RowMask shr(int k) const { return {(lo >> k) | (hi << (64 - k)), hi >> k}; }
+    __device__ __forceinline__ RowMask operator|(const RowMask& o) const { return {lo | o.lo, hi | o.hi}; }
+};
+__device__ __forceinline__ unsigned long long shfl64(unsigned long long v, int src_lane) {
+    const int a = __shfl((int)(unsigned)v, src_lane), b = __shfl((int)(unsigned)(v >> 32), src_lane);
+    return ((unsigned long long)(unsigned)b << 32) | (unsigned)a;
+}
+
+// plain v_max_f32: fmaxf() in IEEE mode canonicalises every operand that comes out of a shuffle or a load first (one more
+// v_max per operand); the scores are never NaN here and -inf orders correctly
+__device__ __forceinline__ float vmax(float a, float b) {
+    float d;
+    asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ float bperm(int byte_addr, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(byte_addr, __builtin_bit_cast(int, v)));
+}
+
+template <int R, int NR>
+__device__ __forceinline__ void pool_rows_cols(float (&p)[NR], int lane) {
+    constexpr int Wn = 2 * R + 1;
+    constexpr int P = Wn >= 8 ? 8 : (Wn >= 4 ? 4 : 2);       // largest power of two <= window
+    constexpr int OFF = P - 1 - R;                            // window [i-R, i+R] = m_P[i-R] U m_P[i-OFF], m_P[i] = max x[i .. i+P-1]
+    // horizontal (across lanes), RB rows at a time so that RB shuffles are in flight together; a clamped source lane puts
+    // garbage only into the columns this pool invalidates anyway
+    constexpr int RB = 8;
+    const int a1 = min(lane + 1, 63) * 4, a2 = min(lane + 2, 63) * 4, a4 = min(lane + 4, 63) * 4;
+    const int ar = max(lane - R, 0) * 4, ao = max(lane - OFF, 0) * 4;
 #pragma unroll
-        for (int k = 0; k < NMS_SEG + 2 * R; ++k) {
-            const int p = p0 - R + k;
-            v[k] = (p >= 0 && p < TW) ? src[ALONG_X ? line * TW + p : p * TW + line] : -INFINITY;
+    for (int r0 = 0; r0 < NR; r0 += RB) {
+        float t[RB];
+#pragma unroll
+        for (int sft = 1; sft < P; sft <<= 1) {
+            const int ad = sft == 1 ? a1 : (sft == 2 ? a2 : a4);
+#pragma unroll
+            for (int j = 0; j < RB; ++j) if (r0 + j < NR) t[j] = bperm(ad, p[r0 + j]);
+#pragma unroll
+            for (int j = 0; j < RB; ++j) if (r0 + j < NR) p[r0 + j] = vmax(p[r0 + j], t[j]);
         }
+        float u[RB];
 #pragma unroll
-        for (int k = 0; k < NMS_SEG; ++k) {
-            float m = v[k];
+        for (int j = 0; j < RB; ++j) if (r0 + j < NR) { t[j] = bperm(ar, p[r0 + j]); if (OFF != 0) u[j] = bperm(ao, p[r0 + j]); }
 #pragma unroll
-            for (int j = 1; j <= 2 * R; ++j) m = fmaxf(m, v[k + j]);
-            const int p = p0 + k;
-            if (p < TW) dst[ALONG_X ? line * TW + p : p * TW + line] = m;
-        }
+        for (int j = 0; j < RB; ++j) if (r0 + j < NR) p[r0 + j] = vmax(t[j], OFF != 0 ? u[j] : p[r0 + j]);
     }
+    // vertical (register array), in place: doubling upwards, then the two shifted copies from the bottom row down
+#pragma unroll
+    for (int sft = 1; sft < P; sft <<= 1)
+#pragma unroll
+        for (int r = 0; r + sft < NR; ++r) p[r] = vmax(p[r], p[r + sft]);
+#pragma unroll
+    for (int r = NR - 1; r >= 0; --r) p[r] = vmax(p[r - R >= 0 ? r - R : 0], p[r - OFF >= 0 ? r - OFF : 0]);
 }
 
 template <int R>
-__global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const float* __restrict__ s, float* __restrict__ out, int H, int W,
-                                                  int border) {
-    constexpr int HALO = 5 * R, TW = NMS_TS + 2 * HALO, NP = TW * TW;
-    extern __shared__ float smem[];
-    float* sc = smem;                 // scores, -inf outside the image
-    float* pa = sc + NP;              // plane being pooled (in: map, out: pooled map)
-    float* pt = pa + NP;              // row-pass scratch
-    unsigned char* mk = reinterpret_cast<unsigned char*>(pt + NP);   // current maxima
-    unsigned char* sp = mk + NP;                                       // suppressed
-    const int b = blockIdx.z, ty0 = blockIdx.y * NMS_TS - HALO, tx0 = blockIdx.x * NMS_TS - HALO;
-    const float* img = s + (int64_t)b * H * W;
-    for (int i = threadIdx.x; i < NP; i += NMS_THREADS) {
-        const int y = ty0 + i / TW, x = tx0 + i % TW;
-        const bool in = y >= 0 && y < H && x >= 0 && x < W;
-        const float v = in ? img[(int64_t)y * W + x] : -INFINITY;
-        sc[i] = v;
-        pa[i] = v;
+__device__ __forceinline__ RowMask dilate(RowMask m, int lane) {
+    RowMask v = m;
+#pragma unroll
+    for (int k = 1; k <= R; ++k) v = v | m.shl(k) | m.shr(k);
+    RowMask h = v;
+#pragma unroll
+    for (int k = 1; k <= R; ++k) {
+        const int up = max(lane - k, 0), dn = min(lane + k, 63);
+        // (a clamped source repeats an edge column: only columns that this pool invalidates anyway are affected)
+        h.lo |= shfl64(v.lo, up) | shfl64(v.lo, dn);
+        h.hi |= shfl64(v.hi, up) | shfl64(v.hi, dn);
     }
-    __syncthreads();
-    auto pool = [&]() {                                      // pa <- (2R+1)^2 max of pa
-        max1d<R, TW, true>(pa, pt);
-        __syncthreads();
-        max1d<R, TW, false>(pt, pa);
-        __syncthreads();
-    };
-    pool();
-    for (int i = threadIdx.x; i < NP; i += NMS_THREADS) {
-        const float v = sc[i];
-        const bool m = v != -INFINITY && v == pa[i];
-        mk[i] = m;
-        pa[i] = v == -INFINITY ? -INFINITY : (m ? 1.f : 0.f);
-    }
-    __syncthreads();
-    for (int it = 0; it < 2; ++it) {
-        pool();                                              // dilated maxima
-        for (int i = threadIdx.x; i < NP; i += NMS_THREADS) {
-            const bool su = pa[i] > 0.f;
-            sp[i] = su;
-            const float v = sc[i];
-            pa[i] = v == -INFINITY ? -INFINITY : (su ? 0.f : v);            // supp_scores
-        }
-        __syncthreads();
-        pool();
-        for (int i = threadIdx.x; i < NP; i += NMS_THREADS) {
-            const float v = sc[i];
-            const bool su = sp[i];
-            const float ss = su ? 0.f : v;
-            const bool m = mk[i] | (v != -INFINITY && ss == pa[i] && !su);
-            mk[i] = m;
-            pa[i] = v == -INFINITY ? -INFINITY : (m ? 1.f : 0.f);
-        }
-        __syncthreads();
-    }
-    for (int i = threadIdx.x; i < NMS_TS * NMS_TS; i += NMS_THREADS) {
-        const int ly = i / NMS_TS, lx = i % NMS_TS;
-        const int y = blockIdx.y * NMS_TS + ly, x = blockIdx.x * NMS_TS + lx;
-        if (y < H && x < W) {
-            const int j = (ly + HALO) * TW + lx + HALO;
-            float v = mk[j] ? sc[j] : 0.f;
-            if (border > 0 && (y < border || x < border || y >= H - border || x >= W - border)) v = -1.f;
-            out[(int64_t)b * H * W + (int64_t)y * W + x] = v;
-        }
-    }
+    return h;
 }
 
-template <int R> size_t nms_lds() {
-    constexpr int TW = NMS_TS + 10 * R;
-    return (size_t)TW * TW * (3 * sizeof(float) + 2) + 16;
+// bit r of the result = (a[r] == b[r]), built 32 rows at a time in plain 32-bit registers
+template <int NR>
+__device__ __forceinline__ RowMask eq_mask(const float (&a)[NR], const float (&b)[NR]) {
+    unsigned w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int r = 0; r < NR; ++r) w[r >> 5] |= (a[r] == b[r]) ? (1u << (r & 31)) : 0u;
+    return {((unsigned long long)w[1] << 32) | w[0], ((unsigned long long)w[3] << 32) | w[2]};
+}
+
+template <int R>
+__global__ __launch_bounds__(256, NMS_WPS) void nms_reg_kernel(const float* __restrict__ s, float* __restrict__ out, int H, int W,
+                                                         int border, int strips, int tiles) {
+    constexpr int HALO = 5 * R, WOUT = 64 - 2 * HALO, NR = NMS_RT + 2 * HALO;
+    static_assert(WOUT > 0 && NR <= 128, "radius too large for a 64-lane strip / a 128-bit row mask");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t = blockIdx.x * 4 + wave;
+    if (t >= tiles) return;
+    const int strip = t % strips, ty = t / strips;
+    const int x = strip * WOUT - HALO + lane, y0 = ty * NMS_RT - HALO;
+    const bool xin = x >= 0 && x < W;
+    const float* img = s + (int64_t)blockIdx.y * H * W + min(max(x, 0), W - 1);
+    // rows of this tile inside the image: bits [rlo, rhi) -- pixels outside carry -inf and never enter a mask
+    const int rlo = max(0, -y0), rhi = min(NR, H - y0);
+    RowMask inside = {~0ull, ~0ull};
+    inside = inside.shl(rlo);                                      // (rlo <= HALO < 64)
+    {
+        const int cut = NR - rhi + (128 - NR);                     // bits to clear at the top: 128 - rhi
+        RowMask top = {~0ull, ~0ull};
+        top = cut >= 64 ? RowMask{~0ull >> (cut - 64), 0ull} : RowMask{~0ull, ~0ull >> cut};
+        if (cut == 64) top = RowMask{~0ull, 0ull};
+        inside.lo &= top.lo; inside.hi &= top.hi;
+    }
+    if (!xin) inside = RowMask{0ull, 0ull};
+    float sc[NR], p[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int yc = min(max(y0 + r, 0), H - 1);                 // clamped, branch-free load; masked below
+        sc[r] = img[(int64_t)yc * W];
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const bool in = ((r < 64 ? inside.lo >> r : inside.hi >> (r - 64)) & 1ull) != 0;
+        sc[r] = in ? sc[r] : -INFINITY;
+        p[r] = sc[r];
+    }
+    pool_rows_cols<R, NR>(p, lane);
+    RowMask mk = eq_mask<NR>(sc, p);
+    mk.lo &= inside.lo; mk.hi &= inside.hi;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        RowMask su = dilate<R>(mk, lane);
+        su.lo &= inside.lo; su.hi &= inside.hi;                    // outside stays -inf (never "suppressed to 0")
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const bool sr = ((r < 64 ? su.lo >> r : su.hi >> (r - 64)) & 1ull) != 0;
+            p[r] = sr ? 0.f : sc[r];                                                 // supp_scores
+        }
+        pool_rows_cols<R, NR>(p, lane);
+        const RowMask e = eq_mask<NR>(sc, p);                      // un-suppressed pixels: supp_scores == scores
+        mk.lo |= e.lo & ~su.lo & inside.lo;
+        mk.hi |= e.hi & ~su.hi & inside.hi;
+    }
+    if (lane < HALO || lane >= 64 - HALO || !xin) return;
+    float* o = out + (int64_t)blockIdx.y * H * W + x;
+    const bool xb = border > 0 && (x < border || x >= W - border);
+#pragma unroll
+    for (int r = HALO; r < HALO + NMS_RT; ++r) {
+        const int y = y0 + r;
+        if (y >= H) break;
+        const bool m = ((r < 64 ? mk.lo >> r : mk.hi >> (r - 64)) & 1ull) != 0;
+        float v = m ? sc[r] : 0.f;
+        if (xb || (border > 0 && (y < border || y >= H - border))) v = -1.f;
+        o[(int64_t)y * W] = v;
+    }
 }
 
 template <int R> int nms_launch(const float* s, float* out, int B, int H, int W, int border, hipStream_t st) {
-    const size_t lds = nms_lds<R>();
-    if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(nms_kernel<R>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-    }
-    dim3 grid((W + NMS_TS - 1) / NMS_TS, (H + NMS_TS - 1) / NMS_TS, B);
-    nms_kernel<R><<<grid, dim3(NMS_THREADS), lds, st>>>(s, out, H, W, border);
+    constexpr int WOUT = 64 - 10 * R;
+    const int strips = (W + WOUT - 1) / WOUT, tiles = strips * ((H + NMS_RT - 1) / NMS_RT);
+    if (B > 65535) return GF_ERR_UNSUPPORTED;
+    nms_reg_kernel<R><<<dim3((tiles + 3) / 4, B), dim3(256), 0, st>>>(s, out, H, W, border, strips, tiles);
     return (int)hipGetLastError();
 }
 
