@@ -371,6 +371,50 @@ __global__ __launch_bounds__(256) void sample_desc_kernel(const T* __restrict__ 
     for (int e = 0; e < nch; ++e) dst[e] = acc[e] * sc;
 }
 
+// ---- detector head tail ---------------------------------------------------------------------------------------------
+// superpoint_open.py:141-147: scores = softmax(detector(features), dim 1)[:, :-1] re-arranged from [B, 64, h, w] cells
+// of 8 x 8 pixels into the [B, 8h, 8w] score map -- together with the tail of detector.1 itself (Conv2d(256, 65, 1) bias
+// and its eval BatchNorm: 65 channels, not a multiple of the tail kernel's vector width).  One thread per cell: the
+// workgroup's 256 cells x 65 channels are contiguous in the channels-last convolution output (256 * 65 elements = a
+// multiple of 16 bytes) and come in through LDS with 16-byte loads; fp32 softmax (max, exp, sum, divide, as torch's);
+// the cell's 64 probabilities leave as 8 rows of two float4.
+template <typename T>
+__global__ __launch_bounds__(256) void detector_scores_kernel(const T* __restrict__ y, const float* __restrict__ bias,
+                                                              const float* __restrict__ scale, const float* __restrict__ shift,
+                                                              float* __restrict__ scores, int64_t cells, int h, int w, int relu) {
+    extern __shared__ __attribute__((aligned(16))) char dsm[];
+    T* tile = reinterpret_cast<T*>(dsm);
+    const int64_t c0 = (int64_t)blockIdx.x * 256;
+    const int ncell = (int)min((int64_t)256, cells - c0);
+    const int nchunk = ncell * 65 * (int)sizeof(T) / 16, tail0 = nchunk * 16 / (int)sizeof(T), nel = ncell * 65;
+    const u32x4* src = reinterpret_cast<const u32x4*>(y + c0 * 65);
+    for (int i = threadIdx.x; i < nchunk; i += 256) reinterpret_cast<u32x4*>(dsm)[i] = src[i];
+    for (int i = tail0 + threadIdx.x; i < nel; i += 256) tile[i] = y[c0 * 65 + i];          // (partial last workgroup only)
+    __syncthreads();
+    if ((int)threadIdx.x >= ncell) return;
+    float v[65];
+    float m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < 65; ++c) {
+        float a = to_f32(tile[threadIdx.x * 65 + c]) + bias[c];
+        if (relu) a = fmaxf(a, 0.f);
+        v[c] = fmaf(a, scale[c], shift[c]);
+        m = fmaxf(m, v[c]);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < 65; ++c) { v[c] = expf(v[c] - m); sum += v[c]; }
+    const int64_t cell = c0 + threadIdx.x;
+    const int x = (int)(cell % w), yy = (int)((cell / w) % h);
+    const int64_t b = cell / ((int64_t)w * h);
+    float* o = scores + (b * h * 8 + (int64_t)yy * 8) * ((int64_t)w * 8) + (int64_t)x * 8;
+#pragma unroll
+    for (int dy = 0; dy < 8; ++dy) {
+        st4(o + (int64_t)dy * w * 8, v[dy * 8] / sum, v[dy * 8 + 1] / sum, v[dy * 8 + 2] / sum, v[dy * 8 + 3] / sum);
+        st4(o + (int64_t)dy * w * 8 + 4, v[dy * 8 + 4] / sum, v[dy * 8 + 5] / sum, v[dy * 8 + 6] / sum, v[dy * 8 + 7] / sum);
+    }
+}
+
 }  // namespace
 
 extern "C" int gf_bias_act_bn_nhwc(const void* x, void* y, const float* bias, const float* scale, const float* shift,
@@ -393,6 +437,25 @@ extern "C" int gf_bias_act_bn_nhwc(const void* x, void* y, const float* bias, co
     if (dtype == GF_BF16) { if (relu) { GF_BAB(bf16_t, true) } else { GF_BAB(bf16_t, false) } }
     else { if (relu) { GF_BAB(float, true) } else { GF_BAB(float, false) } }
 #undef GF_BAB
+    return (int)hipGetLastError();
+}
+
+extern "C" int gf_detector_scores(const void* y, const float* bias, const float* scale, const float* shift, float* scores,
+                                  int B, int h, int w, int relu, int dtype, void* stream) {
+    if (B <= 0 || h <= 0 || w <= 0) return GF_ERR_SHAPE;
+    if ((reinterpret_cast<size_t>(y) | reinterpret_cast<size_t>(scores)) & 15) return GF_ERR_ALIGN;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int64_t cells = (int64_t)B * h * w;
+    const dim3 grid((unsigned)((cells + 255) / 256));
+    if (dtype == GF_BF16) {
+        detector_scores_kernel<bf16_t><<<grid, 256, 256 * 65 * sizeof(bf16_t), st>>>((const bf16_t*)y, bias, scale, shift, scores, cells, h, w, relu);
+    } else if (dtype == GF_F32) {
+        const int lds = 256 * 65 * (int)sizeof(float);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(detector_scores_kernel<float>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        detector_scores_kernel<float><<<grid, 256, lds, st>>>((const float*)y, bias, scale, shift, scores, cells, h, w, relu);
+    } else return GF_ERR_DTYPE;
     return (int)hipGetLastError();
 }
 

@@ -177,6 +177,24 @@ class SuperPoint(BaseModel):
             1 if x.dtype == torch.bfloat16 else 0, torch.cuda.current_stream().cuda_stream), "gf_conv1_bias_act_bn")
         return out
 
+    def _detector_scores(self, name, blk, x, params):
+        """detector.1 (library 1x1 convolution, bias-free) + ONE HIP pass for its bias / BatchNorm(eval), the softmax over
+        the 65 channels and the unfolding of the 64 cell probabilities into the full-resolution score map
+        (gf_detector_scores; superpoint_open.py:105-108, 141-147)."""
+        from .. import lib as _lib
+        w, bias, scale, shift = params[name]
+        with torch.autocast(device_type="cuda", enabled=False):
+            y = F.conv2d(x, w, None, 1, blk.conv.padding)
+        if not y.is_contiguous(memory_format=torch.channels_last):
+            y = y.contiguous(memory_format=torch.channels_last)
+        b, _, h, wd = y.shape
+        scores = torch.empty((b, h * 8, wd * 8), dtype=torch.float32, device=y.device)
+        _lib.check(_lib.load().gf_detector_scores(
+            y.data_ptr(), bias.data_ptr(), scale.data_ptr(), shift.data_ptr(), scores.data_ptr(), b, h, wd,
+            int(isinstance(blk.activation, nn.ReLU)), 1 if y.dtype == torch.bfloat16 else 0,
+            torch.cuda.current_stream().cuda_stream), "gf_detector_scores")
+        return scores
+
     def _fused_features(self, image):
         dtype = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else torch.float32
         if dtype not in (torch.bfloat16, torch.float32):
@@ -202,7 +220,10 @@ class SuperPoint(BaseModel):
                 else:
                     x = self._fused_block(f"backbone.{si}.{bi}", blk, x, params, pool=pool)
         det = self._fused_block("detector.0", self.detector[0], x, params)
-        det = self._fused_block("detector.1", self.detector[1], det, params)
+        if self.detector[1].conv.out_channels == self.stride ** 2 + 1 == 65:
+            det = self._detector_scores("detector.1", self.detector[1], det, params)     # -> the [B, 8h, 8w] score map
+        else:
+            det = self._fused_block("detector.1", self.detector[1], det, params)
         desc = self._fused_block("descriptor.0", self.descriptor[0], x, params)
         desc = self._fused_block("descriptor.1", self.descriptor[1], desc, params)
         return det, desc
@@ -221,10 +242,15 @@ class SuperPoint(BaseModel):
         def dense():          # per-pixel normalised map; the fused sampler normalises the corners itself
             return F.normalize(desc_map.float(), p=2, dim=1)
 
-        scores = F.softmax(det.float(), 1)[:, :-1]
-        b, _, h, w = scores.shape
         s = self.stride
-        scores = scores.permute(0, 2, 3, 1).reshape(b, h, w, s, s).permute(0, 1, 3, 2, 4).reshape(b, h * s, w * s)
+        if det.dim() == 3:                  # the fused detector tail already produced the score map
+            scores = det
+            b = scores.shape[0]
+            h, w = scores.shape[1] // s, scores.shape[2] // s
+        else:
+            scores = F.softmax(det.float(), 1)[:, :-1]
+            b, _, h, w = scores.shape
+            scores = scores.permute(0, 2, 3, 1).reshape(b, h, w, s, s).permute(0, 1, 3, 2, 4).reshape(b, h * s, w * s)
         if fused:
             from .. import lib as _lib
             scores = scores.contiguous()

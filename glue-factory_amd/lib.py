@@ -65,6 +65,7 @@ SIGNATURES = {
     "gf_conv1_bias_act_bn": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "gf_conv3x3_c64": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "gf_nms_scores": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "gf_detector_scores": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "gf_sample_descriptors": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "gf_rowdot_nblk": [_I],
     "gf_rowdot_fwd": [_P, _P, _F, _P, _I, _I, _I, _P],

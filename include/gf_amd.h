@@ -316,6 +316,11 @@ int gf_conv1_bias_act_bn(const void* img, const void* w, const float* bias, cons
 int gf_conv3x3_c64(const void* x, const void* w, const float* bias, const float* scale, const float* shift, void* y,
                    int B, int H, int W, int relu, int pool, int dtype, void* stream);
 int gf_nms_scores(const float* scores, float* out, int B, int H, int W, int radius, int border, void* stream);
+/* gf_detector_scores: tail of the detector head (superpoint_open.py:105-108 detector.1 = Conv2d(256,65,1) [+ReLU] + BatchNorm(eval),
+ * :141-147 softmax over the 65 channels, dustbin dropped, 8 x 8 cells unfolded): y [B,h,w,65] = the bias-free convolution
+ * output, channels-last, 16-byte aligned; scores [B, 8h, 8w] fp32. */
+int gf_detector_scores(const void* y, const float* bias, const float* scale, const float* shift, float* scores,
+                       int B, int h, int w, int relu, int dtype, void* stream);
 /* gf_sample_descriptors: sample_descriptors (:10-16) fused with the dense map's L2 normalisation (:149):
  *   out[b,n,:] = normalize(sum over the 4 bilinear corners of w_k * normalize(map[b,y_k,x_k,:])), zero padding,
  *   x_pix = (kp_x + 0.5) / stride - 0.5.  map [B,h,w,C] channels-last in `dtype` (C % 64 == 0), kpts [B,N,2] fp32

@@ -32,6 +32,27 @@ def test_nms_kernel_equals_max_pool_chain(radius, shape):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 17, 23), (1, 16, 16), (3, 40, 64)])
+def test_detector_scores_kernel(dtype, shape):
+    """gf_detector_scores (bias + BatchNorm(eval) of detector.1, softmax over the 65 channels, dustbin dropped, 8 x 8 cells
+    unfolded into the score map; superpoint_open.py:105-108, 141-147) vs the stock ops on the same convolution output;
+    cell counts that are / are not multiples of the 256-cell workgroup."""
+    from glue_factory_amd import lib as L_
+    B, h, w = shape
+    g = torch.Generator(device="cuda").manual_seed(h * w)
+    y = (torch.randn(B, 65, h, w, device="cuda", generator=g) * 3).to(dtype).contiguous(memory_format=torch.channels_last)
+    bias, scale, shift = (torch.randn(65, device="cuda", generator=g) for _ in range(3))
+    det = (y.float() + bias.view(1, 65, 1, 1)) * scale.view(1, 65, 1, 1) + shift.view(1, 65, 1, 1)
+    ref = torch.softmax(det, 1)[:, :-1]
+    ref = ref.permute(0, 2, 3, 1).reshape(B, h, w, 8, 8).permute(0, 1, 3, 2, 4).reshape(B, h * 8, w * 8)
+    out = torch.full((B, h * 8, w * 8), float("nan"), device="cuda")
+    L_.check(L_.load().gf_detector_scores(y.data_ptr(), bias.data_ptr(), scale.data_ptr(), shift.data_ptr(), out.data_ptr(),
+                                          B, h, w, 0, 1 if dtype == torch.bfloat16 else 0,
+                                          torch.cuda.current_stream().cuda_stream), "gf_detector_scores")
+    torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-9)      # fp32 operation order (fma in the affine, exp)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("pool", [0, 1])
 def test_bias_act_bn_kernel(dtype, pool):
     from glue_factory_amd import lib as L_
