@@ -255,9 +255,39 @@ __device__ __forceinline__ RowMask eq_mask(const float (&a)[NR], const float (&b
     return {((unsigned long long)w[1] << 32) | w[0], ((unsigned long long)w[3] << 32) | w[2]};
 }
 
-template <int R>
+// bit r of the result = (a[r] > 0)
+template <int NR>
+__device__ __forceinline__ RowMask pos_mask(const float (&a)[NR]) {
+    unsigned w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int r = 0; r < NR; ++r) w[r >> 5] |= (a[r] > 0.f) ? (1u << (r & 31)) : 0u;
+    return {((unsigned long long)w[1] << 32) | w[0], ((unsigned long long)w[3] << 32) | w[2]};
+}
+__device__ __forceinline__ RowMask row_range(int lo, int hi) {      // bits [lo, hi), 0 <= lo, hi <= 128
+    auto below = [](int n) -> RowMask {                              // bits [0, n)
+        if (n <= 0) return RowMask{0ull, 0ull};
+        if (n >= 128) return RowMask{~0ull, ~0ull};
+        if (n >= 64) return RowMask{~0ull, n == 64 ? 0ull : (~0ull >> (128 - n))};
+        return RowMask{~0ull >> (64 - n), 0ull};
+    };
+    const RowMask a = below(hi), b = below(lo);
+    return RowMask{a.lo & ~b.lo, a.hi & ~b.hi};
+}
+
+// COMPACT: instead of the dense map, the surviving maxima with a positive score (never in the border) go to a per-image
+// candidate list (score, flat pixel index): what a top-k over the dense map can select before it runs into the zeros.
+// Every wave tile owns a fixed segment of nms_seg(R) slots (>= the number of points more than R apart that fit its
+// 64 - 10 R columns x NMS_RT rows), filled in (column, row) order: deterministic, no atomics; unused slots keep the
+// caller's fill value, entries past the segment are dropped (possible only on plateaus of exactly tied scores).
+constexpr int nms_seg(int R) {
+    const int n = ((NMS_RT + R) / (R + 1)) * ((64 - 10 * R + R) / (R + 1));
+    int p2 = 32;
+    while (p2 < n) p2 <<= 1;
+    return p2;
+}
+template <int R, bool COMPACT>
 __global__ __launch_bounds__(256, NMS_WPS) void nms_reg_kernel(const float* __restrict__ s, float* __restrict__ out, int H, int W,
-                                                         int border, int strips, int tiles) {
+                                                         int border, int strips, int tiles, int* __restrict__ cand_idx) {
     constexpr int HALO = 5 * R, WOUT = 64 - 2 * HALO, NR = NMS_RT + 2 * HALO;
     static_assert(WOUT > 0 && NR <= 128, "radius too large for a 64-lane strip / a 128-bit row mask");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -268,16 +298,7 @@ __global__ __launch_bounds__(256, NMS_WPS) void nms_reg_kernel(const float* __re
     const bool xin = x >= 0 && x < W;
     const float* img = s + (int64_t)blockIdx.y * H * W + min(max(x, 0), W - 1);
     // rows of this tile inside the image: bits [rlo, rhi) -- pixels outside carry -inf and never enter a mask
-    const int rlo = max(0, -y0), rhi = min(NR, H - y0);
-    RowMask inside = {~0ull, ~0ull};
-    inside = inside.shl(rlo);                                      // (rlo <= HALO < 64)
-    {
-        const int cut = NR - rhi + (128 - NR);                     // bits to clear at the top: 128 - rhi
-        RowMask top = {~0ull, ~0ull};
-        top = cut >= 64 ? RowMask{~0ull >> (cut - 64), 0ull} : RowMask{~0ull, ~0ull >> cut};
-        if (cut == 64) top = RowMask{~0ull, 0ull};
-        inside.lo &= top.lo; inside.hi &= top.hi;
-    }
+    RowMask inside = row_range(max(0, -y0), min(NR, H - y0));
     if (!xin) inside = RowMask{0ull, 0ull};
     float sc[NR], p[NR];
 #pragma unroll
@@ -308,6 +329,33 @@ __global__ __launch_bounds__(256, NMS_WPS) void nms_reg_kernel(const float* __re
         mk.lo |= e.lo & ~su.lo & inside.lo;
         mk.hi |= e.hi & ~su.hi & inside.hi;
     }
+    if (COMPACT) {
+        // candidates of this lane: final maxima in the tile's own rows, outside the border, with a positive score
+        const bool col_ok = lane >= HALO && lane < 64 - HALO && xin && !(border > 0 && (x < border || x >= W - border));
+        RowMask c = row_range(max(HALO, border - y0), min(HALO + NMS_RT, H - border - y0));
+        const RowMask pos = pos_mask<NR>(sc);
+        c.lo &= mk.lo & pos.lo; c.hi &= mk.hi & pos.hi;
+        if (!col_ok) c = RowMask{0ull, 0ull};
+        const int mine = __popcll(c.lo) + __popcll(c.hi);
+        int incl = mine;                                              // inclusive prefix sum over the wave
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o_ = __shfl_up(incl, d);
+            if (lane >= d) incl += o_;
+        }
+        constexpr int SEG = nms_seg(R);
+        int slot = incl - mine;                                        // position inside this tile's segment
+        float* cs_ = out + ((int64_t)blockIdx.y * tiles + t) * SEG;
+        int* ci_ = cand_idx + ((int64_t)blockIdx.y * tiles + t) * SEG;
+#pragma unroll
+        for (int r = HALO; r < HALO + NMS_RT; ++r) {
+            if ((r < 64 ? c.lo >> r : c.hi >> (r - 64)) & 1ull) {
+                if (slot < SEG) { cs_[slot] = sc[r]; ci_[slot] = (y0 + r) * W + x; }
+                ++slot;
+            }
+        }
+        return;
+    }
     if (lane < HALO || lane >= 64 - HALO || !xin) return;
     float* o = out + (int64_t)blockIdx.y * H * W + x;
     const bool xb = border > 0 && (x < border || x >= W - border);
@@ -322,11 +370,14 @@ __global__ __launch_bounds__(256, NMS_WPS) void nms_reg_kernel(const float* __re
     }
 }
 
-template <int R> int nms_launch(const float* s, float* out, int B, int H, int W, int border, hipStream_t st) {
+template <int R> int nms_launch(const float* s, float* out, int B, int H, int W, int border, hipStream_t st,
+                                int* cand_idx = nullptr) {
     constexpr int WOUT = 64 - 10 * R;
     const int strips = (W + WOUT - 1) / WOUT, tiles = strips * ((H + NMS_RT - 1) / NMS_RT);
     if (B > 65535) return GF_ERR_UNSUPPORTED;
-    nms_reg_kernel<R><<<dim3((tiles + 3) / 4, B), dim3(256), 0, st>>>(s, out, H, W, border, strips, tiles);
+    const dim3 grid((tiles + 3) / 4, B);
+    if (cand_idx) nms_reg_kernel<R, true><<<grid, dim3(256), 0, st>>>(s, out, H, W, border, strips, tiles, cand_idx);
+    else nms_reg_kernel<R, false><<<grid, dim3(256), 0, st>>>(s, out, H, W, border, strips, tiles, nullptr);
     return (int)hipGetLastError();
 }
 
@@ -468,6 +519,33 @@ extern "C" int gf_nms_scores(const float* scores, float* out, int B, int H, int 
         case 2: return nms_launch<2>(scores, out, B, H, W, border, st);
         case 3: return nms_launch<3>(scores, out, B, H, W, border, st);
         case 4: return nms_launch<4>(scores, out, B, H, W, border, st);
+        default: return GF_ERR_UNSUPPORTED;
+    }
+}
+
+template <int R> int nms_cap(int H, int W) {
+    constexpr int WOUT = 64 - 10 * R;
+    return ((W + WOUT - 1) / WOUT) * ((H + NMS_RT - 1) / NMS_RT) * nms_seg(R);
+}
+extern "C" int gf_nms_candidates_cap(int H, int W, int radius) {
+    switch (radius) {
+        case 1: return nms_cap<1>(H, W);
+        case 2: return nms_cap<2>(H, W);
+        case 3: return nms_cap<3>(H, W);
+        case 4: return nms_cap<4>(H, W);
+        default: return GF_ERR_UNSUPPORTED;
+    }
+}
+extern "C" int gf_nms_candidates(const float* scores, float* cand_scores, int* cand_idx, int B, int H, int W, int radius,
+                                 int border, void* stream) {
+    if (B <= 0 || H <= 0 || W <= 0 || border < 0) return GF_ERR_SHAPE;
+    if ((int64_t)H * W > 0x7fffffff) return GF_ERR_UNSUPPORTED;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    switch (radius) {
+        case 1: return nms_launch<1>(scores, cand_scores, B, H, W, border, st, cand_idx);
+        case 2: return nms_launch<2>(scores, cand_scores, B, H, W, border, st, cand_idx);
+        case 3: return nms_launch<3>(scores, cand_scores, B, H, W, border, st, cand_idx);
+        case 4: return nms_launch<4>(scores, cand_scores, B, H, W, border, st, cand_idx);
         default: return GF_ERR_UNSUPPORTED;
     }
 }

@@ -251,14 +251,29 @@ class SuperPoint(BaseModel):
             scores = F.softmax(det.float(), 1)[:, :-1]
             b, _, h, w = scores.shape
             scores = scores.permute(0, 2, 3, 1).reshape(b, h, w, s, s).permute(0, 1, 3, 2, 4).reshape(b, h * s, w * s)
+        k = conf.max_num_keypoints
+        H, W = h * s, w * s
+        cand = None
         if fused:
             from .. import lib as _lib
             scores = scores.contiguous()
-            nms = torch.empty_like(scores)
-            _lib.check(_lib.load().gf_nms_scores(scores.data_ptr(), nms.data_ptr(), b, h * s, w * s, int(conf.nms_radius),
-                                                 int(conf.remove_borders or 0), torch.cuda.current_stream().cuda_stream),
-                       "gf_nms_scores")
-            scores = nms
+            r = int(conf.nms_radius)
+            cap = _lib.load().gf_nms_candidates_cap(H, W, r)        # a fixed segment per kernel tile
+            if k is not None and conf.detection_threshold >= 0 and k <= cap and H * W < 2 ** 31:
+                # NMS straight into per-image candidate lists (positive maxima outside the border): the top-k below then
+                # sorts ~H W / 49 entries instead of H W, and the dense map is never written
+                cand_s = torch.full((b, cap), -1.0, dtype=torch.float32, device=scores.device)
+                cand_i = torch.zeros((b, cap), dtype=torch.int32, device=scores.device)
+                _lib.check(_lib.load().gf_nms_candidates(scores.data_ptr(), cand_s.data_ptr(), cand_i.data_ptr(), b, H, W, r,
+                                                         int(conf.remove_borders or 0),
+                                                         torch.cuda.current_stream().cuda_stream), "gf_nms_candidates")
+                cand = (cand_s, cand_i)
+            else:
+                nms = torch.empty_like(scores)
+                _lib.check(_lib.load().gf_nms_scores(scores.data_ptr(), nms.data_ptr(), b, H, W, r,
+                                                     int(conf.remove_borders or 0), torch.cuda.current_stream().cuda_stream),
+                           "gf_nms_scores")
+                scores = nms
         else:
             scores = batched_nms(scores, conf.nms_radius)
             if conf.remove_borders:
@@ -267,8 +282,6 @@ class SuperPoint(BaseModel):
                 scores[:, :, :pad] = -1
                 scores[:, -pad:] = -1
                 scores[:, :, -pad:] = -1
-        H, W = scores.shape[1:]
-        k = conf.max_num_keypoints
         if k is None:
             if b != 1:
                 raise ValueError("max_num_keypoints is required for batched extraction")
@@ -276,8 +289,12 @@ class SuperPoint(BaseModel):
             keypoints = torch.stack(idx[::-1], -1).float()[None]
             kscores = scores[0][idx][None]
         else:
-            flat = scores.reshape(b, -1)
-            kscores, ind = torch.topk(flat, min(k, flat.shape[1]), dim=1, sorted=True)
+            if cand is not None:
+                kscores, j = torch.topk(cand[0], min(k, cand[0].shape[1]), dim=1, sorted=True)
+                ind = cand[1].gather(1, j).long()       # (unfilled entries: score -1, index 0 -- never valid below)
+            else:
+                flat = scores.reshape(b, -1)
+                kscores, ind = torch.topk(flat, min(k, flat.shape[1]), dim=1, sorted=True)
             keypoints = torch.stack([ind % W, ind // W], -1).float()
             valid = kscores > conf.detection_threshold
             if conf.force_num_keypoints:

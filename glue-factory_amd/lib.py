@@ -65,6 +65,8 @@ SIGNATURES = {
     "gf_conv1_bias_act_bn": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "gf_conv3x3_c64": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "gf_nms_scores": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "gf_nms_candidates": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "gf_nms_candidates_cap": [_I, _I, _I],
     "gf_detector_scores": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "gf_sample_descriptors": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "gf_rowdot_nblk": [_I],

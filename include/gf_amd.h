@@ -316,6 +316,15 @@ int gf_conv1_bias_act_bn(const void* img, const void* w, const float* bias, cons
 int gf_conv3x3_c64(const void* x, const void* w, const float* bias, const float* scale, const float* shift, void* y,
                    int B, int H, int W, int relu, int pool, int dtype, void* stream);
 int gf_nms_scores(const float* scores, float* out, int B, int H, int W, int radius, int border, void* stream);
+/* gf_nms_candidates: the same NMS, but instead of the dense map the surviving maxima with a POSITIVE score outside the
+ * border go to per-image lists cand_scores / cand_idx [B, cap] (flat pixel index y W + x), cap = gf_nms_candidates_cap(H, W,
+ * radius): a fixed segment per kernel tile, filled deterministically, unused slots keep the caller's fill (use a negative
+ * score); a segment holds every set of points more than `radius` apart that fits its tile, so entries are dropped only
+ * on plateaus of exactly tied scores.  A top-k over the list = the top-k over the dense map (superpoint_open.py:165-170)
+ * as long as it does not run into the zeros. */
+int gf_nms_candidates_cap(int H, int W, int radius);
+int gf_nms_candidates(const float* scores, float* cand_scores, int* cand_idx, int B, int H, int W, int radius, int border,
+                      void* stream);
 /* gf_detector_scores: tail of the detector head (superpoint_open.py:105-108 detector.1 = Conv2d(256,65,1) [+ReLU] + BatchNorm(eval),
  * :141-147 softmax over the 65 channels, dustbin dropped, 8 x 8 cells unfolded): y [B,h,w,65] = the bias-free convolution
  * output, channels-last, 16-byte aligned; scores [B, 8h, 8w] fp32. */

@@ -31,6 +31,54 @@ def test_nms_kernel_equals_max_pool_chain(radius, shape):
     assert torch.equal(out, ref2)
 
 
+@pytest.mark.parametrize("radius", [1, 3, 4])
+@pytest.mark.parametrize("shape", [(2, 97, 130), (3, 256, 256)])
+def test_nms_candidate_lists_equal_dense_positives(radius, shape):
+    """gf_nms_candidates (the NMS kernel appending its surviving maxima to per-image lists) against the dense kernel:
+    the same set of (pixel, score) for every positive entry outside the border, the exact count, nothing else."""
+    from glue_factory_amd import lib as L_
+    B, H, W = shape
+    g = torch.Generator(device="cuda").manual_seed(radius + H)
+    s = torch.rand(*shape, device="cuda", generator=g)
+    s[:, 40:60, 40:60] = 0.25                      # a plateau of exact ties
+    s[:, 5:9, 70:90] = 0.0                         # maxima-free zeros (never candidates)
+    pad = 4
+    dense = torch.empty_like(s)
+    lib = L_.load()
+    st = torch.cuda.current_stream().cuda_stream
+    L_.check(lib.gf_nms_scores(s.data_ptr(), dense.data_ptr(), B, H, W, radius, pad, st), "gf_nms_scores")
+    cap = lib.gf_nms_candidates_cap(H, W, radius)
+    outs = []
+    for _ in range(2):
+        cs = torch.full((B, cap), -1.0, device="cuda")
+        ci = torch.zeros((B, cap), dtype=torch.int32, device="cuda")
+        L_.check(lib.gf_nms_candidates(s.data_ptr(), cs.data_ptr(), ci.data_ptr(), B, H, W, radius, pad, st), "gf_nms_candidates")
+        outs.append((cs, ci))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])       # deterministic layout
+    dropped = 0
+    for b in range(B):
+        ref_idx = torch.nonzero(dense[b].flatten() > 0).flatten()
+        used = cs[b] > -1
+        got_idx, order = ci[b][used].long().sort()
+        got_s = cs[b][used][order]
+        assert got_idx.unique().numel() == got_idx.numel()
+        pos = torch.searchsorted(ref_idx, got_idx)
+        assert bool((ref_idx[pos.clamp(max=ref_idx.numel() - 1)] == got_idx).all())     # nothing but dense positives
+        assert torch.equal(got_s, dense[b].flatten()[got_idx])
+        # per kernel tile (64 - 10 r columns x 48 rows, one fixed segment each): every positive is there unless the tile
+        # holds more than a segment's worth (only the plateau of exact ties can do that) -- then exactly a segment's worth
+        wout, rt = 64 - 10 * radius, 48
+        strips, tys = -(-W // wout), -(-H // rt)
+        seg = cap // (strips * tys)
+        tile_of = lambda idx: (idx // W // rt) * strips + (idx % W) // wout      # noqa: E731
+        n_ref = torch.bincount(tile_of(ref_idx), minlength=strips * tys)
+        n_got = torch.bincount(tile_of(got_idx), minlength=strips * tys)
+        assert torch.equal(n_got, n_ref.clamp(max=seg))
+        assert int((n_ref > seg).sum()) <= 4                # the 20 x 20 plateau touches at most four tiles
+        dropped += ref_idx.numel() - got_idx.numel()
+    print(f"radius {radius} {shape}: {dropped} tied plateau maxima beyond their tile's segment")
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("shape", [(2, 17, 23), (1, 16, 16), (3, 40, 64)])
 def test_detector_scores_kernel(dtype, shape):
