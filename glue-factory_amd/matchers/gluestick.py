@@ -29,7 +29,7 @@ from torch import nn
 from .. import ops
 from ..base_model import BaseModel
 from ..metrics import matcher_metrics
-from .superglue import MLP, AttentionalPropagation, KeypointEncoder, _conv_cl, _mlp_cl
+from .superglue import MLP, AttentionalPropagation, KeypointEncoder, _conv_cl, _mlp_cl, derived_specs_of
 
 ETH_EPS = 1e-8
 
@@ -223,7 +223,8 @@ class GlueStick(BaseModel):
             raise RuntimeError("glue_factory_amd.GlueStick runs on the MI355X HIP path only (no CPU fallback)")
         T = torch.bfloat16 if (self.conf.mp or torch.is_autocast_enabled()) else torch.float32
         with torch.autocast(device_type="cuda", enabled=False):
-            ops.precast(list(self.parameters()), T, key=id(self))   # one launch: compute-dtype + transposed weights
+            # one launch: compute-dtype + transposed weights + the layers' prepared (q | k | v) projections
+            ops.precast(list(self.parameters()), T, key=id(self), derived=derived_specs_of(self) if T != torch.float32 else None)
             return self._forward_impl(data, T)
 
     def _forward_impl(self, data, T):

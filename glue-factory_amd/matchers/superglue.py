@@ -128,11 +128,39 @@ class MultiHeadedAttention(nn.Module):
         perm = (torch.arange(self.dim)[None, :] * h + torch.arange(h)[:, None]).reshape(-1)
         self.register_buffer("_perm", perm, persistent=False)
 
-    def fused_projection(self, x, chain=None):
-        w = torch.cat([p.weight.squeeze(-1).index_select(0, self._perm) for p in self.proj], 0)
-        b = torch.cat([p.bias.index_select(0, self._perm) for p in self.proj], 0)
+    _pc = None      # (precast key, name): set by the owning model (derived_specs_of)
+
+    def derived_specs(self, name):
+        """The stacked (q | k | v) projection in kernel channel order, head_dim^-1/2 log2(e) folded into the q rows, as
+        entries of the model's per-step precast launch (ops.precast(derived=...))."""
+        qs = ops.attn_premul(self.dim)
+        return [(name + ".w", [(p.weight, self._perm, None, qs if i == 0 else 1.0) for i, p in enumerate(self.proj)]),
+                (name + ".b", [(p.bias, self._perm, None, qs if i == 0 else 1.0) for i, p in enumerate(self.proj)])]
+
+    def fused_projection(self, x, chain=None, premul=True):
+        """-> (qkv [B', N, 3, H, D], softmax scale the attention op has to use)."""
+        w = None
+        if premul and self._pc is not None:
+            w = ops.derived_weight(self._pc[0], x.dtype, self._pc[1] + ".w", *[p.weight for p in self.proj])
+        if w is not None:
+            b = ops.derived_weight(self._pc[0], x.dtype, self._pc[1] + ".b", *[p.bias for p in self.proj])
+            scale = ops.LN2
+        else:
+            w = torch.cat([p.weight.squeeze(-1).index_select(0, self._perm) for p in self.proj], 0)
+            b = torch.cat([p.bias.index_select(0, self._perm) for p in self.proj], 0)
+            scale = None
         qkv = ops.linear(x, w, b, chain=chain, chain_last=True)
-        return qkv.view(x.shape[0], x.shape[1], 3, self.h, self.dim)
+        return qkv.view(x.shape[0], x.shape[1], 3, self.h, self.dim), scale
+
+
+def derived_specs_of(model):
+    """Every module of `model` that offers prepared weights, named by its module path."""
+    specs = []
+    for name, mod in model.named_modules():
+        if hasattr(mod, "derived_specs") and mod is not model:
+            mod._pc = (id(model), name)
+            specs += mod.derived_specs(name)
+    return specs
 
 
 class AttentionalPropagation(nn.Module):
@@ -148,14 +176,15 @@ class AttentionalPropagation(nn.Module):
         MLP input, projection -- are summed in GEMM epilogues: ops.GradChain)."""
         b, n, d = x.shape
         chain = ops.GradChain(3) if residual and x.requires_grad and torch.is_grad_enabled() else None
-        o = ops.attention_qkv(self.attn.fused_projection(x, chain), cross=cross)
+        qkv, scale = self.attn.fused_projection(x, chain)
+        o = ops.attention_qkv(qkv, cross=cross, scale=scale)
         msg = _conv_cl(o.view(b, n, d), self.attn.merge, cols=self.attn._perm)
         return _mlp_cl(self.mlp, x, halves, x2=msg, res=x if residual else None, chain=chain)
 
     def forward_pair(self, x0, x1, cross):
         """Different keypoint counts: one projection per image, generic attention op."""
         outs = []
-        p0, p1 = self.attn.fused_projection(x0), self.attn.fused_projection(x1)
+        p0, p1 = self.attn.fused_projection(x0, premul=False)[0], self.attn.fused_projection(x1, premul=False)[0]
         for x, pq, ps in ((x0, p0, p1 if cross else p0), (x1, p1, p0 if cross else p1)):
             o = ops.attention(pq[:, :, 0], ps[:, :, 1], ps[:, :, 2])
             msg = _conv_cl(o.reshape(x.shape), self.attn.merge, cols=self.attn._perm)
@@ -210,7 +239,8 @@ class SuperGlue(BaseModel):
             raise RuntimeError("glue_factory_amd.SuperGlue runs on the MI355X HIP path only (no CPU fallback)")
         T = torch.bfloat16 if (self.conf.mp or torch.is_autocast_enabled()) else torch.float32
         with torch.autocast(device_type="cuda", enabled=False):
-            ops.precast(list(self.parameters()), T, key=id(self))   # one launch: compute-dtype + transposed weights
+            # one launch: compute-dtype + transposed weights + the layers' prepared (q | k | v) projections
+            ops.precast(list(self.parameters()), T, key=id(self), derived=derived_specs_of(self) if T != torch.float32 else None)
             return self._forward_impl(data, T)
 
     def _forward_impl(self, data, T):

@@ -292,7 +292,7 @@ def precast(params, dtype, key="default", derived=None):
         dslot, off32, keep = {}, 0, []
         for name, blocks in derived:
             mat = blocks[0][0].dim() >= 2
-            cols = blocks[0][0].shape[1] if mat else 1
+            cols = blocks[0][0].numel() // blocks[0][0].shape[0]      # (a Conv1d(k=1) weight [O, I, 1] is the matrix [O, I])
             rows_all = sum(b_[0].shape[0] for b_ in blocks)
             if mat:
                 v = flat[off:off + rows_all * cols].view(rows_all, cols)
@@ -306,7 +306,7 @@ def precast(params, dtype, key="default", derived=None):
                 vt, handle = None, v
             r0, meta = 0, []
             for src, perm, rscale, scale in blocks:
-                assert src.is_contiguous() and src.dtype == torch.float32 and (src.shape[1] if mat else 1) == cols
+                assert src.is_contiguous() and src.dtype == torch.float32 and src.numel() == src.shape[0] * cols
                 rows = src.shape[0]
                 perm = None if perm is None else perm.to(device=dev, dtype=torch.int32).contiguous()
                 rscale = None if rscale is None else rscale.to(device=dev, dtype=torch.float32).contiguous()
@@ -314,7 +314,7 @@ def precast(params, dtype, key="default", derived=None):
                 esz = v.element_size()
                 entry(src.data_ptr(), v.data_ptr() + r0 * cols * esz, 0 if vt is None else vt.data_ptr() + r0 * vt.element_size(),
                       rows, cols, perm, rscale, scale, rows_all, 0 if mat else 1)
-                meta.append((r0, rows, perm, rscale, float(scale)))
+                meta.append((r0, rows, perm, rscale, float(scale), tuple(src.shape)))
                 r0 += rows
             dslot[name] = {"view": v, "view_t": vt, "handle": handle, "meta": meta, "cols": cols}
         esz = _lib.load().gf_cast_entry_bytes()
@@ -356,15 +356,15 @@ class _DerivedWeight(torch.autograd.Function):
         d = ctx.d
         g = g.float().contiguous()
         outs = []
-        for i, (r0, rows, perm, rscale, scale) in enumerate(d["meta"]):
+        for i, (r0, rows, perm, rscale, scale, shape) in enumerate(d["meta"]):
             if not ctx.needs_input_grad[1 + i]:
                 outs.append(None)
                 continue
             gi = g[r0:r0 + rows]
             if perm is None and rscale is None and scale == 1.0:
-                outs.append(gi if d["view_t"] is not None else gi.reshape(rows))
+                outs.append(gi.reshape(shape))
                 continue
-            out = torch.empty((rows, d["cols"]) if d["view_t"] is not None else (rows,), dtype=torch.float32, device=g.device)
+            out = torch.empty(shape, dtype=torch.float32, device=g.device)
             _lib.check(_lib.load().gf_weight_grad_map(_p(gi), _p(out), None if perm is None else _p(perm),
                                                       None if rscale is None else _p(rscale), scale, rows, d["cols"], _stream()),
                        "gf_weight_grad_map")
@@ -1118,17 +1118,18 @@ class _AttentionQKV(torch.autograd.Function):
     one call, so the backward writes dq/dk/dv straight into one dqkv buffer."""
 
     @staticmethod
-    def forward(ctx, qkv, cross):
+    def forward(ctx, qkv, cross, scale=None):
         B2, N, _, H, D = qkv.shape
+        sc = ctx.scale = D ** -0.5 if scale is None else scale       # LN2: the caller folded head_dim^-1/2 log2(e) into q
         o = torch.empty((B2, N, H, D), dtype=qkv.dtype, device=qkv.device)
         lse = torch.empty((B2, H, N), dtype=torch.float32, device=qkv.device)
         q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
         if not cross:
-            attn_fwd_raw(q, k, v, D ** -0.5, out=o, lse=lse)
+            attn_fwd_raw(q, k, v, sc, out=o, lse=lse)
         else:
             B = B2 // 2
-            attn_fwd_raw(q[:B], k[B:], v[B:], D ** -0.5, out=o[:B], lse=lse[:B])
-            attn_fwd_raw(q[B:], k[:B], v[:B], D ** -0.5, out=o[B:], lse=lse[B:])
+            attn_fwd_raw(q[:B], k[B:], v[B:], sc, out=o[:B], lse=lse[:B])
+            attn_fwd_raw(q[B:], k[:B], v[:B], sc, out=o[B:], lse=lse[B:])
         ctx.save_for_backward(qkv, o, lse)
         ctx.cross = cross
         return o
@@ -1143,16 +1144,16 @@ class _AttentionQKV(torch.autograd.Function):
         q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
         dq, dk, dv = d[:, :, 0], d[:, :, 1], d[:, :, 2]
         if not ctx.cross:
-            attn_bwd_raw(q, k, v, o, do, lse, dq, dk, dv, D ** -0.5)
+            attn_bwd_raw(q, k, v, o, do, lse, dq, dk, dv, ctx.scale)
         else:
             B = B2 // 2
-            attn_bwd_raw(q[:B], k[B:], v[B:], o[:B], do[:B], lse[:B], dq[:B], dk[B:], dv[B:], D ** -0.5)
-            attn_bwd_raw(q[B:], k[:B], v[:B], o[B:], do[B:], lse[B:], dq[B:], dk[:B], dv[:B], D ** -0.5)
-        return d, None
+            attn_bwd_raw(q[:B], k[B:], v[B:], o[:B], do[:B], lse[:B], dq[:B], dk[B:], dv[B:], ctx.scale)
+            attn_bwd_raw(q[B:], k[:B], v[:B], o[B:], do[B:], lse[B:], dq[B:], dk[:B], dv[:B], ctx.scale)
+        return d, None, None
 
 
-def attention_qkv(qkv, cross=False):
-    return _AttentionQKV.apply(qkv, cross)
+def attention_qkv(qkv, cross=False, scale=None):
+    return _AttentionQKV.apply(qkv, cross, scale)
 
 
 # ------------------------------------------------------------------------------ Sinkhorn optimal transport
