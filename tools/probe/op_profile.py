@@ -1,14 +1,22 @@
-"""torch.profiler view of one LightGlue train step: aten ops by launch count / shape (finds the small-kernel overhead)."""
+"""torch.profiler view of one matcher train step: aten ops by launch count / shape (finds the small-kernel overhead).
+python tools/probe/op_profile.py [lightglue|superglue|gluestick]"""
 import os, sys, torch
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
-from glue_factory_amd.matchers.lightglue import LightGlue
 from glue_factory_amd.synthetic import make_pairs, to_device
 from glue_factory_amd.train_step import TrainStep
 torch.manual_seed(0)
-model = LightGlue({"n_layers": 9}).cuda().train()
+which = sys.argv[1] if len(sys.argv) > 1 else "lightglue"
+if which == "lightglue":
+    from glue_factory_amd.matchers.lightglue import LightGlue
+    model = LightGlue({"n_layers": 9}).cuda().train()
+    data = to_device(make_pairs(32, 2048, dim=256, seed=100), "cuda")
+else:       # the bench's own builders (BASELINE configs[3] / configs[4])
+    import argparse
+    import bench
+    model, cpu_data = bench.build_matcher(argparse.Namespace(batch=32, kpts=2048, lines=512, layers=9, sinkhorn_iters=100), 0, which)
+    data = to_device(cpu_data, "cuda")
 opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)
 step = TrainStep(model, opt, amp_dtype=torch.bfloat16, device_ids=[0])
-data = to_device(make_pairs(32, 2048, dim=256, seed=100), "cuda")
 for _ in range(3): step(data)
 torch.cuda.synchronize()
 from torch.profiler import profile, ProfilerActivity
