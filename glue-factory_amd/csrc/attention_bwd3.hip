@@ -26,7 +26,8 @@ namespace {
 #define DQ3_WPS 2          // workgroups per CU = waves per SIMD
 #endif
 
-template <bool PRE>      // PRE: rr == 1 (operands pre-multiplied by the caller): no multiply in front of exp2
+template <bool PRE, bool EVEN>      // PRE: rr == 1 (operands pre-multiplied by the caller): no multiply in front of exp2;
+                                    // EVEN: Nk % 64 == 0 -- no tile-dependent branch in the loop (see attention_fwd3.hip)
 __global__ __launch_bounds__(256, DQ3_WPS) void attn_dq3_bf16_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const unsigned lds0 = (unsigned)(size_t)smem;
@@ -51,8 +52,13 @@ __global__ __launch_bounds__(256, DQ3_WPS) void attn_dq3_bf16_kernel(AttnParams 
     KvDma dma;
     dma.init(kp, vp, p.skn, p.svn, p.Nk, wave, lane);
     const int nt = (p.Nk + 63) / 64;
-    dma.issue(0, smem + wave * 1024);
-    if (nt > 1) dma.issue(1, smem + FQ_STAGE + wave * 1024);
+    if (EVEN) {                       // no ragged tile; tiles past the end re-fetch the last one
+        dma.issue_full(0, smem + wave * 1024);
+        dma.issue_full(min(1, nt - 1), smem + FQ_STAGE + wave * 1024);
+    } else {
+        dma.issue(0, smem + wave * 1024);
+        if (nt > 1) dma.issue(1, smem + FQ_STAGE + wave * 1024);
+    }
 
     const float p2 = p.p2, rr = PRE ? 1.f : p.rr;
     bf16x8 qf[4], dof[4];
@@ -87,11 +93,12 @@ __global__ __launch_bounds__(256, DQ3_WPS) void attn_dq3_bf16_kernel(AttnParams 
     }
     int stage = 0;
     for (int t = 0; t < nt; ++t) {
-        if (t + 1 >= nt) wait_vm<0>(); else wait_vm<4>();            // tile t landed (this wave's pieces)
+        if (EVEN || t + 1 < nt) wait_vm<4>(); else wait_vm<0>();     // tile t landed (this wave's pieces)
         __builtin_amdgcn_s_barrier();                                // ... everyone's; the stage of tile t-1 is free
         __builtin_amdgcn_sched_barrier(0);
-        if (t + 2 < nt) dma.issue(t + 2, smem + (stage == 0 ? 2 : stage - 1) * FQ_STAGE + wave * 1024);
-        const bool ragged = t * 64 + 64 > p.Nk;
+        if (EVEN) dma.issue_full(min(t + 2, nt - 1), smem + (stage == 0 ? 2 : stage - 1) * FQ_STAGE + wave * 1024);
+        else if (t + 2 < nt) dma.issue(t + 2, smem + (stage == 0 ? 2 : stage - 1) * FQ_STAGE + wave * 1024);
+        const bool ragged = !EVEN && t * 64 + 64 > p.Nk;
 
         u32x4 ka[4], va[4];
         u32x2 kt[2][2][2];
@@ -130,6 +137,7 @@ __global__ __launch_bounds__(256, DQ3_WPS) void attn_dq3_bf16_kernel(AttnParams 
         for (int i = 0; i < 4; ++i) { aR[i] += step; aT[i] += step; }
         stage = stage == 2 ? 0 : stage + 1;
     }
+    if (EVEN) wait_vm<0>();                                          // the re-fetched tail tiles
     if (qrow < p.Nq) {
         bf16_t* dqp = reinterpret_cast<bf16_t*>(p.dq) + b * p.sdqb + h * p.sdqh + (int64_t)qrow * p.sdqn;
         if (p.flags & GF_ATTN_ACC_DQ) add_row<64>(dqp, dq, p.scale, hi); else store_row<bf16_t, 64>(dqp, dq, p.scale, hi);
@@ -141,18 +149,17 @@ __global__ __launch_bounds__(256, DQ3_WPS) void attn_dq3_bf16_kernel(AttnParams 
 int launch_dq3_bf16(const AttnParams& p, hipStream_t st) {
     const int total = ((p.Nq + 127) / 128) * p.H * p.B;
     const size_t lds = FQ_NSTAGE * FQ_STAGE;
+    void (*const kern[4])(AttnParams) = {attn_dq3_bf16_kernel<false, false>, attn_dq3_bf16_kernel<false, true>,
+                                         attn_dq3_bf16_kernel<true, false>, attn_dq3_bf16_kernel<true, true>};
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_dq3_bf16_kernel<false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_dq3_bf16_kernel<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
+        for (auto k : kern) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return (int)e;
+        }
         attr_set = true;
     }
-    if (p.rr == 1.f) attn_dq3_bf16_kernel<true><<<dim3(total), dim3(256), lds, st>>>(p);
-    else attn_dq3_bf16_kernel<false><<<dim3(total), dim3(256), lds, st>>>(p);
+    kern[(p.rr == 1.f ? 2 : 0) + (p.Nk % 64 == 0 ? 1 : 0)]<<<dim3(total), dim3(256), lds, st>>>(p);
     return (int)hipGetLastError();
 }
 
