@@ -102,18 +102,27 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c64_kernel(C3Params p) {
         t.y0 = ty * C3_TH; t.x0 = (r - ty * tx_n) * C3_TW;
         return t;
     };
-    // ---- input window DMA: piece q = LDS chunk positions [64 q, 64 q + 64) = pixels 8 q .. 8 q + 7; the lane for chunk
-    // position (pixel pp, slot c') fetches logical chunk c' ^ ((pp >> 1) & 7) of that pixel (swizzle on the source).
-    // Out-of-image halo pixels are fetched clamped (any valid address) and zeroed after landing (zero_halo).
-    auto issue_piece = [&](const Tile& t, int buf, int i) {
-        const int q = wave + 4 * i;
-        const int pp = min(q * 8 + (lane >> 3), C3_NPIX - 1);
-        const int iy = (pp * 241) >> 13, ix = pp - iy * C3_IW;             // pp / 34 for pp < 340
-        const int gy = min(max(t.y0 - 1 + iy, 0), p.H - 1), gx = min(max(t.x0 - 1 + ix, 0), p.W - 1);
-        const int c = (lane & 7) ^ ((pp >> 1) & 7);
-        const bf16_t* img = p.x + (int64_t)t.b * p.H * p.W * 64;
-        __builtin_amdgcn_global_load_lds((c3_glb_void*)(img + ((int64_t)gy * p.W + gx) * 64 + c * 8),
-                                         (c3_lds_void*)(smem + buf * C3_INBUF + q * 1024), 16, 0, 0);
+    // ---- input window DMA: piece q = wave + 4 i = LDS chunk positions [64 q, 64 q + 64) = window pixels 8 q .. 8 q + 7; the lane
+    // for chunk position (pixel pp, slot c') fetches logical chunk c' ^ ((pp >> 1) & 7) of that pixel (swizzle on the source).
+    // `buffer_load ... lds` through a descriptor of the tile's IMAGE: window rows above / below the image are out of range
+    // and land as zeros (the halo); window columns left / right of it alias neighbouring rows and are zeroed after landing
+    // (zero_halo, border tiles only).  The pieces of a window are issued in order and piece i + 1 is piece i moved on by 32
+    // window pixels: + 32 * 128 bytes, + one image row - 34 pixels where the pixel index wraps into the next window row; the
+    // swizzled chunk is the same for every piece of a lane ((32 i) >> 1 & 7 == 0).  Two registers of running state and 4
+    // instructions per piece instead of ~18 (every instruction of this kernel costs wall time: DESIGN.md section 5).
+    const int pc_pp0 = wave * 8 + (lane >> 3);                                    // piece 0: window row 0, pixel pp0 < 34
+    const int pc_lane0 = pc_pp0 * 128 + ((lane & 7) ^ ((pc_pp0 >> 1) & 7)) * 16;
+    const int pc_wrap = (p.W - C3_IW) * 128;
+    int pc_off = 0, pc_ix = 0;
+    auto image_rsrc = [&](const Tile& t) {
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (int64_t)t.b * p.H * p.W * 64), 0, p.H * p.W * 128, 0x00020000);
+    };
+    auto issue_piece = [&](__amdgpu_buffer_rsrc_t rs, const Tile& t, int buf, int i) {
+        if (i == 0) { pc_ix = pc_pp0; pc_off = ((t.y0 - 1) * p.W + t.x0 - 1) * 128 + pc_lane0; }     // (may be negative: out of range)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (c3_lds_void*)(smem + buf * C3_INBUF + (wave + 4 * i) * 1024), 16, pc_off, 0, 0, 0);
+        const bool wrap = pc_ix >= C3_IW - 32;
+        pc_off += 32 * 128 + (wrap ? pc_wrap : 0);
+        pc_ix += wrap ? 32 - C3_IW : 32;
     };
     // halo pixels outside the image -> 0 (after the DMA of every wave landed)
     auto zero_halo = [&](const Tile& t, int buf) {
@@ -135,14 +144,17 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c64_kernel(C3Params p) {
     // (px >> 1) & 7): tile i is written to staging[i & 1] by its owner lanes right after its MFMA loop and goes
     // to HBM -- whole 128-byte pixels, [2x2 max-pooled] -- from INSIDE the MFMA loop of tile i + 1.
     constexpr int NSTORE = POOL ? 4 : 8;                    // store steps per thread and tile
+    // element offset of this thread's 16-byte chunk inside its tile (step 0) -- a per-lane constant; step k adds whole
+    // output rows (one, or two pooled ones), the tile's origin is uniform: one 32-bit add per store instead of ~8 instructions
+    const int st_off0 = POOL ? ((int)(threadIdx.x >> 7) * (p.W / 2) + ((int)(threadIdx.x >> 3) & 15)) * 64 + ((int)threadIdx.x & 7) * 8
+                             : ((int)(threadIdx.x >> 3)) * 64 + ((int)threadIdx.x & 7) * 8;
     auto store_addr = [&](const Tile& t, int k) -> bf16_t* {
-        const int u = threadIdx.x + 256 * k;
         if (!POOL) {
-            const int opx = u >> 3, c = u & 7;
-            return p.y + ((((int64_t)t.b * p.H + t.y0 + (opx >> 5)) * p.W + t.x0 + (opx & 31)) * 64 + c * 8);
+            bf16_t* base = p.y + (((int64_t)t.b * p.H + t.y0 + k) * p.W + t.x0) * 64;                      // (uniform)
+            return base + st_off0;
         }
-        const int py = u >> 7, px = (u >> 3) & 15, c = u & 7;
-        return p.y + ((((int64_t)t.b * (p.H / 2) + t.y0 / 2 + py) * (p.W / 2) + t.x0 / 2 + px) * 64 + c * 8);
+        bf16_t* base = p.y + (((int64_t)t.b * (p.H / 2) + t.y0 / 2 + 2 * k) * (p.W / 2) + t.x0 / 2) * 64;   // (uniform)
+        return base + st_off0;
     };
     // LDS byte address of (staging buffer sb, pixel opx, logical chunk c)
     auto stage_at = [&](int sb, int opx, int c) { return C3_STAGE + sb * C3_OUT + opx * 128 + ((c ^ ((opx >> 1) & 7)) << 4); };
@@ -191,8 +203,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c64_kernel(C3Params p) {
     const int T = (tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;     // my tiles: blockIdx.x + i gridDim.x
     if (T <= 0) return;
     Tile cur = coords(blockIdx.x), prev = cur;
+    {
+        const __amdgpu_buffer_rsrc_t rs0 = image_rsrc(cur);
 #pragma unroll
-    for (int i = 0; i < C3_PIECES / 4; ++i) issue_piece(cur, 0, i);
+        for (int i = 0; i < C3_PIECES / 4; ++i) issue_piece(rs0, cur, 0, i);
+    }
     c3_wait_vm<0>();
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     if (is_border(cur)) {
@@ -207,6 +222,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c64_kernel(C3Params p) {
         // values one phase later (same thread, same address: program order holds).
         const bool has_next = i + 1 < T;
         const Tile nxt = coords(blockIdx.x + (has_next ? i + 1 : i) * gridDim.x);
+        const __amdgpu_buffer_rsrc_t nxt_rs = image_rsrc(nxt);
 
         // ---- 144 MFMAs: acc[nt][r] (32 channels x 32 pixels of tile row 2 wave + r); between them the next window's
         // DMA pieces are issued and the previous tile's staging buffer is drained to HBM
@@ -245,7 +261,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c64_kernel(C3Params p) {
             } else {
                 c3_wait_lgkm<0>();
             }
-            if (g < C3_PIECES / 4 && !(C3_ABL & 2)) issue_piece(nxt, buf ^ 1, g);
+            if (g < C3_PIECES / 4 && !(C3_ABL & 2)) issue_piece(nxt_rs, nxt, buf ^ 1, g);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) c3_tie(cur_[ks]);
             if (g == 15) {               // (behind group 16's B reads: landed by group 16's counted wait)
@@ -321,6 +337,7 @@ extern "C" int gf_conv3x3_c64(const void* x, const void* w, const float* bias, c
     if (B <= 0 || H <= 0 || W <= 0) return GF_ERR_SHAPE;
     if (dtype != GF_BF16) return GF_ERR_DTYPE;
     if (H % C3_TH || W % C3_TW) return GF_ERR_UNSUPPORTED;
+    if ((int64_t)H * W * 128 >= (1ll << 31)) return GF_ERR_UNSUPPORTED;      // 32-bit byte offsets inside one image (buffer loads)
     C3Params p;
     p.x = static_cast<const bf16_t*>(x); p.w = static_cast<const bf16_t*>(w); p.bias = bias; p.scale = scale; p.shift = shift;
     p.y = static_cast<bf16_t*>(y); p.B = B; p.H = H; p.W = W; p.relu = relu;

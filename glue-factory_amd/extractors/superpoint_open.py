@@ -215,7 +215,7 @@ class SuperPoint(BaseModel):
                         and blk.conv.kernel_size == (3, 3):
                     x = self._first_block(f"backbone.{si}.{bi}", blk, x, params)      # conv + tail in one kernel
                 elif f"backbone.{si}.{bi}/taps" in params and x.shape[2] % 8 == 0 and x.shape[3] % 32 == 0 \
-                        and blk.conv.padding == (1, 1) and blk.conv.stride == (1, 1):
+                        and x.shape[2] * x.shape[3] * 128 < 2 ** 31 and blk.conv.padding == (1, 1) and blk.conv.stride == (1, 1):
                     x = self._conv64_block(f"backbone.{si}.{bi}", blk, x, params, pool)
                 else:
                     x = self._fused_block(f"backbone.{si}.{bi}", blk, x, params, pool=pool)
