@@ -10,7 +10,7 @@
 //   * a workgroup = 4 waves (one per SIMD, the whole 512-register file each) owns an 8 x 32 pixel output tile and
 //     walks tiles persistently; wave w owns tile rows 2w, 2w+1;
 //   * the 64 x 576 weight matrix lives in REGISTERS for the whole kernel (A operands, [tap][k-step] x 2 output-
-//     channel blocks = 288 VGPRs, loaded once from a [tap][cout][cin] copy);
+//     channel blocks = 288 registers, loaded once from a [tap][cout][cin] copy, their register file pinned by hand);
 //   * the input window (10 x 34 pixels x 128 B) arrives by LDS-DMA into a double buffer -- the next tile's window
 //     streams in while this tile's 144 MFMAs per wave run -- pixel-major, its eight 16-byte chunks swizzled by
 //     (pixel >> 1) & 7: the B-operand read (32 consecutive pixels of one row, one chunk) is conflict-free; halo
@@ -38,10 +38,13 @@ constexpr int C3_NPIX = C3_IW * C3_IH;                     // 340 pixels
 constexpr int C3_PIECES = 44;                              // 1-KiB DMA pieces (8 pixels each) per window
 constexpr int C3_INBUF = C3_PIECES * 1024;                 // bytes of one input buffer
 constexpr int C3_OUT = C3_TH * C3_TW * 128;                // bytes of one output staging tile
-constexpr int C3_STAGE = 2 * C3_INBUF;                     // LDS map: 2 input windows | 2 staging tiles | constants
+constexpr int C3_STAGE = 2 * C3_INBUF;                     // LDS map: 2 input windows | 2 staging tiles | epilogue constants
 constexpr int C3_CST = C3_STAGE + 2 * C3_OUT;
-constexpr int C3_WL = C3_CST + 3 * 64 * 4;                 // 4 weight fragments x 1 KiB (tap 8, channels 32..63)
-constexpr int C3_LDS = C3_WL + 4096;
+constexpr int C3_LDS = C3_CST + 3 * 64 * 4;
+#ifndef C3_AGPR_FRAGS_V
+#define C3_AGPR_FRAGS_V 48
+#endif
+constexpr int C3_AGPR_FRAGS = C3_AGPR_FRAGS_V;   // weight fragments kept in AGPRs (4 registers each)
 
 template <int OFF> __device__ __forceinline__ u32x4 c3_rd128(unsigned a) {
     u32x4 v;
@@ -69,8 +72,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c64_kernel(C3Params p) {
     const int tiles = tx_n * ty_n * p.B;
 
     // ---- weights: A operands, lane = output channel 32 nt + l31, elements cin 16 ks + 8 hi .. + 8 of tap t
-    // (all but the last tap's second channel block, which does not fit the register file next to the accumulators
-    // and the staging traffic: those 4 fragments are re-read from LDS for the last two MFMA groups of every tile)
+    // (all 72 fragments = 288 registers stay resident: 192 in the AGPRs next to the 64 accumulator registers, 96 in VGPRs)
     bf16x8 wf[2][9][4];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
@@ -79,10 +81,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c64_kernel(C3Params p) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const bf16x8 v = *reinterpret_cast<const bf16x8*>(p.w + ((t * 64 + 32 * nt + l31) * 64 + 16 * ks + 8 * hi));
-                if (nt == 1 && t == 8) {
-                    if (wave == 0) *reinterpret_cast<bf16x8*>(smem + C3_WL + ks * 1024 + lane * 16) = v;
-                } else {
+                {
                     wf[nt][t][ks] = v;
+                    // pin the register file of every fragment for the whole kernel: 48 fragments (192 registers) in the AGPRs
+                    // next to the 64 accumulator registers, the other 20 in VGPRs -- MFMA reads either directly.  Left to
+                    // itself the allocator "spills" weights to AGPRs and copies them back in front of every use (237
+                    // v_accvgpr_read / _mov per tile).
+                    if ((nt * 9 + t) * 4 + ks < C3_AGPR_FRAGS) asm volatile("" : "+a"(wf[nt][t][ks]));
+                    else asm volatile("" : "+v"(wf[nt][t][ks]));
                 }
             }
     // epilogue constants [bias | scale | shift][64] in LDS (read per tile: registers are full of weights)
@@ -238,7 +244,6 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c64_kernel(C3Params p) {
         // (only 4 window rows x 3 dx distinct addresses per lane: row = r + dy)
         auto base = [&](int t, int r) { return ab[r + t / 3][t % 3] + (unsigned)(buf * C3_INBUF); };
         u32x4 ra[4], rb[4];                                      // [ks], double buffer over (tap, row) groups
-        u32x4 wl[4];                                             // the LDS-resident weight fragments
         if (!(C3_ABL & 4)) {
             const unsigned a = base(0, 0);
 #pragma unroll
@@ -264,18 +269,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c64_kernel(C3Params p) {
             if (g < C3_PIECES / 4 && !(C3_ABL & 2)) issue_piece(nxt_rs, nxt, buf ^ 1, g);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) c3_tie(cur_[ks]);
-            if (g == 15) {               // (behind group 16's B reads: landed by group 16's counted wait)
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) wl[ks] = c3_rd128<0>(lds0 + C3_WL + ks * 1024 + lane * 16);
-            }
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
-                    bf16x8 wv;
-                    if (nt == 1 && t == 8) { c3_tie(wl[ks]); wv = __builtin_bit_cast(bf16x8, wl[ks]); }
-                    else wv = wf[nt][t][ks];
-                    acc[nt][r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wv, __builtin_bit_cast(bf16x8, cur_[ks]), acc[nt][r], 0, 0, 0);
+                    acc[nt][r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt][t][ks], __builtin_bit_cast(bf16x8, cur_[ks]), acc[nt][r], 0, 0, 0);
                 }
             if (k >= 0) store_write(prev, k);
         }
