@@ -117,6 +117,13 @@ class SuperPoint(BaseModel):
                 shift = (bn.bias.float() - bn.running_mean.float() * scale).contiguous()
                 w = blk.conv.weight.detach().to(dtype).contiguous(memory_format=torch.channels_last)
                 out[name] = (w, blk.conv.bias.detach().float().contiguous(), scale, shift)
+                if (dtype == torch.bfloat16 and blk.conv.kernel_size == (1, 1) and not isinstance(blk.activation, nn.ReLU)
+                        and blk.conv.in_channels in (256, 512) and blk.conv.out_channels % 256 == 0):
+                    # 1 x 1 convolution without ReLU in front of the eval BatchNorm = ONE GEMM over the pixels:
+                    # (W x + b) s + h = (s W) x + (s b + h), folded in fp32 before the single rounding of the weights
+                    w2 = blk.conv.weight.detach().float().reshape(blk.conv.out_channels, -1)
+                    out[name + "/gemm"] = ((w2 * scale[:, None]).to(dtype).contiguous(),
+                                           (blk.conv.bias.detach().float() * scale + shift).contiguous())
                 if dtype == torch.bfloat16 and tuple(blk.conv.weight.shape) == (64, 64, 3, 3):
                     # [tap][c_out][c_in] for the register-resident weights of gf_conv3x3_c64
                     out[name + "/taps"] = blk.conv.weight.detach().permute(2, 3, 0, 1).to(dtype).contiguous()
@@ -225,7 +232,14 @@ class SuperPoint(BaseModel):
         else:
             det = self._fused_block("detector.1", self.detector[1], det, params)
         desc = self._fused_block("descriptor.0", self.descriptor[0], x, params)
-        desc = self._fused_block("descriptor.1", self.descriptor[1], desc, params)
+        if "descriptor.1/gemm" in params and desc.is_contiguous(memory_format=torch.channels_last):
+            from .. import ops
+            w2, b2 = params["descriptor.1/gemm"]                    # descriptor.1 (256 -> 256, 1 x 1, no ReLU) + its BatchNorm
+            bb, cc, hh, ww = desc.shape
+            y = ops.gemm(desc.permute(0, 2, 3, 1).reshape(-1, cc), w2, b2)
+            desc = y.view(bb, hh, ww, w2.shape[0]).permute(0, 3, 1, 2)          # channels-last [B, C, h, w]
+        else:
+            desc = self._fused_block("descriptor.1", self.descriptor[1], desc, params)
         return det, desc
 
     def _forward(self, data):
