@@ -747,3 +747,53 @@ def test_line_head_kernels_vs_torch_autograd(B, L0, L1, N0, N1):
     for name, a, r in (("dx0", xd0.grad, xr0.grad), ("dx1", xd1.grad, xr1.grad), ("dbeta", bd.grad, br.grad)):
         sc = max(float(r.abs().max()), 1e-6)
         torch.testing.assert_close(a.double().cpu() / sc, r / sc, rtol=1e-4, atol=1e-4, msg=lambda m: f"{name}: {m}")
+
+
+def test_precast_derived_weights_and_gradient_map():
+    """ops.precast(derived=...): prepared weights built inside the per-step cast launch (gf_multi_cast_transpose entries with
+    a row gather, a per-row scale, a scalar scale and row blocks of one stacked output; biases in fp32) and their way back
+    (gf_weight_grad_map through ops._DerivedWeight) against the torch expressions they replace -- LightGlue's Wqkv row
+    order + q scale (lightglue.py:97-128) and the cross block's stacked (to_qk * s | to_v) (:196-221)."""
+    from glue_factory_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(11)
+    wq = torch.nn.Parameter(torch.randn(96, 40, device="cuda", generator=g))
+    bq = torch.nn.Parameter(torch.randn(96, device="cuda", generator=g))
+    wa = torch.nn.Parameter(torch.randn(24, 40, device="cuda", generator=g))
+    wb = torch.nn.Parameter(torch.randn(40, 40, 1, device="cuda", generator=g))          # a Conv1d(k=1) weight
+    other = torch.nn.Parameter(torch.randn(8, 8, device="cuda", generator=g))
+    perm = torch.randperm(96, device="cuda", generator=g)
+    rs = torch.rand(96, device="cuda", generator=g) + 0.5
+    specs = [("q.w", [(wq, perm, rs, 1.0)]), ("q.b", [(bq, perm, rs, 1.0)]),
+             ("cat.w", [(wa, None, None, 0.75), (wb, None, None, 1.0)])]
+    key = "test-derived"
+    ops.precast([wq, bq, wa, wb, other], torch.bfloat16, key=key, derived=specs)
+    w1 = ops.derived_weight(key, torch.bfloat16, "q.w", wq)
+    b1 = ops.derived_weight(key, torch.bfloat16, "q.b", bq)
+    w2 = ops.derived_weight(key, torch.bfloat16, "cat.w", wa, wb)
+    assert ops.derived_weight(key, torch.float32, "q.w", wq) is None            # no fp32 precast of this key: caller falls back
+    ref_w1 = wq.detach().index_select(0, perm) * rs[:, None]
+    ref_b1 = bq.detach().index_select(0, perm) * rs
+    ref_w2 = torch.cat([wa.detach() * 0.75, wb.detach().squeeze(-1)], 0)
+    lp1, lp2 = ops._lp(w1, torch.bfloat16), ops._lp(w2, torch.bfloat16)
+    assert lp1.dtype == torch.bfloat16 and torch.equal(lp1, ref_w1.to(torch.bfloat16))
+    assert torch.equal(lp2, ref_w2.to(torch.bfloat16))
+    assert torch.equal(ops._wt_t(lp1), ref_w1.to(torch.bfloat16).t().contiguous())
+    assert torch.equal(ops._wt_t(lp2, 8, 24), ref_w2.to(torch.bfloat16)[:, 8:24].t().contiguous())
+    assert b1.dtype == torch.float32 and torch.allclose(b1, ref_b1, rtol=1e-6, atol=0)
+    # gradients: the handle receives the fp32 gradient of the prepared tensor, the sources get theirs
+    g1 = torch.randn(96, 40, device="cuda", generator=g)
+    gb = torch.randn(96, device="cuda", generator=g)
+    g2 = torch.randn(64, 40, device="cuda", generator=g)
+    torch.autograd.backward([w1, b1, w2], [g1, gb, g2])
+    exp_wq = torch.zeros_like(wq).index_add_(0, perm, g1 * rs[:, None])
+    exp_bq = torch.zeros_like(bq).index_add_(0, perm, gb * rs)
+    torch.testing.assert_close(wq.grad, exp_wq, rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(bq.grad, exp_bq, rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(wa.grad, g2[:24] * 0.75, rtol=1e-6, atol=1e-7)
+    assert wb.grad.shape == wb.shape and torch.equal(wb.grad.squeeze(-1), g2[24:])
+    # the launch re-derives from the CURRENT parameter values (optimiser steps do not bump versions under a graph)
+    with torch.no_grad():
+        wq.mul_(2.0)
+    ops.precast([wq, bq, wa, wb, other], torch.bfloat16, key=key, derived=specs)
+    w1b = ops.derived_weight(key, torch.bfloat16, "q.w", wq)
+    assert torch.equal(ops._lp(w1b, torch.bfloat16), (2.0 * ref_w1).to(torch.bfloat16))
