@@ -310,11 +310,11 @@ class GlueStick(BaseModel):
         la = pred[prefix + suffix + "log_assignment"]
         neg0 = (data["gt_" + prefix + "matches0"] == -1).float()
         neg1 = (data["gt_" + prefix + "matches1"] == -1).float()
-        pos_sum, num_pos = ops.nll_positive_terms(la, data, prefix)     # fixed-length gather when the col0 vector is there
+        pos_sum, num_pos, neg_sum = ops.nll_terms(la, data, neg0, neg1, prefix)   # one autograd node with the col0 vector
         num_pos = num_pos.clamp(min=1.0)
         num_neg = (neg0.sum(1) + neg1.sum(1)).clamp(min=1.0)
         nll_pos = -pos_sum / num_pos
-        nll_neg = -((la[:, :-1, -1] * neg0).sum(1) + (la[:, -1, :-1] * neg1).sum(1)) / num_neg
+        nll_neg = -neg_sum / num_neg
         bal = self.conf.loss.nll_balancing
         nll = bal * nll_pos + (1 - bal) * nll_neg
         losses[prefix + suffix + "assignment_nll"] = nll

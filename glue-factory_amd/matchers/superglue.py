@@ -296,11 +296,11 @@ class SuperGlue(BaseModel):
         la = pred["log_assignment"]
         neg0 = (data["gt_matches0"] == -1).float()
         neg1 = (data["gt_matches1"] == -1).float()
-        pos_sum, num_pos = ops.nll_positive_terms(la, data)       # fixed-length gather when gt_assignment_col0 is there
+        pos_sum, num_pos, neg_sum = ops.nll_terms(la, data, neg0, neg1)   # one autograd node when gt_assignment_col0 is there
         num_pos = num_pos.clamp(min=1.0)
         num_neg = (neg0.sum(1) + neg1.sum(1)).clamp(min=1.0)
         nll_pos = -pos_sum / num_pos
-        nll_neg = -((la[:, :-1, -1] * neg0).sum(1) + (la[:, -1, :-1] * neg1).sum(1)) / num_neg
+        nll_neg = -neg_sum / num_neg
         bal = self.conf.loss.nll_balancing
         nll = bal * nll_pos + (1 - bal) * nll_neg
         losses = {"total": nll, "assignment_nll": nll, "nll_pos": nll_pos, "nll_neg": nll_neg,
