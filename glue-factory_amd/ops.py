@@ -1074,15 +1074,16 @@ class _AssignWrite(torch.autograd.Function):
         # materialised matrix (never in the training step, whose loss heads are sparse).
         a, b = ctx.saved_tensors
         core = G[:, :-1, :-1]
-        g = (ctx.alpha * core).to(a.dtype)
-        da = bgemm(g.contiguous(), b)
-        db = bgemm(g.transpose(1, 2), a)
+        g = core.to(a.dtype, memory_format=torch.contiguous_format)      # ONE pass over the dense gradient; alpha rides in the products
+        da = bgemm(g, b, alpha=ctx.alpha) if ctx.needs_input_grad[0] else None
+        db = bgemm(g.transpose(1, 2), a, alpha=ctx.alpha) if ctx.needs_input_grad[1] else None
         d = ctx.dts
         gcorner = None
         if ctx.corner_shape is not None:
             gcorner = G[:, -1, -1].sum() if len(ctx.corner_shape) == 0 else G[:, -1, -1].reshape(ctx.corner_shape)
-        return (da, db, core.sum(2).to(d[0]), core.sum(1).to(d[1]), G[:, :-1, -1].to(d[2]),
-                G[:, -1, :-1].to(d[3]), None, gcorner, None)
+        grow = core.sum(2).to(d[0]) if ctx.needs_input_grad[2] else None     # (SuperGlue's couplings have no row / column bias)
+        gcol = core.sum(1).to(d[1]) if ctx.needs_input_grad[3] else None
+        return (da, db, grow, gcol, G[:, :-1, -1].to(d[2]), G[:, -1, :-1].to(d[3]), None, gcorner, None)
 
 
 def assign_write(a, b, rowbias, colbias, bin_col, bin_row, alpha=2.0, corner=0.0, with_expsum=False):
@@ -1191,7 +1192,8 @@ class _Sinkhorn(torch.autograd.Function):
         L = _lib.load()
         ws = torch.empty(int(L.gf_sinkhorn_ws_bytes(B, M, N, ctx.iters)), dtype=torch.uint8, device=Z.device)
         gZ = torch.empty_like(Z)
-        gr, gc = G.sum(2).contiguous(), G.sum(1).contiguous()
+        known = _known_sums(G)                   # the fused NLL node hands over the sums of its sparse gradient
+        gr, gc = known if known is not None else (G.sum(2).contiguous(), G.sum(1).contiguous())
         _lib.check(L.gf_sinkhorn_bwd(_p(Z), _p(G), _p(gr), _p(gc), _p(uh), _p(vh), _p(gZ), _p(ws),
                                      B, M, N, ctx.iters, _stream()), "gf_sinkhorn_bwd")
         return gZ, None
@@ -1600,6 +1602,16 @@ def dense_log_double_softmax(raw, beta):
 
 
 # ------------------------------------------------------------------------------ sparse positives of the NLL losses
+_SPARSE_SUMS = {}        # data_ptr of the dense gradient _NllTerms just wrote -> (weakref, row sums, column sums)
+
+
+def _known_sums(G):
+    hit = _SPARSE_SUMS.pop(G.data_ptr(), None)
+    if hit is not None and hit[0]() is G and hit[1].shape == G.shape[:2] and hit[2].shape == (G.shape[0], G.shape[2]):
+        return hit[1].contiguous(), hit[2].contiguous()
+    return None
+
+
 class _NllTerms(torch.autograd.Function):
     """(sum over the positives of la[b, i, col0[b, i]], sum over the unmatched rows / columns of their dustbin entries) of a
     log assignment la [B, M+1, N+1] (superglue.py:322-352, gluestick.py:378-414).  The gradient is written ONCE: one fill of
@@ -1621,9 +1633,17 @@ class _NllTerms(torch.autograd.Function):
     def backward(ctx, gpos, gneg):
         idx, valid, neg0, neg1 = ctx.saved_tensors
         G = torch.zeros(ctx.shape, dtype=ctx.dtype, device=idx.device)
-        G[:, :-1, :].scatter_(2, idx, (gpos[:, None] * valid.to(ctx.dtype))[..., None])
-        G[:, :-1, -1] = gneg[:, None] * neg0             # (a positive never sits in the dustbin column)
-        G[:, -1, :-1] = gneg[:, None] * neg1
+        vpos = gpos[:, None] * valid.to(ctx.dtype)
+        n0, n1 = gneg[:, None] * neg0, gneg[:, None] * neg1
+        G[:, :-1, :].scatter_(2, idx, vpos[..., None])
+        G[:, :-1, -1] = n0                               # (a positive never sits in the dustbin column)
+        G[:, -1, :-1] = n1
+        # row / column sums of this sparse matrix, for a consumer that wants them (the Sinkhorn backward): known here
+        # from O(M + N) values instead of two more sweeps of the dense tensor
+        gr = torch.cat([vpos + n0, n1.sum(1, keepdim=True)], 1)
+        gc = torch.cat([n1, n0.sum(1, keepdim=True)], 1).scatter_add_(1, idx.squeeze(-1), vpos)
+        _SPARSE_SUMS.clear()
+        _SPARSE_SUMS[G.data_ptr()] = (weakref.ref(G), gr, gc)
         return G, None, None, None
 
 

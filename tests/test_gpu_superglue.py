@@ -157,3 +157,57 @@ def test_superglue_train_step_hipgraph_replay_equals_eager():
     s2, n2 = ops.nll_positive_terms(la, {k: v for k, v in d.items() if k != "gt_assignment_col0"})
     torch.testing.assert_close(s1, s2, rtol=1e-6, atol=1e-6)
     torch.testing.assert_close(n1, n2)
+
+
+def test_nll_node_gradient_and_sums_handed_to_sinkhorn():
+    """ops.nll_terms (positives + dustbin terms of superglue.py:322-352 as ONE autograd node): same values and the same
+    dense gradient as the gather / slice expressions it replaces, and the row / column sums it hands to the Sinkhorn
+    backward (instead of two more sweeps of the dense gradient) are the sums of that gradient."""
+    from glue_factory_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(5)
+    B, M, N = 3, 37, 41
+    la = torch.randn(B, M + 1, N + 1, device="cuda", generator=g, requires_grad=True)
+    col0 = torch.randint(-1, N, (B, M), device="cuda", generator=g)
+    for b in range(B):                                   # one positive per column at most
+        seen = set()
+        for i in range(M):
+            c = int(col0[b, i])
+            if c >= 0 and c in seen:
+                col0[b, i] = -1
+            seen.add(c)
+    neg0 = (col0 < 0).float()
+    neg1 = torch.ones(B, N, device="cuda")
+    for b in range(B):
+        neg1[b, col0[b][col0[b] >= 0]] = 0.0
+    data = {"gt_assignment_col0": col0}
+    pos, npos, neg = ops.nll_terms(la, data, neg0, neg1)
+    valid = col0 >= 0
+    picked = la[:, :-1, :].gather(2, col0.clamp(min=0)[..., None]).squeeze(-1)
+    pos_ref = (picked * valid.float()).sum(1)
+    neg_ref = (la[:, :-1, -1] * neg0).sum(1) + (la[:, -1, :-1] * neg1).sum(1)
+    torch.testing.assert_close(pos, pos_ref)
+    torch.testing.assert_close(neg, neg_ref)
+    assert torch.equal(npos, valid.sum(1).float())
+    w0, w1 = torch.randn(B, device="cuda", generator=g), torch.randn(B, device="cuda", generator=g)
+    G_ref, = torch.autograd.grad((pos_ref * w0 + neg_ref * w1).sum(), la)
+    seen = []
+    orig = ops._known_sums
+
+    class Probe(torch.autograd.Function):                # stands where the Sinkhorn backward stands
+        @staticmethod
+        def forward(ctx, x):
+            return x.view_as(x)
+
+        @staticmethod
+        def backward(ctx, G):
+            seen.append((G, orig(G)))
+            return G
+
+    la2 = la.detach().clone().requires_grad_(True)
+    pos2, _, neg2 = ops.nll_terms(Probe.apply(la2), data, neg0, neg1)
+    (pos2 * w0 + neg2 * w1).sum().backward()
+    torch.testing.assert_close(la2.grad, G_ref)
+    G, sums = seen[0]
+    assert sums is not None
+    torch.testing.assert_close(sums[0], G.sum(2))
+    torch.testing.assert_close(sums[1], G.sum(1))
