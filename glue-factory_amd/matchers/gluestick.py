@@ -192,7 +192,8 @@ class GlueStick(BaseModel):
         r_raw, c_raw = ops.dual_lse(md0, md1)
         beta = self.bin_score.float()
         r, c = torch.logaddexp(r_raw, beta), torch.logaddexp(c_raw, beta)
-        return ops.assign_write(md0, md1, -0.5 * r, -0.5 * c, beta - r, beta - c, alpha=1.0, corner=0.0)
+        # (+ sum of exp over the rows of the matrix while it is written: the `sinkhorn_norm` statistic of the loss)
+        return ops.assign_write(md0, md1, -0.5 * r, -0.5 * c, beta - r, beta - c, alpha=1.0, corner=0.0, with_expsum=True)
 
     def _line_head(self, ld0, ld1, idx0, idx1, graph0, graph1, proj):
         """gluestick.py:336-376: endpoint descriptors -> final_line_proj -> endpoint scores -> line scores (max over the
@@ -277,9 +278,9 @@ class GlueStick(BaseModel):
         d0, d1 = split(xs)
 
         pred = {}
-        kp_scores = self._point_head(d0, d1)
+        kp_scores, kp_expsum = self._point_head(d0, d1)
         m0, m1, ms0, ms1 = self._filter(kp_scores)
-        pred.update({"log_assignment": kp_scores, "matches0": m0, "matches1": m1,
+        pred.update({"log_assignment": kp_scores, "_log_assignment_expsum": kp_expsum, "matches0": m0, "matches1": m1,
                      "matching_scores0": ms0, "matching_scores1": ms1})
         if have_lines:
             # junction graphs of the two images (the gather's backward is a segment sum over them)
@@ -324,7 +325,9 @@ class GlueStick(BaseModel):
             losses[prefix + "num_matchable"] = num_pos
             losses[prefix + "num_unmatchable"] = num_neg
             with torch.no_grad():
-                losses[prefix + "sinkhorn_norm"] = la.exp()[:, :-1].sum(2).mean(1)
+                es = pred.get("_" + prefix + "log_assignment_expsum")       # accumulated while the matrix was written
+                losses[prefix + "sinkhorn_norm"] = (es / (la.shape[1] - 1) if es is not None
+                                                    else la.exp()[:, :-1].sum(2).mean(1))
             losses[prefix + "bin_score"] = bin_score[None]
         return losses
 

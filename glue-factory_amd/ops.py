@@ -1073,6 +1073,28 @@ class _AssignWrite(torch.autograd.Function):
         # Dense upstream gradient: only reached when somebody differentiates through the
         # materialised matrix (never in the training step, whose loss heads are sparse).
         a, b = ctx.saved_tensors
+        sp = _known_sparse(G)
+        if sp is not None:
+            # the upstream node was the NLL of the matrix itself (GlueStick's point head): G holds one positive per row at
+            # most plus the dustbin row / column, so the two products are a row gather and a row scatter -- O((M + N) D)
+            # instead of two [M, N] x [N, D] products, a cast pass and two reductions over the dense gradient
+            idx, vpos, n0, n1 = sp
+            d = ctx.dts
+            wv = (ctx.alpha * vpos)[..., None]
+            da = db = grow = gcol = None
+            if ctx.needs_input_grad[0]:
+                da = (wv * b.gather(1, idx[..., None].expand(-1, -1, b.shape[2])).float()).to(a.dtype)
+            if ctx.needs_input_grad[1]:
+                db = torch.zeros(b.shape, dtype=torch.float32, device=b.device).scatter_add_(
+                    1, idx[..., None].expand(-1, -1, a.shape[2]), wv * a.float()).to(b.dtype)
+            if ctx.needs_input_grad[2]:
+                grow = vpos.to(d[0])
+            if ctx.needs_input_grad[3]:
+                gcol = torch.zeros((b.shape[0], b.shape[1]), dtype=torch.float32, device=b.device).scatter_add_(1, idx, vpos).to(d[1])
+            gcorner = None
+            if ctx.corner_shape is not None:
+                gcorner = G[:, -1, -1].sum() if len(ctx.corner_shape) == 0 else G[:, -1, -1].reshape(ctx.corner_shape)
+            return (da, db, grow, gcol, n0.to(d[2]), n1.to(d[3]), None, gcorner, None)
         core = G[:, :-1, :-1]
         g = core.to(a.dtype, memory_format=torch.contiguous_format)      # ONE pass over the dense gradient; alpha rides in the products
         da = bgemm(g, b, alpha=ctx.alpha) if ctx.needs_input_grad[0] else None
@@ -1612,6 +1634,15 @@ def _known_sums(G):
     return None
 
 
+def _known_sparse(G):
+    """(col index of each row's positive, its gradient value (0 where none), dustbin-column values, dustbin-row values) when
+    G is the gradient _NllTerms just wrote (so: nothing else anywhere), else None."""
+    hit = _SPARSE_SUMS.pop(G.data_ptr(), None)
+    if hit is not None and hit[0]() is G and hit[3][0].shape == (G.shape[0], G.shape[1] - 1):
+        return hit[3]
+    return None
+
+
 class _NllTerms(torch.autograd.Function):
     """(sum over the positives of la[b, i, col0[b, i]], sum over the unmatched rows / columns of their dustbin entries) of a
     log assignment la [B, M+1, N+1] (superglue.py:322-352, gluestick.py:378-414).  The gradient is written ONCE: one fill of
@@ -1643,7 +1674,7 @@ class _NllTerms(torch.autograd.Function):
         gr = torch.cat([vpos + n0, n1.sum(1, keepdim=True)], 1)
         gc = torch.cat([n1, n0.sum(1, keepdim=True)], 1).scatter_add_(1, idx.squeeze(-1), vpos)
         _SPARSE_SUMS.clear()
-        _SPARSE_SUMS[G.data_ptr()] = (weakref.ref(G), gr, gc)
+        _SPARSE_SUMS[G.data_ptr()] = (weakref.ref(G), gr, gc, (idx.squeeze(-1), vpos, n0, n1))
         return G, None, None, None
 
 
