@@ -8,7 +8,6 @@ reference's LightGlue train step on the GPU box's host cores (``"kind": "referen
 
     python oracle/build_ref.py        # needs /root/reference (build container); no-op message otherwise
 """
-import importlib
 import importlib.util
 import os
 import py_compile
@@ -26,25 +25,55 @@ TARGETS = ["gluefactory.models.matchers.lightglue", "gluefactory.models.utils.lo
            "gluefactory.models.utils.metrics", "gluefactory.models.base_model", "gluefactory.models"]
 
 
+def _closure(targets):
+    """Files under /root/reference that the target modules import, found by reading their import statements (ast): the
+    reference is NOT imported or executed by the build."""
+    import ast
+
+    def mod_file(mod):
+        base = os.path.join(REF, *mod.split("."))
+        for cand in (base + ".py", os.path.join(base, "__init__.py")):
+            if os.path.isfile(cand):
+                return cand
+        return None
+
+    def packages(mod):                     # importing a.b.c executes a/__init__ and a/b/__init__ first
+        parts = mod.split(".")
+        return [".".join(parts[:i]) for i in range(1, len(parts))]
+
+    seen, todo = {}, list(targets)
+    while todo:
+        mod = todo.pop()
+        f = mod_file(mod)
+        if f is None or f in seen.values():
+            continue
+        seen[mod] = f
+        todo += packages(mod)
+        pkg = mod if f.endswith("__init__.py") else mod.rpartition(".")[0]
+        with open(f) as fh:
+            tree = ast.parse(fh.read(), f)
+        for node in ast.walk(tree):
+            if isinstance(node, ast.Import):
+                todo += [a.name for a in node.names if a.name.split(".")[0] == "gluefactory"]
+            elif isinstance(node, ast.ImportFrom):
+                if node.level:
+                    up = pkg.split(".")[:len(pkg.split(".")) - (node.level - 1)]
+                    base = ".".join(up + ([node.module] if node.module else []))
+                else:
+                    base = node.module or ""
+                if base.split(".")[0] != "gluefactory":
+                    continue
+                todo.append(base)
+                todo += [base + "." + a.name for a in node.names]      # `from pkg import submodule`
+    return sorted(set(seen.values()))
+
+
 def build(verbose=True):
     if not os.path.isdir(os.path.join(REF, "gluefactory")):
         if verbose:
             print("oracle/build_ref.py: /root/reference not present; keeping the prebuilt oracle/_ref (if any)")
         return False
-    saved_path, saved_mods = list(sys.path), set(sys.modules)
-    sys.path[:0] = [STUBS]
-    sys.path.append(REF)
-    try:
-        for t in TARGETS:
-            importlib.import_module(t)
-        files = sorted({os.path.abspath(m.__file__) for m in list(sys.modules.values())
-                        if getattr(m, "__file__", None) and os.path.abspath(m.__file__).startswith(REF + os.sep)
-                        and m.__file__.endswith(".py")})
-    finally:
-        sys.path[:] = saved_path
-        for k in set(sys.modules) - saved_mods:     # leave no reference module behind in this interpreter
-            if k.split(".")[0] in ("gluefactory", "gluefactory_nonfree", "omegaconf", "kornia"):
-                del sys.modules[k]
+    files = _closure(TARGETS)
     shutil.rmtree(OUT, ignore_errors=True)
     for src in files:
         rel = os.path.relpath(src, REF)
