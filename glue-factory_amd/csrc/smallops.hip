@@ -30,8 +30,9 @@ struct CastEntry {            // one parameter (or one row block of a DERIVED we
     int ldt;                  // leading dimension of dst_t (rows of the WHOLE output when this is one block of it)
     int flags;                // bit 0: dst is fp32 whatever the launch's dtype (biases stay fp32 for the GEMM epilogues)
     int pad_;
+    const int* cperm;         // dst column c reads src column cperm[c] (NULL: c)
 };
-static_assert(sizeof(CastEntry) == 72, "host table layout (ops.precast)");
+static_assert(sizeof(CastEntry) == 80, "host table layout (ops.precast)");
 
 template <typename T>
 __global__ __launch_bounds__(256) void multi_cast_transpose_kernel(const CastEntry* __restrict__ tab, int n) {
@@ -53,8 +54,8 @@ __global__ __launch_bounds__(256) void multi_cast_transpose_kernel(const CastEnt
         const int r = r0 + ty + 8 * i, c = c0 + tx;
         float v = 0.f;
         if (r < e.rows && c < e.cols) {
-            const int sr = e.perm ? e.perm[r] : r;
-            v = e.src[(size_t)sr * e.cols + c] * e.scale;
+            const int sr = e.perm ? e.perm[r] : r, sc = e.cperm ? e.cperm[c] : c;
+            v = e.src[(size_t)sr * e.cols + sc] * e.scale;
             if (e.rscale) v *= e.rscale[r];
             if (e.dst) {
                 if (e.flags & 1) dst32[(size_t)r * e.cols + c] = v;
@@ -73,17 +74,17 @@ __global__ __launch_bounds__(256) void multi_cast_transpose_kernel(const CastEnt
     }
 }
 
-// gradient of a derived-weight row block back to its source parameter: out[perm[r]][c] = g[r][c] * rscale[r] * scale
-// (perm a bijection onto the source rows: a scatter without accumulation)
+// gradient of a derived-weight row block back to its source parameter: out[perm[r]][cperm[c]] = g[r][c] * rscale[r] * scale
+// (perm / cperm bijections onto the source rows / columns: a scatter without accumulation)
 __global__ __launch_bounds__(256) void weight_grad_map_kernel(const float* __restrict__ g, float* __restrict__ out,
-                                                              const int* __restrict__ perm, const float* __restrict__ rscale,
-                                                              float scale, int rows, int cols) {
+                                                              const int* __restrict__ perm, const int* __restrict__ cperm,
+                                                              const float* __restrict__ rscale, float scale, int rows, int cols) {
     const size_t total = (size_t)rows * cols;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int r = (int)(i / cols), c = (int)(i - (size_t)r * cols);
         float v = g[i] * scale;
         if (rscale) v *= rscale[r];
-        out[(size_t)(perm ? perm[r] : r) * cols + c] = v;
+        out[(size_t)(perm ? perm[r] : r) * cols + (cperm ? cperm[c] : c)] = v;
     }
 }
 
@@ -160,12 +161,12 @@ extern "C" int gf_multi_cast_transpose(const void* table, int n_entries, int tot
 }
 extern "C" int gf_cast_entry_bytes(void) { return (int)sizeof(CastEntry); }
 
-extern "C" int gf_weight_grad_map(const float* g, float* out, const int* perm, const float* rscale, float scale,
-                                  int rows, int cols, void* stream) {
+extern "C" int gf_weight_grad_map(const float* g, float* out, const int* perm, const int* cperm, const float* rscale,
+                                  float scale, int rows, int cols, void* stream) {
     if (rows <= 0 || cols <= 0) return GF_ERR_SHAPE;
     const size_t total = (size_t)rows * cols;
     const int nb = (int)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256);
-    weight_grad_map_kernel<<<dim3(nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(g, out, perm, rscale, scale, rows, cols);
+    weight_grad_map_kernel<<<dim3(nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(g, out, perm, cperm, rscale, scale, rows, cols);
     return (int)hipGetLastError();
 }
 

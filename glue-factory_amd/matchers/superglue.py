@@ -46,6 +46,11 @@ def MLP(channels, do_bn=True):
 
 def _conv_cl(x, conv, rows=None, cols=None):
     """Conv1d(k=1) on channels-last x [..., Cin]; optional gather of output rows / input columns."""
+    pc = getattr(conv, "_pc", None)
+    if pc is not None and rows is None and cols is not None:
+        wd = ops.derived_weight(pc[0], x.dtype, pc[1] + ".w", conv.weight)      # column gather done by the precast launch
+        if wd is not None:
+            return ops.linear(x, wd, conv.bias)
     w = conv.weight.squeeze(-1)
     b = conv.bias
     if rows is not None:
@@ -138,8 +143,11 @@ class MultiHeadedAttention(nn.Module):
         """The stacked (q | k | v) projection in kernel channel order, head_dim^-1/2 log2(e) folded into the q rows, as
         entries of the model's per-step precast launch (ops.precast(derived=...))."""
         qs = ops.attn_premul(self.dim)
+        self.merge._pc = (self._pc[0], name + ".merge") if self._pc is not None else None
         return [(name + ".w", [(p.weight, self._perm, None, qs if i == 0 else 1.0) for i, p in enumerate(self.proj)]),
-                (name + ".b", [(p.bias, self._perm, None, qs if i == 0 else 1.0) for i, p in enumerate(self.proj)])]
+                (name + ".b", [(p.bias, self._perm, None, qs if i == 0 else 1.0) for i, p in enumerate(self.proj)]),
+                # the merge convolution reads the attention output in kernel channel order: its columns gathered
+                (name + ".merge.w", [(self.merge.weight, None, None, 1.0, self._perm)])]
 
     def fused_projection(self, x, chain=None, premul=True):
         """-> (qkv [B', N, 3, H, D], softmax scale the attention op has to use)."""

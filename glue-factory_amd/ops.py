@@ -241,8 +241,8 @@ def precast(params, dtype, key="default", derived=None):
     hipGraph change the values without bumping the version counter (measured: stale bf16 weights in an eval forward
     after fused Adam steps), so skipping it "when nothing moved" is not safe.
 
-    derived: [(name, [(src_param, perm | None, rscale | None, scale), ...]), ...] -- prepared weights built from row blocks
-    of parameters (rows gathered by the int32 vector `perm`, scaled per row by the fp32 vector `rscale` and by the float
+    derived: [(name, [(src_param, perm | None, rscale | None, scale[, cperm]), ...]), ...] -- prepared weights built from row blocks
+    of parameters (rows gathered by the int32 vector `perm` -- columns by `cperm` --, scaled per row by the fp32 vector `rscale` and by the float
     `scale`, in fp32 before the single rounding), written by the SAME launch: matrices in the compute dtype with their
     transposed copy, vectors (biases) in fp32.  derived_weight(key, name) hands them to the linears."""
     params = [p_ for p_ in params if p_.is_cuda and p_.dtype == torch.float32]
@@ -268,11 +268,12 @@ def precast(params, dtype, key="default", derived=None):
         flat32 = torch.empty(sum(al(dsize(bl)) for _, bl in dvec), dtype=torch.float32, device=dev)
         views, tviews, rec, off, toff, tile0 = [], {}, b"", 0, 0, 0
 
-        def entry(src, dst, dst_t, rows, cols, perm=None, rscale=None, scale=1.0, ldt=None, flags=0):
+        def entry(src, dst, dst_t, rows, cols, perm=None, rscale=None, scale=1.0, ldt=None, flags=0, cperm=None):
             nonlocal rec, tile0
             tx = (cols + 31) // 32
-            rec += struct.pack("<QQQiiiiQQfiii", src, dst, dst_t, rows, cols, tile0, tx, 0 if perm is None else perm.data_ptr(),
-                               0 if rscale is None else rscale.data_ptr(), float(scale), rows if ldt is None else ldt, flags, 0)
+            rec += struct.pack("<QQQiiiiQQfiiiQ", src, dst, dst_t, rows, cols, tile0, tx, 0 if perm is None else perm.data_ptr(),
+                               0 if rscale is None else rscale.data_ptr(), float(scale), rows if ldt is None else ldt, flags, 0,
+                               0 if cperm is None else cperm.data_ptr())
             tile0 += tx * ((rows + 31) // 32)
 
         for p_, sz in zip(params, sizes):
@@ -305,20 +306,23 @@ def precast(params, dtype, key="default", derived=None):
                 off32 += al(rows_all)
                 vt, handle = None, v
             r0, meta = 0, []
-            for src, perm, rscale, scale in blocks:
+            for blk in blocks:
+                src, perm, rscale, scale = blk[:4]
+                cperm = blk[4] if len(blk) > 4 else None              # optional column gather (SuperGlue's merge weight)
                 assert src.is_contiguous() and src.dtype == torch.float32 and src.numel() == src.shape[0] * cols
                 rows = src.shape[0]
                 perm = None if perm is None else perm.to(device=dev, dtype=torch.int32).contiguous()
+                cperm = None if cperm is None else cperm.to(device=dev, dtype=torch.int32).contiguous()
                 rscale = None if rscale is None else rscale.to(device=dev, dtype=torch.float32).contiguous()
-                keep += [perm, rscale]
+                keep += [perm, rscale, cperm]
                 esz = v.element_size()
                 entry(src.data_ptr(), v.data_ptr() + r0 * cols * esz, 0 if vt is None else vt.data_ptr() + r0 * vt.element_size(),
-                      rows, cols, perm, rscale, scale, rows_all, 0 if mat else 1)
-                meta.append((r0, rows, perm, rscale, float(scale), tuple(src.shape)))
+                      rows, cols, perm, rscale, scale, rows_all, 0 if mat else 1, cperm)
+                meta.append((r0, rows, perm, rscale, float(scale), tuple(src.shape), cperm))
                 r0 += rows
             dslot[name] = {"view": v, "view_t": vt, "handle": handle, "meta": meta, "cols": cols}
         esz = _lib.load().gf_cast_entry_bytes()
-        assert len(rec) % esz == 0 and esz == 72
+        assert len(rec) % esz == 0 and esz == 80
         table = torch.frombuffer(bytearray(rec), dtype=torch.uint8).to(dev) if rec else None
         slot = {"flat": flat, "flat_t": flat_t, "flat32": flat32, "views": views, "tviews": tviews, "params": params, "table": table,
                 "n": len(rec) // esz, "tiles": tile0, "dkey": dkey, "derived": dslot, "keep": keep}
@@ -356,16 +360,17 @@ class _DerivedWeight(torch.autograd.Function):
         d = ctx.d
         g = g.float().contiguous()
         outs = []
-        for i, (r0, rows, perm, rscale, scale, shape) in enumerate(d["meta"]):
+        for i, (r0, rows, perm, rscale, scale, shape, cperm) in enumerate(d["meta"]):
             if not ctx.needs_input_grad[1 + i]:
                 outs.append(None)
                 continue
             gi = g[r0:r0 + rows]
-            if perm is None and rscale is None and scale == 1.0:
+            if perm is None and rscale is None and scale == 1.0 and cperm is None:
                 outs.append(gi.reshape(shape))
                 continue
             out = torch.empty(shape, dtype=torch.float32, device=g.device)
             _lib.check(_lib.load().gf_weight_grad_map(_p(gi), _p(out), None if perm is None else _p(perm),
+                                                      None if cperm is None else _p(cperm),
                                                       None if rscale is None else _p(rscale), scale, rows, d["cols"], _stream()),
                        "gf_weight_grad_map")
             outs.append(out)

@@ -36,7 +36,7 @@ extern "C" {
 #define GF_ERR_DTYPE (-4)
 
 /* ABI version; bumped on any signature or workspace-size change (2: gf_attn_bwd's delta workspace doubled; 3: line head + gf_bgemm; 4: smallops; 5: gf_attn_bwd_acc). */
-#define GF_AMD_ABI_VERSION 6
+#define GF_AMD_ABI_VERSION 7
 int gf_abi_version(void);
 
 /* ---- multi-head attention over keypoints --------------------------------------------------
@@ -203,21 +203,21 @@ int gf_dense_assign_bwd(const float* raw, const float* r, const float* c, const 
  * gf_multi_cast_transpose: ONE launch converts every fp32 master parameter of a model into the compute dtype and writes
  *   the transposed copy of every matrix (the weight of the input-gradient GEMM dx = dy W).  `table` is a DEVICE array of
  *   n_entries records {const float* src; void* dst; void* dst_t; int rows, cols, tile0, tiles_x; const int* perm;
- *   const float* rscale; float scale; int ldt; int flags; int pad;} (gf_cast_entry_bytes() = 72 each; dst or dst_t may be
+ *   const float* rscale; float scale; int ldt; int flags; int pad; const int* cperm;} (gf_cast_entry_bytes() = 80 each; dst or dst_t may be
  *   NULL), tile0 = running count of the 32 x 32 tiles of the preceding entries, tiles_x = ceil(cols / 32); total_tiles =
- *   the grid.  dst[r][c] = src[perm ? perm[r] : r][c] * (rscale ? rscale[r] : 1) * scale, dst_t[c * ldt + r] the same
+ *   the grid.  dst[r][c] = src[perm ? perm[r] : r][cperm ? cperm[c] : c] * (rscale ? rscale[r] : 1) * scale, dst_t[c * ldt + r] the same
  *   value; flags bit 0: dst is fp32 (biases).  Plain parameters: perm = rscale = NULL, scale = 1, ldt = rows.  DERIVED
  *   weights -- the matcher's prepared projections, e.g. LightGlue's Wqkv with its rows gathered into ({q,k,v}, head,
  *   channel) order and the softmax scale folded into the q rows (lightglue.py:97-128), or the stacked (to_qk | to_v) of the
  *   cross block (:196-221) -- are one entry per row block of the same output.
- * gf_weight_grad_map: the gradient of such a row block back to its parameter: out[perm[r]][c] = g[r][c] rscale[r] scale.
+ * gf_weight_grad_map: the gradient of such a row block back to its parameter: out[perm[r]][cperm[c]] = g[r][c] rscale[r] scale.
  * gf_colsum_f32: out[g, c] = sum_r x[g, r, c] for fp32 x [G, R, C], deterministic (ws: gf_colsum_ws_floats(G, C) floats).
  * gf_small_dw:   dw[o, k] = sum_m dy[m, o] x[m, k], fp32, dy [M, O], x [M, K], K <= 4, O * K <= 256 (the gradient of
  *   lightglue.py:52-65 posenc.Wr); ws: gf_small_dw_ws_floats(O, K) floats. */
 int gf_multi_cast_transpose(const void* table, int n_entries, int total_tiles, int dtype, void* stream);
 int gf_cast_entry_bytes(void);
-int gf_weight_grad_map(const float* g, float* out, const int* perm, const float* rscale, float scale, int rows, int cols,
-                       void* stream);
+int gf_weight_grad_map(const float* g, float* out, const int* perm, const int* cperm, const float* rscale, float scale,
+                       int rows, int cols, void* stream);
 int gf_colsum_f32(const float* x, float* ws, float* out, int G, int R, int C, void* stream);
 int gf_colsum_ws_floats(int G, int C);
 int gf_small_dw(const float* dy, const float* x, float* ws, float* dw, int M, int O, int K, void* stream);

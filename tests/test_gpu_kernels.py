@@ -763,8 +763,10 @@ def test_precast_derived_weights_and_gradient_map():
     other = torch.nn.Parameter(torch.randn(8, 8, device="cuda", generator=g))
     perm = torch.randperm(96, device="cuda", generator=g)
     rs = torch.rand(96, device="cuda", generator=g) + 0.5
+    cperm = torch.randperm(8, device="cuda", generator=g)
     specs = [("q.w", [(wq, perm, rs, 1.0)]), ("q.b", [(bq, perm, rs, 1.0)]),
-             ("cat.w", [(wa, None, None, 0.75), (wb, None, None, 1.0)])]
+             ("cat.w", [(wa, None, None, 0.75), (wb, None, None, 1.0)]),
+             ("colperm.w", [(other, None, None, 1.0, cperm)])]          # column gather (SuperGlue's merge convolution)
     key = "test-derived"
     ops.precast([wq, bq, wa, wb, other], torch.bfloat16, key=key, derived=specs)
     w1 = ops.derived_weight(key, torch.bfloat16, "q.w", wq)
@@ -791,6 +793,11 @@ def test_precast_derived_weights_and_gradient_map():
     torch.testing.assert_close(bq.grad, exp_bq, rtol=1e-6, atol=1e-7)
     torch.testing.assert_close(wa.grad, g2[:24] * 0.75, rtol=1e-6, atol=1e-7)
     assert wb.grad.shape == wb.shape and torch.equal(wb.grad.squeeze(-1), g2[24:])
+    w3 = ops.derived_weight(key, torch.bfloat16, "colperm.w", other)
+    assert torch.equal(ops._lp(w3, torch.bfloat16), other.detach().index_select(1, cperm).to(torch.bfloat16))
+    g3 = torch.randn(8, 8, device="cuda", generator=g)
+    w3.backward(g3)
+    torch.testing.assert_close(other.grad, torch.zeros_like(other).index_add_(1, cperm, g3), rtol=1e-6, atol=1e-7)
     # the launch re-derives from the CURRENT parameter values (optimiser steps do not bump versions under a graph)
     with torch.no_grad():
         wq.mul_(2.0)
