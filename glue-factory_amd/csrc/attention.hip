@@ -699,7 +699,10 @@ __device__ __forceinline__ void dkv_half_tile(f32x16 (&dk)[2], f32x16 (&dv)[2], 
     }
 }
 
-template <int NW, bool PRE>   // NW waves per workgroup (32 keys each) share the Q/dO stream; PRE: rr == 1, no multiply per score
+// NW waves per workgroup (32 keys each) share the Q/dO stream; PRE: rr == 1, no multiply per score; EVEN: Nq % 64 == 0 -- no
+// ragged tile: unconditional re-fetching DMA (tiles past the end fetch the last one again), constant wait counts, no
+// row masking: no tile-dependent branch in the loop (attention_fwd3.hip)
+template <int NW, bool PRE, bool EVEN>
 __global__ __launch_bounds__(64 * NW, 8 / NW) void attn_bwd_dkv_bf16_kernel(AttnParams p) {
     constexpr int KPB = 32 * NW, PPW = 8 / NW;    // keys per block, 1-KiB DMA pieces per wave and matrix
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -749,7 +752,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void attn_bwd_dkv_bf16_kernel(Attn
     auto issue_part = [&](int part, int t, int stage) {
         char* sb = smem + stage * DKV_STAGE;
         const int q0 = t * 64;
-        if (q0 + 64 <= p.Nq) {
+        if (EVEN || q0 + 64 <= p.Nq) {
 #pragma unroll
             for (int i = 0; i < PPW; ++i) {
                 if (part == 0) dma16(gq[i] + t * qstep, sb + (PPW * wave + i) * 1024);
@@ -763,13 +766,14 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void attn_bwd_dkv_bf16_kernel(Attn
                 else dma16(dop + r * p.sdon + dcol[i], sb + FT_TILE + (PPW * wave + i) * 1024);
             }
         }
-        if (part == 0 && stat_wave) dma4(statp + min(q0 + srow, p.Nq - 1), sb + DKV_STATS + wave * 256);
+        if (part == 0 && stat_wave) dma4(statp + (EVEN ? q0 + srow : min(q0 + srow, p.Nq - 1)), sb + DKV_STATS + wave * 256);
     };
     auto issue_tile = [&](int t, int stage) { issue_part(0, t, stage); issue_part(1, t, stage); };
 
     const int nt = (p.Nq + 63) / 64;
     issue_tile(0, 0);
-    if (nt > 1) issue_tile(1, 1);
+    if (EVEN) issue_tile(min(1, nt - 1), 1);
+    else if (nt > 1) issue_tile(1, 1);
 
     const float p2 = p.p2, c = PRE ? 1.f : p.rr;                   // c: the non-power-of-two rest rr of scale * log2(e)
     bf16x8 kf[4], vf[4];
@@ -804,7 +808,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void attn_bwd_dkv_bf16_kernel(Attn
 
     int stage = 0;
     for (int t = 0; t < nt; ++t) {
-        if (t + 1 >= nt) wait_vm<0>();                            // tile t landed (this wave's share)
+        if (!EVEN && t + 1 >= nt) wait_vm<0>();                   // tile t landed (this wave's share)
         else if (stat_wave) wait_vm<2 * PPW + 1>();
         else wait_vm<2 * PPW>();
         __builtin_amdgcn_s_barrier();                             // ... everyone's; stage of tile t-1 is free
@@ -813,15 +817,17 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void attn_bwd_dkv_bf16_kernel(Attn
         unsigned aR[4], aT[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) { aR[i] = bR[i] + so; aT[i] = bT[i] + so; }
-        const int nvalid = p.Nq - t * 64;
+        const int nvalid = EVEN ? 64 : p.Nq - t * 64;
         const int nstage = stage == 0 ? 2 : stage - 1;
-        const bool more = t + 2 < nt;
+        const bool more = EVEN || t + 2 < nt;
+        const int tn = EVEN ? min(t + 2, nt - 1) : t + 2;
         dkv_half_tile<0, PRE>(dk, dv, kf, vf, aR, aT, bS + so, c, hi, nvalid,
-                         [&] { if (more) issue_part(0, t + 2, nstage); });
+                         [&] { if (more) issue_part(0, tn, nstage); });
         dkv_half_tile<1, PRE>(dk, dv, kf, vf, aR, aT, bS + so, c, hi, nvalid,
-                         [&] { if (more) issue_part(1, t + 2, nstage); });
+                         [&] { if (more) issue_part(1, tn, nstage); });
         stage = stage == 2 ? 0 : stage + 1;
     }
+    if (EVEN) wait_vm<0>();                                       // the re-fetched tail tiles
     if (krow < p.Nk) {
         bf16_t* dkp = reinterpret_cast<bf16_t*>(p.dk) + b * p.sdkb + h * p.sdkh + (int64_t)krow * p.sdkn;
         bf16_t* dvp = reinterpret_cast<bf16_t*>(p.dv) + b * p.sdvb + h * p.sdvh + (int64_t)krow * p.sdvn;
@@ -1264,10 +1270,15 @@ template <typename T> int launch_bwd(const AttnParams& p, hipStream_t st) {
 #endif
         total = ((p.Nk + 32 * NW - 1) / (32 * NW)) * p.H * p.B;
         lds = DKV_NSTAGE * DKV_STAGE;
-        if (int e = set_lds(attn_bwd_dkv_bf16_kernel<NW, false>, lds)) return e;
-        if (int e = set_lds(attn_bwd_dkv_bf16_kernel<NW, true>, lds)) return e;
-        if (p.rr == 1.f) attn_bwd_dkv_bf16_kernel<NW, true><<<dim3(total), dim3(64 * NW), lds, st>>>(p);
-        else attn_bwd_dkv_bf16_kernel<NW, false><<<dim3(total), dim3(64 * NW), lds, st>>>(p);
+        void (*const kern[4])(AttnParams) = {attn_bwd_dkv_bf16_kernel<NW, false, false>, attn_bwd_dkv_bf16_kernel<NW, false, true>,
+                                             attn_bwd_dkv_bf16_kernel<NW, true, false>, attn_bwd_dkv_bf16_kernel<NW, true, true>};
+        static bool attr_set = false;               // (one process per GPU: the attribute is set once)
+        if (!attr_set) {
+            for (auto k : kern)
+                if (int e = set_lds(k, lds)) return e;
+            attr_set = true;
+        }
+        kern[(p.rr == 1.f ? 2 : 0) + (p.Nq % 64 == 0 ? 1 : 0)]<<<dim3(total), dim3(64 * NW), lds, st>>>(p);
         return (int)hipGetLastError();
     }
     lds = dkv_lds<T, 64>();
