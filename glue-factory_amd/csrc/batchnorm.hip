@@ -42,22 +42,36 @@ __global__ __launch_bounds__(256) void bn_colsum_kernel(const T* __restrict__ x,
         }
     }
     if (rl < rows_per_iter) {
-        for (int64_t r = (int64_t)blockIdx.x * rows_per_iter + rl; r < M; r += (int64_t)gridDim.x * rows_per_iter) {
-            union { u32x4 u; T e[VEC]; } v, d;
-            v.u = *reinterpret_cast<const u32x4*>(x + r * C + cc * VEC);
-            if (MODE == 1) d.u = *reinterpret_cast<const u32x4*>(dy + r * C + cc * VEC);
+        // UNR rows of this thread in flight at once: with one 16-byte load per thread and iteration the kernel was latency-
+        // bound at ~2 TB/s (512 workgroups x 4 KB)
+        constexpr int UNR = 4;
+        const int64_t stride = (int64_t)gridDim.x * rows_per_iter;
+        for (int64_t r0 = (int64_t)blockIdx.x * rows_per_iter + rl; r0 < M; r0 += UNR * stride) {
+            union Chunk { u32x4 u; T e[VEC]; };
+            Chunk v[UNR], d[UNR];
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                float xv = to_f32(v.e[e]);
-                if (MODE == 0) {
-                    a0[e] += xv;
-                    a1[e] += xv * xv;
-                } else {
-                    float xh = (xv - mu[e]) * rs[e];
-                    float z = xh * ga[e] + be[e];
-                    float dz = (relu && z <= 0.f) ? 0.f : to_f32(d.e[e]);
-                    a0[e] += dz;
-                    a1[e] += dz * xh;
+            for (int j = 0; j < UNR; ++j) {
+                const int64_t r = r0 + j * stride;
+                const int64_t rc = r < M ? r : r0;                       // (clamped load, masked below)
+                v[j].u = *reinterpret_cast<const u32x4*>(x + rc * C + cc * VEC);
+                if (MODE == 1) d[j].u = *reinterpret_cast<const u32x4*>(dy + rc * C + cc * VEC);
+            }
+#pragma unroll
+            for (int j = 0; j < UNR; ++j) {
+                if (r0 + j * stride >= M) continue;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    float xv = to_f32(v[j].e[e]);
+                    if (MODE == 0) {
+                        a0[e] += xv;
+                        a1[e] += xv * xv;
+                    } else {
+                        float xh = (xv - mu[e]) * rs[e];
+                        float z = xh * ga[e] + be[e];
+                        float dz = (relu && z <= 0.f) ? 0.f : to_f32(d[j].e[e]);
+                        a0[e] += dz;
+                        a1[e] += dz * xh;
+                    }
                 }
             }
         }
