@@ -36,7 +36,7 @@ extern "C" {
 #define GF_ERR_DTYPE (-4)
 
 /* ABI version; bumped on any signature or workspace-size change (2: gf_attn_bwd's delta workspace doubled; 3: line head + gf_bgemm; 4: smallops; 5: gf_attn_bwd_acc). */
-#define GF_AMD_ABI_VERSION 7
+#define GF_AMD_ABI_VERSION 8
 int gf_abi_version(void);
 
 /* ---- multi-head attention over keypoints --------------------------------------------------
@@ -222,6 +222,14 @@ int gf_colsum_f32(const float* x, float* ws, float* out, int G, int R, int C, vo
 int gf_colsum_ws_floats(int G, int C);
 int gf_small_dw(const float* dy, const float* x, float* ws, float* dw, int M, int O, int K, void* stream);
 int gf_small_dw_ws_floats(int O, int K);
+/* gf_multi_adam: the Adam update (torch.optim.Adam semantics, amsgrad = maximize = False; train.py:513) of every parameter
+ * tensor in ceil(n_entries / 80) launches.  `table`: HOST array of n_entries records {float* p; const float* g; float* m;
+ * float* v; long long n; int pad[2];} (gf_adam_entry_bytes() = 48) of DEVICE pointers; it travels by value in the kernel
+ * arguments.  lr, step: device fp32 scalars (step = number of updates done so far; it is incremented here); found_inf (device
+ * fp32, may be NULL) > 0 skips update and count; grad_scale (device fp32 or NULL) divides the gradients. */
+int gf_adam_entry_bytes(void);
+int gf_multi_adam(const void* table, int n_entries, const float* lr, float* step, const float* found_inf,
+                  const float* grad_scale, float beta1, float beta2, float eps, float weight_decay, void* stream);
 
 /* ---- small batched GEMM with arbitrary element strides (csrc/bgemm.hip): C[b,i,j] = alpha sum_k A[b,i,k] B[b,k,j],
  * strides {batch, row, column} of A [M,K], B [K,N], C [M,N]; fp32 operands use the exact-fp32 MFMA.  The products of
