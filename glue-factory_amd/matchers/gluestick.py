@@ -102,11 +102,14 @@ class LineLayer(nn.Module):
     def forward(self, ldesc, line_enc, junc_idx, halves, graph):
         """ldesc [B',N,D], line_enc [B',2Nl,D], junc_idx [B',2Nl], graph = ops.line_graph(junc_idx, N)."""
         order, seg = graph
-        msg = ops.line_gather(ldesc, line_enc.to(ldesc.dtype), junc_idx, order, seg)
+        # ldesc feeds the gather and the residual of the aggregation: one gradient chain (the sum happens in the gather's
+        # segment-sum kernel instead of an autograd add over [B', N, D])
+        chain = ops.GradChain(2) if ldesc.requires_grad and torch.is_grad_enabled() else None
+        msg = ops.line_gather(ldesc, line_enc.to(ldesc.dtype), junc_idx, order, seg, chain=chain)
         upd = _mlp_cl(self.mlp, msg, halves)
         if self.line_attention:
             upd = upd * self._attention(msg, ldesc, junc_idx, graph)[..., None].to(upd.dtype)
-        return ops.line_aggregate(ldesc, upd, junc_idx, order, seg, mean=not self.line_attention)
+        return ops.line_aggregate(ldesc, upd, junc_idx, order, seg, mean=not self.line_attention, chain=chain)
 
 
 class AttentionalGNN(nn.Module):
@@ -255,7 +258,7 @@ class GlueStick(BaseModel):
             ln = cat2(normalize_keypoints(data["lines0"].flatten(1, 2), size0).reshape(b, nl0, 2, 2),
                       normalize_keypoints(data["lines1"].flatten(1, 2), size1).reshape(b, nl1, 2, 2))
             lsc = cat2(data["line_scores0"].float(), data["line_scores1"].float())
-            lenc = [self.lenc(l_, s_, halves) for l_, s_ in zip(ln, lsc)]
+            lenc = [self.lenc(l_, s_, halves).to(T) for l_, s_ in zip(ln, lsc)]     # cast once, not in every line layer
             graphs = [ops.line_graph(ji, x.shape[1]) for ji, x in zip(jidx, xs)]   # shared by all line layers
         inter_desc = {}
         inter = self.gnn.inter_supervision

@@ -1460,7 +1460,7 @@ class _LineGather(torch.autograd.Function):
     """msg [B,E,3D] = [x[idx[e]] | x[idx[e^1]] | enc[e]] (gluestick.py:609-621); backward: deterministic segment sums."""
 
     @staticmethod
-    def forward(ctx, x, enc, idx, order, seg):
+    def forward(ctx, x, enc, idx, order, seg, chain=None):
         _chk(x, enc, idx)
         x, enc, idx = x.contiguous(), enc.contiguous(), idx.contiguous()
         B, N, D = x.shape
@@ -1470,6 +1470,7 @@ class _LineGather(torch.autograd.Function):
                    "gf_line_gather")
         ctx.save_for_backward(order, seg)
         ctx.dims = (B, E, N, D)
+        ctx.chain = chain
         return msg
 
     @staticmethod
@@ -1478,15 +1479,17 @@ class _LineGather(torch.autograd.Function):
         B, E, N, D = ctx.dims
         if not dmsg.is_contiguous():
             dmsg = dmsg.contiguous()
-        dx = _segsum(dmsg[:, :, :D], dmsg[:, :, D:2 * D], order, seg, None, B, E, N, D, 0)
-        return dx, dmsg[:, :, 2 * D:], None, None, None
+        # chain: the residual gradient of the same x (parked by _LineAggregate.backward) is the base of the segment sum
+        base = ctx.chain.take() if ctx.chain is not None else None
+        dx = _segsum(dmsg[:, :, :D], dmsg[:, :, D:2 * D], order, seg, base, B, E, N, D, 0)
+        return dx, dmsg[:, :, 2 * D:], None, None, None, None
 
 
 class _LineAggregate(torch.autograd.Function):
     """x + (mean | sum) over the endpoints on each junction of upd [B,E,D] (gluestick.py:660-700)."""
 
     @staticmethod
-    def forward(ctx, x, upd, idx, order, seg, mean):
+    def forward(ctx, x, upd, idx, order, seg, mean, chain=None):
         _chk(x, upd, idx)
         x, upd = x.contiguous(), upd.contiguous()
         B, N, D = x.shape
@@ -1494,6 +1497,7 @@ class _LineAggregate(torch.autograd.Function):
         out = _segsum(upd, None, order, seg, x, B, E, N, D, 1 if mean else 0)
         ctx.save_for_backward(idx.contiguous(), seg)
         ctx.dims = (B, E, N, D, mean)
+        ctx.chain = chain
         return out
 
     @staticmethod
@@ -1505,15 +1509,20 @@ class _LineAggregate(torch.autograd.Function):
         dupd = torch.empty((B, E, D), dtype=g.dtype, device=g.device)
         _lib.check(_lib.load().gf_line_expand(_p(g), _p(idx), _p(seg), _p(dupd), B, E, N, D, 1 if mean else 0, _dt(g),
                                               _stream()), "gf_line_expand")
-        return g, dupd, None, None, None, None
+        if ctx.chain is not None:                  # x's residual gradient rides in the gather's segment sum (see GradChain)
+            ctx.chain.park(g)
+            g = None
+        return g, dupd, None, None, None, None, None
 
 
-def line_gather(x, enc, idx, order, seg):
-    return _LineGather.apply(x, enc, idx, order, seg)
+def line_gather(x, enc, idx, order, seg, chain=None):
+    """chain: ops.GradChain(2) shared with the line_aggregate of the same x (a LineLayer reads its descriptors twice: the
+    endpoint gather and the residual of the aggregation): the two gradients meet in the gather's segment-sum kernel."""
+    return _LineGather.apply(x, enc, idx, order, seg, chain if x.requires_grad else None)
 
 
-def line_aggregate(x, upd, idx, order, seg, mean=True):
-    return _LineAggregate.apply(x, upd, idx, order, seg, mean)
+def line_aggregate(x, upd, idx, order, seg, mean=True, chain=None):
+    return _LineAggregate.apply(x, upd, idx, order, seg, mean, chain if x.requires_grad else None)
 
 
 # ------------------------------------------------------------------------------ GlueStick line head (dense scores)

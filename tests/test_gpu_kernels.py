@@ -575,6 +575,15 @@ def test_line_message_passing_kernels(dtype, mean):
     sc = xr.grad.abs().max().item()
     torch.testing.assert_close(xc.grad.float().cpu().double() / sc, xr.grad / sc, **tol)
     torch.testing.assert_close(ec.grad.float().cpu().double(), er.grad, **tol)
+    # the same through a gradient chain (LineLayer: the residual gradient of x rides in the gather's segment sum)
+    x2 = xc.detach().clone().requires_grad_(True)
+    chain = ops.GradChain(2)
+    msg2 = ops.line_gather(x2, ec.detach(), ic, order, seg, chain=chain)
+    upd2 = (msg2[..., :D] - 0.5 * msg2[..., D:2 * D] + msg2[..., 2 * D:]) * wt.cuda().to(dtype)
+    out2 = ops.line_aggregate(x2, upd2, ic, order, seg, mean=mean, chain=chain)
+    (out2.float() * gout.cuda()).sum().backward()
+    assert torch.equal(out2, out)
+    torch.testing.assert_close(x2.grad.float().cpu().double() / sc, xr.grad / sc, **tol)
 
 
 @pytest.mark.parametrize("shape", [(2, 128, 128), (3, 200, 333), (1, 64, 1), (2, 2048, 2048)])
