@@ -252,8 +252,9 @@ def precast(params, dtype, key="default", derived=None):
     assert not derived or dtype != torch.float32, "derived weights are a compute-dtype (cast) feature"
     dkey = tuple((name, tuple(id(b_[0]) for b_ in blocks)) for name, blocks in derived)
     slot = _LP_FLAT.get((key, dtype))
+    ptrs = tuple(p_.data_ptr() for p_ in params)          # (`p.data = ...` / module.to() move the storage under the same object)
     if (slot is None or len(slot["params"]) != len(params) or any(a is not b for a, b in zip(slot["params"], params))
-            or slot["dkey"] != dkey):
+            or slot["dkey"] != dkey or slot["ptrs"] != ptrs):
         import struct
         cast = dtype != torch.float32
         dev = params[0].device
@@ -325,7 +326,7 @@ def precast(params, dtype, key="default", derived=None):
         assert len(rec) % esz == 0 and esz == 80
         table = torch.frombuffer(bytearray(rec), dtype=torch.uint8).to(dev) if rec else None
         slot = {"flat": flat, "flat_t": flat_t, "flat32": flat32, "views": views, "tviews": tviews, "params": params, "table": table,
-                "n": len(rec) // esz, "tiles": tile0, "dkey": dkey, "derived": dslot, "keep": keep}
+                "n": len(rec) // esz, "tiles": tile0, "dkey": dkey, "derived": dslot, "keep": keep, "ptrs": ptrs}
         _LP_FLAT[(key, dtype)] = slot
     if slot["table"] is not None:
         _lib.check(_lib.load().gf_multi_cast_transpose(_p(slot["table"]), slot["n"], slot["tiles"], BF16 if dtype == torch.bfloat16 else F32, _stream()),
