@@ -80,3 +80,28 @@ def test_train_step_graph_with_fused_adam_matches_eager():
         assert abs(la - lb) < 5e-3 * max(1.0, abs(la))
     for pa, pb in zip(outs[0][1], outs[1][1]):
         torch.testing.assert_close(pa, pb, rtol=5e-3, atol=5e-4)
+
+
+def test_fused_adam_on_unaligned_flat_gradient_views():
+    """Gradients that are views of one flat buffer at arbitrary element offsets (what train_step.GradBuckets leaves in
+    p.grad on a multi-rank run): the 16-byte path is not usable, the scalar one gives the same numbers."""
+    from glue_factory_amd.optim import FusedAdam
+    g = torch.Generator(device="cuda").manual_seed(9)
+    base = _params(g)
+    a = [torch.nn.Parameter(t.clone()) for t in base]
+    b = [torch.nn.Parameter(t.clone()) for t in base]
+    ref, ours = torch.optim.Adam(a, lr=2e-3), FusedAdam(b, lr=2e-3)
+    flat = torch.empty(sum(t.numel() + 3 for t in base) + 1, device="cuda")
+    for it in range(3):
+        off = 1
+        for pa, pb in zip(a, b):
+            gr = torch.randn(pa.shape, device="cuda", generator=g)
+            view = flat[off:off + gr.numel()].view(gr.shape)
+            view.copy_(gr)
+            pa.grad, pb.grad = gr.clone(), view
+            off += gr.numel() + 3
+        assert any(p.grad.data_ptr() % 16 for p in b)
+        ref.step()
+        ours.step()
+        for i, (pa, pb) in enumerate(zip(a, b)):
+            torch.testing.assert_close(pb, pa, rtol=2e-6, atol=1e-8, msg=lambda m: f"step {it} tensor {i}: {m}")
