@@ -70,3 +70,29 @@ def test_reference_get_model_and_pipeline_construct_the_plugin(ref_path, name):
     # and the reverse direction: ours -> reference
     res = ref.load_state_dict(matcher.state_dict(), strict=True)
     assert not res.missing_keys and not res.unexpected_keys
+
+
+def test_build_ref_closure_is_static_and_complete():
+    """oracle/build_ref.py finds the reference's LightGlue module closure by READING import statements (the build imports
+    and executes no reference module); the byte-compiled tree it produces is importable and complete."""
+    import importlib.util
+    import subprocess
+    import sys
+    if not os.path.isdir("/root/reference/gluefactory"):
+        pytest.skip("reference not present")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from oracle import build_ref
+    before = set(sys.modules)
+    files = build_ref._closure(build_ref.TARGETS)
+    assert not [m for m in set(sys.modules) - before if m.split(".")[0] in ("gluefactory", "gluefactory_nonfree")]
+    rel = {os.path.relpath(f, "/root/reference") for f in files}
+    assert "gluefactory/models/matchers/lightglue.py" in rel and "gluefactory/models/utils/losses.py" in rel
+    assert not any(r.startswith("gluefactory_nonfree") for r in rel)
+    # a fresh interpreter imports the reference's LightGlue from the byte-compiled tree alone
+    if importlib.util.find_spec("torch") is None or not os.path.exists(os.path.join(root, "oracle", "_ref", "MANIFEST.txt")):
+        pytest.skip("oracle/_ref not built")
+    code = ("import sys; sys.path.insert(0, %r); from oracle import build_ref; assert build_ref.import_reference(); "
+            "import gluefactory.models.matchers.lightglue as m; assert m.__file__.endswith('.pyc'); print(m.LightGlue.__name__)" % root)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "LightGlue" in out.stdout, out.stderr[-2000:]
