@@ -16,9 +16,19 @@ IGNORE_FEATURE = -2
 UNMATCHED_FEATURE = -1
 
 
+def inv3x3(H):
+    """Inverse of [..., 3, 3] matrices by the adjugate (cross products of the rows): plain elementwise kernels, so it
+    runs inside a hipGraph capture -- torch.linalg.inv goes through a solver with host-side bookkeeping and does not
+    ("operation not permitted when stream is capturing")."""
+    r0, r1, r2 = H[..., 0, :], H[..., 1, :], H[..., 2, :]
+    c0, c1, c2 = torch.linalg.cross(r1, r2, dim=-1), torch.linalg.cross(r2, r0, dim=-1), torch.linalg.cross(r0, r1, dim=-1)
+    det = (r0 * c0).sum(-1, keepdim=True)
+    return torch.stack([c0, c1, c2], -1) / det[..., None]
+
+
 def warp_points(points, H, inverse=False, eps=1e-5):
     """points [B,N,2], H [B,3,3] (or [3,3]) -> H (or H^-1) applied in homogeneous coords."""
-    Hm = torch.linalg.inv(H) if inverse else H
+    Hm = inv3x3(H) if inverse else H
     if Hm.dim() == 2:
         Hm = Hm[None]
     ones = torch.ones_like(points[..., :1])
