@@ -1272,11 +1272,13 @@ template <typename T> int launch_bwd(const AttnParams& p, hipStream_t st) {
         lds = DKV_NSTAGE * DKV_STAGE;
         void (*const kern[4])(AttnParams) = {attn_bwd_dkv_bf16_kernel<NW, false, false>, attn_bwd_dkv_bf16_kernel<NW, false, true>,
                                              attn_bwd_dkv_bf16_kernel<NW, true, false>, attn_bwd_dkv_bf16_kernel<NW, true, true>};
-        static bool attr_set = false;               // (one process per GPU: the attribute is set once)
-        if (!attr_set) {
+        static unsigned long long attr_set = 0;     // function attributes are per DEVICE: one bit per device ordinal
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev >= 64 || !((attr_set >> dev) & 1ull)) {
             for (auto k : kern)
                 if (int e = set_lds(k, lds)) return e;
-            attr_set = true;
+            if (dev < 64) attr_set |= 1ull << dev;
         }
         kern[(p.rr == 1.f ? 2 : 0) + (p.Nq % 64 == 0 ? 1 : 0)]<<<dim3(total), dim3(64 * NW), lds, st>>>(p);
         return (int)hipGetLastError();

@@ -45,7 +45,8 @@ __global__ void pair_scores_bwd_kernel(const float* __restrict__ S, const float*
     const size_t o = ((size_t)b * 2 * M + 2 * a) * 2 * N + 2 * c;
     const f32x2 top = *reinterpret_cast<const f32x2*>(S + o), bot = *reinterpret_cast<const f32x2*>(S + o + 2 * N);
     const float g = 0.5f * draw[((size_t)b * M + a) * N + c];
-    const bool straight = top[0] + bot[1] >= top[1] + bot[0];      // torch.maximum sends the gradient to the first on ties
+    const bool straight = top[0] + bot[1] >= top[1] + bot[0];      // ties: torch.maximum splits the gradient evenly; exact ties only arise
+                                                                   // from duplicate endpoints, where both pairings sum to the same junction gradients
     const f32x2 dt = {straight ? g : 0.f, straight ? 0.f : g}, db = {straight ? 0.f : g, straight ? g : 0.f};
     *reinterpret_cast<f32x2*>(dS + o) = dt;
     *reinterpret_cast<f32x2*>(dS + o + 2 * N) = db;

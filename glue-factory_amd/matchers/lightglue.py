@@ -270,6 +270,33 @@ class TokenConfidence(nn.Module):
         return torch.sigmoid(self.logits(desc0)), torch.sigmoid(self.logits(desc1))
 
 
+class _RefDescriptors(torch.autograd.Function):
+    """The public ``ref_descriptors0/1`` [B, L, N, C] of a training forward as VIEWS of the per-layer buffer the layers'
+    last GEMMs wrote (no stack of L copies), differentiable w.r.t. the batch-stacked layer outputs: a loss built from
+    them by somebody else (a pred dict that went through the reference's stack / unstack helpers,
+    gluefactory/utils/misc.py:31-46, or a filtered copy) trains the model exactly like the fused loss does.  The
+    backward only runs in that case."""
+
+    @staticmethod
+    def forward(ctx, holder, b, *layer_x):
+        ctx.b = b
+        d = holder[0].detach()
+        return d[:, :b].transpose(0, 1), d[:, b:].transpose(0, 1)
+
+    @staticmethod
+    def backward(ctx, g0, g1):
+        n_layers = (g0 if g0 is not None else g1).shape[1]
+        out = []
+        for i in range(n_layers):
+            a = g0[:, i] if g0 is not None else torch.zeros_like(g1[:, i])
+            c = g1[:, i] if g1 is not None else torch.zeros_like(g0[:, i])
+            out.append(torch.cat([a, c], 0))
+        return (None, None, *out)
+
+
+_PRIVATE = "_gf_private"       # attribute of the returned log_assignment TENSOR that carries the fused loss's state
+
+
 class LightGlue(nn.Module):
     default_conf = {
         "name": "lightglue",
@@ -432,19 +459,23 @@ class LightGlue(nn.Module):
         am = MatchAssignment.argmaxes(head)
         m0, m1, ms0, ms1 = ops.filter_matches(am["max0"], am["arg0"], am["arg1"], conf.filter_threshold)
         if stacked and self.training:
-            # ref_descriptors are detached in this mode: the loss differentiates through the private
-            # stacked list below (identical values), which keeps every gradient batch-stacked.
             if lbuf is not None:
-                rd0, rd1 = lbuf.detach()[:, :b].transpose(0, 1), lbuf.detach()[:, b:].transpose(0, 1)   # [B, L, N, C] views
+                if grad and layer_x[0].requires_grad:
+                    rd0, rd1 = _RefDescriptors.apply([lbuf], b, *layer_x)           # [B, L, N, C] views, differentiable
+                else:
+                    rd0, rd1 = lbuf.detach()[:, :b].transpose(0, 1), lbuf.detach()[:, b:].transpose(0, 1)
             else:
-                rd0, rd1 = torch.stack(all0, 1), torch.stack(all1, 1)
-            extra = {"_layer_desc": layer_x, "_final_head": head, "_row_norm": expsum / (scores.shape[1] - 1),
-                     "_layer_chain": chains[1:] + [None]}        # chain of layer_x[i] = the one entering layer i + 1
+                rd0, rd1 = torch.stack([x_[:b] for x_ in layer_x], 1), torch.stack([x_[b:] for x_ in layer_x], 1)
+            # State of the fused loss (batch-stacked layer outputs, the last head's statistics, the gradient chains).  It is
+            # NOT part of the pred dict -- the reference's pipelines slice / concatenate every entry of it along the batch
+            # axis (triplet_pipeline.py:62-71), which only tensors survive -- but rides on the log_assignment tensor OBJECT:
+            # loss() takes the fused path when it is handed that very tensor, and the reference's dense formulation on the
+            # (differentiable) ref_descriptors otherwise.
+            setattr(scores, _PRIVATE, {"layer_desc": layer_x, "final_head": head, "row_norm": expsum / (scores.shape[1] - 1),
+                                       "layer_chain": chains[1:] + [None]})  # chain of layer_x[i] = the one entering layer i + 1
         else:
             rd0, rd1 = torch.stack(all0, 1), torch.stack(all1, 1)
-            extra = {}
         return {
-            **extra,
             "matches0": m0, "matches1": m1,
             "matching_scores0": ms0, "matching_scores1": ms1,
             "ref_descriptors0": rd0, "ref_descriptors1": rd1,
@@ -584,10 +615,10 @@ class LightGlue(nn.Module):
             cache[key] = torch.tensor(w, device=device, dtype=torch.float32)
         return cache[key]
 
-    def _loss_fused(self, pred, data, gt):
+    def _loss_fused(self, pred, priv, data, gt):
         """Training loss on the batch-stacked per-layer descriptors: one fused HIP node per layer
         (ops.lg_layer_loss) and a handful of [L,B] tensor ops for the whole step."""
-        layer_x = pred["_layer_desc"]
+        layer_x = priv["layer_desc"]
         L = len(layer_x)
         b = pred["ref_descriptors0"].shape[0]
         n = layer_x[0].shape[1]
@@ -596,12 +627,12 @@ class LightGlue(nn.Module):
         for i in range(L):
             x = layer_x[i]
             la = self.log_assignment[i]
-            fh = pred.get("_final_head") if i == L - 1 else None
+            fh = priv["final_head"] if i == L - 1 else None
             if fh is not None:           # the forward pass already projected the last layer
                 md, z, rc = fh["md"], fh["z"], (fh["r"], fh["c"])
             else:
                 # the gradients of x from these two heads ride in the next block's chain (GEMM / row-dot epilogues)
-                ch = pred["_layer_chain"][i] if "_layer_chain" in pred else None
+                ch = priv["layer_chain"][i]
                 w, bias = la.scaled_proj(x.dtype)
                 md = ops.linear(x, w, bias, chain=ch, chain_last="extra")
                 z = ops.rowdot(x, la.matchability.weight, la.matchability.bias, chain=ch, counted=False)
@@ -624,35 +655,29 @@ class LightGlue(nn.Module):
         else:
             losses["confidence"] = torch.zeros_like(total)
         with torch.no_grad():
-            rn = pred.get("_row_norm")
-            losses["row_norm"] = rn if rn is not None else pred["log_assignment"].exp()[:, :-1].sum(2).mean(1)
+            losses["row_norm"] = priv["row_norm"]
         losses["total"] = losses["total"] + losses["confidence"]
         return losses, {}
 
     def _loss(self, pred, data):
         rd0, rd1 = pred["ref_descriptors0"], pred["ref_descriptors1"]
         L = rd0.shape[1]
-        layer_x = pred.get("_layer_desc")
-        if layer_x is not None and self.training and "_final_argmax0" in pred:
-            return self._loss_fused(pred, data, self._gt_sparse(data, fixed=True))
-        if (layer_x is None and self.training and torch.is_grad_enabled() and not rd0.requires_grad
-                and any(p.requires_grad for p in self.parameters())):
-            # the stacked training forward hands out DETACHED ref_descriptors next to the private differentiable list:
-            # a pred dict that was rebuilt / filtered without it would train on constants without any error
-            raise RuntimeError("LightGlue.loss: training-mode pred has detached ref_descriptors and no '_layer_desc' "
-                               "(pass the dict returned by forward unchanged, or keep its private keys)")
+        priv = getattr(pred["log_assignment"], _PRIVATE, None)
+        if priv is not None and self.training and "_final_argmax0" in pred and not priv.get("used"):
+            # the tensors forward() returned, untouched: one fused node per layer.  (Once: the gradient chains of the step
+            # are single-use; a second loss() on the same pred takes the dense formulation below.)
+            priv["used"] = True
+            return self._loss_fused(pred, priv, data, self._gt_sparse(data, fixed=True))
+        # anything else -- eval mode, a pred dict that was sliced / concatenated / rebuilt by the caller (the reference's
+        # TripletPipeline does both), different keypoint counts: the reference's own formulation on ref_descriptors
         gt = self._gt_sparse(data)
 
         def head(i):
             # i = -1 is the LAST assignment module on the LAST stored descriptors, as the reference's
             # loss_params(pred, -1) (lightglue.py:579-590): in eval mode only one layer is stored (L == 1).
-            if layer_x is not None:
-                return self.log_assignment[i].stats_stacked(layer_x[i], rd0.shape[0])
             return self.log_assignment[i].stats(rd0[:, i], rd1[:, i])
 
         def conf_inputs(i):
-            if layer_x is not None:
-                return layer_x[i][:rd0.shape[0]], layer_x[i][rd0.shape[0]:]
             return rd0[:, i], rd1[:, i]
 
         nll, stats = self._nll(head(-1), gt)

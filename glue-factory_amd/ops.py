@@ -1644,7 +1644,8 @@ _SPARSE_SUMS = {}        # data_ptr of the dense gradient _NllTerms just wrote -
 
 def _known_sums(G):
     hit = _SPARSE_SUMS.pop(G.data_ptr(), None)
-    if hit is not None and hit[0]() is G and hit[1].shape == G.shape[:2] and hit[2].shape == (G.shape[0], G.shape[2]):
+    if (hit is not None and hit[0]() is G and hit[4] == G._version and hit[1].shape == G.shape[:2]
+            and hit[2].shape == (G.shape[0], G.shape[2])):
         return hit[1].contiguous(), hit[2].contiguous()
     return None
 
@@ -1653,7 +1654,7 @@ def _known_sparse(G):
     """(col index of each row's positive, its gradient value (0 where none), dustbin-column values, dustbin-row values) when
     G is the gradient _NllTerms just wrote (so: nothing else anywhere), else None."""
     hit = _SPARSE_SUMS.pop(G.data_ptr(), None)
-    if hit is not None and hit[0]() is G and hit[3][0].shape == (G.shape[0], G.shape[1] - 1):
+    if hit is not None and hit[0]() is G and hit[4] == G._version and hit[3][0].shape == (G.shape[0], G.shape[1] - 1):
         return hit[3]
     return None
 
@@ -1689,7 +1690,9 @@ class _NllTerms(torch.autograd.Function):
         gr = torch.cat([vpos + n0, n1.sum(1, keepdim=True)], 1)
         gc = torch.cat([n1, n0.sum(1, keepdim=True)], 1).scatter_add_(1, idx.squeeze(-1), vpos)
         _SPARSE_SUMS.clear()
-        _SPARSE_SUMS[G.data_ptr()] = (weakref.ref(G), gr, gc, (idx.squeeze(-1), vpos, n0, n1))
+        # G._version: autograd's input buffer ACCUMULATES a second gradient of the same tensor in place (version bump) --
+        # the sparse description would then be incomplete, and the consumers fall back to the dense tensor
+        _SPARSE_SUMS[G.data_ptr()] = (weakref.ref(G), gr, gc, (idx.squeeze(-1), vpos, n0, n1), G._version)
         return G, None, None, None
 
 

@@ -220,6 +220,9 @@ class TrainStep:
             self._capture(data, sig)
         _, g, static_in, static_out = self._g
         _copy_into(static_in, data)
+        sync_lr = getattr(self.optimizer, "sync_lr", None)
+        if sync_lr is not None:     # the reference steps its lr scheduler every iteration (train.py:517): the captured Adam
+            sync_lr()               # reads a DEVICE scalar, refreshed here (a fill kernel in front of the replay, only on change)
         g.replay()
         from . import ops as _ops       # parameters changed behind the precast cache's back (no version bump)
         _ops.invalidate_precast()

@@ -4,7 +4,8 @@ TEST / BENCH INFRASTRUCTURE ONLY.  The reference is Python, so "building" it mea
 closure of ``gluefactory.models.matchers.lightglue`` from the sources WHERE THEY LIE under /root/reference into ``oracle/_ref/**.pyc`` -- outputs only; no
 reference source is copied into the repository, and ``oracle/_ref/`` is git-ignored (it travels to the GPU box with
 the snapshot, like the built libgf_amd.so).  Consumers: ``bench.py``'s ``cpu_baseline`` leg, which times the
-reference's LightGlue train step on the GPU box's host cores (``"kind": "reference"``), and nothing else.
+reference's LightGlue train step on the GPU box's host cores (``"kind": "reference"``), and tests/test_gpu_reference_boundary.py,
+where the reference's own TwoViewPipeline / TripletPipeline drive the HIP matchers on the GPU box.
 
     python oracle/build_ref.py        # needs /root/reference (build container); no-op message otherwise
 """
@@ -22,7 +23,10 @@ STUBS = os.path.join(HERE, "stubs")          # omegaconf / kornia stand-ins (our
 # its own non-commercial licence -- is NOT bundled; SuperGlue / GlueStick goldens come from oracle/gen_golden.py, which
 # imports the reference in place.)
 TARGETS = ["gluefactory.models.matchers.lightglue", "gluefactory.models.utils.losses",
-           "gluefactory.models.utils.metrics", "gluefactory.models.base_model", "gluefactory.models"]
+           "gluefactory.models.utils.metrics", "gluefactory.models.base_model", "gluefactory.models",
+           # the CALLERS of the plugin boundary (two_view_pipeline.py:70-113, triplet_pipeline.py:23-99): the GPU tests drive
+           # the HIP matchers through the reference's own pipeline code (tests/test_gpu_reference_boundary.py)
+           "gluefactory.models.two_view_pipeline", "gluefactory.models.triplet_pipeline"]
 
 
 def _closure(targets):

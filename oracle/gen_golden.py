@@ -296,14 +296,20 @@ def _data_checksum(data):
     return np.array([float(sum(v.double().abs().sum() for v in data.values() if torch.is_tensor(v) and v.is_floating_point()))])
 
 
-def gen_lightglue_config(name, batch, n, n_layers, seed, size, stride=61):
+def gen_lightglue_config(name, batch, n, n_layers, seed, size, stride=61, sharp=None):
     """Compact golden of a BASELINE.json configuration run through the REFERENCE LightGlue itself (config 1:
     B=4, N=512, L=4; config 2 shape at B=1: N=2048, L=9).  Inputs and weights are regenerated from the seed by
     the test (checksums stored); stored are every loss entry, the eval-mode matcher metrics, the match
     vectors, a strided sample of the (N+1)^2 log-assignment plus its row sums, and the gradient norm of every
-    parameter (full gradients for the small tensors)."""
-    params = lgo.init_params(n_layers, 256, 4, seed=seed)
-    data = make_pairs(batch, n, dim=256, size=size, seed=seed + 1)
+    parameter (full gradients for the small tensors).
+    sharp=(damp, sharp, noise): the decisive case of lgo.sharp_case instead (every row / column arg-max of the reference's
+    own output is separated from the runner-up by the stored margin, so the tests compare matches0/1 bit for bit on
+    100 % of the rows)."""
+    if sharp is None:
+        params = lgo.init_params(n_layers, 256, 4, seed=seed)
+        data = make_pairs(batch, n, dim=256, size=size, seed=seed + 1)
+    else:
+        params, data = lgo.sharp_case(batch, n, n_layers, seed, size, *sharp)
     model = ref_lightglue(n_layers, 256, 4, params, filter_threshold=0.0)
     out = {}
     model.eval()
@@ -331,6 +337,12 @@ def gen_lightglue_config(name, batch, n, n_layers, seed, size, stride=61):
     out["param_checksum"] = np.array([float(sum(v.double().abs().sum() for v in params.values()))])
     out["data_checksum"] = _data_checksum(data)
     out["meta"] = np.array([batch, n, n_layers, seed, size[0], size[1], stride])
+    if sharp is not None:
+        out["sharp"] = np.array(sharp, dtype=np.float64)
+        out["margins"] = np.array(lgo.decision_margins(la) + lgo.decision_margins(pe["log_assignment"]))
+        assert out["margins"].min() > 1.0, out["margins"]          # decisive in train AND eval mode
+        assert (pred["matches0"] > -1).all() and (pe["matches0"] == pred["matches0"]).all()
+        print(name, "decision margins (train rows, cols, eval rows, cols)", out["margins"].tolist())
     np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
     print(name, "total loss", losses["total"].tolist(), "matches", (pred["matches0"] > -1).sum(1).tolist(),
           "metrics", {k: v.tolist() for k, v in me.items()})
@@ -494,6 +506,8 @@ def main():
             "lightglue_config1": lambda: gen_lightglue_config("lightglue_config1", 4, 512, 4, seed=101, size=(640, 480)),
             "lightglue_n2048_l9": lambda: gen_lightglue_config("lightglue_n2048_l9", 1, 2048, 9, seed=103,
                                                                 size=(1024, 1024), stride=997),
+            "lightglue_sharp": lambda: gen_lightglue_config("lightglue_sharp", 1, 2048, 9, seed=131, size=(1024, 1024),
+                                                             stride=997, sharp=(0.04, 11.0, 0.06)),
             "lightglue_adaptive": lambda: gen_lightglue_adaptive("lightglue_adaptive", 160, 200, 3, seed=107),
             "metrics": lambda: gen_metrics("metrics", seed=109),
             "superglue_config4": lambda: gen_superglue_config("superglue_config4", 1, 2048, 100, seed=113),
@@ -516,6 +530,7 @@ def main():
     gen_superglue("superglue_d256", batch=2, n0=60, n1=52, gnn=["self", "cross"] * 2, iters=20, seed=31)
     gen_lightglue_config("lightglue_config1", 4, 512, 4, seed=101, size=(640, 480))
     gen_lightglue_config("lightglue_n2048_l9", 1, 2048, 9, seed=103, size=(1024, 1024), stride=997)
+    gen_lightglue_config("lightglue_sharp", 1, 2048, 9, seed=131, size=(1024, 1024), stride=997, sharp=(0.04, 11.0, 0.06))
     gen_lightglue_adaptive("lightglue_adaptive", 160, 200, 3, seed=107)
     gen_metrics("metrics", seed=109)
     gen_superglue_config("superglue_config4", 1, 2048, 100, seed=113)

@@ -286,3 +286,45 @@ def train_step_grads(p, data, n_layers, heads=4, filter_threshold=0.0):
     losses["total"].mean().backward()
     grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaves.items()}
     return pred, losses, grads
+
+
+# --------------------------------------------------------------------------- sharpened case (bit-exact matches)
+def sharp_case(batch, n, n_layers, seed, size=(1024, 1024), damp=0.1, sharp=6.0, noise=0.1):
+    """Seeded weights + a seeded pair batch on which EVERY row and column of the final log-assignment has a decisive
+    arg-max (so matches0/1 can be compared bit for bit on 100 % of the rows, lightglue.py:293-309): image 1's keypoints
+    are a permutation of image 0's (warped by a similarity) with descriptors normalise(d0 + noise N(0, I)); the blocks'
+    output linears (out_proj / to_out / ffn.3) are damped so the residual stream stays close to the input
+    descriptors, and every final_proj is `sharp * I + init`.  Returns (params, data) of CPU fp32 tensors."""
+    p = init_params(n_layers, 256, 4, seed=seed)
+    for k in p:
+        if k.endswith(("out_proj.weight", "out_proj.bias", "to_out.weight", "to_out.bias", "ffn.3.weight", "ffn.3.bias")):
+            p[k] = p[k] * damp
+        if k.endswith("final_proj.weight"):
+            p[k] = p[k] + sharp * torch.eye(p[k].shape[0])
+    g = torch.Generator().manual_seed(seed + 1)
+    w, h = size
+    wh = torch.tensor([w, h], dtype=torch.float32)
+    kp0 = torch.rand(batch, n, 2, generator=g) * wh
+    a = math.radians(10.0)
+    c, s = math.cos(a) * 1.1, math.sin(a) * 1.1
+    ctr = wh / 2
+    rot = torch.tensor([[c, -s], [s, c]])
+    d0 = F.normalize(torch.randn(batch, n, 256, generator=g), dim=-1)
+    perm = torch.stack([torch.randperm(n, generator=g) for _ in range(batch)])          # kp1[j] = image of kp0[perm[j]]
+    kp1 = ((kp0 - ctr) @ rot.T + ctr + torch.tensor([15.0, -10.0])).gather(1, perm[..., None].expand(-1, -1, 2))
+    d1 = F.normalize(d0 + noise * torch.randn(batch, n, 256, generator=g), dim=-1).gather(1, perm[..., None].expand(-1, -1, 256))
+    inv = torch.argsort(perm, 1)                                                        # gt_matches0[i] = j with perm[j] = i
+    gt = torch.zeros(batch, n, n, dtype=torch.bool)
+    gt.scatter_(2, inv[..., None], True)
+    data = {"keypoints0": kp0, "keypoints1": kp1, "descriptors0": d0, "descriptors1": d1,
+            "view0": {"image_size": wh[None].repeat(batch, 1)}, "view1": {"image_size": wh[None].repeat(batch, 1)},
+            "gt_assignment": gt, "gt_assignment_col0": inv.clone(), "gt_matches0": inv, "gt_matches1": perm}
+    return p, data
+
+
+def decision_margins(la):
+    """(min over rows, min over columns) of top-1 minus top-2 of the core block of a log-assignment [B,M+1,N+1]."""
+    core = la[:, :-1, :-1]
+    r = core.topk(2, dim=2).values
+    c = core.topk(2, dim=1).values
+    return float((r[..., 0] - r[..., 1]).min()), float((c[:, 0] - c[:, 1]).min())

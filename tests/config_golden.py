@@ -15,10 +15,13 @@ def config_inputs(name):
     from oracle import lightglue_oracle as lgo
     z = load_golden(name)
     batch, n, L, seed, w, h, _ = (int(v) for v in z["meta"])
-    params = lgo.init_params(L, 256, 4, seed=seed)
+    if "sharp" in z:        # the decisive case (every arg-max separated from its runner-up by z["margins"])
+        params, data = lgo.sharp_case(batch, n, L, seed, (w, h), *(float(v) for v in z["sharp"]))
+    else:
+        params = lgo.init_params(L, 256, 4, seed=seed)
+        data = make_pairs(batch, n, dim=256, size=(w, h), seed=seed + 1)
     chk = float(sum(v.double().abs().sum() for v in params.values()))
     assert abs(chk - float(z["param_checksum"][0])) < 1e-9 * chk
-    data = make_pairs(batch, n, dim=256, size=(w, h), seed=seed + 1)
     dchk = float(sum(v.double().abs().sum() for v in data.values() if torch.is_tensor(v) and v.is_floating_point()))
     assert abs(dchk - float(z["data_checksum"][0])) < 1e-9 * dchk
     return z, params, data, L
@@ -28,8 +31,9 @@ def _np(t):
     return t.detach().float().cpu().numpy()
 
 
-def check_train(z, pred, losses, grads, tol=1e-4, grad_tol=2e-3, tie_margin=1e-3):
-    """pred / losses / grads (name -> tensor) of one train step vs the reference's."""
+def check_train(z, pred, losses, grads, tol=1e-4, grad_tol=2e-3, tie_margin=1e-3, exact_matches=False):
+    """pred / losses / grads (name -> tensor) of one train step vs the reference's.
+    exact_matches: matches0 / matches1 must equal the reference's on 100 % of the rows (goldens with decisive margins)."""
     stride = int(z["meta"][6])
     la = pred["log_assignment"].detach().float().cpu()
     np.testing.assert_allclose(la.flatten(1)[:, ::stride].numpy(), z["train.la_sample"], rtol=tol, atol=tol)
@@ -50,7 +54,9 @@ def check_train(z, pred, losses, grads, tol=1e-4, grad_tol=2e-3, tie_margin=1e-3
         j = np.clip(ref0[b], 0, None)
         partner_ok[b] = clear_c[b].numpy()[j] | (ref0[b] < 0)
     ok = clear_r.numpy() & partner_ok & clear_c.numpy().all()  # all columns clear -> every mutual check is stable
-    if clear_c.numpy().all() and clear_r.numpy().all():
+    if exact_matches:
+        assert "margins" in z and float(z["margins"].min()) > 100 * tie_margin
+    if exact_matches or (clear_c.numpy().all() and clear_r.numpy().all()):
         np.testing.assert_array_equal(m0, ref0)
         np.testing.assert_array_equal(pred["matches1"].cpu().numpy(), z["train.matches1"])
     else:

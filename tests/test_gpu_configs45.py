@@ -103,7 +103,7 @@ def test_superglue_config4_fp32_train_step_vs_reference():
     print("superglue config4 fp32: matches0 agreement", agree)
     assert agree >= 0.999
     _check_losses(z, losses, 1e-4)
-    _fp32_grads(z, grads, norm_tol=1e-3, sample_tol=4e-3)        # measured 3.1e-4 / 1.0e-3
+    _fp32_grads(z, grads, norm_tol=6e-4, sample_tol=2e-3)        # 2x the measured 3.1e-4 / 1.0e-3
 
 
 def test_superglue_config4_bf16_train_step_bounds():
@@ -124,7 +124,7 @@ def test_gluestick_config5_fp32_train_step_vs_reference():
         print("gluestick config5 fp32:", k, "agreement", agree)
         assert agree >= 0.999
     _check_losses(z, losses, 1e-4)
-    _fp32_grads(z, grads, norm_tol=1e-3, sample_tol=4e-3)        # measured 1.3e-4 / 7.3e-4
+    _fp32_grads(z, grads, norm_tol=3e-4, sample_tol=1.5e-3)      # 2x the measured 1.3e-4 / 7.3e-4
 
 
 def test_gluestick_config5_bf16_train_step_bounds():

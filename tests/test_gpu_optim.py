@@ -105,3 +105,67 @@ def test_fused_adam_on_unaligned_flat_gradient_views():
         ours.step()
         for i, (pa, pb) in enumerate(zip(a, b)):
             torch.testing.assert_close(pb, pa, rtol=2e-6, atol=1e-8, msg=lambda m: f"step {it} tensor {i}: {m}")
+
+
+@pytest.mark.parametrize("source", ["fused", "torch"])
+def test_fused_adam_resumes_from_a_cpu_mapped_checkpoint(source, tmp_path):
+    """The reference's resume flow (train.py:229/256 torch.load(map_location='cpu'), :380 optimizer.load_state_dict): a
+    FusedAdam restored from its own or from a torch.optim.Adam checkpoint continues exactly like torch.optim.Adam."""
+    from glue_factory_amd.optim import FusedAdam
+    g = torch.Generator(device="cuda").manual_seed(11)
+    base = _params(g)
+    a = [torch.nn.Parameter(t.clone()) for t in base]
+    b = [torch.nn.Parameter(t.clone()) for t in base]
+    ref = torch.optim.Adam(a, lr=2e-3, weight_decay=0.01)
+    first = FusedAdam(b, lr=2e-3, weight_decay=0.01) if source == "fused" else torch.optim.Adam(b, lr=2e-3, weight_decay=0.01)
+    grads = [[torch.randn(t.shape, device="cuda", generator=g) for t in base] for _ in range(5)]
+
+    def run(opt, ps, its):
+        for it in its:
+            for p_, gr in zip(ps, grads[it]):
+                p_.grad = gr.clone()
+            opt.step()
+
+    run(ref, a, range(5))
+    run(first, b, range(2))
+    torch.save(first.state_dict(), tmp_path / "opt.tar")
+    sd = torch.load(tmp_path / "opt.tar", map_location="cpu")
+    assert not any(k.startswith("_") for k in sd["param_groups"][0])
+    ours = FusedAdam(b, lr=1.0)                       # hyper-parameters come from the checkpoint
+    ours.load_state_dict(sd)
+    run(ours, b, range(2, 5))
+    for i, (pa, pb) in enumerate(zip(a, b)):
+        torch.testing.assert_close(pb, pa, rtol=4e-6, atol=1e-8, msg=lambda m: f"tensor {i}: {m}")
+    assert float(ours.state[b[0]]["step"]) == 5.0 and ours.state[b[0]]["step"].is_cuda
+
+
+def test_train_step_graph_follows_a_learning_rate_schedule():
+    """the reference steps its scheduler every iteration (train.py:517); a REPLAYED step must see the new
+    learning rate (device scalar refreshed by TrainStep in front of the replay), like the eager one."""
+    from glue_factory_amd.matchers.lightglue import LightGlue
+    from glue_factory_amd.optim import FusedAdam
+    from glue_factory_amd.synthetic import make_pairs, to_device
+    from glue_factory_amd.train_step import TrainStep
+    data = to_device(make_pairs(2, 128, dim=256, seed=5), "cuda")
+    outs = []
+    for graph in (False, True):
+        torch.manual_seed(0)
+        model = LightGlue({"n_layers": 2}).cuda().train()
+        opt = FusedAdam(model.parameters(), lr=1e-3)
+        step = TrainStep(model, opt, amp_dtype=torch.bfloat16, device_ids=[0], graph=graph)
+        for it in range(7):
+            if it >= 4:                             # replays (graph_warmup = 2, capture at call 3): the schedule moves
+                opt.param_groups[0]["lr"] = 1e-3 * 0.5 ** (it - 3)
+            step(data)
+        outs.append([p.detach().clone() for p in model.parameters()])
+    frozen = []
+    torch.manual_seed(0)
+    model = LightGlue({"n_layers": 2}).cuda().train()
+    step = TrainStep(model, FusedAdam(model.parameters(), lr=1e-3), amp_dtype=torch.bfloat16, device_ids=[0], graph=False)
+    for it in range(7):
+        step(data)
+    frozen = [p.detach().clone() for p in model.parameters()]
+    err = max(float((pa - pb).abs().max()) for pa, pb in zip(*outs))
+    gap = max(float((pa - pf).abs().max()) for pa, pf in zip(outs[0], frozen))
+    assert gap > 5e-4, "the schedule must matter for this test to say anything"
+    assert err < 0.1 * gap, (err, gap)

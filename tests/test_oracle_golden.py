@@ -155,7 +155,7 @@ def test_gluestick_oracle_matches_reference():
         assert abs(float(g.double().norm()) - ref) <= 3e-3 * ref + 1e-5, (k, float(g.norm()), ref)
 
 
-@pytest.mark.parametrize("name", ["lightglue_config1", "lightglue_n2048_l9"])
+@pytest.mark.parametrize("name", ["lightglue_config1", "lightglue_n2048_l9", "lightglue_sharp"])
 def test_oracle_at_baseline_configs_matches_reference(name):
     """BASELINE.json config 1 (B=4, N=512, L=4) and the config-2 shape (N=2048, L=9, B=1): the oracle's whole
     train step vs the compact vectors the reference itself produced at those sizes."""
@@ -163,7 +163,7 @@ def test_oracle_at_baseline_configs_matches_reference(name):
     z, params, data, L = config_inputs(name)
     odata = dict(data, image_size0=data["view0"]["image_size"], image_size1=data["view1"]["image_size"])
     pred, losses, grads = lgo.train_step_grads(params, odata, L, 4)
-    worst = check_train(z, pred, losses, grads, tol=1e-4, grad_tol=1e-3)
+    worst = check_train(z, pred, losses, grads, tol=1e-4, grad_tol=1e-3, exact_matches=name == "lightglue_sharp")
     print(name, "worst relative gradient-norm error", worst)
 
 
