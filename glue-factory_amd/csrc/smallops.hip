@@ -29,10 +29,13 @@ struct CastEntry {            // one parameter (or one row block of a DERIVED we
     float scale;              // ... and by this scalar, all in fp32 before the single rounding
     int ldt;                  // leading dimension of dst_t (rows of the WHOLE output when this is one block of it)
     int flags;                // bit 0: dst is fp32 whatever the launch's dtype (biases stay fp32 for the GEMM epilogues)
-    int pad_;
+    int ldd;                  // leading dimension of dst (0: cols) -- a COLUMN block of a wider output (the folded FFN weight
+                              // [W0a | W0b Wo], csrc/fold.hip) has ldd = the whole output's width
     const int* cperm;         // dst column c reads src column cperm[c] (NULL: c)
+    int lds;                  // leading dimension of src (0: cols) -- the left columns of a wider parameter
+    int pad_;
 };
-static_assert(sizeof(CastEntry) == 80, "host table layout (ops.precast)");
+static_assert(sizeof(CastEntry) == 88, "host table layout (ops.precast)");
 
 template <typename T>
 __global__ __launch_bounds__(256) void multi_cast_transpose_kernel(const CastEntry* __restrict__ tab, int n) {
@@ -49,17 +52,18 @@ __global__ __launch_bounds__(256) void multi_cast_transpose_kernel(const CastEnt
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;         // 32 x 8 threads
     T* dst = static_cast<T*>(e.dst);
     float* dst32 = static_cast<float*>(e.dst);
+    const int lds = e.lds ? e.lds : e.cols, ldd = e.ldd ? e.ldd : e.cols;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = r0 + ty + 8 * i, c = c0 + tx;
         float v = 0.f;
         if (r < e.rows && c < e.cols) {
             const int sr = e.perm ? e.perm[r] : r, sc = e.cperm ? e.cperm[c] : c;
-            v = e.src[(size_t)sr * e.cols + sc] * e.scale;
+            v = e.src[(size_t)sr * lds + sc] * e.scale;
             if (e.rscale) v *= e.rscale[r];
             if (e.dst) {
-                if (e.flags & 1) dst32[(size_t)r * e.cols + c] = v;
-                else dst[(size_t)r * e.cols + c] = from_f32<T>(v);
+                if (e.flags & 1) dst32[(size_t)r * ldd + c] = v;
+                else dst[(size_t)r * ldd + c] = from_f32<T>(v);
             }
         }
         tile[ty + 8 * i][tx] = v;
@@ -222,8 +226,10 @@ struct AdamTable { AdamEntry e[ADAM_MAXT]; };
 __global__ __launch_bounds__(256) void multi_adam_kernel(const AdamTable tab, int n_entries,
                                                          const float* __restrict__ lr_p, const float* __restrict__ step_p,
                                                          const float* __restrict__ found_inf, const float* __restrict__ grad_scale,
-                                                         float b1, float b2, float eps, float wd) {
+                                                         double b1d, double b2d, float eps, float wd) {
     if (found_inf != nullptr && *found_inf > 0.f) return;
+    // beta, 1 - beta: rounded to fp32 from the DOUBLE values, each on its own (1.f - 0.999f is 1.3e-5 away from 0.001f)
+    const float b2 = (float)b2d, omb1 = (float)(1.0 - b1d), omb2 = (float)(1.0 - b2d);
     int lo = 0, hi = n_entries - 1;
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
@@ -231,15 +237,18 @@ __global__ __launch_bounds__(256) void multi_adam_kernel(const AdamTable tab, in
     }
     const AdamEntry e = tab.e[lo];
     const float t = *step_p + 1.f;
-    const float bc1 = 1.f - powf(b1, t), bc2 = 1.f - powf(b2, t);
+    // bias corrections in DOUBLE from the double betas (torch.optim.Adam keeps them as python floats): 1 - 0.999^t in fp32
+    // loses 5 digits to cancellation for small t -- and 0.999f itself is 1.3e-5 off in (1 - beta2) -- which showed as a
+    // 1e-5 relative error of the first updates after a resume
+    const float bc1 = (float)(-expm1((double)t * log(b1d))), bc2 = (float)(-expm1((double)t * log(b2d)));
     const float step_size = *lr_p / bc1, rsq_bc2 = 1.f / sqrtf(bc2);
     const float inv_scale = grad_scale != nullptr ? 1.f / *grad_scale : 1.f;
     const long long base = (long long)(blockIdx.x - e.block0) * ADAM_CHUNK;
     const bool vec = (((size_t)e.p | (size_t)e.g | (size_t)e.m | (size_t)e.v) & 15) == 0;
     auto upd = [&](float& p, float g, float& m, float& v) {
         g = g * inv_scale + wd * p;
-        m = m + (1.f - b1) * (g - m);
-        v = b2 * v + (1.f - b2) * g * g;
+        m = m + omb1 * (g - m);
+        v = b2 * v + omb2 * g * g;
         p -= step_size * m / (sqrtf(v) * rsq_bc2 + eps);
     };
 #pragma unroll
@@ -276,7 +285,7 @@ __global__ void adam_step_kernel(float* step, const float* found_inf) {
 extern "C" int gf_adam_entry_bytes(void) { return (int)sizeof(AdamEntry); }
 // `table`: HOST array of n_entries records {p, g, m, v, n, (block0, pad: ignored on entry)}
 extern "C" int gf_multi_adam(const void* table, int n_entries, const float* lr, float* step, const float* found_inf,
-                             const float* grad_scale, float beta1, float beta2, float eps, float weight_decay, void* stream) {
+                             const float* grad_scale, double beta1, double beta2, float eps, float weight_decay, void* stream) {
     if (n_entries <= 0) return GF_ERR_SHAPE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const AdamEntry* src = static_cast<const AdamEntry*>(table);

@@ -46,14 +46,19 @@ def gt_matches_from_homography_fused(kp0, kp1, H, pos_th=3.0, neg_th=6.0, with_r
     b, m = kp0.shape[:2]
     n = kp1.shape[1]
     kp0, kp1 = kp0.float().contiguous(), kp1.float().contiguous()
-    kp0_1 = warp_points(kp0, H.float(), inverse=False).contiguous()
-    kp1_0 = warp_points(kp1, H.float(), inverse=True).contiguous()
+    # fp32 whatever the caller's autocast state: the reference calls its ground truth from inside the autocast region of
+    # the train loop (train.py:470-476), where the einsum of warp_points would come back in bf16 -- 3 significant digits
+    # for pixel coordinates, and a half-sized buffer for the fp32 kernel below (found as a GPU memory fault)
+    with torch.autocast(device_type="cuda", enabled=False):
+        kp0_1 = warp_points(kp0, H.float(), inverse=False).float().contiguous()
+        kp1_0 = warp_points(kp1, H.float(), inverse=True).float().contiguous()
     dev = kp0.device
     L = _lib.load()
     st = torch.cuda.current_stream().cuda_stream
 
     def nn(own, own_w, oth, oth_w):
         no = own.shape[1]
+        assert all(t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda for t in (own, own_w, oth, oth_w))
         arg = torch.empty((b, no), dtype=torch.int64, device=dev)
         dmin = torch.empty((b, no), dtype=torch.float32, device=dev)
         omin = torch.empty((b, no), dtype=torch.float32, device=dev)
@@ -225,6 +230,7 @@ def gt_matches_from_pose_depth_fused(kp0, kp1, data, pos_th=3, neg_th=5, cc_th=N
 
     def nn(own, own_w, oth, oth_w):
         no = own.shape[1]
+        assert all(t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda for t in (own, own_w, oth, oth_w))
         arg = torch.empty((b, no), dtype=torch.int64, device=dev)
         dmin = torch.empty((b, no), dtype=torch.float32, device=dev)
         omin = torch.empty((b, no), dtype=torch.float32, device=dev)

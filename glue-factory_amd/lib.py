@@ -10,10 +10,10 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgf_amd.so")
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 8      # == GF_AMD_ABI_VERSION in include/gf_amd.h (bumped with every signature / workspace change)
+ABI_VERSION = 9      # == GF_AMD_ABI_VERSION in include/gf_amd.h (bumped with every signature / workspace change)
 
 _c = ctypes
-_P, _I, _F, _L = _c.c_void_p, _c.c_int, _c.c_float, _c.c_int64
+_P, _I, _F, _L, _D = _c.c_void_p, _c.c_int, _c.c_float, _c.c_int64, _c.c_double
 _S = _c.POINTER(_c.c_int64)
 
 # name -> argument types; mirrors include/gf_amd.h one to one
@@ -45,8 +45,11 @@ SIGNATURES = {
     "gf_bgemm": [_P, _P, _P, _I, _I, _I, _I, _S, _S, _S, _F, _I, _P],
     "gf_multi_cast_transpose": [_P, _I, _I, _I, _P],
     "gf_cast_entry_bytes": [],
+    "gf_fold_entry_bytes": [],
+    "gf_fold_linear_fwd": [_P, _I, _I, _P],
+    "gf_fold_linear_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "gf_adam_entry_bytes": [],
-    "gf_multi_adam": [_P, _I, _P, _P, _P, _P, _F, _F, _F, _F, _P],
+    "gf_multi_adam": [_P, _I, _P, _P, _P, _P, _D, _D, _F, _F, _P],
     "gf_weight_grad_map": [_P, _P, _P, _P, _P, _F, _I, _I, _P],
     "gf_colsum_f32": [_P, _P, _P, _I, _I, _I, _P],
     "gf_colsum_ws_floats": [_I, _I],

@@ -47,9 +47,13 @@ class HomographyMatcher(BaseModel):
         return {"line_matches0": fwd, "line_matches1": bwd, "line_assignment": assignment, "line_assignment_col0": col0}
 
     def _forward(self, data):
-        out = self._label_points(data) if self.conf.use_points else {}
-        if self.conf.use_lines:
-            out.update(self._label_lines(data))
+        import torch
+        # labels are geometry in pixels: always fp32, also when the caller's train loop wraps the pipeline's loss -- and
+        # with it this module -- in torch.autocast (gluefactory/train.py:470-476)
+        with torch.autocast(device_type=data["H_0to1"].device.type, enabled=False):
+            out = self._label_points(data) if self.conf.use_points else {}
+            if self.conf.use_lines:
+                out.update(self._label_lines(data))
         return out
 
     def loss(self, pred, data):

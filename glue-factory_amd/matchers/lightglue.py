@@ -75,12 +75,31 @@ def _lin(x, layer):
     return ops.linear(x, layer.weight, layer.bias)
 
 
-def _ffn(ffn, x, msg, chain=None, out=None):
+def _ffn(ffn, x, msg, chain=None, out=None, first=None):
     """x + ffn(cat(x, msg)).  ``chain``: the GradChain of x (its three consumers in a block are this residual, the
-    FFN input and the block's projection): the residual and FFN-input gradients ride in GEMM epilogues."""
-    h = ops.linear_cat(x, msg, ffn[0].weight, ffn[0].bias, chain1=chain)
+    FFN input and the block's projection): the residual and FFN-input gradients ride in GEMM epilogues.
+    ``first``: (weight, bias) of the first linear when the block's output projection was folded into it (``msg`` is then
+    the attention context itself, see _folded_ffn0)."""
+    w0, b0 = (ffn[0].weight, ffn[0].bias) if first is None else first
+    h = ops.linear_cat(x, msg, w0, b0, chain1=chain)
     h = ops.ln_gelu(h, ffn[1].weight, ffn[1].bias, ffn[1].eps)
     return ops.linear(h, ffn[3].weight, ffn[3].bias, res=x, res_chain=chain, out=out)   # residual fused into the GEMM epilogue
+
+
+def _fold_spec(name, ffn, proj):
+    """out_proj / to_out feed ONLY ffn.0, through a concatenation and with no non-linearity in between (lightglue.py:131-163,
+    166-221): ffn.0(cat[x, Wo c + bo]) = [W0a | W0b Wo] cat[x, c] + (b0 + W0b bo).  The folded weight is prepared by the
+    per-step precast launch (ops.precast / csrc/fold.hip): one forward GEMM, one input-gradient GEMM and one weight-gradient
+    reduction over all tokens fewer per block, and no message tensor."""
+    return (name + ".ffn0", "fold", ffn[0].weight, ffn[0].bias, proj.weight, proj.bias, ffn[0].in_features - proj.out_features, None)
+
+
+def _folded_ffn0(pc, dtype, ffn, proj):
+    """(weight, bias) of ffn.0 with `proj` folded in, from this forward's precast launch; None in the fp32 parity mode (the
+    reference's two linears run as written)."""
+    if pc is None:
+        return None
+    return ops.folded_linear(pc[0], dtype, pc[1] + ".ffn0", ffn[0].weight, ffn[0].bias, proj.weight, proj.bias)
 
 
 class SelfBlock(nn.Module):
@@ -107,7 +126,8 @@ class SelfBlock(nn.Module):
     def derived_specs(self, name):
         """Row gather + q-row scale of the projection as entries of the model's per-step precast launch (ops.precast)."""
         return [(name + ".w", [(self.Wqkv.weight, self._perm, self._rowscale, 1.0)]),
-                (name + ".b", [(self.Wqkv.bias, self._perm, self._rowscale, 1.0)])]
+                (name + ".b", [(self.Wqkv.bias, self._perm, self._rowscale, 1.0)]),
+                _fold_spec(name, self.ffn, self.out_proj)]
 
     def _prepared(self, dtype):
         if self._pc is not None:
@@ -131,6 +151,9 @@ class SelfBlock(nn.Module):
         else:
             qkv = ops.linear(x, w, bias, chain=chain, chain_last=True).view(b, n, 3, self.heads, self.head_dim)
             ctx = ops.self_attention_rotary(qkv, theta, cs, scale=ops.LN2)
+        first = _folded_ffn0(self._pc, x.dtype, self.ffn, self.out_proj)
+        if first is not None:          # out_proj lives inside ffn.0's weight: the FFN reads the attention context directly
+            return _ffn(self.ffn, x, ctx.view(b, n, d), chain, first=first)
         msg = _lin(ctx.view(b, n, d), self.out_proj)
         return _ffn(self.ffn, x, msg, chain)
 
@@ -149,7 +172,8 @@ class CrossBlock(nn.Module):
     def derived_specs(self, name):
         sq = ops.attn_premul(self.head_dim) ** 0.5
         return [(name + ".w", [(self.to_qk.weight, None, None, sq), (self.to_v.weight, None, None, 1.0)]),
-                (name + ".b", [(self.to_qk.bias, None, None, sq), (self.to_v.bias, None, None, 1.0)])]
+                (name + ".b", [(self.to_qk.bias, None, None, sq), (self.to_v.bias, None, None, 1.0)]),
+                _fold_spec(name, self.ffn, self.to_out)]
 
     def _proj(self, x, chain=None):
         # sqrt(head_dim^-1/2 * log2(e)) on BOTH images' qk (each is query in one direction and key in the other)
@@ -169,10 +193,16 @@ class CrossBlock(nn.Module):
         b2, n, d = x.shape
         chain = ops.GradChain(3) if x.requires_grad and torch.is_grad_enabled() else None
         m = ops.cross_attention_stacked(self._proj(x, chain), scale=ops.LN2)
+        first = _folded_ffn0(self._pc, x.dtype, self.ffn, self.to_out)
+        if first is not None:          # to_out lives inside ffn.0's weight
+            return _ffn(self.ffn, x, m.view(b2, n, d), chain, out, first=first)
         return _ffn(self.ffn, x, _lin(m.view(b2, n, d), self.to_out), chain, out)
 
     def forward(self, x0, x1):
         m0, m1 = ops.cross_attention(self._proj(x0), self._proj(x1), scale=ops.LN2)
+        first = _folded_ffn0(self._pc, x0.dtype, self.ffn, self.to_out)
+        if first is not None:
+            return (_ffn(self.ffn, x0, m0.reshape(x0.shape), first=first), _ffn(self.ffn, x1, m1.reshape(x1.shape), first=first))
         m0 = _lin(m0.view(x0.shape), self.to_out)
         m1 = _lin(m1.view(x1.shape), self.to_out)
         return _ffn(self.ffn, x0, m0), _ffn(self.ffn, x1, m1)

@@ -66,17 +66,20 @@ def _conv_cl(x, conv, rows=None, cols=None):
     return ops.linear(x, w, b)
 
 
-def _mlp_cl(seq, x, halves, x2=None, res=None, chain=None):
+def _mlp_cl(seq, x, halves, x2=None, res=None, chain=None, first_wb=None):
     """Run an MLP Sequential (Conv1d / BatchNorm1d / ReLU) on channels-last x [B',N,C].
     BatchNorm (+ the ReLU that follows it) is one fused HIP pass pair, applied per image set
     (``halves`` = 2 when two images are stacked on the batch axis), reproducing the reference's
     one-call-per-image statistics and running-stat updates.  ``res``: added to the output inside the last
-    convolution's GEMM epilogue; ``chain``: ops.GradChain of x (= res) for the first convolution and the residual."""
+    convolution's GEMM epilogue; ``chain``: ops.GradChain of x (= res) for the first convolution and the residual.
+    ``first_wb``: (weight, bias) replacing the first convolution's (the merge convolution folded into it: x2 is then the
+    attention output itself, AttentionalPropagation.forward)."""
     layers = list(seq)
     i = 0
     if x2 is not None:      # first conv on cat[x, x2] without building the concatenation
         first = layers[0]
-        x = ops.linear_cat(x, x2, first.weight.squeeze(-1), first.bias, chain1=chain)
+        w0, b0 = (first.weight.squeeze(-1), first.bias) if first_wb is None else first_wb
+        x = ops.linear_cat(x, x2, w0, b0, chain1=chain)
         i = 1
     while i < len(layers):
         layer = layers[i]
@@ -149,6 +152,13 @@ class MultiHeadedAttention(nn.Module):
                 # the merge convolution reads the attention output in kernel channel order: its columns gathered
                 (name + ".merge.w", [(self.merge.weight, None, None, 1.0, self._perm)])]
 
+    def fold_spec(self, name, first):
+        """merge feeds ONLY the MLP's first convolution, through a concatenation (superglue.py:137-160): mlp.0(cat[x, Wm o +
+        bm]) = [W0a | W0b Wm] cat[x, o] + (b0 + W0b bm) -- prepared by the per-step precast launch (csrc/fold.hip), with the
+        merge columns gathered into kernel channel order on the way."""
+        return (name + ".mlp0", "fold", first.weight, first.bias, self.merge.weight, self.merge.bias,
+                first.in_channels - self.merge.out_channels, self._perm)
+
     def fused_projection(self, x, chain=None, premul=True):
         """-> (qkv [B', N, 3, H, D], softmax scale the attention op has to use)."""
         w = None
@@ -172,6 +182,8 @@ def derived_specs_of(model):
         if hasattr(mod, "derived_specs") and mod is not model:
             mod._pc = (id(model), name)
             specs += mod.derived_specs(name)
+        if isinstance(mod, AttentionalPropagation):      # (its attention module's specs follow under "<name>.attn")
+            specs.append(mod.attn.fold_spec(name + ".attn", mod.mlp[0]))
     return specs
 
 
@@ -190,6 +202,11 @@ class AttentionalPropagation(nn.Module):
         chain = ops.GradChain(3) if residual and x.requires_grad and torch.is_grad_enabled() else None
         qkv, scale = self.attn.fused_projection(x, chain)
         o = ops.attention_qkv(qkv, cross=cross, scale=scale)
+        pc = self.attn._pc
+        first = None if pc is None else ops.folded_linear(pc[0], x.dtype, pc[1] + ".mlp0", self.mlp[0].weight, self.mlp[0].bias,
+                                                          self.attn.merge.weight, self.attn.merge.bias)
+        if first is not None:       # merge lives inside mlp.0's weight: the MLP reads the attention output directly
+            return _mlp_cl(self.mlp, x, halves, x2=o.view(b, n, d), res=x if residual else None, chain=chain, first_wb=first)
         msg = _conv_cl(o.view(b, n, d), self.attn.merge, cols=self.attn._perm)
         return _mlp_cl(self.mlp, x, halves, x2=msg, res=x if residual else None, chain=chain)
 

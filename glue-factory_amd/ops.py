@@ -250,7 +250,12 @@ def precast(params, dtype, key="default", derived=None):
         return
     derived = derived or []
     assert not derived or dtype != torch.float32, "derived weights are a compute-dtype (cast) feature"
-    dkey = tuple((name, tuple(id(b_[0]) for b_ in blocks)) for name, blocks in derived)
+    # (name, "fold", W0, b0, Wo, bo, c0, cperm): the FOLDED weight [W0[:, :c0] | W0[:, c0:] Wo[:, cperm]] and bias
+    # b0 + W0[:, c0:] bo of a linear that consumes cat[x, Wo ctx + bo] (csrc/fold.hip; served by folded_linear())
+    folds = [d_ for d_ in derived if len(d_) > 2 and d_[1] == "fold"]
+    derived = [d_ for d_ in derived if not (len(d_) > 2 and d_[1] == "fold")]
+    dkey = (tuple((name, tuple(id(b_[0]) for b_ in blocks)) for name, blocks in derived)
+            + tuple((f[0], "fold", id(f[2]), id(f[4]), f[6]) for f in folds))
     slot = _LP_FLAT.get((key, dtype))
     ptrs = tuple(p_.data_ptr() for p_ in params)          # (`p.data = ...` / module.to() move the storage under the same object)
     if (slot is None or len(slot["params"]) != len(params) or any(a is not b for a, b in zip(slot["params"], params))
@@ -263,18 +268,27 @@ def precast(params, dtype, key="default", derived=None):
         dmat = [(name, blocks) for name, blocks in derived if blocks[0][0].dim() >= 2]
         dvec = [(name, blocks) for name, blocks in derived if blocks[0][0].dim() < 2]
         dsize = lambda blocks: sum(b_[0].numel() for b_ in blocks)   # noqa: E731
-        flat = torch.empty((sum(sizes) if cast else 0) + sum(al(dsize(bl)) for _, bl in dmat), dtype=dtype, device=dev)
+        fgeo = []                                               # (R, ldw0, K, N, c0) of every folded linear
+        for f in folds:
+            w0, wo, c0 = f[2], f[4], int(f[6])
+            R, K = w0.shape[0], wo.shape[0]
+            ldw0, N = w0.numel() // R, wo.numel() // K
+            assert w0.is_contiguous() and wo.is_contiguous() and ldw0 == c0 + K, "fold: W0 must be [R, c0 + K], Wo [K, N]"
+            fgeo.append((R, ldw0, K, N, c0))
+        fsize = sum(al(R * (c0 + N)) for R, _, _, N, c0 in fgeo)
+        flat = torch.empty((sum(sizes) if cast else 0) + sum(al(dsize(bl)) for _, bl in dmat) + fsize, dtype=dtype, device=dev)
         mats = [p_ for p_ in params if p_.dim() >= 2]
-        flat_t = torch.empty(sum(al(p_.numel()) for p_ in mats) + sum(al(dsize(bl)) for _, bl in dmat), dtype=dtype, device=dev)
+        flat_t = torch.empty(sum(al(p_.numel()) for p_ in mats) + sum(al(dsize(bl)) for _, bl in dmat) + fsize, dtype=dtype, device=dev)
+        fold32 = torch.empty(sum(al(R * N) + al(R) for R, _, _, N, _ in fgeo), dtype=torch.float32, device=dev)
         flat32 = torch.empty(sum(al(dsize(bl)) for _, bl in dvec), dtype=torch.float32, device=dev)
         views, tviews, rec, off, toff, tile0 = [], {}, b"", 0, 0, 0
 
-        def entry(src, dst, dst_t, rows, cols, perm=None, rscale=None, scale=1.0, ldt=None, flags=0, cperm=None):
+        def entry(src, dst, dst_t, rows, cols, perm=None, rscale=None, scale=1.0, ldt=None, flags=0, cperm=None, lds=0, ldd=0):
             nonlocal rec, tile0
             tx = (cols + 31) // 32
-            rec += struct.pack("<QQQiiiiQQfiiiQ", src, dst, dst_t, rows, cols, tile0, tx, 0 if perm is None else perm.data_ptr(),
-                               0 if rscale is None else rscale.data_ptr(), float(scale), rows if ldt is None else ldt, flags, 0,
-                               0 if cperm is None else cperm.data_ptr())
+            rec += struct.pack("<QQQiiiiQQfiiiQii", src, dst, dst_t, rows, cols, tile0, tx, 0 if perm is None else perm.data_ptr(),
+                               0 if rscale is None else rscale.data_ptr(), float(scale), rows if ldt is None else ldt, flags, ldd,
+                               0 if cperm is None else cperm.data_ptr(), lds, 0)
             tile0 += tx * ((rows + 31) // 32)
 
         for p_, sz in zip(params, sizes):
@@ -322,12 +336,45 @@ def precast(params, dtype, key="default", derived=None):
                 meta.append((r0, rows, perm, rscale, float(scale), tuple(src.shape), cperm))
                 r0 += rows
             dslot[name] = {"view": v, "view_t": vt, "handle": handle, "meta": meta, "cols": cols}
+        # folded linears: fp32 products by gf_fold_linear_fwd (its own table, launched first), stacked / cast / transposed by
+        # two column-block entries of the cast table
+        frec, ftile0, foff = b"", 0, 0
+        for f, (R, ldw0, K, N, c0) in zip(folds, fgeo):
+            name, _, w0, b0, wo, bo, _, cperm = f
+            cperm = None if cperm is None else cperm.to(device=dev, dtype=torch.int32).contiguous()
+            keep.append(cperm)
+            wc = fold32[foff:foff + R * N].view(R, N)
+            foff += al(R * N)
+            bc = fold32[foff:foff + R] if (b0 is not None or bo is not None) else None
+            foff += al(R)
+            wid = c0 + N
+            v = flat[off:off + R * wid].view(R, wid)
+            vt = flat_t[toff:toff + R * wid].view(wid, R)
+            off += al(R * wid)
+            toff += al(R * wid)
+            esz_ = v.element_size()
+            entry(w0.data_ptr(), v.data_ptr(), vt.data_ptr(), R, c0, ldt=R, lds=ldw0, ldd=wid)
+            entry(wc.data_ptr(), v.data_ptr() + c0 * esz_, vt.data_ptr() + c0 * R * esz_, R, N, ldt=R, ldd=wid)
+            ftx = (N + 63) // 64
+            frec += struct.pack("<QQQQQQQiiiiiiii", w0.data_ptr(), wo.data_ptr(), 0 if b0 is None else b0.data_ptr(),
+                                0 if bo is None else bo.data_ptr(), 0 if cperm is None else cperm.data_ptr(), wc.data_ptr(),
+                                0 if bc is None else bc.data_ptr(), R, K, N, ldw0, c0, ftile0, ftx, 0)
+            ftile0 += (ftx + 1) * ((R + 63) // 64)           # (+ 1: the bias tile column of every row block)
+            handle = torch.empty((R, wid), dtype=torch.float32, device=dev)      # never written: _lp() maps it to v
+            dslot[name] = {"view": v, "view_t": vt, "handle": handle, "bias": bc, "fold": (R, ldw0, K, N, c0), "cperm": cperm}
         esz = _lib.load().gf_cast_entry_bytes()
-        assert len(rec) % esz == 0 and esz == 80
+        assert len(rec) % esz == 0 and esz == 88
         table = torch.frombuffer(bytearray(rec), dtype=torch.uint8).to(dev) if rec else None
+        ftable = None
+        if frec:
+            assert len(frec) == len(folds) * _lib.load().gf_fold_entry_bytes()
+            ftable = torch.frombuffer(bytearray(frec), dtype=torch.uint8).to(dev)
         slot = {"flat": flat, "flat_t": flat_t, "flat32": flat32, "views": views, "tviews": tviews, "params": params, "table": table,
-                "n": len(rec) // esz, "tiles": tile0, "dkey": dkey, "derived": dslot, "keep": keep, "ptrs": ptrs}
+                "n": len(rec) // esz, "tiles": tile0, "dkey": dkey, "derived": dslot, "keep": keep, "ptrs": ptrs,
+                "fold32": fold32, "ftable": ftable, "fn": len(folds), "ftiles": ftile0}
         _LP_FLAT[(key, dtype)] = slot
+    if slot["ftable"] is not None:
+        _lib.check(_lib.load().gf_fold_linear_fwd(_p(slot["ftable"]), slot["fn"], slot["ftiles"], _stream()), "gf_fold_linear_fwd")
     if slot["table"] is not None:
         _lib.check(_lib.load().gf_multi_cast_transpose(_p(slot["table"]), slot["n"], slot["tiles"], BF16 if dtype == torch.bfloat16 else F32, _stream()),
                    "gf_multi_cast_transpose")
@@ -387,6 +434,53 @@ def derived_weight(key, dtype, name, *srcs):
     if d is None:
         return None
     return _DerivedWeight.apply(d, *srcs)
+
+
+class _FoldedLinear(torch.autograd.Function):
+    """The autograd face of a folded linear (precast(derived=[(name, "fold", ...)]), csrc/fold.hip): forward hands out the
+    fp32 HANDLE of the stacked weight [W0a | W0b Wo] (resolved by _lp() / _wt_t() to the compute-dtype copy and its transpose
+    this forward's precast launch wrote) and the folded bias b0 + W0b bo (fp32 values); backward turns their gradients into
+    those of W0, b0, Wo, bo with ONE launch (gf_fold_linear_bwd)."""
+
+    @staticmethod
+    def forward(ctx, d, w0, b0, wo, bo):
+        ctx.d = d
+        ctx.save_for_backward(w0, wo, bo)
+        ctx.has = (b0 is not None, bo is not None)
+        bias = d["bias"]
+        return d["handle"].view(d["handle"].shape), (None if bias is None else bias.view(bias.shape))
+
+    @staticmethod
+    def backward(ctx, gw, gb):
+        w0, wo, bo = ctx.saved_tensors
+        R, ldw0, K, N, c0 = ctx.d["fold"]
+        if gw is None:
+            gw = torch.zeros((R, c0 + N), dtype=torch.float32, device=w0.device)
+        gw = gw.float().contiguous()
+        gb = None if gb is None else gb.float().contiguous()
+        dw0, dwo = torch.empty_like(w0), torch.empty_like(wo)
+        dbo = torch.empty_like(bo) if ctx.has[1] else None
+        cperm = ctx.d["cperm"]
+        _lib.check(_lib.load().gf_fold_linear_bwd(_p(gw), _p(gb), _p(w0), _p(wo), _p(bo) if ctx.has[1] else None,
+                                                  None if cperm is None else _p(cperm), _p(dw0), _p(dwo), _p(dbo),
+                                                  R, K, N, ldw0, c0, _stream()), "gf_fold_linear_bwd")
+        if dbo is not None and gb is None:
+            dbo = None
+        return None, dw0, (gb if ctx.has[0] else None), dwo, dbo
+
+
+FOLD_ENABLED = True      # tools/probe/ab_matcher.py switches it off for a same-process A/B of the folded blocks
+
+
+def folded_linear(key, dtype, name, w0, b0, wo, bo):
+    """(weight handle, bias) of the folded linear `name` of this forward's precast(key=..., derived=...) launch --
+    y = linear_cat(x, ctx, weight, bias) then equals W0 cat[x, Wo ctx + bo] + b0 -- differentiable w.r.t. the four
+    parameters, or None when this forward did not prepare it (fp32 parity mode: the caller runs the two linears)."""
+    slot = _LP_FLAT.get((key, dtype)) if FOLD_ENABLED else None
+    d = None if slot is None else slot["derived"].get(name)
+    if d is None or "fold" not in d:
+        return None
+    return _FoldedLinear.apply(d, w0, b0, wo, bo)
 
 
 def invalidate_precast():

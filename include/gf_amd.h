@@ -35,8 +35,8 @@ extern "C" {
 #define GF_ERR_ALIGN (-3)
 #define GF_ERR_DTYPE (-4)
 
-/* ABI version; bumped on any signature or workspace-size change (2: gf_attn_bwd's delta workspace doubled; 3: line head + gf_bgemm; 4: smallops; 5: gf_attn_bwd_acc). */
-#define GF_AMD_ABI_VERSION 8
+/* ABI version; bumped on any signature or workspace-size change (2: gf_attn_bwd's delta workspace doubled; 3: line head + gf_bgemm; 4: smallops; 5: gf_attn_bwd_acc; 9: cast entries with leading dimensions, gf_fold_linear_*, double betas in gf_multi_adam). */
+#define GF_AMD_ABI_VERSION 9
 int gf_abi_version(void);
 
 /* ---- multi-head attention over keypoints --------------------------------------------------
@@ -203,7 +203,8 @@ int gf_dense_assign_bwd(const float* raw, const float* r, const float* c, const 
  * gf_multi_cast_transpose: ONE launch converts every fp32 master parameter of a model into the compute dtype and writes
  *   the transposed copy of every matrix (the weight of the input-gradient GEMM dx = dy W).  `table` is a DEVICE array of
  *   n_entries records {const float* src; void* dst; void* dst_t; int rows, cols, tile0, tiles_x; const int* perm;
- *   const float* rscale; float scale; int ldt; int flags; int pad; const int* cperm;} (gf_cast_entry_bytes() = 80 each; dst or dst_t may be
+ *   const float* rscale; float scale; int ldt; int flags; int ldd; const int* cperm; int lds; int pad;} (gf_cast_entry_bytes() = 88 each;
+ *   lds / ldd = leading dimensions of src / dst, 0 = cols: column blocks of a wider tensor; dst or dst_t may be
  *   NULL), tile0 = running count of the 32 x 32 tiles of the preceding entries, tiles_x = ceil(cols / 32); total_tiles =
  *   the grid.  dst[r][c] = src[perm ? perm[r] : r][cperm ? cperm[c] : c] * (rscale ? rscale[r] : 1) * scale, dst_t[c * ldt + r] the same
  *   value; flags bit 0: dst is fp32 (biases).  Plain parameters: perm = rscale = NULL, scale = 1, ldt = rows.  DERIVED
@@ -215,6 +216,21 @@ int gf_dense_assign_bwd(const float* raw, const float* r, const float* c, const 
  * gf_small_dw:   dw[o, k] = sum_m dy[m, o] x[m, k], fp32, dy [M, O], x [M, K], K <= 4, O * K <= 256 (the gradient of
  *   lightglue.py:52-65 posenc.Wr); ws: gf_small_dw_ws_floats(O, K) floats. */
 int gf_multi_cast_transpose(const void* table, int n_entries, int total_tiles, int dtype, void* stream);
+/* Folding a linear into its consumer (csrc/fold.hip): h = ffn.0(cat[x, out_proj(ctx)]) = [W0a | W0b Wo] cat[x, ctx] + (b0 + W0b bo)
+ * (lightglue.py:131-163, :166-221 to_out; superglue.py:137-160 merge -> mlp.0) -- weights only, fp32 FMA arithmetic.
+ * gf_fold_linear_fwd: DEVICE table of n_entries records {const float* W0 [R, ldw0]; const float* Wo [K, N]; const float* b0;
+ *   const float* bo; const int* cperm; float* Wc [R, N]; float* bc [R]; int R, K, N, ldw0, c0, tile0, tiles_x, pad;}
+ *   (gf_fold_entry_bytes() = 88): Wc = W0[:, c0:c0+K] Wo[:, cperm], bc = b0 + W0[:, c0:c0+K] bo (b0 / bo / cperm / bc may be
+ *   NULL); an entry owns ceil(R / 64) * (tiles_x + 1) blocks (the extra tile column computes bc), tile0 = running count of
+ *   the preceding entries' blocks, tiles_x = ceil(N / 64), total_tiles = the grid.  One launch for all
+ *   blocks of a model, in front of gf_multi_cast_transpose, whose entries stack [W0a | Wc] into the compute-dtype weight.
+ * gf_fold_linear_bwd: g [R, c0 + N] (gradient of the stacked weight), gb [R] or NULL (gradient of bc) ->
+ *   dW0 [R, ldw0] = [g[:, :c0] | g[:, c0:] Wo[:, cperm]^T + gb bo^T], dWo[:, cperm] = W0[:, c0:]^T g[:, c0:] ([K, N]),
+ *   dbo [K] = W0[:, c0:]^T gb (written when bo != NULL); the gradient of b0 is gb itself.  Needs ldw0 >= c0 + K. */
+int gf_fold_entry_bytes(void);
+int gf_fold_linear_fwd(const void* table, int n_entries, int total_tiles, void* stream);
+int gf_fold_linear_bwd(const float* g, const float* gb, const float* W0, const float* Wo, const float* bo, const int* cperm,
+                       float* dW0, float* dWo, float* dbo, int R, int K, int N, int ldw0, int c0, void* stream);
 int gf_cast_entry_bytes(void);
 int gf_weight_grad_map(const float* g, float* out, const int* perm, const int* cperm, const float* rscale, float scale,
                        int rows, int cols, void* stream);
@@ -226,10 +242,11 @@ int gf_small_dw_ws_floats(int O, int K);
  * tensor in ceil(n_entries / 80) launches.  `table`: HOST array of n_entries records {float* p; const float* g; float* m;
  * float* v; long long n; int pad[2];} (gf_adam_entry_bytes() = 48) of DEVICE pointers; it travels by value in the kernel
  * arguments.  lr, step: device fp32 scalars (step = number of updates done so far; it is incremented here); found_inf (device
- * fp32, may be NULL) > 0 skips update and count; grad_scale (device fp32 or NULL) divides the gradients. */
+ * fp32, may be NULL) > 0 skips update and count; grad_scale (device fp32 or NULL) divides the gradients.  beta1 / beta2 are
+ * doubles: the bias corrections 1 - beta^t are evaluated in double (as torch's python-float arithmetic does). */
 int gf_adam_entry_bytes(void);
 int gf_multi_adam(const void* table, int n_entries, const float* lr, float* step, const float* found_inf,
-                  const float* grad_scale, float beta1, float beta2, float eps, float weight_decay, void* stream);
+                  const float* grad_scale, double beta1, double beta2, float eps, float weight_decay, void* stream);
 
 /* ---- small batched GEMM with arbitrary element strides (csrc/bgemm.hip): C[b,i,j] = alpha sum_k A[b,i,k] B[b,k,j],
  * strides {batch, row, column} of A [M,K], B [K,N], C [M,N]; fp32 operands use the exact-fp32 MFMA.  The products of

@@ -62,15 +62,16 @@ def test_sinkhorn_multichunk_and_generic_paths_vs_oracle(Bsz, M, N, T, pairs):
     print(f"sinkhorn B={Bsz} {M}x{N} T={T}: max|out - fp64| {worst_o:.2e}, max|dZ - fp64|/max|dZ| {worst_g:.2e} on pairs {pairs}")
     assert worst_o < 1e-4 and worst_g < 5e-4
     # every pair of the batch == the same pair launched alone (one chunk, chunk offset 0)
-    worst = 0.0
+    # (the two launch geometries are not bit-identical: a pair's rows are cut into row blocks at different places)
+    wo = wg = 0.0
     for b in range(Bsz):
         z1 = Z[b:b + 1].cuda().requires_grad_(True)
         o1 = ops.sinkhorn(z1, T)
         (o1 * Gd[b:b + 1].cuda()).sum().backward()
-        worst = max(worst, float((o1.detach() - out[b:b + 1].detach()).abs().max()),
-                    float((z1.grad - Zd.grad[b:b + 1]).abs().max()) / float(z1.grad.abs().max()))
-    print(f"   batch vs single-pair launches, all {Bsz} pairs: max deviation {worst:.2e}")
-    assert worst < 1e-6
+        wo = max(wo, float((o1.detach() - out[b:b + 1].detach()).abs().max()))
+        wg = max(wg, float((z1.grad - Zd.grad[b:b + 1]).abs().max()) / float(z1.grad.abs().max()))
+    print(f"   batch vs single-pair launches, all {Bsz} pairs: max |d out| {wo:.2e}, max |d dZ| / max|dZ| {wg:.2e}")
+    assert wo < 1e-5 and wg < 1e-5
 
 
 # ------------------------------------------------------------------------------------------------ batch consistency
@@ -122,9 +123,11 @@ def _consistency(tag, model, data, bf16, keys, out_tol, grad_tol):
         rels[k] = float((gb.double() - mean).norm() / mean.norm().clamp(min=1e-30))
     # gradients that are analytically zero hold rounding noise only (e.g. key biases the softmax cancels): judged by
     # their size relative to the layer's weight gradient
+    # (SuperGlue / GlueStick key bias `attn.proj.1.bias`: softmax is invariant to a shift of all its logits of a row)
     sig = {k: v for k, v in rels.items()
-           if not (k.endswith(".bias") and k[:-5] + ".weight" in grads_b
-                   and float(grads_b[k].norm()) < 1e-4 * float(grads_b[k[:-5] + ".weight"].norm()))}
+           if not k.endswith("attn.proj.1.bias")
+           and not (k.endswith(".bias") and k[:-5] + ".weight" in grads_b
+                    and float(grads_b[k].norm()) < 1e-4 * float(grads_b[k[:-5] + ".weight"].norm()))}
     k_w = max(sig, key=sig.get)
     print(f"{tag} {'bf16' if bf16 else 'fp32'} B={B}: pairs {PAIRS} vs their B=1 runs: max |d| {worst_out}; batch gradient vs "
           f"mean of {B} per-pair gradients: worst relative error {sig[k_w]:.2e} ({k_w}), tensors {len(sig)}")

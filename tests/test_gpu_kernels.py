@@ -813,3 +813,42 @@ def test_precast_derived_weights_and_gradient_map():
     ops.precast([wq, bq, wa, wb, other], torch.bfloat16, key=key, derived=specs)
     w1b = ops.derived_weight(key, torch.bfloat16, "q.w", wq)
     assert torch.equal(ops._lp(w1b, torch.bfloat16), (2.0 * ref_w1).to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("R,K,N,c0,perm,bias", [(512, 256, 256, 256, False, True), (512, 256, 256, 256, True, True),
+                                                (96, 40, 72, 24, True, True), (130, 64, 64, 64, False, False)])
+def test_folded_linear_weights_and_gradients(R, K, N, c0, perm, bias):
+    """gf_fold_linear_fwd + the cast launch's column-block entries (ops.precast(derived=[(name, "fold", ...)])) and
+    gf_fold_linear_bwd vs torch autograd of  W' = [W0[:, :c0] | W0[:, c0:] Wo[:, cperm]],  b' = b0 + W0[:, c0:] bo
+    (lightglue.py:131-163 out_proj -> ffn.0; superglue.py:137-160 merge -> mlp.0)."""
+    from glue_factory_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(R + K)
+    rnd = lambda *s: torch.randn(*s, device="cuda", generator=g)                      # noqa: E731
+    W0 = torch.nn.Parameter(rnd(R, c0 + K) * 0.1)
+    Wo = torch.nn.Parameter(rnd(K, N) * 0.1)
+    b0 = torch.nn.Parameter(rnd(R)) if bias else None
+    bo = torch.nn.Parameter(rnd(K)) if bias else None
+    cperm = torch.randperm(N, device="cuda", generator=g) if perm else None
+    params = [p for p in (W0, Wo, b0, bo) if p is not None]
+    ops.precast(params, torch.bfloat16, key="foldtest", derived=[("blk.ffn0", "fold", W0, b0, Wo, bo, c0, cperm)])
+    out = ops.folded_linear("foldtest", torch.bfloat16, "blk.ffn0", W0, b0, Wo, bo)
+    assert out is not None
+    handle, bc = out
+    wo_g = Wo if cperm is None else Wo[:, cperm]
+    ref_w = torch.cat([W0[:, :c0], W0[:, c0:] @ wo_g], 1)
+    v = ops._lp(handle, torch.bfloat16)
+    assert v.dtype == torch.bfloat16 and v.shape == (R, c0 + N)
+    torch.testing.assert_close(v.float(), ref_w.detach().bfloat16().float(), rtol=0, atol=2e-3 * float(ref_w.abs().max()))
+    torch.testing.assert_close(ops._wt_t(v).float(), v.float().t())                  # the transposed copy of the same values
+    if bias:
+        ref_b = b0 + W0[:, c0:] @ bo
+        torch.testing.assert_close(bc.detach(), ref_b.detach(), rtol=1e-5, atol=1e-5)
+    gW, gb = rnd(R, c0 + N), rnd(R)
+    loss = (handle * gW).sum() + ((bc * gb).sum() if bias else 0.0)
+    loss.backward()
+    got = [p.grad.clone() for p in params]
+    for p in params:
+        p.grad = None
+    ((ref_w * gW).sum() + ((ref_b * gb).sum() if bias else 0.0)).backward()
+    for p, a in zip(params, got):
+        torch.testing.assert_close(a, p.grad, rtol=2e-5, atol=2e-5 * float(p.grad.abs().max()))
