@@ -76,9 +76,11 @@ class SuperPoint(BaseModel):
         "weights": None,
     }
     required_data_keys = ["image"]
+    batchable_views = True      # forward reads data["image"] only, image by image: a frozen instance may see both views at once
 
     def _init(self, conf):
         self.stride = 2 ** (len(conf.channels) - 2)
+        self.register_buffer("_gray", torch.tensor([0.299, 0.587, 0.114]).view(1, 3, 1, 1), persistent=False)
         channels = [1, *conf.channels[:-1]]
         backbone = []
         for i, c in enumerate(channels[1:], 1):
@@ -98,7 +100,11 @@ class SuperPoint(BaseModel):
 
     # ------------------------------------------------------------------ fused inference path (HIP)
     def _use_fused(self, image):
-        if not image.is_cuda or self.training or not 1 <= self.conf.nms_radius <= 4:
+        if not image.is_cuda or not 1 <= self.conf.nms_radius <= 4:
+            return False
+        # the fused kernels apply BatchNorm with its running statistics: every BatchNorm layer must be in eval mode -- the
+        # whole module (`.eval()`), or a frozen extractor inside a training pipeline (`freeze_batch_normalization: true`)
+        if any(m.training for m in self.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm)):
             return False
         return not (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()))
 
@@ -245,8 +251,8 @@ class SuperPoint(BaseModel):
     def _forward(self, data):
         conf = self.conf
         image = data["image"]
-        if image.shape[1] == 3:
-            image = (image * image.new_tensor([0.299, 0.587, 0.114]).view(1, 3, 1, 1)).sum(1, keepdim=True)
+        if image.shape[1] == 3:       # (the weights live in a buffer: a host -> device copy per call cannot be captured in a graph)
+            image = (image * self._gray.to(image.dtype)).sum(1, keepdim=True)
         fused = self._use_fused(image)
         if fused:
             det, desc_map = self._fused_features(image)
@@ -303,7 +309,16 @@ class SuperPoint(BaseModel):
             keypoints = torch.stack(idx[::-1], -1).float()[None]
             kscores = scores[0][idx][None]
         else:
-            if cand is not None:
+            if cand is not None and k <= min(4096, cand[0].shape[1]):
+                # own top-k over the candidate lists (csrc/topk.hip): sorted scores + pixel indices in one launch, and
+                # -- unlike torch.topk, whose memset nodes fault on the second replay of a captured graph -- capturable
+                from .. import lib as _lib
+                kscores = torch.empty((b, k), dtype=torch.float32, device=scores.device)
+                ind = torch.empty((b, k), dtype=torch.int64, device=scores.device)
+                _lib.check(_lib.load().gf_topk_candidates(cand[0].data_ptr(), cand[1].data_ptr(), kscores.data_ptr(),
+                                                          ind.data_ptr(), b, cand[0].shape[1], k,
+                                                          torch.cuda.current_stream().cuda_stream), "gf_topk_candidates")
+            elif cand is not None:
                 kscores, j = torch.topk(cand[0], min(k, cand[0].shape[1]), dim=1, sorted=True)
                 ind = cand[1].gather(1, j).long()       # (unfilled entries: score -1, index 0 -- never valid below)
             else:

@@ -72,6 +72,7 @@ SIGNATURES = {
     "gf_nms_scores": [_P, _P, _I, _I, _I, _I, _I, _P],
     "gf_nms_candidates": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "gf_nms_candidates_cap": [_I, _I, _I],
+    "gf_topk_candidates": [_P, _P, _P, _P, _I, _I, _I, _P],
     "gf_detector_scores": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "gf_sample_descriptors": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "gf_rowdot_nblk": [_I],

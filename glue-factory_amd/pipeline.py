@@ -8,6 +8,9 @@ per-view extractor outputs get the suffix 0/1 (a view's ``cache`` dict stands in
 raising NotImplementedError are skipped).
 Convention: ``matches0[i]`` is the index in image 1 matched to keypoint i of image 0, -1 if none.
 """
+import torch
+from torch import nn
+
 from .base_model import BaseModel, get_model
 from .conf import to_container
 
@@ -49,12 +52,32 @@ class TwoViewPipeline(BaseModel):
             return cached
         return {**cached, **self.extractor(view)}          # extractor outputs win over cached entries
 
+    def _extract_pair(self, data):
+        """Both views' extractor outputs.  A FROZEN extractor (no trainable parameter, BatchNorm layers in eval mode) sees
+        the two image batches as one call on their concatenation when they have the same shape -- per-image results are
+        what two calls give, every kernel launch covers 2B images -- otherwise view by view like the reference."""
+        v0, v1 = data["view0"], data["view1"]
+        ext = getattr(self, "extractor", None)
+        batched = (ext is not None and getattr(ext, "batchable_views", False)      # (its forward reads data["image"] only)
+                   and not v0.get("cache") and not v1.get("cache") and "image" in v0 and "image" in v1
+                   and v0["image"].shape == v1["image"].shape and v0["image"].is_cuda
+                   and not any(p_.requires_grad for p_ in ext.parameters())
+                   and not any(m.training for m in ext.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm)))
+        if not batched:
+            return self.extract_view(data, "0"), self.extract_view(data, "1")
+        b = v0["image"].shape[0]
+        out = self.extractor({"image": torch.cat([v0["image"], v1["image"]], 0)})
+        if not all(torch.is_tensor(t) and t.dim() > 0 and t.shape[0] == 2 * b for t in out.values()):
+            return self.extract_view(data, "0"), self.extract_view(data, "1")      # (an extractor with non-batched outputs)
+        return {k: t[:b] for k, t in out.items()}, {k: t[b:] for k, t in out.items()}
+
     def _inject_gt(self, pred, data):
         labels = self.ground_truth({**data, **pred})
         pred.update(_with_suffix_prefix(labels))
 
     def _forward(self, data):
-        pred = {**_with_suffix(self.extract_view(data, "0"), "0"), **_with_suffix(self.extract_view(data, "1"), "1")}
+        p0, p1 = self._extract_pair(data)
+        pred = {**_with_suffix(p0, "0"), **_with_suffix(p1, "1")}
         for stage in _AFTER_EXTRACTION:
             if self._has(stage):
                 pred = {**pred, **getattr(self, stage)({**data, **pred})}

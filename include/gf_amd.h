@@ -348,6 +348,14 @@ int gf_nms_scores(const float* scores, float* out, int B, int H, int W, int radi
  * on plateaus of exactly tied scores.  A top-k over the list = the top-k over the dense map (superpoint_open.py:165-170)
  * as long as it does not run into the zeros. */
 int gf_nms_candidates_cap(int H, int W, int radius);
+/* gf_topk_candidates (csrc/topk.hip): the K largest entries of each of B lists scores [B, n] (fp32; a NEGATIVE score marks
+ * an unfilled slot and ranks below every real entry, in list order), sorted by descending score, ties by ascending list
+ * position: out_scores [B, K] fp32 and out_payload [B, K] int64 = payload [B, n] (int32) of the selected entries -- the
+ * `torch.topk(scores, k, sorted=True)` + index gather of superpoint_open.py:165-170 on the candidate lists, without the
+ * hipMemsetAsync nodes of the library implementation (a captured graph holding those faults on its second replay on
+ * ROCm 7.2).  K <= min(n, 4096), else GF_ERR_UNSUPPORTED. */
+int gf_topk_candidates(const float* scores, const int* payload, float* out_scores, int64_t* out_payload, int B, int n, int K,
+                       void* stream);
 int gf_nms_candidates(const float* scores, float* cand_scores, int* cand_idx, int B, int H, int W, int radius, int border,
                       void* stream);
 /* gf_detector_scores: tail of the detector head (superpoint_open.py:105-108 detector.1 = Conv2d(256,65,1) [+ReLU] + BatchNorm(eval),

@@ -219,3 +219,35 @@ def test_conv3x3_c64_rejects():
                               1, 8, 32, 1, 0, 0, None) == -4          # fp32: GF_ERR_DTYPE
     assert lib.gf_conv3x3_c64(z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(),
                               1, 12, 32, 1, 0, 1, None) == -1         # H % 8: GF_ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("B,n,K,valid_frac", [(3, 87040, 2048, 0.25), (2, 5000, 2048, 0.1), (4, 4096, 4096, 0.6),
+                                              (1, 300, 7, 1.0), (2, 9000, 1000, 0.0), (2, 20000, 2048, 0.5)])
+def test_topk_candidates_equals_torch_topk(B, n, K, valid_frac):
+    """gf_topk_candidates (csrc/topk.hip) vs torch.topk(sorted=True) + gather on NMS-style candidate lists: positive scores
+    in scattered slots, -1 in the unfilled ones; incl. lists with fewer than K real entries, none at all, exact ties at
+    the threshold (quantised scores) and K == n."""
+    import ctypes
+    from glue_factory_amd import lib
+    g = torch.Generator(device="cuda").manual_seed(n + K)
+    s = torch.rand(B, n, device="cuda", generator=g)
+    if n == 20000:
+        s = (s * 64).floor() / 64 + 1.0 / 128          # heavy ties: 64 distinct values
+    s = torch.where(torch.rand(B, n, device="cuda", generator=g) < valid_frac, s, torch.full_like(s, -1.0)).contiguous()
+    payload = torch.randint(0, 2 ** 20, (B, n), device="cuda", generator=g, dtype=torch.int32)
+    out_s = torch.empty(B, K, device="cuda")
+    out_p = torch.empty(B, K, device="cuda", dtype=torch.int64)
+    lib.check(lib.load().gf_topk_candidates(s.data_ptr(), payload.data_ptr(), out_s.data_ptr(), out_p.data_ptr(), B, n, K,
+                                            torch.cuda.current_stream().cuda_stream), "gf_topk_candidates")
+    ref_s, ref_j = torch.topk(s, K, dim=1, sorted=True)
+    assert torch.equal(out_s, ref_s)                                   # the sorted score vectors are identical
+    # payloads: identical wherever the score is unique; inside a group of tied scores ours are in list order
+    order = torch.sort(s, dim=1, descending=True, stable=True).indices[:, :K]      # (score descending, position ascending)
+    assert torch.equal(out_p, payload.gather(1, order).long())
+    uniq = torch.ones_like(ref_s, dtype=torch.bool)
+    uniq[:, 1:] &= ref_s[:, 1:] != ref_s[:, :-1]
+    uniq[:, :-1] &= ref_s[:, :-1] != ref_s[:, 1:]
+    assert torch.equal(out_p[uniq], payload.gather(1, ref_j).long()[uniq])
+    with pytest.raises(RuntimeError):
+        lib.check(lib.load().gf_topk_candidates(s.data_ptr(), payload.data_ptr(), out_s.data_ptr(), out_p.data_ptr(), B, n, n + 1,
+                                                torch.cuda.current_stream().cuda_stream), "gf_topk_candidates")

@@ -141,3 +141,45 @@ def test_triplet_pipeline_trains_lightglue_batched_equals_pairwise():
     for k in grads[0]:
         sc = grads[1][k].abs().max().clamp(min=1e-6)
         torch.testing.assert_close(grads[0][k] / sc, grads[1][k] / sc, rtol=5e-3, atol=5e-3, msg=lambda m: f"{k}: {m}")   # (6-pair vs 3 x 2-pair fp32 summation order: measured up to 2.1e-3)
+
+
+def test_scope_p_replays_as_one_hipgraph_for_40_steps():
+    """extractor + ground truth + matcher step (forward, loss, backward, fused Adam) captured as ONE hipGraph
+    through the product API (TwoViewPipeline inside TrainStep(graph=True)) and replayed 40 times, with eager GPU work
+    between the replays and no host synchronisation, equals the eager run.  The graph faulted on its second replay while
+    the extractor's top-k was torch.topk (hipMemsetAsync nodes; tools/probe/capture_scope_p.py bisected it): the top-k is
+    now csrc/topk.hip."""
+    from glue_factory_amd.optim import FusedAdam
+    from glue_factory_amd.pipeline import TwoViewPipeline
+    from glue_factory_amd.synthetic import to_device
+    from glue_factory_amd.train_step import TrainStep
+
+    def build():
+        torch.manual_seed(0)
+        return TwoViewPipeline({
+            "extractor": {"name": "extractors.superpoint_open", "max_num_keypoints": 256, "force_num_keypoints": True,
+                          "detection_threshold": 0.0, "nms_radius": 3, "trainable": False, "freeze_batch_normalization": True},
+            "ground_truth": {"name": "matchers.homography_matcher", "th_positive": 3, "th_negative": 3, "with_reward": False},
+            "matcher": {"name": "matchers.lightglue", "n_layers": 2, "filter_threshold": 0.1},
+        }).cuda()
+
+    data = to_device(_batch(b=2, h=256, w=320, seed=3), "cuda")
+    runs = []
+    for graph in (False, True):
+        pipe = build()
+        step = TrainStep(pipe, FusedAdam([p for p in pipe.parameters() if p.requires_grad], lr=1e-3), amp_dtype=torch.bfloat16,
+                         device_ids=[0], graph=graph)
+        losses = []
+        junk = torch.zeros(1 << 20, device="cuda")
+        for it in range(43):                       # 2 eager warm-up calls + capture + 40 replays
+            losses.append(step(data)["total"].mean().clone())
+            junk.add_(1.0)                         # eager work queued between the replays
+            if it % 7 == 0:
+                pipe.extractor.eval()({"image": data["view0"]["image"]})      # ... incl. the library convolutions
+        assert step.graph == graph and (not graph or step.static_inputs() is not None)
+        runs.append((torch.stack(losses).cpu(), [p.detach().clone() for p in pipe.matcher.parameters()]))
+    (le, pe), (lg, pg) = runs
+    assert torch.isfinite(lg).all() and float(lg[-1]) < float(lg[0])                 # it trains
+    torch.testing.assert_close(lg, le, rtol=2e-2, atol=2e-2)                          # bf16 steps, 43 updates apart at most
+    for a, b_ in zip(pe, pg):
+        torch.testing.assert_close(b_, a, rtol=5e-2, atol=5e-3)
