@@ -335,7 +335,7 @@ def _calibrate_threads(step_small):
 
 
 def cpu_baseline(n, layers):
-    """The reference's own CPU path beside the GPU number: full LightGlue train step (forward + loss + backward,
+    """The reference's own CPU path beside the GPU number: full LightGlue train step (forward + loss + backward + Adam,
     fp32, `flash: false` as in the training yamls) at B=1 pair, same N and L; pairs/s = 1 / step.
     kind "reference": gluefactory's LightGlue module itself, from oracle/_ref (byte-compiled from /root/reference by
     oracle/build_ref.py in the build container; the GPU box only has the .pyc files).  kind "port": the oracle
@@ -354,12 +354,14 @@ def cpu_baseline(n, layers):
                                   "weights": None, "flash": False, "checkpointed": False}).train()
             model.load_state_dict(params, strict=True)
             data = make_pairs(1, nn_, dim=DIM, seed=1)
+            opt = torch.optim.Adam(model.parameters(), lr=1e-4)      # the optimiser of the reference's training configs
 
             def step():
-                model.zero_grad(set_to_none=True)
+                opt.zero_grad(set_to_none=True)
                 pred = model(data)
                 losses, _ = model.loss(pred, {**pred, **data})
                 losses["total"].mean().backward()
+                opt.step()
             return step
     else:
         kind = "port"
@@ -368,7 +370,15 @@ def cpu_baseline(n, layers):
             params = lgo.init_params(ll, DIM, HEADS, seed=0)
             data = make_pairs(1, nn_, dim=DIM, seed=1)
             data = dict(data, image_size0=data["view0"]["image_size"], image_size1=data["view1"]["image_size"])
-            return lambda: lgo.train_step_grads(params, data, ll, HEADS)
+            leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+            opt = torch.optim.Adam(list(leaves.values()), lr=1e-4)
+
+            def step():
+                _, _, grads = lgo.train_step_grads(params, data, ll, HEADS)
+                for k, v in leaves.items():
+                    v.grad = grads[k]
+                opt.step()
+            return step
 
     cores, avail = _calibrate_threads(make_step(512, 1))
     step = make_step(n, layers)
@@ -383,13 +393,14 @@ def cpu_baseline(n, layers):
     what = ("gluefactory.models.matchers.lightglue.LightGlue (the reference module, oracle/_ref)" if kind == "reference"
             else "the torch-CPU oracle port")
     return {"value": round(1.0 / dt, 4), "unit": "image-pairs/s", "cores": cores, "kind": kind,
-            "sample": f"B=1 pair, N={n}, L={layers}, fp32, 1 warm + {reps} timed train steps = forward + loss + backward "
-                      f"(NO optimiser step, `checkpointed: false`, no extractor) ({dt:.2f} s/step) of {what} on {cores} of "
-                      f"{avail} host threads"}
+            "sample": f"B=1 pair, N={n}, L={layers}, fp32, 1 warm + {reps} timed train steps = forward + loss + backward + "
+                      f"torch.optim.Adam step (`checkpointed: false`, no extractor) ({dt:.2f} s/step) of {what} on {cores} of "
+                      f"{avail} host threads (thread count calibrated on a small problem: torch's CPU backend collapses with "
+                      f"all {avail})"}
 
 
 # ------------------------------------------------------------------------------------------- model setup
-def build_matcher(args, rank, name):
+def build_matcher(args, rank, name, conf=None):
     from glue_factory_amd.synthetic import make_pairs
     torch.manual_seed(0)
     if name == "lightglue":
@@ -403,7 +414,7 @@ def build_matcher(args, rank, name):
     else:
         from glue_factory_amd.matchers.gluestick import GlueStick
         from glue_factory_amd.synthetic import make_point_line_pairs
-        model = GlueStick({}).cuda().train()
+        model = GlueStick(conf or {}).cuda().train()
         cpu_data = make_point_line_pairs(args.batch, args.kpts, args.lines, dim=DIM, seed=100 + rank)
     return model, cpu_data
 
@@ -481,10 +492,10 @@ def timed_steps(step, warmup, steps, barrier, dist):
     return dt, float(loss.item())
 
 
-def other_config(args, name, local):
+def other_config(args, name, local, conf=None):
     """BASELINE.json configs[3] / configs[4]: matcher train step of SuperGlue / GlueStick, inputs resident in HBM."""
     from glue_factory_amd.synthetic import to_device
-    model, cpu_data = build_matcher(args, 0, name)
+    model, cpu_data = build_matcher(args, 0, name, conf)
     # captured like the LightGlue step: their losses gather the positives through the fixed-length col0 vectors
     stepper = make_stepper(args, model, local, allow_graph=True)
     data = to_device(cpu_data, "cuda")
@@ -498,6 +509,34 @@ def other_config(args, name, local):
                                        "inputs resident in HBM", "final_loss": round(loss, 4)}
     del stepper, model, data
     torch.cuda.empty_cache()
+    return out
+
+
+def data_parallel_report(dist, rank, world, stepper):
+    """What a reader needs to trust an N > 1 line: which ranks actually took part (all-gathered RANK / device), how the
+    gradient buckets were cut, and the measured bus bandwidth of an all-reduce of one bucket over RCCL (ring: 2 (N-1)/N x
+    bytes / time) -- xGMI is point to point, so this is the number the bucket size was chosen against."""
+    ids = torch.tensor([rank, torch.cuda.current_device()], device="cuda", dtype=torch.int64)
+    seen = [torch.zeros_like(ids) for _ in range(world)]
+    dist.all_gather(seen, ids)
+    out = {"ranks_seen": [int(t[0]) for t in seen], "devices": [int(t[1]) for t in seen], "backend": dist.get_backend(),
+           "reducer": "buckets" if stepper.buckets is not None else "ddp"}
+    if stepper.buckets is not None:
+        out["buckets"] = len(stepper.buckets.buckets)
+        out["bucket_mbytes"] = [round((hi - lo) * 4 / 2 ** 20, 2) for lo, hi, _ in stepper.buckets.buckets]
+    buf = torch.zeros(4 * 2 ** 20, device="cuda")                       # 16 MB of fp32: the bucket cap
+    for _ in range(3):
+        dist.all_reduce(buf)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    reps = 20
+    for _ in range(reps):
+        dist.all_reduce(buf)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    out["allreduce_16MB_ms"] = round(dt * 1e3, 4)
+    out["allreduce_busbw_GBps"] = round(2.0 * (world - 1) / world * buf.numel() * 4 / dt / 1e9, 2)
     return out
 
 
@@ -563,17 +602,21 @@ def main():
                                        / world / (MFMA_BF16_PEAK_TFLOPS * 1e12), 4),
                "final_loss": round(m_loss, 4)}
     if not headline_is_pipeline:
+        dp_m = data_parallel_report(dist, rank, world, stepper) if dist is not None else None
         if rank == 0:
             print(json.dumps({"metric": f"image-pairs/sec (train step) {args.model} matcher only", "n_gpus": world,
                               "warmup": args.warmup, "dtype": args.dtype, "data": "synthetic",
                               "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                               "config": {"workload": f"{args.model} matcher train step, {args.batch} pairs/GPU, N={args.kpts}"},
-                              **matcher}), flush=True)
+                              **({"data_parallel": dp_m} if dp_m is not None else {}), **matcher}), flush=True)
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
         return
 
+    dp_info = None
+    if dist is not None:
+        dp_info = data_parallel_report(dist, rank, world, stepper)
     pipeline_step, extract, p_stepper = make_pipeline_step(args, rank, local)
     pipeline_step()                                   # MIOpen's convolution search happens here, outside any timing
     p_dt, p_loss = timed_steps(pipeline_step, args.warmup, args.steps, barrier, dist)
@@ -596,6 +639,8 @@ def main():
         "extractor_ms": round(t_ext * 1e3, 2), "final_loss": round(p_loss, 4),
         "matcher_step": matcher,
     }
+    if dp_info is not None:
+        out["data_parallel"] = dp_info
     if rank == 0 and world == 1:
         if not args.no_roofline:
             try:
@@ -611,6 +656,12 @@ def main():
             for name in ("superglue", "gluestick"):
                 try:
                     oc[name] = other_config(args, name, local)
+                    if name == "gluestick":
+                        # the line above runs the module's default, the reference's own AMP arithmetic (its attention pinned
+                        # to fp32-equivalent products, gluestick.py:524-529); the all-bf16 kernels beside it
+                        oc[name]["attention_precision"] = "reference"
+                        alt = other_config(args, name, local, {"attention_precision": "bf16"})
+                        oc[name]["attention_precision_bf16"] = {k: alt[k] for k in ("value", "ms_per_step", "final_loss")}
                 except Exception as e:
                     oc[name] = {"error": f"{type(e).__name__}: {e}"}
             out["other_configs"] = oc

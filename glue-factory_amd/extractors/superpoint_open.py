@@ -112,7 +112,10 @@ class SuperPoint(BaseModel):
         """Per-block (channels-last weight in `dtype`, bias, BN scale, BN shift), rebuilt when a tensor changed."""
         tensors = list(self.parameters()) + list(self.buffers())
         key = (dtype, tuple(t._version for t in tensors), tuple(t.data_ptr() for t in tensors))
-        cache = getattr(self, "_fused_cache", None)
+        # one entry PER DTYPE: a captured graph (TrainStep(graph=True) around a pipeline) points at the bf16 tensors of its
+        # entry, and an fp32 call in between (an eval pass outside autocast) must not evict -- and free -- them
+        caches = self.__dict__.setdefault("_fused_cache", {})
+        cache = caches.get(dtype)
         if cache is not None and cache[0] == key:
             return cache[1]
         out = {}
@@ -133,7 +136,7 @@ class SuperPoint(BaseModel):
                 if dtype == torch.bfloat16 and tuple(blk.conv.weight.shape) == (64, 64, 3, 3):
                     # [tap][c_out][c_in] for the register-resident weights of gf_conv3x3_c64
                     out[name + "/taps"] = blk.conv.weight.detach().permute(2, 3, 0, 1).to(dtype).contiguous()
-        self._fused_cache = (key, out)
+        caches[dtype] = (key, out)
         return out
 
     def _fused_block(self, name, blk, x, params, pool=False):

@@ -138,6 +138,13 @@ class GlueStick(BaseModel):
         "skip_init": False,
         "inter_supervision": None,
         "mp": False,
+        # Mixed precision only: arithmetic of the GNN's attention.  The reference pins this one function to fp32 under
+        # autocast (gluestick.py:18-22, 524-529 @AMP_CUSTOM_FWD_F32: scores, softmax and weighted sum in fp32 on the
+        # bf16-valued projections).  "reference": the same -- fp32-equivalent second products; "bf16": P and dS are
+        # rounded to bf16 in front of the second products like every other bf16 kernel here (the only difference; measured on
+        # config 5: per-tensor gradient error against the fp32 reference 7.0 % median with "bf16", 6.8 % with "reference" --
+        # the error of a bf16 GlueStick step is the linear layers', not the attention's).
+        "attention_precision": "reference",
         "loss": {"nll_weight": 1.0, "nll_balancing": 0.5, "inter_supervision": [0.3, 0.6]},
     }
     required_data_keys = ["view0", "view1", "keypoints0", "keypoints1", "descriptors0", "descriptors1",
@@ -147,6 +154,8 @@ class GlueStick(BaseModel):
     def _init(self, conf):
         if conf.descriptor_dim != 256:
             raise NotImplementedError("the HIP attention kernels are built for 4 heads of 64 channels")
+        if conf.attention_precision not in ("reference", "bf16"):
+            raise ValueError(f"attention_precision: 'reference' or 'bf16', got {conf.attention_precision!r}")
         d = conf.descriptor_dim
         if conf.input_dim != d:
             self.input_proj = nn.Conv1d(conf.input_dim, d, kernel_size=1)
@@ -167,6 +176,8 @@ class GlueStick(BaseModel):
                 nn.init.constant_(self.inter_line_proj[i].bias, 0.0)
                 nn.init.orthogonal_(self.inter_line_proj[i].weight, gain=1)
                 self.layer2idx[layer] = i
+        for layer in self.gnn.layers:
+            layer.update.attention_fp32 = conf.attention_precision == "reference"
         self.register_parameter("bin_score", nn.Parameter(torch.tensor(1.0)))
         self.register_parameter("line_bin_score", nn.Parameter(torch.tensor(1.0)))
         if conf.weights:

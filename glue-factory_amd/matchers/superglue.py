@@ -188,6 +188,8 @@ def derived_specs_of(model):
 
 
 class AttentionalPropagation(nn.Module):
+    attention_fp32 = False      # GlueStick sets it per its `attention_precision` configuration
+
     def __init__(self, num_dim, num_heads):
         super().__init__()
         self.attn = MultiHeadedAttention(num_heads, num_dim)
@@ -201,7 +203,12 @@ class AttentionalPropagation(nn.Module):
         b, n, d = x.shape
         chain = ops.GradChain(3) if residual and x.requires_grad and torch.is_grad_enabled() else None
         qkv, scale = self.attn.fused_projection(x, chain)
-        o = ops.attention_qkv(qkv, cross=cross, scale=scale)
+        if self.attention_fp32 and qkv.dtype != torch.float32:
+            # the reference forces THIS attention to fp32 under mixed precision (gluestick.py:18-22, 524-529
+            # @AMP_CUSTOM_FWD_F32): scores, softmax and the weighted sum in fp32 on the (bf16-valued) projections
+            o = ops.attention_qkv(qkv.float(), cross=cross, scale=scale).to(qkv.dtype)
+        else:
+            o = ops.attention_qkv(qkv, cross=cross, scale=scale)
         pc = self.attn._pc
         first = None if pc is None else ops.folded_linear(pc[0], x.dtype, pc[1] + ".mlp0", self.mlp[0].weight, self.mlp[0].bias,
                                                           self.attn.merge.weight, self.attn.merge.bias)

@@ -20,6 +20,27 @@ for k in 1 2 4 $N; do
   [ "$k" -gt "$N" ] && continue
   python bench.py --gpus $k --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-other-configs > "$OUT/n$k.json" 2> "$OUT/n$k.err" || echo "n=$k failed"
 done
+# N = 1 through the launcher must be the single-process number (same code path, no collective): within 2 %
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --no-other-configs > "$OUT/single.json" 2> "$OUT/single.err" || echo "single-process run failed"
+python - "$OUT" <<'PY'
+import json, sys
+out = sys.argv[1]
+rd = lambda f: json.loads(open(f).read().strip().splitlines()[-1])
+try:
+    a, b = rd(f"{out}/n1.json")["value"], rd(f"{out}/single.json")["value"]
+    print(f"N=1 via the launcher {a} vs single process {b}: {abs(a - b) / b * 100:.2f} %")
+    assert abs(a - b) <= 0.02 * b, "N=1 differs from the single-process number by more than 2 %"
+    for k in (2, 4, 8):
+        try:
+            d = rd(f"{out}/n{k}.json")
+        except Exception:
+            continue
+        dp = d.get("data_parallel", {})
+        assert sorted(dp.get("ranks_seen", [])) == list(range(k)), f"N={k}: ranks seen {dp.get('ranks_seen')}"
+        print(f"N={k}: value {d['value']}  ranks {dp.get('ranks_seen')}  buckets {dp.get('buckets')}  all-reduce busbw {dp.get('allreduce_busbw_GBps')} GB/s")
+except Exception as e:
+    print("scale check:", e)
+PY
 cd /tmp
 for mode in graph nograph; do
   extra=""; [ "$mode" = nograph ] && extra="--no-graph"
