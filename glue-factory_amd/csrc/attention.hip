@@ -619,7 +619,7 @@ constexpr int DKV_STATS = 2 * FT_TILE;                 // per wave: 16 lse | 16 
 constexpr int DKV_STAGE = 2 * FT_TILE + 1024;
 constexpr int DKV_NSTAGE = 3;
 
-template <int QB, bool PRE, typename Mid>
+template <int QB, bool PRE, bool SPLIT, typename Mid>      // SPLIT: P and dS as hi + lo bf16 pairs (attention_fwd3.hip)
 __device__ __forceinline__ void dkv_half_tile(f32x16 (&dk)[2], f32x16 (&dv)[2], const bf16x8 (&kf)[4],
                                               const bf16x8 (&vf)[4], const unsigned (&aR)[4],
                                               const unsigned (&aT)[4], unsigned aS, float c,
@@ -686,6 +686,14 @@ __device__ __forceinline__ void dkv_half_tile(f32x16 (&dk)[2], f32x16 (&dv)[2], 
             mma16(dv[db], as_frag(dot[0][db][0], dot[0][db][1]), pf0);
             mma16(dv[db], as_frag(dot[1][db][0], dot[1][db][1]), pf1);
         }
+        if (SPLIT) {
+            const bf16x8 pl0 = cvt_frag_lo(sa, 0, pf0), pl1 = cvt_frag_lo(sa, 1, pf1);
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                mma16(dv[db], as_frag(dot[0][db][0], dot[0][db][1]), pl0);
+                mma16(dv[db], as_frag(dot[1][db][0], dot[1][db][1]), pl1);
+            }
+        }
     }
     wait_lgkm<0>();
     {
@@ -696,13 +704,21 @@ __device__ __forceinline__ void dkv_half_tile(f32x16 (&dk)[2], f32x16 (&dv)[2], 
             mma16(dk[db], as_frag(qt[0][db][0], qt[0][db][1]), pf0);
             mma16(dk[db], as_frag(qt[1][db][0], qt[1][db][1]), pf1);
         }
+        if (SPLIT) {
+            const bf16x8 pl0 = cvt_frag_lo(dp, 0, pf0), pl1 = cvt_frag_lo(dp, 1, pf1);
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                mma16(dk[db], as_frag(qt[0][db][0], qt[0][db][1]), pl0);
+                mma16(dk[db], as_frag(qt[1][db][0], qt[1][db][1]), pl1);
+            }
+        }
     }
 }
 
 // NW waves per workgroup (32 keys each) share the Q/dO stream; PRE: rr == 1, no multiply per score; EVEN: Nq % 64 == 0 -- no
 // ragged tile: unconditional re-fetching DMA (tiles past the end fetch the last one again), constant wait counts, no
 // row masking: no tile-dependent branch in the loop (attention_fwd3.hip)
-template <int NW, bool PRE, bool EVEN>
+template <int NW, bool PRE, bool EVEN, bool SPLIT = false>
 __global__ __launch_bounds__(64 * NW, 8 / NW) void attn_bwd_dkv_bf16_kernel(AttnParams p) {
     constexpr int KPB = 32 * NW, PPW = 8 / NW;    // keys per block, 1-KiB DMA pieces per wave and matrix
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -821,9 +837,9 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void attn_bwd_dkv_bf16_kernel(Attn
         const int nstage = stage == 0 ? 2 : stage - 1;
         const bool more = EVEN || t + 2 < nt;
         const int tn = EVEN ? min(t + 2, nt - 1) : t + 2;
-        dkv_half_tile<0, PRE>(dk, dv, kf, vf, aR, aT, bS + so, c, hi, nvalid,
+        dkv_half_tile<0, PRE, SPLIT>(dk, dv, kf, vf, aR, aT, bS + so, c, hi, nvalid,
                          [&] { if (more) issue_part(0, tn, nstage); });
-        dkv_half_tile<1, PRE>(dk, dv, kf, vf, aR, aT, bS + so, c, hi, nvalid,
+        dkv_half_tile<1, PRE, SPLIT>(dk, dv, kf, vf, aR, aT, bS + so, c, hi, nvalid,
                          [&] { if (more) issue_part(1, tn, nstage); });
         stage = stage == 2 ? 0 : stage + 1;
     }
@@ -1270,8 +1286,10 @@ template <typename T> int launch_bwd(const AttnParams& p, hipStream_t st) {
 #endif
         total = ((p.Nk + 32 * NW - 1) / (32 * NW)) * p.H * p.B;
         lds = DKV_NSTAGE * DKV_STAGE;
-        void (*const kern[4])(AttnParams) = {attn_bwd_dkv_bf16_kernel<NW, false, false>, attn_bwd_dkv_bf16_kernel<NW, false, true>,
-                                             attn_bwd_dkv_bf16_kernel<NW, true, false>, attn_bwd_dkv_bf16_kernel<NW, true, true>};
+        void (*const kern[8])(AttnParams) = {attn_bwd_dkv_bf16_kernel<NW, false, false>, attn_bwd_dkv_bf16_kernel<NW, false, true>,
+                                             attn_bwd_dkv_bf16_kernel<NW, true, false>, attn_bwd_dkv_bf16_kernel<NW, true, true>,
+                                             attn_bwd_dkv_bf16_kernel<NW, false, false, true>, attn_bwd_dkv_bf16_kernel<NW, false, true, true>,
+                                             attn_bwd_dkv_bf16_kernel<NW, true, false, true>, attn_bwd_dkv_bf16_kernel<NW, true, true, true>};
         static unsigned long long attr_set = 0;     // function attributes are per DEVICE: one bit per device ordinal
         int dev = 0;
         (void)hipGetDevice(&dev);
@@ -1280,7 +1298,7 @@ template <typename T> int launch_bwd(const AttnParams& p, hipStream_t st) {
                 if (int e = set_lds(k, lds)) return e;
             if (dev < 64) attr_set |= 1ull << dev;
         }
-        kern[(p.rr == 1.f ? 2 : 0) + (p.Nq % 64 == 0 ? 1 : 0)]<<<dim3(total), dim3(64 * NW), lds, st>>>(p);
+        kern[((p.flags & GF_ATTN_SPLIT) ? 4 : 0) + (p.rr == 1.f ? 2 : 0) + (p.Nq % 64 == 0 ? 1 : 0)]<<<dim3(total), dim3(64 * NW), lds, st>>>(p);
         return (int)hipGetLastError();
     }
     lds = dkv_lds<T, 64>();
@@ -1297,12 +1315,28 @@ bool bad_stride(const int64_t* s, int n, int align) {
 
 }  // namespace
 
+extern "C" int gf_attn_fwd_ex(const void* q, const void* k, const void* v, void* o, float* lse,
+                              int B, int H, int Nq, int Nk, int D,
+                              const int64_t* q_strides, const int64_t* k_strides,
+                              const int64_t* v_strides, const int64_t* o_strides,
+                              float scale, int dtype, int flags, void* stream);
 extern "C" int gf_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
                            int B, int H, int Nq, int Nk, int D,
                            const int64_t* q_strides, const int64_t* k_strides,
                            const int64_t* v_strides, const int64_t* o_strides,
                            float scale, int dtype, void* stream) {
+    return gf_attn_fwd_ex(q, k, v, o, lse, B, H, Nq, Nk, D, q_strides, k_strides, v_strides, o_strides, scale, dtype, 0, stream);
+}
+extern "C" int gf_attn_fwd_ex(const void* q, const void* k, const void* v, void* o, float* lse,
+                              int B, int H, int Nq, int Nk, int D,
+                              const int64_t* q_strides, const int64_t* k_strides,
+                              const int64_t* v_strides, const int64_t* o_strides,
+                              float scale, int dtype, int flags, void* stream) {
     if (D != 64) return GF_ERR_UNSUPPORTED;
+    if (flags & ~GF_ATTN_SPLIT) return GF_ERR_UNSUPPORTED;
+    if (dtype == GF_F32) flags = 0;                                  // fp32 operands: nothing to split
+    // the split products exist in the LDS-DMA bf16 kernels only (rows addressed through 32-bit buffer offsets)
+    if ((flags & GF_ATTN_SPLIT) && !(kvdma_ok(Nk, k_strides[1]) && kvdma_ok(Nk, v_strides[1]))) return GF_ERR_UNSUPPORTED;
     if (B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0) return GF_ERR_SHAPE;
     const int align = dtype == GF_BF16 ? 8 : 4;
     if (bad_stride(q_strides, 3, align) || bad_stride(k_strides, 3, align) ||
@@ -1312,6 +1346,7 @@ extern "C" int gf_attn_fwd(const void* q, const void* k, const void* v, void* o,
     p.q = q; p.k = k; p.v = v; p.o = o; p.lse = lse;
     p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk; p.scale = scale;
     host_split_scale(scale, p.p2, p.rr);
+    p.flags = flags;
     p.sqb = q_strides[0]; p.sqn = q_strides[1]; p.sqh = q_strides[2];
     p.skb = k_strides[0]; p.skn = k_strides[1]; p.skh = k_strides[2];
     p.svb = v_strides[0]; p.svn = v_strides[1]; p.svh = v_strides[2];
@@ -1345,7 +1380,9 @@ extern "C" int gf_attn_bwd_acc(const void* q, const void* k, const void* v, cons
                                const int64_t* dk_strides, const int64_t* dv_strides,
                                float scale, int dtype, int flags, void* stream) {
     if (D != 64) return GF_ERR_UNSUPPORTED;
-    if (flags & ~3) return GF_ERR_UNSUPPORTED;
+    if (flags & ~7) return GF_ERR_UNSUPPORTED;
+    if (dtype == GF_F32) flags &= ~GF_ATTN_SPLIT;                    // fp32 operands: nothing to split
+    if ((flags & GF_ATTN_SPLIT) && !(kvdma_ok(Nk, k_strides[1]) && kvdma_ok(Nk, v_strides[1]))) return GF_ERR_UNSUPPORTED;
     if (B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0) return GF_ERR_SHAPE;
     const int align = dtype == GF_BF16 ? 8 : 4;
     const int64_t* all[8] = {q_strides, k_strides, v_strides, o_strides,

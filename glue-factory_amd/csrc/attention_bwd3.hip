@@ -26,8 +26,9 @@ namespace {
 #define DQ3_WPS 2          // workgroups per CU = waves per SIMD
 #endif
 
-template <bool PRE, bool EVEN>      // PRE: rr == 1 (operands pre-multiplied by the caller): no multiply in front of exp2;
-                                    // EVEN: Nk % 64 == 0 -- no tile-dependent branch in the loop (see attention_fwd3.hip)
+template <bool PRE, bool EVEN, bool SPLIT = false>   // PRE: rr == 1 (operands pre-multiplied by the caller): no multiply in front of exp2;
+                                    // EVEN: Nk % 64 == 0 -- no tile-dependent branch in the loop (see attention_fwd3.hip);
+                                    // SPLIT: dS = hi + lo bf16 pair in front of the dQ product (attention_fwd3.hip)
 __global__ __launch_bounds__(256, DQ3_WPS) void attn_dq3_bf16_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const unsigned lds0 = (unsigned)(size_t)smem;
@@ -128,6 +129,13 @@ __global__ __launch_bounds__(256, DQ3_WPS) void attn_dq3_bf16_kernel(AttnParams 
                 mma16(dq[db], as_frag(kt[0][db][0], kt[0][db][1]), d0);      /* dQ^T[d][q] += K^T[d][key] dS */     \
                 mma16(dq[db], as_frag(kt[1][db][0], kt[1][db][1]), d1);                                             \
             }                                                                                                       \
+            if (SPLIT) {                                                                                            \
+                const bf16x8 e0 = cvt_frag_lo(s, 0, d0), e1 = cvt_frag_lo(s, 1, d1);                                \
+                _Pragma("unroll") for (int db = 0; db < 2; ++db) {                                                  \
+                    mma16(dq[db], as_frag(kt[0][db][0], kt[0][db][1]), e0);                                         \
+                    mma16(dq[db], as_frag(kt[1][db][0], kt[1][db][1]), e1);                                         \
+                }                                                                                                   \
+            }                                                                                                       \
         }
         GF_DQ3_HALF(0)
         GF_DQ3_HALF(1)
@@ -149,17 +157,21 @@ __global__ __launch_bounds__(256, DQ3_WPS) void attn_dq3_bf16_kernel(AttnParams 
 int launch_dq3_bf16(const AttnParams& p, hipStream_t st) {
     const int total = ((p.Nq + 127) / 128) * p.H * p.B;
     const size_t lds = FQ_NSTAGE * FQ_STAGE;
-    void (*const kern[4])(AttnParams) = {attn_dq3_bf16_kernel<false, false>, attn_dq3_bf16_kernel<false, true>,
-                                         attn_dq3_bf16_kernel<true, false>, attn_dq3_bf16_kernel<true, true>};
-    static bool attr_set = false;
-    if (!attr_set) {
+    void (*const kern[8])(AttnParams) = {attn_dq3_bf16_kernel<false, false, false>, attn_dq3_bf16_kernel<false, true, false>,
+                                         attn_dq3_bf16_kernel<true, false, false>, attn_dq3_bf16_kernel<true, true, false>,
+                                         attn_dq3_bf16_kernel<false, false, true>, attn_dq3_bf16_kernel<false, true, true>,
+                                         attn_dq3_bf16_kernel<true, false, true>, attn_dq3_bf16_kernel<true, true, true>};
+    static unsigned long long attr_set = 0;          // function attributes are per device: one bit per device ordinal
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 64 || !((attr_set >> dev) & 1ull)) {
         for (auto k : kern) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return (int)e;
         }
-        attr_set = true;
+        if (dev < 64) attr_set |= 1ull << dev;
     }
-    kern[(p.rr == 1.f ? 2 : 0) + (p.Nk % 64 == 0 ? 1 : 0)]<<<dim3(total), dim3(256), lds, st>>>(p);
+    kern[((p.flags & GF_ATTN_SPLIT) ? 4 : 0) + (p.rr == 1.f ? 2 : 0) + (p.Nk % 64 == 0 ? 1 : 0)]<<<dim3(total), dim3(256), lds, st>>>(p);
     return (int)hipGetLastError();
 }
 

@@ -80,7 +80,10 @@ __device__ __forceinline__ void fw3_scores(f32x16 (&sc)[2], const unsigned (&aR)
 #endif
 }
 
-template <bool PRE>      // PRE: rr == 1 (operands pre-multiplied by the caller): no multiply in front of exp2
+// SPLIT ("fp32-equivalent second product", GF_ATTN_SPLIT): P = P_hi + P_lo with both halves bf16 (16 mantissa bits kept), and
+// O accumulates V^T P_hi + V^T P_lo -- what remains of the difference to an fp32 softmax(QK^T) V on the same bf16 operands is
+// the summation order.  Costs one more pass of the PV MFMAs (V^T read again from the same LDS tile) and 2.5 VALU per score.
+template <bool PRE, bool SPLIT = false>      // PRE: rr == 1 (operands pre-multiplied by the caller): no multiply in front of exp2
 __device__ __forceinline__ void fw3_tile(bool force_slow, int kv0, int Nk, const unsigned (&aR)[4], const unsigned (&aT)[4],
                                          const bf16x8 (&qf)[4], f32x16 (&o)[2], f32x16& negm, float& m, float& lsum, int hi, float rr) {
     constexpr int VB = FT_TILE;
@@ -145,7 +148,15 @@ __device__ __forceinline__ void fw3_tile(bool force_slow, int kv0, int Nk, const
     }
     // ---- O^T[d][q] += V^T[d][key] P[key][q]
     u32x2 vt0[2][2][2], vt1[2][2][2];
-    const bf16x8 p00 = cvt_frag(sc[0], 0), p01 = cvt_frag(sc[0], 1), p10 = cvt_frag(sc[1], 0), p11 = cvt_frag(sc[1], 1);
+    bf16x8 p00 = cvt_frag(sc[0], 0), p01 = cvt_frag(sc[0], 1), p10 = cvt_frag(sc[1], 0), p11 = cvt_frag(sc[1], 1);
+    bf16x8 l00, l01, l10, l11;
+    if (SPLIT) {
+        l00 = cvt_frag_lo(sc[0], 0, p00); l01 = cvt_frag_lo(sc[0], 1, p01);
+        l10 = cvt_frag_lo(sc[1], 0, p10); l11 = cvt_frag_lo(sc[1], 1, p11);
+    }
+#pragma unroll
+    for (int pass = 0; pass < (SPLIT ? 2 : 1); ++pass) {
+    if (SPLIT && pass == 1) { p00 = l00; p01 = l01; p10 = l10; p11 = l11; }
 #if FW3_ABL & 4
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -184,13 +195,14 @@ __device__ __forceinline__ void fw3_tile(bool force_slow, int kv0, int Nk, const
             mma16(o[db], as_frag(vt1[tt][db][0], vt1[tt][db][1]), tt ? p11 : p10);
         }
 #endif
+    }
 }
 
 // EVEN: Nk % 64 == 0 -- no ragged tile, so the loop carries no tile-dependent branches: tile 0 (always conventional) is
 // peeled, tiles past the end re-fetch the last one (unconditional DMA, constant wait count).  Every instruction of the
 // loop costs an issue slot: the scalar bookkeeping of the general loop is ~25 of them per tile.
-template <bool PRE, bool EVEN>
-__global__ __launch_bounds__(256, FW3_WPS) void attn_fwd3_bf16_kernel(AttnParams p) {
+template <bool PRE, bool EVEN, bool SPLIT = false>
+__global__ __launch_bounds__(256, SPLIT ? 2 : FW3_WPS) void attn_fwd3_bf16_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const unsigned lds0 = (unsigned)(size_t)smem;
     const int nqb = (p.Nq + 127) / 128;
@@ -250,7 +262,7 @@ __global__ __launch_bounds__(256, FW3_WPS) void attn_fwd3_bf16_kernel(AttnParams
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         dma.issue_full(min(2, nt - 1), wbase + 2 * FQ_STAGE);
-        fw3_tile<PRE>(true, 0, p.Nk, aR, aT, qf, o, negm, m, lsum, hi, rr);
+        fw3_tile<PRE, SPLIT>(true, 0, p.Nk, aR, aT, qf, o, negm, m, lsum, hi, rr);
 #pragma unroll
         for (int i = 0; i < 4; ++i) { aR[i] += FQ_STAGE; aT[i] += FQ_STAGE; }
         stage = 1;
@@ -259,7 +271,7 @@ __global__ __launch_bounds__(256, FW3_WPS) void attn_fwd3_bf16_kernel(AttnParams
             __builtin_amdgcn_s_barrier();                                // ... everyone's; the stage of tile t-1 is free
             __builtin_amdgcn_sched_barrier(0);
             dma.issue_full(min(t + 2, nt - 1), wbase + (stage == 0 ? 2 : stage - 1) * FQ_STAGE);
-            fw3_tile<PRE>(false, t * 64, p.Nk, aR, aT, qf, o, negm, m, lsum, hi, rr);
+            fw3_tile<PRE, SPLIT>(false, t * 64, p.Nk, aR, aT, qf, o, negm, m, lsum, hi, rr);
             const int step = stage == 2 ? -2 * FQ_STAGE : FQ_STAGE;
 #pragma unroll
             for (int i = 0; i < 4; ++i) { aR[i] += step; aT[i] += step; }
@@ -276,7 +288,7 @@ __global__ __launch_bounds__(256, FW3_WPS) void attn_fwd3_bf16_kernel(AttnParams
 #if !(FW3_ABL & 64)
         if (t + 2 < nt) dma.issue(t + 2, smem + (stage == 0 ? 2 : stage - 1) * FQ_STAGE + wave * 1024);
 #endif
-        fw3_tile<PRE>(t == 0 || t * 64 + 64 > p.Nk, t * 64, p.Nk, aR, aT, qf, o, negm, m, lsum, hi, rr);
+        fw3_tile<PRE, SPLIT>(t == 0 || t * 64 + 64 > p.Nk, t * 64, p.Nk, aR, aT, qf, o, negm, m, lsum, hi, rr);
         const int step = stage == 2 ? -2 * FQ_STAGE : FQ_STAGE;      // ring: per-lane read addresses follow the stage
 #pragma unroll
         for (int i = 0; i < 4; ++i) { aR[i] += step; aT[i] += step; }
@@ -297,28 +309,28 @@ __global__ __launch_bounds__(256, FW3_WPS) void attn_fwd3_bf16_kernel(AttnParams
 int launch_fwd3_bf16(const AttnParams& p, hipStream_t st) {
     const int total = ((p.Nq + 127) / 128) * p.H * p.B;
     const size_t lds = FQ_NSTAGE * FQ_STAGE;
-    static bool attr_set = false;
-    if (!attr_set) {
-        const void* ks[4] = {reinterpret_cast<const void*>(attn_fwd3_bf16_kernel<false, false>),
-                             reinterpret_cast<const void*>(attn_fwd3_bf16_kernel<false, true>),
-                             reinterpret_cast<const void*>(attn_fwd3_bf16_kernel<true, false>),
-                             reinterpret_cast<const void*>(attn_fwd3_bf16_kernel<true, true>)};
-        for (const void* k : ks) {
-            hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    void (*const kern[8])(AttnParams) = {
+        attn_fwd3_bf16_kernel<false, false, false>, attn_fwd3_bf16_kernel<false, true, false>,
+        attn_fwd3_bf16_kernel<true, false, false>, attn_fwd3_bf16_kernel<true, true, false>,
+        attn_fwd3_bf16_kernel<false, false, true>, attn_fwd3_bf16_kernel<false, true, true>,
+        attn_fwd3_bf16_kernel<true, false, true>, attn_fwd3_bf16_kernel<true, true, true>};
+    static unsigned long long attr_set = 0;          // function attributes are per device: one bit per device ordinal
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 64 || !((attr_set >> dev) & 1ull)) {
+        for (auto k : kern) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return (int)e;
         }
-        attr_set = true;
+        if (dev < 64) attr_set |= 1ull << dev;
     }
 #ifdef FW3_NO_EVEN
     const bool pre = p.rr == 1.f, even = false;
 #else
     const bool pre = p.rr == 1.f, even = p.Nk % 64 == 0;
 #endif
-    const dim3 g(total), b(256);
-    if (pre && even) attn_fwd3_bf16_kernel<true, true><<<g, b, lds, st>>>(p);
-    else if (pre) attn_fwd3_bf16_kernel<true, false><<<g, b, lds, st>>>(p);
-    else if (even) attn_fwd3_bf16_kernel<false, true><<<g, b, lds, st>>>(p);
-    else attn_fwd3_bf16_kernel<false, false><<<g, b, lds, st>>>(p);
+    const bool split = (p.flags & GF_ATTN_SPLIT) != 0;
+    kern[(split ? 4 : 0) + (pre ? 2 : 0) + (even ? 1 : 0)]<<<dim3(total), dim3(256), lds, st>>>(p);
     return (int)hipGetLastError();
 }
 

@@ -7,7 +7,7 @@
 
 namespace gfattn {
 
-enum { GF_ATTN_ACC_DQ = 1, GF_ATTN_ACC_DK = 2 };
+enum { GF_ATTN_ACC_DQ = 1, GF_ATTN_ACC_DK = 2 };      // (+ GF_ATTN_SPLIT = 4, include/gf_amd.h)
 
 struct AttnParams {
     const void* q; const void* k; const void* v; void* o;
@@ -18,7 +18,8 @@ struct AttnParams {
     // gradients: dq/dout use the o-like strides given below
     int64_t sdob, sdon, sdoh, sdqb, sdqn, sdqh, sdkb, sdkn, sdkh, sdvb, sdvn, sdvh;
     float scale;
-    int flags;        // GF_ATTN_ACC_DQ / GF_ATTN_ACC_DK: add to what dq / dk hold instead of overwriting (gf_attn_bwd_acc)
+    int flags;        // GF_ATTN_ACC_DQ / GF_ATTN_ACC_DK: add to what dq / dk hold instead of overwriting (gf_attn_bwd_acc);
+                      // GF_ATTN_SPLIT: P and dS enter the second products as hi + lo bf16 pairs (fp32-equivalent)
     float p2, rr;     // scale * log2(e) = p2 * rr, p2 a power of two, rr in [1, 2) (host_split_scale); rr == 1 exactly when the
                       // caller pre-multiplied its operands (scale = ln 2): the kernels then skip the multiply per score
 };
@@ -121,6 +122,13 @@ __device__ __forceinline__ bf16x8 cvt_frag(const f32x16& c, int t) {
     bf16x8 f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) f[e] = (bf16_t)c[8 * t + e];
+    return f;
+}
+// the low half of a split operand: bf16(c - float(hi)) for the 8 values hi = cvt_frag(c, t) was rounded from
+__device__ __forceinline__ bf16x8 cvt_frag_lo(const f32x16& c, int t, bf16x8 hi) {
+    bf16x8 f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = (bf16_t)(c[8 * t + e] - (float)hi[e]);
     return f;
 }
 __device__ __forceinline__ void mma16(f32x16& acc, bf16x8 a, bf16x8 b) {

@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgf_amd.so")
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 9      # == GF_AMD_ABI_VERSION in include/gf_amd.h (bumped with every signature / workspace change)
+ABI_VERSION = 10      # == GF_AMD_ABI_VERSION in include/gf_amd.h (bumped with every signature / workspace change)
 
 _c = ctypes
 _P, _I, _F, _L, _D = _c.c_void_p, _c.c_int, _c.c_float, _c.c_int64, _c.c_double
@@ -20,6 +20,7 @@ _S = _c.POINTER(_c.c_int64)
 SIGNATURES = {
     "gf_abi_version": [],
     "gf_attn_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _S, _S, _S, _S, _F, _I, _P],
+    "gf_attn_fwd_ex": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _S, _S, _S, _S, _F, _I, _I, _P],
     "gf_attn_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I,
                     _S, _S, _S, _S, _S, _S, _S, _S, _F, _I, _P],
     "gf_attn_bwd_acc": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I,

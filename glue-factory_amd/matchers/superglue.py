@@ -203,12 +203,10 @@ class AttentionalPropagation(nn.Module):
         b, n, d = x.shape
         chain = ops.GradChain(3) if residual and x.requires_grad and torch.is_grad_enabled() else None
         qkv, scale = self.attn.fused_projection(x, chain)
-        if self.attention_fp32 and qkv.dtype != torch.float32:
-            # the reference forces THIS attention to fp32 under mixed precision (gluestick.py:18-22, 524-529
-            # @AMP_CUSTOM_FWD_F32): scores, softmax and the weighted sum in fp32 on the (bf16-valued) projections
-            o = ops.attention_qkv(qkv.float(), cross=cross, scale=scale).to(qkv.dtype)
-        else:
-            o = ops.attention_qkv(qkv, cross=cross, scale=scale)
+        # attention_fp32 (GlueStick, `attention_precision: reference`): the reference forces THIS attention to fp32 under mixed
+        # precision (gluestick.py:18-22, 524-529 @AMP_CUSTOM_FWD_F32) -- scores, softmax and the weighted sum in fp32 on the
+        # bf16-valued projections: the bf16 kernels with the softmax weights / score gradients split into hi + lo pairs
+        o = ops.attention_qkv(qkv, cross=cross, scale=scale, split=self.attention_fp32 and qkv.dtype != torch.float32)
         pc = self.attn._pc
         first = None if pc is None else ops.folded_linear(pc[0], x.dtype, pc[1] + ".mlp0", self.mlp[0].weight, self.mlp[0].bias,
                                                           self.attn.merge.weight, self.attn.merge.bias)
@@ -222,7 +220,7 @@ class AttentionalPropagation(nn.Module):
         outs = []
         p0, p1 = self.attn.fused_projection(x0, premul=False)[0], self.attn.fused_projection(x1, premul=False)[0]
         for x, pq, ps in ((x0, p0, p1 if cross else p0), (x1, p1, p0 if cross else p1)):
-            o = ops.attention(pq[:, :, 0], ps[:, :, 1], ps[:, :, 2])
+            o = ops.attention(pq[:, :, 0], ps[:, :, 1], ps[:, :, 2], split=self.attention_fp32 and pq.dtype != torch.float32)
             msg = _conv_cl(o.reshape(x.shape), self.attn.merge, cols=self.attn._perm)
             outs.append(_mlp_cl(self.mlp, x, 1, x2=msg))
         return outs

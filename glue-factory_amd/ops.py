@@ -53,20 +53,23 @@ def _s3(t):
 
 
 # ------------------------------------------------------------------------------ attention
-def attn_fwd_raw(q, k, v, scale, out=None, lse=None):
+ATTN_SPLIT = 4       # GF_ATTN_SPLIT (include/gf_amd.h): P / dS as hi + lo bf16 pairs = fp32-equivalent second products
+
+
+def attn_fwd_raw(q, k, v, scale, out=None, lse=None, split=False):
     _chk(q, k, v)
     B, Nq, H, D = q.shape
     Nk = k.shape[1]
     o = torch.empty((B, Nq, H, D), dtype=q.dtype, device=q.device) if out is None else out
     if lse is None:
         lse = torch.empty((B, H, Nq), dtype=torch.float32, device=q.device)
-    _lib.check(_lib.load().gf_attn_fwd(_p(q), _p(k), _p(v), _p(o), _p(lse), B, H, Nq, Nk, D,
-                                       _s3(q), _s3(k), _s3(v), _s3(o), float(scale), _dt(q),
-                                       _stream()), "gf_attn_fwd")
+    _lib.check(_lib.load().gf_attn_fwd_ex(_p(q), _p(k), _p(v), _p(o), _p(lse), B, H, Nq, Nk, D,
+                                          _s3(q), _s3(k), _s3(v), _s3(o), float(scale), _dt(q), ATTN_SPLIT if split else 0,
+                                          _stream()), "gf_attn_fwd_ex")
     return o, lse
 
 
-def attn_bwd_raw(q, k, v, o, do, lse, dq, dk, dv, scale, acc_dq=False, acc_dk=False):
+def attn_bwd_raw(q, k, v, o, do, lse, dq, dk, dv, scale, acc_dq=False, acc_dk=False, split=False):
     B, Nq, H, D = q.shape
     Nk = k.shape[1]
     if do.stride(3) != 1:
@@ -75,7 +78,8 @@ def attn_bwd_raw(q, k, v, o, do, lse, dq, dk, dv, scale, acc_dq=False, acc_dk=Fa
     _lib.check(_lib.load().gf_attn_bwd_acc(_p(q), _p(k), _p(v), _p(o), _p(do), _p(lse), _p(delta),
                                        _p(dq), _p(dk), _p(dv), B, H, Nq, Nk, D,
                                        _s3(q), _s3(k), _s3(v), _s3(o), _s3(do), _s3(dq), _s3(dk),
-                                       _s3(dv), float(scale), _dt(q), int(acc_dq) | 2 * int(acc_dk), _stream()),
+                                       _s3(dv), float(scale), _dt(q),
+                                       int(acc_dq) | 2 * int(acc_dk) | (ATTN_SPLIT if split else 0), _stream()),
                "gf_attn_bwd_acc")
 
 
@@ -83,10 +87,10 @@ class _Attention(torch.autograd.Function):
     """o = softmax(scale q k^T) v on [B,N,H,D] views (generic entry, used by SuperGlue/GlueStick)."""
 
     @staticmethod
-    def forward(ctx, q, k, v, scale):
-        o, lse = attn_fwd_raw(q, k, v, scale)
+    def forward(ctx, q, k, v, scale, split=False):
+        o, lse = attn_fwd_raw(q, k, v, scale, split=split)
         ctx.save_for_backward(q, k, v, o, lse)
-        ctx.scale = scale
+        ctx.scale, ctx.split = scale, split
         return o
 
     @staticmethod
@@ -94,13 +98,14 @@ class _Attention(torch.autograd.Function):
         q, k, v, o, lse = ctx.saved_tensors
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         dq, dk, dv = (t.contiguous() for t in (dq, dk, dv))
-        attn_bwd_raw(q, k, v, o, do, lse, dq, dk, dv, ctx.scale)
-        return dq, dk, dv, None
+        attn_bwd_raw(q, k, v, o, do, lse, dq, dk, dv, ctx.scale, split=ctx.split)
+        return dq, dk, dv, None, None
 
 
-def attention(q, k, v, scale=None):
+def attention(q, k, v, scale=None, split=False):
+    """split: fp32-equivalent second products on bf16 operands (GF_ATTN_SPLIT; no effect on fp32 tensors)."""
     scale = q.shape[-1] ** -0.5 if scale is None else scale
-    return _Attention.apply(q, k, v, scale)
+    return _Attention.apply(q, k, v, scale, split)
 
 
 class _SelfAttentionRotary(torch.autograd.Function):
@@ -1241,20 +1246,20 @@ class _AttentionQKV(torch.autograd.Function):
     one call, so the backward writes dq/dk/dv straight into one dqkv buffer."""
 
     @staticmethod
-    def forward(ctx, qkv, cross, scale=None):
+    def forward(ctx, qkv, cross, scale=None, split=False):
         B2, N, _, H, D = qkv.shape
         sc = ctx.scale = D ** -0.5 if scale is None else scale       # LN2: the caller folded head_dim^-1/2 log2(e) into q
         o = torch.empty((B2, N, H, D), dtype=qkv.dtype, device=qkv.device)
         lse = torch.empty((B2, H, N), dtype=torch.float32, device=qkv.device)
         q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
         if not cross:
-            attn_fwd_raw(q, k, v, sc, out=o, lse=lse)
+            attn_fwd_raw(q, k, v, sc, out=o, lse=lse, split=split)
         else:
             B = B2 // 2
-            attn_fwd_raw(q[:B], k[B:], v[B:], sc, out=o[:B], lse=lse[:B])
-            attn_fwd_raw(q[B:], k[:B], v[:B], sc, out=o[B:], lse=lse[B:])
+            attn_fwd_raw(q[:B], k[B:], v[B:], sc, out=o[:B], lse=lse[:B], split=split)
+            attn_fwd_raw(q[B:], k[:B], v[:B], sc, out=o[B:], lse=lse[B:], split=split)
         ctx.save_for_backward(qkv, o, lse)
-        ctx.cross = cross
+        ctx.cross, ctx.split = cross, split
         return o
 
     @staticmethod
@@ -1266,17 +1271,20 @@ class _AttentionQKV(torch.autograd.Function):
         d = torch.empty_like(qkv)
         q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
         dq, dk, dv = d[:, :, 0], d[:, :, 1], d[:, :, 2]
+        sp = ctx.split
         if not ctx.cross:
-            attn_bwd_raw(q, k, v, o, do, lse, dq, dk, dv, ctx.scale)
+            attn_bwd_raw(q, k, v, o, do, lse, dq, dk, dv, ctx.scale, split=sp)
         else:
             B = B2 // 2
-            attn_bwd_raw(q[:B], k[B:], v[B:], o[:B], do[:B], lse[:B], dq[:B], dk[B:], dv[B:], ctx.scale)
-            attn_bwd_raw(q[B:], k[:B], v[:B], o[B:], do[B:], lse[B:], dq[B:], dk[:B], dv[:B], ctx.scale)
-        return d, None, None
+            attn_bwd_raw(q[:B], k[B:], v[B:], o[:B], do[:B], lse[:B], dq[:B], dk[B:], dv[B:], ctx.scale, split=sp)
+            attn_bwd_raw(q[B:], k[:B], v[:B], o[B:], do[B:], lse[B:], dq[B:], dk[:B], dv[:B], ctx.scale, split=sp)
+        return d, None, None, None
 
 
-def attention_qkv(qkv, cross=False, scale=None):
-    return _AttentionQKV.apply(qkv, cross, scale)
+def attention_qkv(qkv, cross=False, scale=None, split=False):
+    """split: fp32-equivalent second products on bf16 operands (GF_ATTN_SPLIT) -- the reference's fp32-pinned attention of
+    GlueStick under mixed precision (gluestick.py:524-529)."""
+    return _AttentionQKV.apply(qkv, cross, scale, split)
 
 
 # ------------------------------------------------------------------------------ Sinkhorn optimal transport

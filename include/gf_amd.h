@@ -35,8 +35,8 @@ extern "C" {
 #define GF_ERR_ALIGN (-3)
 #define GF_ERR_DTYPE (-4)
 
-/* ABI version; bumped on any signature or workspace-size change (2: gf_attn_bwd's delta workspace doubled; 3: line head + gf_bgemm; 4: smallops; 5: gf_attn_bwd_acc; 9: cast entries with leading dimensions, gf_fold_linear_*, double betas in gf_multi_adam). */
-#define GF_AMD_ABI_VERSION 9
+/* ABI version; bumped on any signature or workspace-size change (2: gf_attn_bwd's delta workspace doubled; 3: line head + gf_bgemm; 4: smallops; 5: gf_attn_bwd_acc; 9: cast entries with leading dimensions, gf_fold_linear_*, double betas in gf_multi_adam; 10: gf_attn_fwd_ex / GF_ATTN_SPLIT, gf_topk_candidates). */
+#define GF_AMD_ABI_VERSION 10
 int gf_abi_version(void);
 
 /* ---- multi-head attention over keypoints --------------------------------------------------
@@ -51,6 +51,16 @@ int gf_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse
                 const int64_t* q_strides, const int64_t* k_strides,
                 const int64_t* v_strides, const int64_t* o_strides,
                 float scale, int dtype, void* stream);
+/* gf_attn_fwd_ex: the same with `flags`.  GF_ATTN_SPLIT (bf16 only; ignored for fp32): the softmax weights enter the second
+ * product as a hi + lo pair of bf16 values (16 mantissa bits), i.e. scores, softmax and weighted sum are fp32-equivalent on the
+ * bf16 operands -- the arithmetic gluestick.py:18-22, 524-529 (@AMP_CUSTOM_FWD_F32) prescribes for GlueStick's attention under
+ * mixed precision.  gf_attn_bwd_acc takes the same flag (P and dS split in front of dV / dK / dQ). */
+#define GF_ATTN_SPLIT 4
+int gf_attn_fwd_ex(const void* q, const void* k, const void* v, void* o, float* lse,
+                   int B, int H, int Nq, int Nk, int D,
+                   const int64_t* q_strides, const int64_t* k_strides,
+                   const int64_t* v_strides, const int64_t* o_strides,
+                   float scale, int dtype, int flags, void* stream);
 
 /* Backward of gf_attn_fwd (what autograd derives from the lines above).  delta is WORKSPACE of 2*B*H*Nq floats,
  * written by the call: the two per-row vectors the dQ kernel hands to the dK/dV kernel (fp32: delta = rowsum(dout * o)

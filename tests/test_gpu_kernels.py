@@ -852,3 +852,35 @@ def test_folded_linear_weights_and_gradients(R, K, N, c0, perm, bias):
     ((ref_w * gW).sum() + ((ref_b * gb).sum() if bias else 0.0)).backward()
     for p, a in zip(params, got):
         torch.testing.assert_close(a, p.grad, rtol=2e-5, atol=2e-5 * float(p.grad.abs().max()))
+
+
+@pytest.mark.parametrize("B,H,Nq,Nk,scale", [(2, 4, 256, 320, None), (1, 4, 1000, 1024, None), (2, 2, 192, 192, "ln2")])
+def test_attention_split_products_are_fp32_equivalent(B, H, Nq, Nk, scale):
+    """GF_ATTN_SPLIT (gf_attn_fwd_ex / gf_attn_bwd_acc): P and dS enter the second products as hi + lo bf16 pairs, so on the
+    same bf16 operands the kernels agree with an fp64 attention up to the bf16 rounding of the OUTPUTS -- the arithmetic the
+    reference prescribes for GlueStick's attention under mixed precision (gluestick.py:524-529, fp32 on autocast inputs).
+    Measured as the error before that last rounding would matter: relative L2 error of O, dq, dk, dv against fp64, split vs
+    not split."""
+    from glue_factory_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(Nq + Nk)
+    mk = lambda n: (torch.randn(B, n, H, 64, device="cuda", generator=g) * 1.5).bfloat16()      # noqa: E731
+    q, k, v = mk(Nq), mk(Nk), mk(Nk)
+    do = mk(Nq)
+    sc = 64 ** -0.5 if scale is None else ops.LN2
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
+    ref, _ = _attn_ref(qd, kd, vd, sc)
+    (ref * do.double()).sum().backward()
+    errs = {}
+    for split in (False, True):
+        qq, kk, vv = (t.clone().requires_grad_(True) for t in (q, k, v))
+        out = ops.attention(qq, kk, vv, scale=sc, split=split)
+        (out.float() * do.float()).sum().backward()
+        rel = lambda a, r: float((a.double() - r).norm() / r.norm())                                # noqa: E731
+        errs[split] = (rel(out, ref.detach()), rel(qq.grad, qd.grad), rel(kk.grad, kd.grad), rel(vv.grad, vd.grad))
+    print(f"attention {B}x{H}x{Nq}x{Nk}: relative L2 error vs fp64 (O, dq, dk, dv): bf16 products {errs[False]}, split {errs[True]}")
+    exact = (ref.detach(), qd.grad, kd.grad, vd.grad)
+    rounding = [float((t.bfloat16().double() - t).norm() / t.norm()) for t in exact]      # the fp64 result rounded to bf16
+    print(f"   rounding the exact results to bf16 alone: {rounding}")
+    for e_split, e_plain, e0 in zip(errs[True], errs[False], rounding):
+        assert e_split <= 1.1 * e0                          # nothing left but the rounding of the result itself
+        assert e_split <= e_plain * 1.02

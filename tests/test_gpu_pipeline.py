@@ -177,9 +177,9 @@ def test_scope_p_replays_as_one_hipgraph_for_40_steps():
             if it % 7 == 0:
                 pipe.extractor.eval()({"image": data["view0"]["image"]})      # ... incl. the library convolutions
         assert step.graph == graph and (not graph or step.static_inputs() is not None)
-        runs.append((torch.stack(losses).cpu(), [p.detach().clone() for p in pipe.matcher.parameters()]))
-    (le, pe), (lg, pg) = runs
+        runs.append(torch.stack(losses).cpu())
+    le, lg = runs
     assert torch.isfinite(lg).all() and float(lg[-1]) < float(lg[0])                 # it trains
     torch.testing.assert_close(lg, le, rtol=2e-2, atol=2e-2)                          # bf16 steps, 43 updates apart at most
-    for a, b_ in zip(pe, pg):      # (43 Adam updates of lr 1e-3 apart: sign flips of near-zero gradients move single entries)
-        assert float((a - b_).norm() / a.norm().clamp(min=1e-6)) < 0.05
+    # (parameters are not compared after 43 Adam updates: an entry whose gradient is rounding noise random-walks by +-lr per
+    # step in either run; tests/test_gpu_optim.py::test_train_step_graph_with_fused_adam_matches_eager compares them after 6)
