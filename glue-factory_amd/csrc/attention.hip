@@ -1319,19 +1319,19 @@ extern "C" int gf_attn_fwd_ex(const void* q, const void* k, const void* v, void*
                               int B, int H, int Nq, int Nk, int D,
                               const int64_t* q_strides, const int64_t* k_strides,
                               const int64_t* v_strides, const int64_t* o_strides,
-                              float scale, int dtype, int flags, void* stream);
+                              float scale, int dtype, int flags, float* o32, void* stream);
 extern "C" int gf_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
                            int B, int H, int Nq, int Nk, int D,
                            const int64_t* q_strides, const int64_t* k_strides,
                            const int64_t* v_strides, const int64_t* o_strides,
                            float scale, int dtype, void* stream) {
-    return gf_attn_fwd_ex(q, k, v, o, lse, B, H, Nq, Nk, D, q_strides, k_strides, v_strides, o_strides, scale, dtype, 0, stream);
+    return gf_attn_fwd_ex(q, k, v, o, lse, B, H, Nq, Nk, D, q_strides, k_strides, v_strides, o_strides, scale, dtype, 0, nullptr, stream);
 }
 extern "C" int gf_attn_fwd_ex(const void* q, const void* k, const void* v, void* o, float* lse,
                               int B, int H, int Nq, int Nk, int D,
                               const int64_t* q_strides, const int64_t* k_strides,
                               const int64_t* v_strides, const int64_t* o_strides,
-                              float scale, int dtype, int flags, void* stream) {
+                              float scale, int dtype, int flags, float* o32, void* stream) {
     if (D != 64) return GF_ERR_UNSUPPORTED;
     if (flags & ~GF_ATTN_SPLIT) return GF_ERR_UNSUPPORTED;
     if (dtype == GF_F32) flags = 0;                                  // fp32 operands: nothing to split
@@ -1347,6 +1347,7 @@ extern "C" int gf_attn_fwd_ex(const void* q, const void* k, const void* v, void*
     p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk; p.scale = scale;
     host_split_scale(scale, p.p2, p.rr);
     p.flags = flags;
+    p.o32 = (flags & GF_ATTN_SPLIT) ? o32 : nullptr;
     p.sqb = q_strides[0]; p.sqn = q_strides[1]; p.sqh = q_strides[2];
     p.skb = k_strides[0]; p.skn = k_strides[1]; p.skh = k_strides[2];
     p.svb = v_strides[0]; p.svn = v_strides[1]; p.svh = v_strides[2];
@@ -1387,8 +1388,8 @@ extern "C" int gf_attn_bwd_acc(const void* q, const void* k, const void* v, cons
     const int align = dtype == GF_BF16 ? 8 : 4;
     const int64_t* all[8] = {q_strides, k_strides, v_strides, o_strides,
                              do_strides, dq_strides, dk_strides, dv_strides};
-    for (int i = 0; i < 8; ++i)
-        if (bad_stride(all[i], 3, align)) return GF_ERR_ALIGN;
+    for (int i = 0; i < 8; ++i)          // (GF_ATTN_SPLIT: `o` is the forward's fp32 copy, strides in fp32 elements)
+        if (bad_stride(all[i], 3, (i == 3 && (flags & GF_ATTN_SPLIT)) ? 4 : align)) return GF_ERR_ALIGN;
     AttnParams p = {};
     p.q = q; p.k = k; p.v = v; p.o = const_cast<void*>(o); p.dout = dout;
     p.lse = const_cast<float*>(lse); p.delta = delta; p.dq = dq; p.dk = dk; p.dv = dv;

@@ -68,9 +68,16 @@ __global__ __launch_bounds__(256, DQ3_WPS) void attn_dq3_bf16_kernel(AttnParams 
     for (int s = 0; s < 4; ++s) {
         const bf16x8 q8 = *reinterpret_cast<const bf16x8*>(qp + (int64_t)qld * p.sqn + 16 * s + 8 * hi);
         dof[s] = *reinterpret_cast<const bf16x8*>(dop + (int64_t)qld * p.sdon + 16 * s + 8 * hi);
-        const bf16x8 o8 = *reinterpret_cast<const bf16x8*>(op + (int64_t)qld * p.son + 16 * s + 8 * hi);
+        if (SPLIT) {          // `o` is the forward's fp32 copy (strides in fp32 elements): delta without the rounding of o
+            const float* o32 = reinterpret_cast<const float*>(p.o) + b * p.sob + h * p.soh + (int64_t)qld * p.son + 16 * s + 8 * hi;
+            const f32x4 oa = *reinterpret_cast<const f32x4*>(o32), ob = *reinterpret_cast<const f32x4*>(o32 + 4);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) delta += (float)o8[e] * (float)dof[s][e];
+            for (int e = 0; e < 4; ++e) delta += oa[e] * (float)dof[s][e] + ob[e] * (float)dof[s][4 + e];
+        } else {
+            const bf16x8 o8 = *reinterpret_cast<const bf16x8*>(op + (int64_t)qld * p.son + 16 * s + 8 * hi);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) delta += (float)o8[e] * (float)dof[s][e];
+        }
         qf[s] = p2 != 1.f ? scale_frag(q8, p2) : q8;
     }
     delta += xhalf(delta);

@@ -299,6 +299,8 @@ __global__ __launch_bounds__(256, SPLIT ? 2 : FW3_WPS) void attn_fwd3_bf16_kerne
     if (qrow < p.Nq) {
         bf16_t* op = reinterpret_cast<bf16_t*>(p.o) + b * p.sob + h * p.soh + (int64_t)qrow * p.son;
         store_row<bf16_t, 64>(op, o, 1.f / l, hi);
+        if (SPLIT && p.o32 != nullptr)
+            store_row<float, 64>(p.o32 + (((int64_t)b * p.Nq + qrow) * p.H + h) * 64, o, 1.f / l, hi);
         if (hi == 0) p.lse[((int64_t)b * p.H + h) * p.Nq + qrow] = (m * rr + fast_log2(l)) * GF_LN2;
     }
 }

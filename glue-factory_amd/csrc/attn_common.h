@@ -13,6 +13,8 @@ struct AttnParams {
     const void* q; const void* k; const void* v; void* o;
     const void* dout; void* dq; void* dk; void* dv;
     float* lse; float* delta;
+    float* o32;       // GF_ATTN_SPLIT forward: fp32 copy of the output, [B, Nq, H, 64] contiguous (the backward's delta = sum o dO
+                      // then carries no bf16 rounding of o: the reference's fp32 attention keeps its output in fp32 as well)
     int B, H, Nq, Nk;
     int64_t sqb, sqn, sqh, skb, skn, skh, svb, svn, svh, sob, son, soh;
     // gradients: dq/dout use the o-like strides given below

@@ -20,7 +20,8 @@ _S = _c.POINTER(_c.c_int64)
 SIGNATURES = {
     "gf_abi_version": [],
     "gf_attn_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _S, _S, _S, _S, _F, _I, _P],
-    "gf_attn_fwd_ex": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _S, _S, _S, _S, _F, _I, _I, _P],
+    "gf_attn_fwd_ex": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _S, _S, _S, _S, _F, _I, _I, _P, _P],
+    "gf_attn_cross_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _S, _S, _S, _S, _S, _S, _F, _I, _P],
     "gf_attn_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I,
                     _S, _S, _S, _S, _S, _S, _S, _S, _F, _I, _P],
     "gf_attn_bwd_acc": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I,

@@ -56,21 +56,28 @@ def _s3(t):
 ATTN_SPLIT = 4       # GF_ATTN_SPLIT (include/gf_amd.h): P / dS as hi + lo bf16 pairs = fp32-equivalent second products
 
 
-def attn_fwd_raw(q, k, v, scale, out=None, lse=None, split=False):
+def attn_fwd_raw(q, k, v, scale, out=None, lse=None, split=False, o32=None):
+    """split (bf16 only): fp32-equivalent second products; o32: [B, Nq, H, D] fp32 contiguous buffer that receives the
+    un-rounded output next to `out` (attn_bwd_raw(split=True) takes it as its `o`)."""
     _chk(q, k, v)
     B, Nq, H, D = q.shape
     Nk = k.shape[1]
     o = torch.empty((B, Nq, H, D), dtype=q.dtype, device=q.device) if out is None else out
     if lse is None:
         lse = torch.empty((B, H, Nq), dtype=torch.float32, device=q.device)
+    split = bool(split) and q.dtype == torch.bfloat16
+    assert o32 is None or (o32.dtype == torch.float32 and o32.is_contiguous() and tuple(o32.shape) == (B, Nq, H, D))
     _lib.check(_lib.load().gf_attn_fwd_ex(_p(q), _p(k), _p(v), _p(o), _p(lse), B, H, Nq, Nk, D,
                                           _s3(q), _s3(k), _s3(v), _s3(o), float(scale), _dt(q), ATTN_SPLIT if split else 0,
-                                          _stream()), "gf_attn_fwd_ex")
+                                          _p(o32) if split else None, _stream()), "gf_attn_fwd_ex")
     return o, lse
 
 
 def attn_bwd_raw(q, k, v, o, do, lse, dq, dk, dv, scale, acc_dq=False, acc_dk=False, split=False):
+    """split (bf16 only): `o` must be the fp32 copy attn_fwd_raw(split=True, o32=...) wrote."""
     B, Nq, H, D = q.shape
+    split = bool(split) and q.dtype == torch.bfloat16
+    assert not split or o.dtype == torch.float32
     Nk = k.shape[1]
     if do.stride(3) != 1:
         do = do.contiguous()
@@ -88,8 +95,10 @@ class _Attention(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, q, k, v, scale, split=False):
-        o, lse = attn_fwd_raw(q, k, v, scale, split=split)
-        ctx.save_for_backward(q, k, v, o, lse)
+        split = bool(split) and q.dtype == torch.bfloat16
+        o32 = torch.empty(q.shape, dtype=torch.float32, device=q.device) if split else None
+        o, lse = attn_fwd_raw(q, k, v, scale, split=split, o32=o32)
+        ctx.save_for_backward(q, k, v, o32 if split else o, lse)
         ctx.scale, ctx.split = scale, split
         return o
 
@@ -211,6 +220,14 @@ class _CrossAttentionStacked(torch.autograd.Function):
         if not dm.is_contiguous():
             dm = dm.contiguous()
         d = torch.empty_like(p)
+        if XBWD_ENABLED and p.dtype == torch.bfloat16 and D == 64 and H <= 4 and N % 64 == 0:
+            # both directions from ONE score tile per image side (csrc/attention_xbwd.hip): 10 MFMA products instead of 14
+            stat = torch.empty((2, B2, H, N), dtype=torch.float32, device=p.device)
+            _lib.check(_lib.load().gf_attn_cross_bwd(_p(p[:, :, 0]), _p(p[:, :, 1]), _p(m), _p(dm), _p(lse), _p(stat),
+                                                     _p(d[:, :, 0]), _p(d[:, :, 1]), B2, B, H, N, D,
+                                                     _s3(p[:, :, 0]), _s3(p[:, :, 1]), _s3(m), _s3(dm), _s3(d[:, :, 0]),
+                                                     _s3(d[:, :, 1]), float(ctx.scale), _dt(p), _stream()), "gf_attn_cross_bwd")
+            return d, None
         p0, p1, d0, d1 = p[:B], p[B:], d[:B], d[B:]
         attn_bwd_raw(p0[:, :, 0], p1[:, :, 0], p1[:, :, 1], m[:B], dm[:B], lse[:B],
                      d0[:, :, 0], d1[:, :, 0], d1[:, :, 1], ctx.scale)
@@ -218,6 +235,9 @@ class _CrossAttentionStacked(torch.autograd.Function):
         attn_bwd_raw(p1[:, :, 0], p0[:, :, 0], p0[:, :, 1], m[B:], dm[B:], lse[B:],
                      d1[:, :, 0], d0[:, :, 0], d0[:, :, 1], ctx.scale, acc_dq=True, acc_dk=True)
         return d, None
+
+
+XBWD_ENABLED = True      # tools/probe/ab_matcher.py --switch XBWD_ENABLED: same-process A/B against two gf_attn_bwd_acc calls
 
 
 def cross_attention(p0, p1, scale=None):
@@ -1249,16 +1269,18 @@ class _AttentionQKV(torch.autograd.Function):
     def forward(ctx, qkv, cross, scale=None, split=False):
         B2, N, _, H, D = qkv.shape
         sc = ctx.scale = D ** -0.5 if scale is None else scale       # LN2: the caller folded head_dim^-1/2 log2(e) into q
+        split = bool(split) and qkv.dtype == torch.bfloat16
         o = torch.empty((B2, N, H, D), dtype=qkv.dtype, device=qkv.device)
+        o32 = torch.empty((B2, N, H, D), dtype=torch.float32, device=qkv.device) if split else None   # kept for the backward's delta
         lse = torch.empty((B2, H, N), dtype=torch.float32, device=qkv.device)
         q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
         if not cross:
-            attn_fwd_raw(q, k, v, sc, out=o, lse=lse, split=split)
+            attn_fwd_raw(q, k, v, sc, out=o, lse=lse, split=split, o32=o32)
         else:
             B = B2 // 2
-            attn_fwd_raw(q[:B], k[B:], v[B:], sc, out=o[:B], lse=lse[:B], split=split)
-            attn_fwd_raw(q[B:], k[:B], v[:B], sc, out=o[B:], lse=lse[B:], split=split)
-        ctx.save_for_backward(qkv, o, lse)
+            attn_fwd_raw(q[:B], k[B:], v[B:], sc, out=o[:B], lse=lse[:B], split=split, o32=None if o32 is None else o32[:B])
+            attn_fwd_raw(q[B:], k[:B], v[:B], sc, out=o[B:], lse=lse[B:], split=split, o32=None if o32 is None else o32[B:])
+        ctx.save_for_backward(qkv, o32 if split else o, lse)
         ctx.cross, ctx.split = cross, split
         return o
 

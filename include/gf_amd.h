@@ -54,13 +54,29 @@ int gf_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse
 /* gf_attn_fwd_ex: the same with `flags`.  GF_ATTN_SPLIT (bf16 only; ignored for fp32): the softmax weights enter the second
  * product as a hi + lo pair of bf16 values (16 mantissa bits), i.e. scores, softmax and weighted sum are fp32-equivalent on the
  * bf16 operands -- the arithmetic gluestick.py:18-22, 524-529 (@AMP_CUSTOM_FWD_F32) prescribes for GlueStick's attention under
- * mixed precision.  gf_attn_bwd_acc takes the same flag (P and dS split in front of dV / dK / dQ). */
+ * mixed precision.  o32 (GF_ATTN_SPLIT only, may be NULL): fp32 copy of the output, [B, Nq, H, 64] contiguous -- the reference's
+ * fp32 attention hands its output on in fp32.  gf_attn_bwd_acc takes the same flag (P and dS split in front of dV / dK / dQ);
+ * its `o` / `o_strides` then describe that fp32 copy (delta = sum o dO without the bf16 rounding of o). */
 #define GF_ATTN_SPLIT 4
 int gf_attn_fwd_ex(const void* q, const void* k, const void* v, void* o, float* lse,
                    int B, int H, int Nq, int Nk, int D,
                    const int64_t* q_strides, const int64_t* k_strides,
                    const int64_t* v_strides, const int64_t* o_strides,
-                   float scale, int dtype, int flags, void* stream);
+                   float scale, int dtype, int flags, float* o32, void* stream);
+
+/* gf_attn_cross_bwd (csrc/attention_xbwd.hip): backward of LightGlue's BIDIRECTIONAL cross attention with its shared
+ * similarity (lightglue.py:203-216: sim = qk0 qk1^T, m0 = softmax(sim) v1, m1 = softmax(sim^T) v0) for B2 stacked images
+ * where image b is paired with image (b + pair) mod B2 (pair = B2 / 2 for [image 0 batch | image 1 batch]).  qk, v
+ * [B2,N,H,64] views (strides {batch, token, head}); o = the forward's messages, dout their gradient; lse [B2,H,N] of the
+ * direction in which the image's tokens are the QUERIES; stat: workspace of 2 * B2 * H * N floats.  Writes dqk and dv (every
+ * row once: nothing to accumulate between launches).  One kernel per image side takes all of its gradients from ONE score
+ * tile: 10 MFMA products per tile pair instead of the 14 of two gf_attn_bwd_acc calls.  bf16, D == 64, H <= 4, N % 64 == 0
+ * (else GF_ERR_UNSUPPORTED: call gf_attn_bwd_acc twice). */
+int gf_attn_cross_bwd(const void* qk, const void* v, const void* o, const void* dout, const float* lse, float* stat,
+                      void* dqk, void* dv, int B2, int pair, int H, int N, int D,
+                      const int64_t* qk_strides, const int64_t* v_strides, const int64_t* o_strides,
+                      const int64_t* do_strides, const int64_t* dqk_strides, const int64_t* dv_strides,
+                      float scale, int dtype, void* stream);
 
 /* Backward of gf_attn_fwd (what autograd derives from the lines above).  delta is WORKSPACE of 2*B*H*Nq floats,
  * written by the call: the two per-row vectors the dQ kernel hands to the dK/dV kernel (fp32: delta = rowsum(dout * o)

@@ -884,3 +884,40 @@ def test_attention_split_products_are_fp32_equivalent(B, H, Nq, Nk, scale):
     for e_split, e_plain, e0 in zip(errs[True], errs[False], rounding):
         assert e_split <= 1.1 * e0                          # nothing left but the rounding of the result itself
         assert e_split <= e_plain * 1.02
+
+
+@pytest.mark.parametrize("B,N,H,scale", [(2, 128, 4, None), (1, 448, 4, "ln2"), (3, 192, 2, None), (2, 2048, 4, "ln2")])
+def test_cross_attention_fused_backward(B, N, H, scale):
+    """gf_attn_cross_bwd (csrc/attention_xbwd.hip: both directions of LightGlue's cross attention from ONE score tile per
+    image side, lightglue.py:203-216) against the fp64 reference and against the two gf_attn_bwd_acc calls it replaces."""
+    D = 64
+    g = torch.Generator().manual_seed(N + H)
+    p = (torch.randn(2 * B, N, 2, H, D, generator=g) * (1.0 if scale is None else 0.6)).to(DEV, torch.bfloat16)
+    dm = torch.randn(2 * B, N, H, D, generator=g).to(DEV, torch.bfloat16)
+    sc = D ** -0.5 if scale is None else ops.LN2
+    grads = {}
+    for fused in (True, False):
+        ops.XBWD_ENABLED = fused
+        try:
+            ps = p.clone().requires_grad_(True)
+            m = ops.cross_attention_stacked(ps, scale=sc)
+            (m * dm).sum().backward()
+            grads[fused] = ps.grad.clone()
+        finally:
+            ops.XBWD_ENABLED = True
+    x = p.detach().cpu().double().requires_grad_(True)
+    if N <= 512:
+        m0, _ = _attn_ref(x[:B, :, 0], x[B:, :, 0], x[B:, :, 1], sc)
+        m1, _ = _attn_ref(x[B:, :, 0], x[:B, :, 0], x[:B, :, 1], sc)
+        (torch.cat([m0, m1], 0) * dm.cpu().double()).sum().backward()
+        ref = x.grad
+        s_ = ref.abs().max().item()
+        tol = _tols(torch.bfloat16)
+        torch.testing.assert_close(grads[True].cpu().double() / s_, ref / s_, **tol)
+        e_f = float((grads[True].cpu().double() - ref).norm() / ref.norm())
+        e_o = float((grads[False].cpu().double() - ref).norm() / ref.norm())
+        print(f"cross bwd {B}x{N}x{H}: relative L2 error vs fp64: fused {e_f:.2e}, two launches {e_o:.2e}")
+        assert e_f <= 1.25 * e_o + 1e-4
+    d = float((grads[True].float() - grads[False].float()).norm() / grads[False].float().norm())
+    print(f"cross bwd {B}x{N}x{H}: fused vs two launches relative L2 difference {d:.2e}")
+    assert d < 8e-3
