@@ -183,36 +183,35 @@ __global__ __launch_bounds__(256, 2) void attn_xbwd_bf16_kernel(XbParams p) {
     const float* lsey = p.stat + ((int64_t)by * p.H + h) * p.N;      // stat[0] of the streamed image
     const float* dely = lsey + plane;                                // stat[1]
 
-    // ---- DMA: chunk (PPW wave + i) * 64 + lane of a tile -> row, swizzled source column
-    int drow[PPW], dcol[PPW];
+    // ---- DMA: chunk (PPW wave + i) * 64 + lane of a tile -> row, swizzled source column.  Per-lane state = one 32-bit element
+    // offset per piece and matrix (the tile advance rides in the uniform base): registers are the scarce resource here
+    int oq[PPW], od[PPW], ov[PPW];
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
-        drow[i] = (PPW * wave + i) * 8 + (lane >> 3);
-        dcol[i] = ((lane & 7) ^ fswz(drow[i])) * 8;
+        const int drow = (PPW * wave + i) * 8 + (lane >> 3);
+        const int dcol = ((lane & 7) ^ fswz(drow)) * 8;
+        oq[i] = drow * (int)p.sqn + dcol;
+        od[i] = drow * (int)p.sdon + dcol;
+        ov[i] = drow * (int)p.svn + dcol;
     }
-    const float* statp = (lane & 16) ? dely : lsey;
-    const int srow = 16 * wave + s16;
+    const float* statp = ((lane & 16) ? dely : lsey) + 16 * wave + s16;
     const int64_t qstep = 64 * p.sqn, dostep = 64 * p.sdon, vstep = 64 * p.svn;
-    const bf16_t *gq[PPW], *gdo[PPW], *gv[PPW];
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-        gq[i] = qky + (int64_t)drow[i] * p.sqn + dcol[i];
-        gdo[i] = doy + (int64_t)drow[i] * p.sdon + dcol[i];
-        gv[i] = vy + (int64_t)drow[i] * p.svn + dcol[i];
-    }
     // part 0: qk pieces + statistics + dO pieces, part 1: v pieces (issued in the VALU gaps of the two half tiles)
     auto issue_part = [&](int part, int t, int stage) {
         char* sb = smem + stage * XB_STAGE;
+        const bf16_t* tq = qky + t * qstep;
+        const bf16_t* td = doy + t * dostep;
+        const bf16_t* tv = vy + t * vstep;
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
             if (part == 0) {
-                dma16(gq[i] + t * qstep, sb + (PPW * wave + i) * 1024);
-                dma16(gdo[i] + t * dostep, sb + FT_TILE + (PPW * wave + i) * 1024);
+                dma16(tq + oq[i], sb + (PPW * wave + i) * 1024);
+                dma16(td + od[i], sb + FT_TILE + (PPW * wave + i) * 1024);
             } else {
-                dma16(gv[i] + t * vstep, sb + 2 * FT_TILE + (PPW * wave + i) * 1024);
+                dma16(tv + ov[i], sb + 2 * FT_TILE + (PPW * wave + i) * 1024);
             }
         }
-        if (part == 0) dma4(statp + t * 64 + srow, sb + XB_STATS + wave * 256);
+        if (part == 0) dma4(statp + t * 64, sb + XB_STATS + wave * 256);
     };
     constexpr int VM_TILE = 3 * PPW + 1;                             // vector-memory operations of one tile per wave
     const int nt = p.N / 64;                                         // (N % 64 == 0: checked by the launcher)
@@ -234,20 +233,20 @@ __global__ __launch_bounds__(256, 2) void attn_xbwd_bf16_kernel(XbParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dqk[0][r] = 0.f; dqk[1][r] = 0.f; dv[0][r] = 0.f; dv[1][r] = 0.f; ndx[r] = ndx_; }
 
-    // ---- per-lane LDS read addresses (stage 0): see attn_bwd_dkv_bf16_kernel
-    unsigned bR[4], bT[4];
+    // ---- per-lane LDS read addresses (see attn_bwd_dkv_bf16_kernel), advanced IN PLACE from stage to stage
+    unsigned aR[4], aT[4];
     {
         const unsigned rb = l31 * 128 + 16 * (hi ^ fswz(l31));
 #pragma unroll
-        for (int s = 0; s < 4; ++s) bR[s] = lds0 + (rb ^ (32 * s));
+        for (int s = 0; s < 4; ++s) aR[s] = lds0 + (rb ^ (32 * s));
         const int bq = s16 >> 3;
         const unsigned tbs = (4 * hi + (s16 >> 2)) * 128 + 8 * (s16 & 1) + 16 * ((2 * half + ((s16 & 3) >> 1)) ^ (4 * bq + hi));
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int db = 0; db < 2; ++db) bT[2 * u + db] = lds0 + (tbs ^ (32 * u) ^ (64 * db));
+            for (int db = 0; db < 2; ++db) aT[2 * u + db] = lds0 + (tbs ^ (32 * u) ^ (64 * db));
     }
-    const unsigned bS = lds0 + XB_STATS + 16 * hi;
+    unsigned aS = lds0 + XB_STATS + 16 * hi;
 
     tie(ndx);
     int stage = 0;
@@ -255,17 +254,17 @@ __global__ __launch_bounds__(256, 2) void attn_xbwd_bf16_kernel(XbParams p) {
         wait_vm<VM_TILE>();                                          // tile t landed (this wave's share; tile t + 1 may be in flight)
         __builtin_amdgcn_s_barrier();                                // ... everyone's; the stage of tile t - 1 is free
         __builtin_amdgcn_sched_barrier(0);
-        const unsigned so = stage * XB_STAGE;
-        unsigned aR[4], aT[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { aR[i] = bR[i] + so; aT[i] = bT[i] + so; }
         const int nstage = stage == 0 ? 2 : stage - 1;
         const int tn = min(t + 2, nt - 1);                           // tiles past the end re-fetch the last one (constant wait count)
         XbHalf h0;
-        xb_scores<0>(h0, kf, vf, dof, ndx, nlx, aR, bS + so);
+        xb_scores<0>(h0, kf, vf, dof, ndx, nlx, aR, aS);
         xb_update<0, PRE>(h0, dqk, dv, aT, c, [&] { issue_part(0, tn, nstage); });
-        xb_scores<1>(h0, kf, vf, dof, ndx, nlx, aR, bS + so);
+        xb_scores<1>(h0, kf, vf, dof, ndx, nlx, aR, aS);
         xb_update<1, PRE>(h0, dqk, dv, aT, c, [&] { issue_part(1, tn, nstage); });
+        const int step = stage == 2 ? -2 * XB_STAGE : XB_STAGE;      // ring: the read addresses follow the stage
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { aR[i] += step; aT[i] += step; }
+        aS += step;
         stage = stage == 2 ? 0 : stage + 1;
     }
     wait_vm<0>();                                                    // the re-fetched tail tiles
