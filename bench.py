@@ -152,12 +152,34 @@ def roofline_attention(batch, n, dtype):
     f_fwd = 4.0 * n * n * D * B2 * H
     f_bwd = 2.5 * f_fwd
     ach = f_bwd / t_bwd / 1e12
+    # the cross layers' backward (both directions of one layer = the same algorithmic FLOPs as one self-attention launch):
+    # ONE gf_attn_cross_bwd launch (csrc/attention_xbwd.hip, 10 MFMA products per tile pair) against the two gf_attn_bwd_acc
+    # launches (14 products) it replaced, same process, same operands
+    pc = (torch.randn(B2, n, 2, H, D, device="cuda", generator=g) * 0.6).to(dtype).requires_grad_(True)
+    dm = torch.randn(B2, n, H, D, device="cuda", dtype=dtype, generator=g)
+    mc = ops.cross_attention_stacked(pc, scale=ops.LN2)
+
+    def cross_bwd(fused):
+        ops.XBWD_ENABLED = fused
+        try:
+            pc.grad = None
+            mc.backward(dm, retain_graph=True)
+        finally:
+            ops.XBWD_ENABLED = True
+    t_x = time_kernel(lambda: cross_bwd(True)) if dtype == torch.bfloat16 else None
+    t_x2 = time_kernel(lambda: cross_bwd(False))
+    cross = {"kernel": "gf_attn_cross_bwd (attn_stats_kernel + attn_xbwd_bf16_kernel): backward of one cross layer, both directions",
+             "two_launch_ms": round(t_x2 * 1e3, 4), "two_launch_frac": round(f_bwd / t_x2 / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)}
+    if t_x is not None:
+        cross.update({"launch_ms": round(t_x * 1e3, 4), "achieved": round(f_bwd / t_x / 1e12, 2),
+                      "frac": round(f_bwd / t_x / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)})
     return {
         "bound": "mfma", "kernel": "gf_attn_bwd (attn_dq3_bf16_kernel + attn_bwd_dkv_bf16_kernel of one launch)",
         "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": _traffic("gf_attn_bwd"),
         "launch_ms": round(t_bwd * 1e3, 4), "algorithmic_flop_per_launch": f_bwd,
         "traffic_source": _traffic_source(),
+        "cross_bwd": cross,
         "fwd_kernel": {"kernel": "attn_fwd3_bf16_kernel", "launch_ms": round(t_fwd * 1e3, 4),
                        "achieved": round(f_fwd / t_fwd / 1e12, 2),
                        "frac": round(f_fwd / t_fwd / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),

@@ -27,6 +27,9 @@
 namespace gfattn {
 namespace {
 
+#ifndef XB_ABL
+#define XB_ABL 0           // timing-only ablations (wrong results; tools/probe/time_xbwd.py): 1 no exponentials, 2 no output MFMAs,
+#endif                     // 4 no dP_X product, 8 no transposed LDS reads, 16 no statistics pass, 32 no DMA
 constexpr int XB_STATS = 3 * FT_TILE;                 // per wave: 16 lse | 16 delta | duplicates (256 B)
 constexpr int XB_STAGE = 3 * FT_TILE + 1024;
 constexpr int XB_NSTAGE = 3;
@@ -95,13 +98,13 @@ __device__ __forceinline__ void xb_scores(XbHalf& o, const bf16x8 (&kf)[4], cons
     }
 #pragma unroll
     for (int s = 0; s < 4; ++s) da[s] = lds_rd128<FT_TILE + QB * 4096>(aR[s]);
+    // (the k-steps of a product stay chained on ONE accumulator: interleaving the three chains measured 6 % slower)
     wait_lgkm<4>();
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         tie(qa[s]);
         mma16(o.sy, as_frag(qa[s]), kf[s]);                         // s[u][t] - lse_Y[u]
     }
-
 #pragma unroll
     for (int s = 0; s < 4; ++s) va[s] = lds_rd128<2 * FT_TILE + QB * 4096>(aR[s]);
     wait_lgkm<4>();
@@ -113,9 +116,15 @@ __device__ __forceinline__ void xb_scores(XbHalf& o, const bf16x8 (&kf)[4], cons
     wait_lgkm<0>();
 #pragma unroll
     for (int s = 0; s < 4; ++s) tie(va[s]);
+#if XB_ABL & 4
+    o.dpx = ndx;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o.dpx[r] += __builtin_bit_cast(float, va[r][0]) * 1e-30f;
+#else
     o.dpx = mma16c(as_frag(va[0]), dof[0], ndx);                    // dP_X[t][u] - delta_X[t]
 #pragma unroll
     for (int s = 1; s < 4; ++s) mma16(o.dpx, as_frag(va[s]), dof[s]);
+#endif
 }
 
 // exponentials, D = dS_Y + dS_X, and the two output products of half tile QB
@@ -129,8 +138,12 @@ __device__ __forceinline__ void xb_update(XbHalf& o, f32x16 (&dqk)[2], f32x16 (&
     mid();                                                          // DMA issue rides in the VALU gap
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
+#if XB_ABL & 1
+        const float py = o.sy[r] * 0.5f, px = (o.sy[r] + o.lv[r]) * 0.25f;
+#else
         const float py = fast_exp2(PRE ? o.sy[r] : o.sy[r] * c);
         const float px = fast_exp2(PRE ? o.sy[r] + o.lv[r] : (o.sy[r] + o.lv[r]) * c);
+#endif
         o.sy[r] = py;
         o.dpy[r] = fmaf(px, o.dpx[r], py * o.dpy[r]);               // D = dS_Y + dS_X overwrites dP_Y
     }
@@ -138,11 +151,18 @@ __device__ __forceinline__ void xb_update(XbHalf& o, f32x16 (&dqk)[2], f32x16 (&
     {
         const bf16x8 pf0 = cvt_frag(o.sy, 0), pf1 = cvt_frag(o.sy, 1);
 #pragma unroll
+        for (int db = 0; db < 2; ++db) { tie(dot[0][db][0]); tie(dot[0][db][1]); tie(dot[1][db][0]); tie(dot[1][db][1]); }
+#if XB_ABL & 2
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+            dv[db][0] += (float)pf0[0] + (float)pf1[0] + __builtin_bit_cast(float, dot[0][db][0][0]) * 1e-30f + __builtin_bit_cast(float, dot[1][db][1][0]) * 1e-30f;
+#else
+#pragma unroll
         for (int db = 0; db < 2; ++db) {
-            tie(dot[0][db][0]); tie(dot[0][db][1]); tie(dot[1][db][0]); tie(dot[1][db][1]);
-            mma16(dv[db], as_frag(dot[0][db][0], dot[0][db][1]), pf0);      // d v_X^T[d][t] += dO_Y^T[d][u] P_Y[u][t]
+            mma16(dv[db], as_frag(dot[0][db][0], dot[0][db][1]), pf0);
             mma16(dv[db], as_frag(dot[1][db][0], dot[1][db][1]), pf1);
         }
+#endif
     }
     GF_TR(qt, 0, 0, 0) GF_TR(qt, 0, 0, 1) GF_TR(qt, 0, 1, 0) GF_TR(qt, 0, 1, 1)      // (late: 16 registers fewer across the exponentials)
 #undef GF_TR
@@ -150,11 +170,18 @@ __device__ __forceinline__ void xb_update(XbHalf& o, f32x16 (&dqk)[2], f32x16 (&
         const bf16x8 pf0 = cvt_frag(o.dpy, 0), pf1 = cvt_frag(o.dpy, 1);
         wait_lgkm<0>();
 #pragma unroll
+        for (int db = 0; db < 2; ++db) { tie(qt[0][db][0]); tie(qt[0][db][1]); tie(qt[1][db][0]); tie(qt[1][db][1]); }
+#if XB_ABL & 2
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+            dqk[db][0] += (float)pf0[0] + (float)pf1[0] + __builtin_bit_cast(float, qt[0][db][0][0]) * 1e-30f + __builtin_bit_cast(float, qt[1][db][1][0]) * 1e-30f;
+#else
+#pragma unroll
         for (int db = 0; db < 2; ++db) {
-            tie(qt[0][db][0]); tie(qt[0][db][1]); tie(qt[1][db][0]); tie(qt[1][db][1]);
-            mma16(dqk[db], as_frag(qt[0][db][0], qt[0][db][1]), pf0);       // d qk_X^T[d][t] += qk_Y^T[d][u] D[u][t]
+            mma16(dqk[db], as_frag(qt[0][db][0], qt[0][db][1]), pf0);
             mma16(dqk[db], as_frag(qt[1][db][0], qt[1][db][1]), pf1);
         }
+#endif
     }
 }
 
@@ -306,7 +333,9 @@ extern "C" int gf_attn_cross_bwd(const void* qk, const void* v, const void* o, c
     p.scale = scale;
     host_split_scale(scale, p.p2, p.rr);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#if !(XB_ABL & 16)
     attn_stats_kernel<<<dim3((unsigned)(((int64_t)B2 * N + 3) / 4)), dim3(256), 0, st>>>(p);
+#endif
     const size_t lds = XB_NSTAGE * XB_STAGE;
     void (*const kern[2])(XbParams) = {attn_xbwd_bf16_kernel<false>, attn_xbwd_bf16_kernel<true>};
     static unsigned long long attr_set = 0;                         // function attributes are per device

@@ -577,7 +577,8 @@ def gemm(x2, wt, bias=None, res2=None, out=None, x2b=None, cs=None, rot_n=0):
             p1 = _k_pieces(K1, dtype) if x2b is not None else []
             if p0 is not None and p1 is not None:
                 plan = "pieces"
-    if plan is None:                                  # library fallback for the odd shapes
+    if plan is None:                                  # library fallback for the odd shapes: counted and reported once per shape
+        _note_library_gemm(M, N, K0 + K1, dtype)
         xx = x2 if x2b is None else torch.cat([x2, x2b], 1)
         y = torch.nn.functional.linear(xx, wt, None if bias is None else _lp(bias, dtype))
         if res2 is not None:
@@ -615,6 +616,21 @@ def gemm(x2, wt, bias=None, res2=None, out=None, x2b=None, cs=None, rot_n=0):
                    "gf_gemm")
         wofs += n
     return y
+
+
+LIBRARY_GEMMS = {}       # (M, N, K, dtype) -> number of products that left the hand-written path (ops.gemm's fallback)
+
+
+def _note_library_gemm(M, N, K, dtype):
+    """A product outside gf_gemm's plans (N % 32, K not a sum of powers of two >= 32, misaligned rows, fp32 K > 256 pieces ...)
+    runs on the vendor library.  Correct, but not the path the rooflines describe: say so once per shape instead of silently."""
+    key = (int(M), int(N), int(K), str(dtype))
+    n = LIBRARY_GEMMS.get(key, 0)
+    LIBRARY_GEMMS[key] = n + 1
+    if n == 0:
+        import warnings
+        warnings.warn(f"glue_factory_amd.ops.gemm: [{M} x {K}] x [{N} x {K}]^T in {dtype} is outside gf_gemm's plans and runs on the "
+                      "vendor library (ops.LIBRARY_GEMMS counts these calls)", RuntimeWarning, stacklevel=3)
 
 
 def gemm_takes(k, n, dtype):
@@ -1555,18 +1571,29 @@ def batch_norm_act(x, bn, relu=True):
 
 # ------------------------------------------------------------------------------ GlueStick line message passing
 @torch.no_grad()
+def _line_graph_sorted(idx, n):
+    """line_graph by a stable sort (any size): endpoints grouped by junction in their original order + segment starts."""
+    B = idx.shape[0]
+    order = torch.argsort(idx, dim=1, stable=True)
+    sorted_idx = idx.gather(1, order).contiguous()
+    seg = torch.searchsorted(sorted_idx, torch.arange(n + 1, device=idx.device).expand(B, -1).contiguous())
+    return order.to(torch.int32).contiguous(), seg.to(torch.int32).contiguous()
+
+
+@torch.no_grad()
 def line_graph(idx, n):
     """idx [B,E] int64 junction of every line endpoint -> (order [B,E] int32: endpoints grouped by junction, stable;
     seg [B,n+1] int32: segment starts).  Built once per forward: all line layers (and the backward) share it."""
     _chk(idx)
     idx = idx.contiguous()
     B, E = idx.shape
-    if E > 4096 or n > 8192:
-        raise NotImplementedError(f"gf_line_csr keeps one image's junction graph in LDS: E={E} endpoints (max 4096), "
-                                  f"n={n} junctions (max 8192)")
     # a junction index outside [0, n) would corrupt LDS in the kernels below; the torch gather they replace raises too
     # (device-side assert: no host synchronisation)
     torch._assert_async(((idx >= 0) & (idx < n)).all())
+    if E > 4096 or n > 8192:
+        # gf_line_csr keeps one image's junction graph in LDS (4096 endpoints, 8192 junctions): larger graphs -- far beyond the
+        # 250-512 lines of the shipped configurations -- are built by a stable sort instead (same order / segment arrays)
+        return _line_graph_sorted(idx, n)
     order = torch.empty((B, E), dtype=torch.int32, device=idx.device)
     seg = torch.empty((B, n + 1), dtype=torch.int32, device=idx.device)
     _lib.check(_lib.load().gf_line_csr(_p(idx), _p(order), _p(seg), B, E, n, _stream()), "gf_line_csr")

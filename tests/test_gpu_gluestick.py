@@ -112,3 +112,22 @@ def test_gluestick_train_step_hipgraph_replay_equals_eager():
         torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5, msg=lambda m: f"step {i}: {m}")
     for k in results[0][1]:
         torch.testing.assert_close(results[0][1][k], results[1][1][k], rtol=1e-5, atol=1e-6, msg=lambda m: f"{k}: {m}")
+
+
+def test_line_graph_of_any_size_equals_the_lds_kernel():
+    """ops.line_graph: graphs beyond gf_line_csr's LDS capacity (4096 endpoints / 8192 junctions) are built by a stable sort;
+    on a graph both paths take, they agree entry for entry -- and a 6000-endpoint graph goes through the line kernels."""
+    from glue_factory_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(2)
+    idx = torch.randint(0, 300, (3, 1024), device="cuda", generator=g)
+    o1, s1 = ops.line_graph(idx, 300)
+    o2, s2 = ops._line_graph_sorted(idx, 300)
+    assert torch.equal(o1, o2) and torch.equal(s1, s2)
+    big = torch.randint(0, 9000, (2, 6000), device="cuda", generator=g)
+    order, seg = ops.line_graph(big, 9000)
+    x = torch.randn(2, 9000, 64, device="cuda", generator=g).requires_grad_(True)
+    out = ops.rows_gather(x, big, order, seg)
+    torch.testing.assert_close(out, x.gather(1, big[..., None].expand(-1, -1, 64)))
+    out.sum().backward()
+    ref = torch.zeros(2, 9000, device="cuda").scatter_add_(1, big, torch.ones(2, 6000, device="cuda"))
+    torch.testing.assert_close(x.grad[..., 0], ref)
