@@ -18,6 +18,9 @@
 #include "gf_common.h"
 #include "gf_amd.h"
 
+#ifndef GF_WRITE_SPLIT    // workgroups per column block of gf_assign_write (disjoint row ranges)
+#define GF_WRITE_SPLIT 4
+#endif
 #ifndef GF_BWD_SPLIT      // workgroups per column block of the dual-softmax backward (probe builds override it)
 #define GF_BWD_SPLIT 4
 #endif
@@ -332,8 +335,13 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void rows_lse_argmax_k
 template <typename T, int D>
 __global__ __launch_bounds__(256) void assign_write_kernel(HeadParams p) {
     GF_HEAD_PROLOGUE(T, D)
+#ifdef GF_WRITE_LDPAD      // timing probe only (tools/probe/time_assign.py): rows padded to a multiple of GF_WRITE_LDPAD floats
+    const int64_t ldo = (p.No + 1 + GF_WRITE_LDPAD - 1) / GF_WRITE_LDPAD * GF_WRITE_LDPAD;
+    float* out = reinterpret_cast<float*>(p.out) + (int64_t)b * (p.Ns + 1) * ldo;
+#else
     float* out = reinterpret_cast<float*>(p.out) + (int64_t)b * (p.Ns + 1) * (p.No + 1);
     const int64_t ldo = p.No + 1;
+#endif
     const float ocb = p.obias ? p.obias[(int64_t)b * p.No + old_] : 0.f;
     const float* sb = p.sbias ? p.sbias + (int64_t)b * p.Ns : nullptr;
     auto bias = [&](int si, float& v0, float& v1) {
@@ -365,10 +373,14 @@ __global__ __launch_bounds__(256) void assign_write_kernel(HeadParams p) {
             }
         }
     };
-    stream_tiles<T, D>(tiles, vecs, othp, 0, p.Ns, p.Ns, bias, body);
+    // the streamed rows are divided among nsplit workgroups (disjoint row ranges of the same column panel): 512 workgroups of
+    // 2048 x 128 outputs each left three quarters of the chip's store queues idle (0.21 ms = 2.5 TB/s at B=32, N=2048)
+    const int per = ((p.Ns + 63) / 64 + nsp - 1) / nsp * 64;
+    const int s_begin = split * per, s_end = min(p.Ns, s_begin + per);
+    if (s_begin < s_end) stream_tiles<T, D>(tiles, vecs, othp, s_begin, s_end, p.Ns, bias, body);
     // dustbins: last row for the owned columns, last column by the first block, corner once
-    if (orow < p.No && hi == 0) out[(int64_t)p.Ns * ldo + orow] = p.g1 ? p.g1[(int64_t)b * p.No + orow] : 0.f;
-    if (ob == 0) {
+    if (split == 0 && orow < p.No && hi == 0) out[(int64_t)p.Ns * ldo + orow] = p.g1 ? p.g1[(int64_t)b * p.No + orow] : 0.f;
+    if (ob == 0 && split == 0) {
         for (int si = threadIdx.x; si < p.Ns; si += 256) {
             const float v = p.g0 ? p.g0[(int64_t)b * p.Ns + si] : 0.f;
             out[(int64_t)si * ldo + p.No] = v;
@@ -555,6 +567,7 @@ extern "C" int gf_assign_write(const void* a, const void* b, const float* rowbia
     HeadParams p = {};
     p.own = b; p.oth = a; p.B = B; p.No = N; p.Ns = M; p.sbias = rowbias; p.obias = colbias;
     p.alpha = alpha; p.corner = corner; p.g0 = bin_col; p.g1 = bin_row; p.out = out; p.f0 = expsum;
+    p.nsplit = GF_WRITE_SPLIT;
     if (expsum)
         if (hipError_t e = gf_zero_f32(expsum, (size_t)B, reinterpret_cast<hipStream_t>(stream))) return (int)e;
     return launch(K_WRITE, p, D, dtype, stream);

@@ -39,46 +39,53 @@ static_assert(sizeof(FoldEntry) == 88, "host table layout (ops.precast)");
 // and the next tile's loads issued before the current tile's FMAs (register prefetch) -- 16-deep tiles without prefetch
 // measured 83 us per backward launch, i.e. one exposed memory round trip per k step.
 constexpr int FK = 64;
-template <bool AI, bool BJ, class FA, class FB>
-__device__ __forceinline__ void mm64(float (&acc)[4][4], FA a, FB b, int KK, float (*As)[68], float (*Bs)[68]) {
+// TS x TS output tile (TS = 64: 4 x 4 outputs per thread, TS = 32: 2 x 2).  The backward uses 32: 64 x 64 tiles made 84
+// workgroups of 20 us of plain FMA work each -- a third of the chip for 42 us per launch; 32 x 32 tiles fill it.
+template <int TS, bool AI, bool BJ, class FA, class FB>
+__device__ __forceinline__ void mmT(float (&acc)[TS / 16][TS / 16], FA a, FB b, int KK, float (*As)[68], float (*Bs)[68]) {
+    constexpr int R = TS / 16, NQ = TS * FK / 256, SH = TS == 64 ? 6 : 5, MK = TS - 1;
     const int t = threadIdx.x, ty = t >> 4, tx = t & 15;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < R; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
-    float ra[16], rb[16];
+        for (int j = 0; j < R; ++j) acc[i][j] = 0.f;
+    float ra[NQ], rb[NQ];
     auto fetch = [&](int k0) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int e = t + 256 * q;                 // 4096 elements of each operand tile
-            ra[q] = AI ? a(e & 63, k0 + (e >> 6)) : a(e >> 6, k0 + (e & 63));
-            rb[q] = BJ ? b(k0 + (e >> 6), e & 63) : b(k0 + (e & 63), e >> 6);
+        for (int q = 0; q < NQ; ++q) {
+            const int e = t + 256 * q;                 // TS * FK elements of each operand tile
+            ra[q] = AI ? a(e & MK, k0 + (e >> SH)) : a(e >> 6, k0 + (e & 63));
+            rb[q] = BJ ? b(k0 + (e >> SH), e & MK) : b(k0 + (e & 63), e >> 6);
         }
     };
     fetch(0);
     for (int k0 = 0; k0 < KK; k0 += FK) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             const int e = t + 256 * q;
-            if (AI) As[e >> 6][e & 63] = ra[q]; else As[e & 63][e >> 6] = ra[q];
-            if (BJ) Bs[e >> 6][e & 63] = rb[q]; else Bs[e & 63][e >> 6] = rb[q];
+            if (AI) As[e >> SH][e & MK] = ra[q]; else As[e & 63][e >> 6] = ra[q];
+            if (BJ) Bs[e >> SH][e & MK] = rb[q]; else Bs[e & 63][e >> 6] = rb[q];
         }
         __syncthreads();
         if (k0 + FK < KK) fetch(k0 + FK);
 #pragma unroll 16
         for (int k = 0; k < FK; ++k) {
-            float av[4], bv[4];
+            float av[R], bv[R];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) av[i] = As[k][ty * 4 + i];
+            for (int i = 0; i < R; ++i) av[i] = As[k][ty * R + i];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bv[j] = Bs[k][tx * 4 + j];
+            for (int j = 0; j < R; ++j) bv[j] = Bs[k][tx * R + j];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < R; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
+                for (int j = 0; j < R; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
         }
         __syncthreads();
     }
+}
+template <bool AI, bool BJ, class FA, class FB>
+__device__ __forceinline__ void mm64(float (&acc)[4][4], FA a, FB b, int KK, float (*As)[68], float (*Bs)[68]) {
+    mmT<64, AI, BJ>(acc, a, b, KK, As, Bs);
 }
 
 // tiles of one entry: ceil(R / 64) x (ceil(N / 64) + 1) -- the extra tile column of each row block computes the folded bias
@@ -136,12 +143,13 @@ struct FoldBwd {
     int tiles_a, tiles_b, tiles_c;      // copy part | dW0b | dWo (+ dbo)
 };
 
+constexpr int BT = 32;                                      // backward tile
 __global__ __launch_bounds__(256) void fold_bwd_kernel(const FoldBwd p) {
     __shared__ float As[FK][68], Bs[FK][68];
     const int ldg = p.c0 + p.N;
     const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
     int tl = blockIdx.x;
-    if (tl < p.tiles_a) {                                   // dW0[:, :c0] = g[:, :c0]
+    if (tl < p.tiles_a) {                                   // dW0[:, :c0] = g[:, :c0]   (64 x 64 copy tiles)
         const int tcx = (p.c0 + 63) / 64, r0 = (tl / tcx) * 64, c0_ = (tl % tcx) * 64;
         for (int e = threadIdx.x; e < 4096; e += 256) {
             const int r = r0 + (e >> 6), c = c0_ + (e & 63);
@@ -150,22 +158,22 @@ __global__ __launch_bounds__(256) void fold_bwd_kernel(const FoldBwd p) {
         return;
     }
     tl -= p.tiles_a;
-    float acc[4][4];
+    float acc[2][2];
     const float* gc = p.g + p.c0;
     if (tl < p.tiles_b) {                                   // dW0[r, c0 + k] = sum_c g_c[r, c] Wo[k, cp(c)] + gb[r] bo[k]
-        const int tkx = (p.K + 63) / 64, r0 = (tl / tkx) * 64, k0 = (tl % tkx) * 64;
-        mm64<false, false>(acc,
-                           [&](int i, int c) { return (r0 + i < p.R && c < p.N) ? gc[(size_t)(r0 + i) * ldg + c] : 0.f; },
-                           [&](int c, int j) {
-                               if (c >= p.N || k0 + j >= p.K) return 0.f;
-                               return p.Wo[(size_t)(k0 + j) * p.N + (p.cperm ? p.cperm[c] : c)];
-                           },
-                           p.N, As, Bs);
+        const int tkx = (p.K + BT - 1) / BT, r0 = (tl / tkx) * BT, k0 = (tl % tkx) * BT;
+        mmT<BT, false, false>(acc,
+                              [&](int i, int c) { return (r0 + i < p.R && c < p.N) ? gc[(size_t)(r0 + i) * ldg + c] : 0.f; },
+                              [&](int c, int j) {
+                                  if (c >= p.N || k0 + j >= p.K) return 0.f;
+                                  return p.Wo[(size_t)(k0 + j) * p.N + (p.cperm ? p.cperm[c] : c)];
+                              },
+                              p.N, As, Bs);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int r = r0 + ty * 4 + i, k = k0 + tx * 4 + j;
+            for (int j = 0; j < 2; ++j) {
+                const int r = r0 + ty * 2 + i, k = k0 + tx * 2 + j;
                 if (r < p.R && k < p.K) {
                     float v = acc[i][j];
                     if (p.gb && p.bo) v = fmaf(p.gb[r], p.bo[k], v);
@@ -176,26 +184,26 @@ __global__ __launch_bounds__(256) void fold_bwd_kernel(const FoldBwd p) {
     }
     tl -= p.tiles_b;
     {   // dWo[k, cp(c)] = sum_r W0[r, c0 + k] g_c[r, c]; the extra tile column: dbo[k] = sum_r W0[r, c0 + k] gb[r]
-        const int tnx = (p.N + 63) / 64 + 1, k0 = (tl / tnx) * 64, tn = tl % tnx;
+        const int tnx = (p.N + BT - 1) / BT + 1, k0 = (tl / tnx) * BT, tn = tl % tnx;
         const float* A = p.W0 + p.c0;
         auto fa = [&](int i, int r) { return (k0 + i < p.K && r < p.R) ? A[(size_t)r * p.ldw0 + k0 + i] : 0.f; };
         if (tn == tnx - 1) {
             if (p.dbo == nullptr) return;
-            mm64<true, true>(acc, fa, [&](int r, int j) { return (j == 0 && r < p.R && p.gb) ? p.gb[r] : 0.f; }, p.R, As, Bs);
+            mmT<BT, true, true>(acc, fa, [&](int r, int j) { return (j == 0 && r < p.R && p.gb) ? p.gb[r] : 0.f; }, p.R, As, Bs);
             if (tx == 0)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (k0 + ty * 4 + i < p.K) p.dbo[k0 + ty * 4 + i] = acc[i][0];
+                for (int i = 0; i < 2; ++i)
+                    if (k0 + ty * 2 + i < p.K) p.dbo[k0 + ty * 2 + i] = acc[i][0];
             return;
         }
-        const int n0 = tn * 64;
-        mm64<true, true>(acc, fa, [&](int r, int j) { return (r < p.R && n0 + j < p.N) ? gc[(size_t)r * ldg + n0 + j] : 0.f; },
-                         p.R, As, Bs);
+        const int n0 = tn * BT;
+        mmT<BT, true, true>(acc, fa, [&](int r, int j) { return (r < p.R && n0 + j < p.N) ? gc[(size_t)r * ldg + n0 + j] : 0.f; },
+                            p.R, As, Bs);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int k = k0 + ty * 4 + i, c = n0 + tx * 4 + j;
+            for (int j = 0; j < 2; ++j) {
+                const int k = k0 + ty * 2 + i, c = n0 + tx * 2 + j;
                 if (k < p.K && c < p.N) p.dWo[(size_t)k * p.N + (p.cperm ? p.cperm[c] : c)] = acc[i][j];
             }
     }
@@ -221,10 +229,9 @@ extern "C" int gf_fold_linear_bwd(const float* g, const float* gb, const float* 
     p.g = g; p.gb = gb; p.W0 = W0; p.Wo = Wo; p.bo = bo; p.cperm = cperm;
     p.dW0 = dW0; p.dWo = dWo; p.dbo = bo ? dbo : nullptr;
     p.R = R; p.K = K; p.N = N; p.ldw0 = ldw0; p.c0 = c0;
-    const int tr = (R + 63) / 64;
-    p.tiles_a = tr * ((c0 + 63) / 64);
-    p.tiles_b = tr * ((K + 63) / 64);
-    p.tiles_c = ((K + 63) / 64) * ((N + 63) / 64 + 1);
+    p.tiles_a = ((R + 63) / 64) * ((c0 + 63) / 64);             // copy tiles 64 x 64, product tiles BT x BT
+    p.tiles_b = ((R + BT - 1) / BT) * ((K + BT - 1) / BT);
+    p.tiles_c = ((K + BT - 1) / BT) * ((N + BT - 1) / BT + 1);
     fold_bwd_kernel<<<dim3(p.tiles_a + p.tiles_b + p.tiles_c), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(p);
     return (int)hipGetLastError();
 }
