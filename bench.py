@@ -172,7 +172,7 @@ def roofline_attention(batch, n, dtype):
              "two_launch_ms": round(t_x2 * 1e3, 4), "two_launch_frac": round(f_bwd / t_x2 / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)}
     if t_x is not None:
         cross.update({"launch_ms": round(t_x * 1e3, 4), "achieved": round(f_bwd / t_x / 1e12, 2),
-                      "frac": round(f_bwd / t_x / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)})
+                      "frac": round(f_bwd / t_x / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": _traffic("gf_attn_cross_bwd")})
     return {
         "bound": "mfma", "kernel": "gf_attn_bwd (attn_dq3_bf16_kernel + attn_bwd_dkv_bf16_kernel of one launch)",
         "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -98,6 +98,29 @@ class SuperPoint(BaseModel):
                 raise FileNotFoundError(f"SuperPoint weights '{conf.weights}' not found locally")
             self.load_state_dict(torch.load(str(path), map_location="cpu"))
 
+    # ------------------------------------------------------------------ network layout (overridden by the non-free variant)
+    def _named_blocks(self):
+        """(name, block) of every conv block; a block has .conv, .activation, .bn (or None) and is callable."""
+        return [(n, m) for n, m in self.named_modules() if isinstance(m, VGGBlock)]
+
+    def _stages(self):
+        """Backbone as [( [(name, block), ...], followed_by_a_2x2_max_pool ), ...]."""
+        out = []
+        for si, stage in enumerate(self.backbone):
+            blocks = [m for m in stage if isinstance(m, VGGBlock)]
+            out.append(([(f"backbone.{si}.{bi}", m) for bi, m in enumerate(blocks)],
+                        any(isinstance(m, nn.MaxPool2d) for m in stage)))
+        return out
+
+    def _heads(self):
+        """((name, block) x 2 of the detector head, (name, block) x 2 of the descriptor head)."""
+        return ([("detector.0", self.detector[0]), ("detector.1", self.detector[1])],
+                [("descriptor.0", self.descriptor[0]), ("descriptor.1", self.descriptor[1])])
+
+    def _dense_unfused(self, image):
+        features = self.backbone(image)
+        return self.detector(features), self.descriptor(features)
+
     # ------------------------------------------------------------------ fused inference path (HIP)
     def _use_fused(self, image):
         if not image.is_cuda or not 1 <= self.conf.nms_radius <= 4:
@@ -119,11 +142,15 @@ class SuperPoint(BaseModel):
         if cache is not None and cache[0] == key:
             return cache[1]
         out = {}
-        for name, blk in self.named_modules():
-            if isinstance(blk, VGGBlock):
+        for name, blk in self._named_blocks():
+            if True:
                 bn = blk.bn
-                scale = (bn.weight.float() * torch.rsqrt(bn.running_var.float() + bn.eps)).contiguous()
-                shift = (bn.bias.float() - bn.running_mean.float() * scale).contiguous()
+                if bn is None:        # (the non-free variant has no BatchNorm: identity scale / shift)
+                    scale = torch.ones(blk.conv.out_channels, dtype=torch.float32, device=blk.conv.weight.device)
+                    shift = torch.zeros_like(scale)
+                else:
+                    scale = (bn.weight.float() * torch.rsqrt(bn.running_var.float() + bn.eps)).contiguous()
+                    shift = (bn.bias.float() - bn.running_mean.float() * scale).contiguous()
                 w = blk.conv.weight.detach().to(dtype).contiguous(memory_format=torch.channels_last)
                 out[name] = (w, blk.conv.bias.detach().float().contiguous(), scale, shift)
                 if (dtype == torch.bfloat16 and blk.conv.kernel_size == (1, 1) and not isinstance(blk.activation, nn.ReLU)
@@ -222,33 +249,33 @@ class SuperPoint(BaseModel):
             x = x.as_strided(x.shape, (h_ * w_, 1, w_, 1))
         else:
             x = x.contiguous(memory_format=torch.channels_last)
-        for si, stage in enumerate(self.backbone):
-            blocks = [m for m in stage if isinstance(m, VGGBlock)]
-            has_pool = any(isinstance(m, nn.MaxPool2d) for m in stage)
-            for bi, blk in enumerate(blocks):
+        for si, (blocks, has_pool) in enumerate(self._stages()):
+            for bi, (name, blk) in enumerate(blocks):
                 pool = has_pool and bi == len(blocks) - 1
                 if si == 0 and bi == 0 and not pool and x.shape[1] == 1 and blk.conv.out_channels == 64 \
                         and blk.conv.kernel_size == (3, 3):
-                    x = self._first_block(f"backbone.{si}.{bi}", blk, x, params)      # conv + tail in one kernel
-                elif f"backbone.{si}.{bi}/taps" in params and x.shape[2] % 8 == 0 and x.shape[3] % 32 == 0 \
+                    x = self._first_block(name, blk, x, params)      # conv + tail in one kernel
+                elif name + "/taps" in params and x.shape[2] % 8 == 0 and x.shape[3] % 32 == 0 \
                         and x.shape[2] * x.shape[3] * 128 < 2 ** 31 and blk.conv.padding == (1, 1) and blk.conv.stride == (1, 1):
-                    x = self._conv64_block(f"backbone.{si}.{bi}", blk, x, params, pool)
+                    x = self._conv64_block(name, blk, x, params, pool)
                 else:
-                    x = self._fused_block(f"backbone.{si}.{bi}", blk, x, params, pool=pool)
-        det = self._fused_block("detector.0", self.detector[0], x, params)
-        if self.detector[1].conv.out_channels == self.stride ** 2 + 1 == 65:
-            det = self._detector_scores("detector.1", self.detector[1], det, params)     # -> the [B, 8h, 8w] score map
+                    x = self._fused_block(name, blk, x, params, pool=pool)
+        (d0n, d0), (d1n, d1) = self._heads()[0]
+        (e0n, e0), (e1n, e1) = self._heads()[1]
+        det = self._fused_block(d0n, d0, x, params)
+        if d1.conv.out_channels == self.stride ** 2 + 1 == 65:
+            det = self._detector_scores(d1n, d1, det, params)     # -> the [B, 8h, 8w] score map
         else:
-            det = self._fused_block("detector.1", self.detector[1], det, params)
-        desc = self._fused_block("descriptor.0", self.descriptor[0], x, params)
-        if "descriptor.1/gemm" in params and desc.is_contiguous(memory_format=torch.channels_last):
+            det = self._fused_block(d1n, d1, det, params)
+        desc = self._fused_block(e0n, e0, x, params)
+        if e1n + "/gemm" in params and desc.is_contiguous(memory_format=torch.channels_last):
             from .. import ops
-            w2, b2 = params["descriptor.1/gemm"]                    # descriptor.1 (256 -> 256, 1 x 1, no ReLU) + its BatchNorm
+            w2, b2 = params[e1n + "/gemm"]                    # descriptor.1 (256 -> 256, 1 x 1, no ReLU) + its BatchNorm
             bb, cc, hh, ww = desc.shape
             y = ops.gemm(desc.permute(0, 2, 3, 1).reshape(-1, cc), w2, b2)
             desc = y.view(bb, hh, ww, w2.shape[0]).permute(0, 3, 1, 2)          # channels-last [B, C, h, w]
         else:
-            desc = self._fused_block("descriptor.1", self.descriptor[1], desc, params)
+            desc = self._fused_block(e1n, e1, desc, params)
         return det, desc
 
     def _forward(self, data):
@@ -260,8 +287,7 @@ class SuperPoint(BaseModel):
         if fused:
             det, desc_map = self._fused_features(image)
         else:
-            features = self.backbone(image)
-            det, desc_map = self.detector(features), self.descriptor(features)
+            det, desc_map = self._dense_unfused(image)
         def dense():          # per-pixel normalised map; the fused sampler normalises the corners itself
             return F.normalize(desc_map.float(), p=2, dim=1)
 
@@ -274,9 +300,11 @@ class SuperPoint(BaseModel):
             scores = F.softmax(det.float(), 1)[:, :-1]
             b, _, h, w = scores.shape
             scores = scores.permute(0, 2, 3, 1).reshape(b, h, w, s, s).permute(0, 1, 3, 2, 4).reshape(b, h * s, w * s)
-        k = conf.max_num_keypoints
+        k = self._max_keypoints()
         H, W = h * s, w * s
         cand = None
+        dense_scores = scores                     # (pre-NMS map: the non-free variant's soft-argmax refinement reads it)
+        limits = self._border_limits(data)        # None, or per-image (x_max, y_max) [B,1] beyond which keypoints are dropped
         if fused:
             from .. import lib as _lib
             scores = scores.contiguous()
@@ -290,6 +318,9 @@ class SuperPoint(BaseModel):
                 _lib.check(_lib.load().gf_nms_candidates(scores.data_ptr(), cand_s.data_ptr(), cand_i.data_ptr(), b, H, W, r,
                                                          int(conf.remove_borders or 0),
                                                          torch.cuda.current_stream().cuda_stream), "gf_nms_candidates")
+                if limits is not None:      # (after the NMS, like the reference's border writes; elementwise, no host read)
+                    ci = cand_i.long()
+                    cand_s = torch.where((ci % W >= limits[0]) | (ci // W >= limits[1]), torch.full_like(cand_s, -1.0), cand_s)
                 cand = (cand_s, cand_i)
             else:
                 nms = torch.empty_like(scores)
@@ -297,14 +328,18 @@ class SuperPoint(BaseModel):
                                                      int(conf.remove_borders or 0), torch.cuda.current_stream().cuda_stream),
                            "gf_nms_scores")
                 scores = nms
+                if limits is not None:
+                    scores = self._apply_limits(scores, limits)
         else:
-            scores = batched_nms(scores, conf.nms_radius)
+            scores = batched_nms(scores.float(), conf.nms_radius)
             if conf.remove_borders:
                 pad = conf.remove_borders
                 scores[:, :pad] = -1
                 scores[:, :, :pad] = -1
                 scores[:, -pad:] = -1
                 scores[:, :, -pad:] = -1
+            if limits is not None:
+                scores = self._apply_limits(scores, limits)
         if k is None:
             if b != 1:
                 raise ValueError("max_num_keypoints is required for batched extraction")
@@ -329,6 +364,7 @@ class SuperPoint(BaseModel):
                 kscores, ind = torch.topk(flat, min(k, flat.shape[1]), dim=1, sorted=True)
             keypoints = torch.stack([ind % W, ind // W], -1).float()
             valid = kscores > conf.detection_threshold
+            keypoints = self._refine(keypoints, dense_scores)
             if conf.force_num_keypoints:
                 # pad like pad_and_stack(mode="random_c"): uniform in the detections' bounding box
                 big = torch.full_like(keypoints, float("inf"))
@@ -348,22 +384,45 @@ class SuperPoint(BaseModel):
                 keypoints, kscores = keypoints[:, valid[0]], kscores[:, valid[0]]
             elif not bool(valid.all()):
                 raise ValueError("images yield different keypoint counts: set force_num_keypoints")
+        descriptors = self._sample(keypoints, desc_map, dense, fused, s)
+        pred = {"keypoints": keypoints + 0.5, "keypoint_scores": kscores, "descriptors": descriptors}
+        if conf.dense_outputs:
+            pred["dense_descriptors"] = dense()
+        return pred
+
+    # ------------------------------------------------------------------ hooks of the post-processing (see superpoint.py)
+    def _max_keypoints(self):
+        return self.conf.max_num_keypoints
+
+    def _border_limits(self, data):
+        return None
+
+    @staticmethod
+    def _apply_limits(scores, limits):
+        H, W = scores.shape[-2:]
+        xs = torch.arange(W, device=scores.device)[None, None, :]
+        ys = torch.arange(H, device=scores.device)[None, :, None]
+        return torch.where((xs >= limits[0][..., None]) | (ys >= limits[1][..., None]), torch.full_like(scores, -1.0), scores)
+
+    def _refine(self, keypoints, dense_scores):
+        return keypoints
+
+    def _sample(self, keypoints, desc_map, dense, fused, s, shift=0.0):
+        """Descriptors at the keypoints (superpoint_open.py:10-16): bilinear sample of the per-pixel-normalised map, then L2
+        normalisation; `shift` is added to the keypoints first (the non-free variant's corrected sampling omits the +0.5)."""
+        b = keypoints.shape[0]
         if fused and desc_map.shape[1] % 64 == 0 and desc_map.shape[1] <= 512:
             from .. import lib as _lib
             dm = desc_map if desc_map.is_contiguous(memory_format=torch.channels_last) else \
                 desc_map.contiguous(memory_format=torch.channels_last)
-            kp = keypoints.float().contiguous()
+            kp = (keypoints.float() + shift).contiguous()
             descriptors = torch.empty((b, kp.shape[1], dm.shape[1]), dtype=torch.float32, device=dm.device)
             _lib.check(_lib.load().gf_sample_descriptors(
                 dm.data_ptr(), kp.data_ptr(), descriptors.data_ptr(), b, kp.shape[1], dm.shape[2], dm.shape[3],
                 dm.shape[1], s, 1 if dm.dtype == torch.bfloat16 else 0, torch.cuda.current_stream().cuda_stream),
                 "gf_sample_descriptors")
-        else:
-            descriptors = sample_descriptors(keypoints, dense(), s).transpose(-1, -2)
-        pred = {"keypoints": keypoints + 0.5, "keypoint_scores": kscores, "descriptors": descriptors}
-        if conf.dense_outputs:
-            pred["dense_descriptors"] = dense()
-        return pred
+            return descriptors
+        return sample_descriptors(keypoints + shift, dense(), s).transpose(-1, -2)
 
     def loss(self, pred, data):
         raise NotImplementedError

@@ -198,6 +198,35 @@ def gen_superpoint(name, seed):
     print(name, "keypoints", tuple(pr["keypoints"].shape))
 
 
+def gen_superpoint_nonfree(name, seed):
+    """Reference gluefactory_nonfree.superpoint (the MagicLeap-layout extractor the N=2048 LightGlue yaml names) on seeded
+    random weights: the reference constructor downloads superpoint_v1.pth, so torch.hub is pointed at the state_dict of OUR
+    module's seeded initialisation (same names / shapes: that is the drop-in claim); eval-mode outputs for three
+    configurations (legacy sampling, corrected sampling, soft-argmax refinement), with and without `image_size`."""
+    from gluefactory_nonfree.superpoint import SuperPoint as RefSP
+    from glue_factory_amd.extractors.superpoint import SuperPoint
+    g = torch.Generator().manual_seed(seed + 1)
+    image = torch.rand(2, 1, 120, 160, generator=g)
+    size = torch.tensor([[160, 120], [131, 97]])
+    out = {"image": image.numpy(), "image_size": size.numpy(), "seed": np.array(seed)}
+    cases = {"legacy": {"nms_radius": 3}, "fixed": {"nms_radius": 4, "legacy_sampling": False},
+             "refine": {"nms_radius": 3, "refinement_radius": 2}}
+    for cname, extra in cases.items():
+        conf = {"max_num_keypoints": 100, "force_num_keypoints": True, "detection_threshold": 0.0, **extra}
+        torch.manual_seed(seed)
+        ours = SuperPoint(conf)
+        sd = ours.state_dict()
+        torch.hub.load_state_dict_from_url = lambda *a, **k: sd
+        ref = RefSP(conf).eval()
+        assert set(ref.state_dict()) == set(sd)
+        for tag, data in (("plain", {"image": image}), ("sized", {"image": image, "image_size": size})):
+            with torch.no_grad():
+                pr = ref(dict(data))
+            out.update(_np(pr, f"{cname}.{tag}."))
+        print(name, cname, "keypoints", tuple(pr["keypoints"].shape))
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+
+
 def gen_gt(name, batch, n0, n1, seed):
     from gluefactory.geometry.gt_generation import gt_matches_from_homography
 
@@ -509,6 +538,7 @@ def main():
             "lightglue_sharp": lambda: gen_lightglue_config("lightglue_sharp", 1, 2048, 9, seed=131, size=(1024, 1024),
                                                              stride=997, sharp=(0.04, 11.0, 0.06)),
             "lightglue_adaptive": lambda: gen_lightglue_adaptive("lightglue_adaptive", 160, 200, 3, seed=107),
+            "superpoint_nonfree": lambda: gen_superpoint_nonfree("superpoint_nonfree", seed=53),
             "metrics": lambda: gen_metrics("metrics", seed=109),
             "superglue_config4": lambda: gen_superglue_config("superglue_config4", 1, 2048, 100, seed=113),
             "gluestick_config5": lambda: gen_gluestick_config("gluestick_config5", 1, 2048, 512, seed=127),
@@ -526,6 +556,7 @@ def main():
     gen_gt_depth("gt_depth", batch=2, n0=120, n1=100, seed=61)
     gen_gt_lines("gt_lines", batch=2, n0=40, n1=36, seed=71)
     gen_superpoint("superpoint_open", seed=51)
+    gen_superpoint_nonfree("superpoint_nonfree", seed=53)
     gen_gluestick("gluestick_d256", batch=2, n_kpts=40, n_lines=12, gnn=["self", "cross"] * 2, inter=[0], seed=41)
     gen_superglue("superglue_d256", batch=2, n0=60, n1=52, gnn=["self", "cross"] * 2, iters=20, seed=31)
     gen_lightglue_config("lightglue_config1", 4, 512, 4, seed=101, size=(640, 480))
