@@ -215,6 +215,7 @@ def gen_superpoint_nonfree(name, seed):
         conf = {"max_num_keypoints": 100, "force_num_keypoints": True, "detection_threshold": 0.0, **extra}
         torch.manual_seed(seed)
         ours = SuperPoint(conf)
+        ours.convPb.weight.data.mul_(40.0)      # spread the detector logits: random weights give 1/65 everywhere (all scores tied)
         sd = ours.state_dict()
         torch.hub.load_state_dict_from_url = lambda *a, **k: sd
         ref = RefSP(conf).eval()

@@ -9,12 +9,6 @@ CASES = {"legacy": {"nms_radius": 3}, "fixed": {"nms_radius": 4, "legacy_samplin
          "refine": {"nms_radius": 3, "refinement_radius": 2}}
 
 
-def _canon(kp, sc, desc):
-    """Rows sorted by (score descending, x, y): exactly tied scores come back in an unspecified order from any top-k."""
-    key = np.lexsort((kp[:, 1], kp[:, 0], -sc))
-    return kp[key], sc[key], desc[key]
-
-
 def check(device, autocast=False, tol=1e-4):
     from glue_factory_amd.extractors.superpoint import SuperPoint
     z = load_golden("superpoint_nonfree")
@@ -25,25 +19,29 @@ def check(device, autocast=False, tol=1e-4):
     for cname, extra in CASES.items():
         conf = {"max_num_keypoints": 100, "force_num_keypoints": True, "detection_threshold": 0.0, **extra}
         torch.manual_seed(seed)
-        model = SuperPoint(conf).to(device).eval()
+        model = SuperPoint(conf)
+        model.convPb.weight.data.mul_(40.0)      # (as in oracle/gen_golden.py: spreads the detector logits)
+        model = model.to(device).eval()
         for tag, data in (("plain", {"image": image}), ("sized", {"image": image, "image_size": size})):
             with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
                 pred = model(dict(data))
             for b in range(image.shape[0]):
-                ref = _canon(z[f"{cname}.{tag}.keypoints"][b], z[f"{cname}.{tag}.keypoint_scores"][b], z[f"{cname}.{tag}.descriptors"][b])
-                got = _canon(pred["keypoints"][b].float().cpu().numpy(), pred["keypoint_scores"][b].float().cpu().numpy(),
-                             pred["descriptors"][b].float().cpu().numpy())
-                valid = ref[1] > 0                       # (padding keypoints are random in both)
-                # a top-k that cuts through a group of exactly tied scores may keep any of them: compared strictly above the cut
-                valid &= ref[1] > ref[1][valid].min()
+                rk, rs, rd = (z[f"{cname}.{tag}.{k}"][b] for k in ("keypoints", "keypoint_scores", "descriptors"))
+                gk, gs, gd = (pred[k][b].float().cpu().numpy() for k in ("keypoints", "keypoint_scores", "descriptors"))
+                valid = rs > 0                           # (padding keypoints are random in both)
+                # a top-k that cuts through a group of (nearly) tied scores may keep any of them: compared above the cut
+                valid &= rs > rs[valid].min() * (1 + 10 * tol)
                 assert valid.sum() >= 16, valid.sum()
                 if not autocast:
-                    np.testing.assert_allclose(got[1][valid], ref[1][valid], rtol=tol, atol=tol * 1e-2, err_msg=f"{cname}.{tag} scores")
-                    np.testing.assert_allclose(got[0][valid], ref[0][valid], rtol=0, atol=2e-3 if cname == "refine" else 0,
-                                               err_msg=f"{cname}.{tag} keypoints")
-                    np.testing.assert_allclose(got[2][valid], ref[2][valid], rtol=tol, atol=5 * tol, err_msg=f"{cname}.{tag} descriptors")
+                    # rows are matched by POSITION (the order inside a group of tied scores is unspecified in any top-k)
+                    d2 = ((rk[valid][:, None, :] - gk[None, :, :]) ** 2).sum(-1)
+                    j = d2.argmin(1)
+                    assert float(np.sqrt(d2[np.arange(len(j)), j].max())) <= (2e-3 if cname == "refine" else 0.0), f"{cname}.{tag}: keypoints"
+                    assert len(set(j.tolist())) == len(j)
+                    np.testing.assert_allclose(gs[j], rs[valid], rtol=tol, atol=tol * 1e-2, err_msg=f"{cname}.{tag} scores")
+                    np.testing.assert_allclose(gd[j], rd[valid], rtol=tol, atol=5 * tol, err_msg=f"{cname}.{tag} descriptors")
                 else:           # bf16 convolutions: the detections move; report the overlap of the keypoint sets
-                    a = {tuple(np.round(k).astype(int)) for k in got[0][got[1] > 0]}
-                    r = {tuple(np.round(k).astype(int)) for k in ref[0][valid]}
+                    a = {tuple(np.round(k).astype(int)) for k in gk[gs > 0]}
+                    r = {tuple(np.round(k).astype(int)) for k in rk[valid]}
                     worst = max(worst, 1.0 - len(a & r) / max(len(r), 1))
     return worst
