@@ -671,12 +671,15 @@ size_t rows_lds(const Geo& g, bool bwd) {
 }
 
 // workspace carve (floats): [ partials | u cur | v cur | ubar hist | vbar hist | Zp (fast path) ]
-struct Ws { float *part, *ucur, *vcur, *ubar_hist, *vbar_hist, *zp, *a2p, *vbp, *P, *Q; int KP; size_t total; };
+constexpr int SKR_PART_CUS = 320;    // partial rows reserved for the resident path: 4 waves x this many CUs
+struct Ws { float *part, *ucur, *vcur, *ubar_hist, *vbar_hist, *zp, *a2p, *vbp, *P, *Q; unsigned* ctr; int KP; size_t part_rows, total; };
 Ws carve(void* ws, const Geo& g, int iters) {
     Ws w;
     float* p = reinterpret_cast<float*>(ws);
     const size_t wid = g.fast ? g.Cp : g.C;
-    w.part = p;       p += 2 * (size_t)g.B * g.nblk * wid;
+    w.part_rows = 2 * (size_t)g.B * g.nblk;
+    if (g.fast && w.part_rows < 4 * (size_t)SKR_PART_CUS) w.part_rows = 4 * (size_t)SKR_PART_CUS;   // resident path: one row per wave
+    w.part = p;       p += w.part_rows * wid;
     w.ucur = p;       p += (size_t)g.B * g.R;
     w.vcur = p;       p += (size_t)g.B * wid;
     w.ubar_hist = p;  p += (size_t)(iters + 1) * g.B * g.R;
@@ -685,6 +688,7 @@ Ws carve(void* ws, const Geo& g, int iters) {
     w.zp = p;
     w.KP = (2 * iters + 15) & ~15;
     w.a2p = w.vbp = w.P = w.Q = nullptr;
+    w.ctr = nullptr;
     if (g.fast) {
         const size_t ch = (size_t)batch_chunk(g);
         p += ch * g.R * g.Cp;
@@ -692,10 +696,13 @@ Ws carve(void* ws, const Geo& g, int iters) {
         w.vbp = p;  p += (size_t)g.B * g.Cp;
         w.P = p;    p += ch * g.R * w.KP;        // rank-2T factors of the final gradient (backward only)
         w.Q = p;    p += ch * g.C * w.KP;
+        w.ctr = reinterpret_cast<unsigned*>(p);  p += 64;       // pair-barrier counters of the resident path
     }
     w.total = (size_t)(p - reinterpret_cast<float*>(ws)) * 4 + 1024;
     return w;
 }
+
+#include "sinkhorn_resident.h"
 
 }  // namespace
 
@@ -714,7 +721,10 @@ extern "C" int gf_sinkhorn_fwd(const float* Z, float* out, float* u_hist, float*
     if (reinterpret_cast<uintptr_t>(ws) & 15) return GF_ERR_ALIGN;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const Ws w = carve(ws, g, iters);
-    const int ch = batch_chunk(g);
+    SkrPlan rp;
+    const bool resident = g.fast && iters > 0 && skr_mode() != 0 && skr_plan(g, B, skr_cus(), false, rp) &&
+                          (size_t)rp.nw * rp.bc <= w.part_rows;
+    const int ch = resident ? rp.bc : batch_chunk(g);
     const size_t zs = (size_t)g.R * g.C;
     const size_t lds = g.fast ? 0 : rows_lds(g, false);
     if (!g.fast) {
@@ -728,6 +738,16 @@ extern "C" int gf_sinkhorn_fwd(const float* Z, float* out, float* u_hist, float*
             if (iters > 0) {
                 const size_t nv4 = (size_t)bc * g.R * (g.Cp >> 2);
                 skf_prescale<<<dim3((unsigned)((nv4 + 255) / 256)), 256, 0, st>>>(Z + b0 * zs, w.zp, g, bc * g.R);
+                if (resident) {                       // the chunk stays on the chip for all iterations
+                    SkrArgs ra{};
+                    ra.Zp = w.zp; ra.part = w.part; ra.ctr = w.ctr;
+                    ra.colA = w.a2p; ra.colB = w.vbp;                 // 16-byte aligned [B, Cp] scratch (free in the forward)
+                    ra.u_hist = u_hist + (size_t)b0 * g.R; ra.v_hist = v_hist + (size_t)b0 * g.C;
+                    ra.ustride = (size_t)B * g.R; ra.vstride = (size_t)B * g.C;
+                    ra.iters = iters; ra.d = rp; ra.d.bc = bc; ra.g = g;
+                    int rc = skr_launch<false>(ra, st);
+                    if (rc) return rc;
+                } else {
                 const int ns = ((g.Cp >> 2) + 63) / 64;
                 float* part = w.part + (size_t)b0 * g.nblk * g.Cp;
                 float* u2 = w.ucur + (size_t)b0 * g.R;
@@ -744,6 +764,7 @@ extern "C" int gf_sinkhorn_fwd(const float* Z, float* out, float* u_hist, float*
 #undef SKF_CALL_FWD
                 }();
                 if (rc) return rc;
+                }
             }
         } else {
             float* pm = w.part;
@@ -792,7 +813,10 @@ extern "C" int gf_sinkhorn_bwd(const float* Z, const float* gout, const float* g
     // vbar^T = colsum(G)
     e = gf_copy_f32(vbar_hist + (size_t)iters * B * g.C, gsum_col, (size_t)B * g.C, st);
     if (e != hipSuccess) return (int)e;
-    const int ch = batch_chunk(g);
+    SkrPlan rp;
+    const bool resident = g.fast && skr_mode() != 0 && skr_plan(g, B, skr_cus(), true, rp) &&
+                          (size_t)rp.nw * rp.bc <= w.part_rows;
+    const int ch = resident ? rp.bc : batch_chunk(g);
     for (int b0 = 0; b0 < B; b0 += ch) {
         const int bc = (B - b0) < ch ? (B - b0) : ch;
         if (g.fast) {
@@ -800,7 +824,20 @@ extern "C" int gf_sinkhorn_bwd(const float* Z, const float* gout, const float* g
             skf_prescale<<<dim3((unsigned)((nv4 + 255) / 256)), 256, 0, st>>>(Z + b0 * zs, w.zp, g, bc * g.R);
             const int ns = ((g.Cp >> 2) + 63) / 64;
             float* part = w.part + (size_t)b0 * g.nblk * g.Cp;
-            int rc = [&]() -> int {
+            int rc = resident ? [&]() -> int {
+                skf_bwd_prep<<<dim3((g.Cp + 255) / 256, bc), 256, 0, st>>>(
+                    v_hist + ((size_t)(iters - 1) * B + b0) * g.C, gsum_col + (size_t)b0 * g.C, w.a2p, w.vbp, g);
+                SkrArgs ra{};
+                ra.Zp = w.zp; ra.part = w.part; ra.ctr = w.ctr;
+                ra.colA = w.a2p; ra.colB = w.vbp;
+                ra.u_hist = const_cast<float*>(u_hist) + (size_t)b0 * g.R;
+                ra.v_hist = const_cast<float*>(v_hist) + (size_t)b0 * g.C;
+                ra.base_row = gsum_row + (size_t)b0 * g.R;
+                ra.ubar_hist = ubar_hist + (size_t)b0 * g.R; ra.vbar_hist = vbar_hist + (size_t)b0 * g.C;
+                ra.ustride = (size_t)B * g.R; ra.vstride = (size_t)B * g.C;
+                ra.iters = iters; ra.d = rp; ra.d.bc = bc; ra.g = g;
+                return skr_launch<true>(ra, st);
+            }() : [&]() -> int {
 #define SKF_CALL_BWD(NSV) skf_bwd_launch<NSV>(w.zp, u_hist + (size_t)b0 * g.R, v_hist + (size_t)b0 * g.C,          \
                                               gsum_row + (size_t)b0 * g.R, gsum_col + (size_t)b0 * g.C,              \
                                               ubar_hist + (size_t)b0 * g.R, vbar_hist + (size_t)b0 * g.C, part,      \

@@ -25,9 +25,14 @@ def test_sinkhorn_fwd_bwd_vs_reference_golden():
     np.testing.assert_allclose(float(alpha.grad), float(z["galpha"]), rtol=1e-3, atol=1e-3)
 
 
-@pytest.mark.parametrize("B,M,N,T", [(3, 130, 97, 7), (1, 1, 5, 3), (2, 300, 300, 0), (2, 2100, 2050, 2)])
-def test_sinkhorn_shapes_vs_oracle(B, M, N, T):
+@pytest.mark.parametrize("B,M,N,T", [(3, 130, 97, 7), (1, 1, 5, 3), (2, 300, 300, 0), (2, 2100, 2050, 2),
+                                     # N % 256 == 0: the chip-resident sweeps (csrc/sinkhorn_resident.h), ragged M, one and
+                                     # several pairs per launch, rows in registers only / registers + LDS
+                                     (3, 300, 256, 6), (2, 1000, 1024, 4), (5, 700, 512, 25), (11, 1500, 1280, 3),
+                                     (1, 2048, 2048, 1)])
+def test_sinkhorn_shapes_vs_oracle(B, M, N, T, monkeypatch):
     from glue_factory_amd import ops
+    monkeypatch.setenv("GF_SINKHORN_RESIDENT", "2")        # resident sweeps wherever they fit, small batches included
     from oracle import sinkhorn_oracle as so
     g = torch.Generator().manual_seed(M + N + T)
     scores = torch.randn(B, M, N, generator=g) * 3
@@ -48,6 +53,26 @@ def test_sinkhorn_shapes_vs_oracle(B, M, N, T):
     if T > 0:
         col = (out.detach()[:, :, :-1] ).exp().sum(1)
         torch.testing.assert_close(col, torch.ones_like(col), rtol=1e-3, atol=1e-3)
+
+
+def test_sinkhorn_resident_equals_streaming(monkeypatch):
+    """The chip-resident sweeps and the streaming kernels are two schedules of the same recurrence: outputs and gradients
+    agree to rounding (summation order of the column partials differs), at a multi-chunk geometry with LDS-resident rows."""
+    from glue_factory_amd import ops
+    g = torch.Generator().manual_seed(5)
+    Z = (torch.randn(9, 1801, 2049, generator=g) * 2).cuda()
+    G = torch.randn(9, 1801, 2049, generator=g).cuda()
+    res = []
+    for mode in ("0", "1"):                                 # 9 pairs: two launches of 5 and 4 pairs by default
+        monkeypatch.setenv("GF_SINKHORN_RESIDENT", mode)
+        z = Z.clone().requires_grad_(True)
+        out = ops.sinkhorn(z, 20)
+        (out * G).sum().backward()
+        res.append((out.detach(), z.grad))
+    do = float((res[0][0] - res[1][0]).abs().max())
+    dg = float((res[0][1] - res[1][1]).abs().max()) / float(res[0][1].abs().max())
+    print(f"resident vs streaming Sinkhorn: max |d out| {do:.2e}, max |d dZ| / max|dZ| {dg:.2e}")
+    assert do < 2e-5 and dg < 2e-5
 
 
 def _sg_data(z, device):

@@ -1,7 +1,9 @@
 """time gf_sinkhorn_fwd / gf_sinkhorn_bwd of probe builds (B=32, N=2048, 100 iterations) in ONE process and check each
-against the first: python tools/probe/time_sinkhorn.py libv_a.so libv_b.so ..."""
-import ctypes, sys, torch
-B, N, T = 32, 2048, 100
+against the first: python tools/probe/time_sinkhorn.py libv_a.so libv_b.so ...
+An argument of the form  path@0 / path@1  sets GF_SINKHORN_RESIDENT for that run (streaming vs chip-resident sweeps);
+GF_PROBE_B / GF_PROBE_T override the batch and the iteration count."""
+import ctypes, os, sys, torch
+B, N, T = int(os.environ.get("GF_PROBE_B", 32)), 2048, int(os.environ.get("GF_PROBE_T", 100))
 P, I = ctypes.c_void_p, ctypes.c_int
 g = torch.Generator(device="cuda").manual_seed(0)
 Z = torch.randn(B, N + 1, N + 1, device="cuda", generator=g) * 2
@@ -21,7 +23,10 @@ def timeit(fn, iters=3):
         best = min(best, a.elapsed_time(b) / iters)
     return best
 ref = None
-for path in sys.argv[1:]:
+for arg in sys.argv[1:]:
+    path, _, mode = arg.partition("@")
+    if mode:
+        os.environ["GF_SINKHORN_RESIDENT"] = mode
     lib = ctypes.CDLL(path)
     lib.gf_sinkhorn_ws_bytes.restype = ctypes.c_int64
     lib.gf_sinkhorn_ws_bytes.argtypes = [I, I, I, I]
@@ -38,4 +43,4 @@ for path in sys.argv[1:]:
     if ref is None:
         ref = cur
     d = [float((a - b).abs().max()) for a, b in zip(cur, ref)]
-    print(f"{path}: fwd {tf:.2f} ms  bwd {tb:.2f} ms   max|d out| {d[0]:.2e} max|d gZ| {d[1]:.2e} vs first", flush=True)
+    print(f"{arg}: fwd {tf:.2f} ms  bwd {tb:.2f} ms   max|d out| {d[0]:.2e} max|d gZ| {d[1]:.2e} vs first", flush=True)
