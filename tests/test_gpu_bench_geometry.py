@@ -71,7 +71,9 @@ def test_sinkhorn_multichunk_and_generic_paths_vs_oracle(Bsz, M, N, T, pairs):
         wo = max(wo, float((o1.detach() - out[b:b + 1].detach()).abs().max()))
         wg = max(wg, float((z1.grad - Zd.grad[b:b + 1]).abs().max()) / float(z1.grad.abs().max()))
     print(f"   batch vs single-pair launches, all {Bsz} pairs: max |d out| {wo:.2e}, max |d dZ| / max|dZ| {wg:.2e}")
-    assert wo < 1e-5 and wg < 1e-5
+    # (single pairs run the streaming kernels, the batch the chip-resident sweeps: two summation orders of the column
+    # partials; 1.5e-5 is ONE fp32 ulp of an output in [128, 256))
+    assert wo < 4e-5 and wg < 1e-5
 
 
 # ------------------------------------------------------------------------------------------------ batch consistency
