@@ -213,30 +213,31 @@ def roofline_hbm(batch, n, dtype, sinkhorn_iters=100):
     st = torch.cuda.current_stream().cuda_stream
     t = time_kernel(lambda: lib.gf_sinkhorn_fwd(Z.data_ptr(), o.data_ptr(), uh.data_ptr(), vh.data_ptr(), ws.data_ptr(),
                                                 batch, n, n, sinkhorn_iters, st), iters=10, warm=2)
-    byt = 2.0 * batch * (n + 1) * (n + 1) * 4.0 * sinkhorn_iters
-    out["sinkhorn_fwd"] = {"bound": "hbm", "kernel": f"gf_sinkhorn_fwd ({sinkhorn_iters} iterations, B={batch})",
-                           "achieved": round(byt / t / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(byt / t / 1e9 / HBM_PEAK_GBS, 4),
-                           "frac_one_sweep": round(byt / 2 / t / 1e9 / HBM_PEAK_GBS, 4),
-                           "traffic": _traffic("gf_sinkhorn_fwd"),
-                           "launch_ms": round(t * 1e3, 3), "algorithmic_bytes_per_launch": byt}
-    note = ("accounting, not measurement: `frac` prices SURVEY 8(d)'s TWO sweeps of the couplings per iteration (the "
-            "reference's row LSE, then column LSE) although the kernel needs and makes ONE (row and column sums share one "
-            "exp), so it can exceed 1; `frac_one_sweep` is the fraction of the 8 TB/s peak against the kernel's own "
-            "one-sweep minimum, and `traffic` (PMC) is what reached HBM (the rest of each sweep hits the 256 MiB MALL)")
-    out["sinkhorn_fwd"]["note"] = note
+    byt = batch * (n + 1) * (n + 1) * 4.0 * sinkhorn_iters          # ONE sweep of the couplings per iteration
+    nexp = batch * (n + 1) * (n + 1) * float(sinkhorn_iters)
+
+    def sk_entry(name, t):
+        return {"bound": "hbm", "kernel": f"{name} ({sinkhorn_iters} iterations, B={batch})",
+                "achieved": round(byt / t / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(byt / t / 1e9 / HBM_PEAK_GBS, 4),
+                "frac_two_sweeps": round(2 * byt / t / 1e9 / HBM_PEAK_GBS, 4),
+                "gexp_per_s": round(nexp / t / 1e9, 1),
+                "traffic": _traffic(name), "launch_ms": round(t * 1e3, 3), "algorithmic_bytes_per_launch": byt,
+                "path": "streaming" if os.environ.get("GF_SINKHORN_RESIDENT") == "0" else "resident (>= 5 pairs per launch)",
+                "note": note}
+    note = ("`achieved` / `frac` price ONE fp32 sweep of the couplings per iteration (row and column sums share one exp) -- the "
+            "minimum of a kernel that streams them; SURVEY 8(d)'s two-sweep accounting (the reference's row LSE, then column "
+            "LSE) is `frac_two_sweeps`.  The chip-resident sweeps (csrc/sinkhorn_resident.h) load a chunk of pairs ONCE and "
+            "keep it in registers + LDS for all iterations, so `traffic` (PMC) is ~2 sweeps per launch, not per iteration, and "
+            "the bound is the exponential (`gexp_per_s`) plus one workgroup hand-off per half iteration, not HBM")
+    out["sinkhorn_fwd"] = sk_entry("gf_sinkhorn_fwd", t)
     G = torch.randn_like(Z)
     gZ = torch.empty_like(Z)
     gr, gc = G.sum(2).contiguous(), G.sum(1).contiguous()
     t = time_kernel(lambda: lib.gf_sinkhorn_bwd(Z.data_ptr(), G.data_ptr(), gr.data_ptr(), gc.data_ptr(), uh.data_ptr(),
                                                 vh.data_ptr(), gZ.data_ptr(), ws.data_ptr(), batch, n, n,
                                                 sinkhorn_iters, st), iters=10, warm=2)
-    out["sinkhorn_bwd"] = {"bound": "hbm", "kernel": f"gf_sinkhorn_bwd ({sinkhorn_iters} iterations, B={batch})",
-                           "achieved": round(byt / t / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(byt / t / 1e9 / HBM_PEAK_GBS, 4),
-                           "frac_one_sweep": round(byt / 2 / t / 1e9 / HBM_PEAK_GBS, 4),
-                           "traffic": _traffic("gf_sinkhorn_bwd"),
-                           "launch_ms": round(t * 1e3, 3), "algorithmic_bytes_per_launch": byt, "note": note}
+    out["sinkhorn_bwd"] = sk_entry("gf_sinkhorn_bwd", t)
     return out
 
 

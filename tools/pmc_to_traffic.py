@@ -15,7 +15,7 @@ import sys
 
 tag, root = sys.argv[1], sys.argv[2]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KEEP = ("attn_", "assign_write", "sk_", "skf_", "sinkhorn", "gemm_st", "conv3x3_c64")
+KEEP = ("attn_", "assign_write", "sk_", "skf_", "skr_", "sinkhorn", "gemm_st", "conv3x3_c64")
 agg = collections.defaultdict(lambda: [0.0, 0])
 allrows = []
 for f in glob.glob(os.path.join(root, "pmc*", "**", "*counter_collection.csv"), recursive=True):
@@ -67,7 +67,10 @@ def per_dispatch(sub, counter):
     return tot, disp
 
 
-def group(subs, launches_from, half=()):
+SINKHORN_CALLS = 12      # bench.py roofline_hbm: time_kernel(..., iters=10, warm=2) calls of gf_sinkhorn_fwd / _bwd each
+
+
+def group(subs, launches_from, half=(), launches=None):
     """HBM bytes per launch for a launch made of the kernels matching `subs`; the launch count is the dispatch count
     of the kernel matching `launches_from` (one dispatch of it per launch).  Kernels in `half` are shared by two
     launch groups (one dispatch in each): half of their total is charged to this one."""
@@ -76,7 +79,7 @@ def group(subs, launches_from, half=()):
     n = per_dispatch(launches_from, "FETCH_SIZE")[1]
     if not n or fetch + write == 0:
         return None
-    launches = n[0]
+    launches = launches or n[0]         # (a Sinkhorn call runs several batch chunks: its final pass is NOT once per call)
     return {"hbm_bytes_per_launch": round((fetch * 2 + write) * 1024 / launches), "fetch_kib_raw_per_launch": round(fetch / launches, 1),
             "write_kib_per_launch": round(write / launches, 1), "launches": launches,
             "formula": "FETCH_SIZE*1024*2 + WRITE_SIZE*1024 (gfx950 correction, MI355X_MICROARCH.md HBM section)"}
@@ -87,10 +90,12 @@ out = {"gf_attn_bwd": group(["attn_bwd", "attn_dq3"], "attn_dq3"), "attn_fwd_ker
        "gemm_st_kernel": group(["gemm_st"], "gemm_st"), "conv3x3_c64_kernel": group(["conv3x3_c64"], "conv3x3_c64"),
        "assign_write_kernel": group(["assign_write"], "assign_write"),
        # N <= 2304: the register-resident "skf_" kernels (one launch = prescale + T iterations + final pass)
-       "gf_sinkhorn_fwd": group(["sk_rows_fwd", "sk_cols_fwd", "sk_final_fwd", "sk_fwd", "skf_fwd_iter", "skf_cols_fwd"],
-                                "sk_final_fwd", half=["skf_prescale"]),
+       "gf_sinkhorn_fwd": group(["sk_rows_fwd", "sk_cols_fwd", "sk_final_fwd", "sk_fwd", "skf_fwd_iter", "skf_cols_fwd", "skr_kernel<8, false>",
+                                 "skr_reset"],
+                                "sk_final_fwd", half=["skf_prescale"], launches=SINKHORN_CALLS),
        "gf_sinkhorn_bwd": group(["sk_rows_bwd", "sk_cols_bwd", "sk_final_bwd", "sk_bwd", "skf_bwd_iter", "skf_cols_bwd",
-                                 "skf_bwd_prep", "skf_factors", "skf_final_bwd"], "skf_final_bwd", half=["skf_prescale"])}
+                                 "skf_bwd_prep", "skf_factors", "skf_final_bwd", "skr_kernel<8, true>"], "skf_final_bwd",
+                                half=["skf_prescale"], launches=SINKHORN_CALLS)}
 out = {k: v for k, v in out.items() if v}
 import hashlib
 try:      # (no git on the GPU box: the build is identified by the library it measured)
