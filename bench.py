@@ -206,6 +206,7 @@ def roofline_hbm(batch, n, dtype, sinkhorn_iters=100):
                            "algorithmic_bytes_per_launch": byt}
     Z = torch.randn(batch, n + 1, n + 1, device="cuda", generator=g)
     lib = L_.load()
+    ops._sinkhorn_mode(lib)                      # GF_SINKHORN_RESIDENT, as ops.sinkhorn applies it
     ws = torch.empty(int(lib.gf_sinkhorn_ws_bytes(batch, n, n, sinkhorn_iters)), dtype=torch.uint8, device="cuda")
     o = torch.empty_like(Z)
     uh = torch.empty((sinkhorn_iters, batch, n + 1), device="cuda")
@@ -223,7 +224,7 @@ def roofline_hbm(batch, n, dtype, sinkhorn_iters=100):
                 "frac_two_sweeps": round(2 * byt / t / 1e9 / HBM_PEAK_GBS, 4),
                 "gexp_per_s": round(nexp / t / 1e9, 1),
                 "traffic": _traffic(name), "launch_ms": round(t * 1e3, 3), "algorithmic_bytes_per_launch": byt,
-                "path": "streaming" if os.environ.get("GF_SINKHORN_RESIDENT") == "0" else "resident (>= 5 pairs per launch)",
+                "path": {0: "streaming", 1: "resident (>= 5 pairs per launch)", 2: "resident"}[lib.gf_sinkhorn_mode(-1)],
                 "note": note}
     note = ("`achieved` / `frac` price ONE fp32 sweep of the couplings per iteration (row and column sums share one exp) -- the "
             "minimum of a kernel that streams them; SURVEY 8(d)'s two-sweep accounting (the reference's row LSE, then column "

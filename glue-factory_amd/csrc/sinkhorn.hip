@@ -706,6 +706,12 @@ Ws carve(void* ws, const Geo& g, int iters) {
 
 }  // namespace
 
+extern "C" int gf_sinkhorn_mode(int mode) {
+    const int prev = g_skr_mode;
+    if (mode >= 0 && mode <= 2) g_skr_mode = mode;
+    return prev;
+}
+
 extern "C" int64_t gf_sinkhorn_ws_bytes(int B, int M, int N, int iters) {
     if (B <= 0 || M <= 0 || N <= 0 || iters < 0) return GF_ERR_SHAPE;
     Geo g = make_geo(B, M, N);

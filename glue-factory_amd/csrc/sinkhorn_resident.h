@@ -324,16 +324,14 @@ __global__ __launch_bounds__(256, 1) void skr_kernel(const SkrArgs a) {
     }
 }
 
-// GF_SINKHORN_RESIDENT: 0 = streaming kernels only, 2 = resident whenever the problem fits (tests: small batches too);
-// default: resident from SKR_MIN_BC pairs per launch.  Measured on MI355X (tools/probe/time_sinkhorn.py, N = 2048, T = 100,
+// gf_sinkhorn_mode: 0 = streaming kernels only, 1 (default) = resident from SKR_MIN_BC pairs per launch, 2 = resident
+// whenever the problem fits (tests: small batches too).  Measured on MI355X (tools/probe/time_sinkhorn.py, N = 2048, T = 100,
 // forward / backward ms, streaming -> resident): B = 32 10.81 / 12.18 -> 8.35 / 10.66, B = 8 3.05 / 3.45 -> 2.10 / 2.73,
 // B = 4 2.25 / 2.51 -> 2.64 / 3.12, B = 1 1.46 / 1.56 -> 5.92 / 6.11 (a pair spread over the whole chip pays a 256-workgroup
 // barrier and 1024 partial rows per iteration): few pairs stay on the streaming path.
 constexpr int SKR_MIN_BC = 5;
-int skr_mode() {
-    const char* e = getenv("GF_SINKHORN_RESIDENT");
-    return e && e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : 1;
-}
+int g_skr_mode = 1;
+int skr_mode() { return g_skr_mode; }
 
 // Distribution of B pairs over the chip, or false when the problem does not fit the resident layout
 bool skr_plan(const Geo& g, int B, int ncu, bool bwd, SkrPlan& d) {

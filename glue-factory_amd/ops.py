@@ -1338,6 +1338,7 @@ class _Sinkhorn(torch.autograd.Function):
         B, R, C = Z.shape
         M, N = R - 1, C - 1
         L = _lib.load()
+        _sinkhorn_mode(L)
         nbytes = L.gf_sinkhorn_ws_bytes(B, M, N, iters)
         if nbytes < 0:
             _lib.check(int(nbytes), "gf_sinkhorn_ws_bytes")
@@ -1358,6 +1359,7 @@ class _Sinkhorn(torch.autograd.Function):
         M, N = R - 1, C - 1
         G = G.float().contiguous()
         L = _lib.load()
+        _sinkhorn_mode(L)
         ws = torch.empty(int(L.gf_sinkhorn_ws_bytes(B, M, N, ctx.iters)), dtype=torch.uint8, device=Z.device)
         gZ = torch.empty_like(Z)
         known = _known_sums(G)                   # the fused NLL node hands over the sums of its sparse gradient
@@ -1365,6 +1367,13 @@ class _Sinkhorn(torch.autograd.Function):
         _lib.check(L.gf_sinkhorn_bwd(_p(Z), _p(G), _p(gr), _p(gc), _p(uh), _p(vh), _p(gZ), _p(ws),
                                      B, M, N, ctx.iters, _stream()), "gf_sinkhorn_bwd")
         return gZ, None
+
+
+def _sinkhorn_mode(L):
+    """GF_SINKHORN_RESIDENT (host-side knob; the library itself reads no environment): 0 = streaming Sinkhorn kernels only,
+    1 = chip-resident sweeps from 5 pairs per launch (default), 2 = resident whenever the problem fits (csrc/sinkhorn_resident.h)."""
+    m = os.environ.get("GF_SINKHORN_RESIDENT", "1")
+    L.gf_sinkhorn_mode(int(m) if m in ("0", "1", "2") else 1)
 
 
 def sinkhorn(Z, iters):

@@ -36,7 +36,7 @@ extern "C" {
 #define GF_ERR_DTYPE (-4)
 
 /* ABI version; bumped on any signature or workspace-size change (2: gf_attn_bwd's delta workspace doubled; 3: line head + gf_bgemm; 4: smallops; 5: gf_attn_bwd_acc; 9: cast entries with leading dimensions, gf_fold_linear_*, double betas in gf_multi_adam; 10: gf_attn_fwd_ex / GF_ATTN_SPLIT, gf_topk_candidates). */
-#define GF_AMD_ABI_VERSION 10
+#define GF_AMD_ABI_VERSION 11
 int gf_abi_version(void);
 
 /* ---- multi-head attention over keypoints --------------------------------------------------
@@ -181,7 +181,13 @@ int gf_filter_matches(const float* max0, const int64_t* arg0, const int64_t* arg
  * times: u = log_mu - LSE_j(Z + v), v = log_nu - LSE_i(Z + u) with the marginals of
  * superglue.py:206-209.  Stores every iterate in u_hist [iters, B, M+1], v_hist [iters, B, N+1]
  * (all the backward needs) and writes out = Z + u + v - norm ([B, M+1, N+1], norm = -log(M+N)).
- * ws: device workspace of gf_sinkhorn_ws_bytes(B, M, N, iters) bytes (same buffer size for both calls). */
+ * ws: device workspace of gf_sinkhorn_ws_bytes(B, M, N, iters) bytes (same buffer size for both calls).
+ * Two schedules of the same recurrence: streaming kernels (one sweep of Z per iteration, two launches each) and, for
+ * N % 256 == 0, N <= 2048, chip-resident sweeps (a chunk of <= 8-16 pairs is loaded once and stays in registers + LDS for
+ * all iterations, one persistent launch per chunk with per-pair workgroup barriers; csrc/sinkhorn_resident.h).
+ * gf_sinkhorn_mode(mode): 0 = streaming only, 1 = resident from 5 pairs per launch (default), 2 = resident whenever the
+ * problem fits; any other value only queries.  Returns the previous mode.  Process-wide, not thread-safe. */
+int gf_sinkhorn_mode(int mode);
 int64_t gf_sinkhorn_ws_bytes(int B, int M, int N, int iters);
 int gf_sinkhorn_fwd(const float* Z, float* out, float* u_hist, float* v_hist, void* ws,
                     int B, int M, int N, int iters, void* stream);

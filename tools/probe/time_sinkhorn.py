@@ -1,6 +1,6 @@
 """time gf_sinkhorn_fwd / gf_sinkhorn_bwd of probe builds (B=32, N=2048, 100 iterations) in ONE process and check each
 against the first: python tools/probe/time_sinkhorn.py libv_a.so libv_b.so ...
-An argument of the form  path@0 / path@1  sets GF_SINKHORN_RESIDENT for that run (streaming vs chip-resident sweeps);
+An argument of the form  path@0 / path@1  calls gf_sinkhorn_mode(0 / 1) for that run (streaming vs chip-resident sweeps);
 GF_PROBE_B / GF_PROBE_T override the batch and the iteration count."""
 import ctypes, os, sys, torch
 B, N, T = int(os.environ.get("GF_PROBE_B", 32)), 2048, int(os.environ.get("GF_PROBE_T", 100))
@@ -25,9 +25,9 @@ def timeit(fn, iters=3):
 ref = None
 for arg in sys.argv[1:]:
     path, _, mode = arg.partition("@")
-    if mode:
-        os.environ["GF_SINKHORN_RESIDENT"] = mode
     lib = ctypes.CDLL(path)
+    if mode:
+        lib.gf_sinkhorn_mode(int(mode))
     lib.gf_sinkhorn_ws_bytes.restype = ctypes.c_int64
     lib.gf_sinkhorn_ws_bytes.argtypes = [I, I, I, I]
     lib.gf_sinkhorn_fwd.argtypes = [P, P, P, P, P, I, I, I, I, P]
