@@ -599,13 +599,17 @@ def main():
     rank, world, local = init_distributed()          # RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    local = local % torch.cuda.device_count()        # (GF_DIST_BACKEND=gloo smoke runs put several ranks on one GPU)
     torch.cuda.set_device(local)
     dist = dist_mod if world > 1 else None
     lib.load()
 
     def barrier():
         if dist is not None:
-            dist.barrier(device_ids=[local])
+            if dist.get_backend() == "nccl":
+                dist.barrier(device_ids=[local])
+            else:
+                dist.barrier()
         torch.cuda.synchronize()
 
     model, cpu_data = build_matcher(args, rank, args.model)

@@ -361,15 +361,11 @@ bool skr_plan(const Geo& g, int B, int ncu, bool bwd, SkrPlan& d) {
     return false;
 }
 
-int skr_cus() {
-    static int n = 0;
-    if (!n) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) return 0;
-        n = v;
-    }
-    return n;
+int skr_cus() {                            // CU count of the CURRENT device (asked per call: one process may drive several)
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) return 0;
+    return v;
 }
 
 template <bool BWD> int skr_launch(const SkrArgs& a, hipStream_t st) {

@@ -36,8 +36,8 @@ def init_distributed(backend=None, init_method=None, rank=None, world_size=None)
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
     if world_size == 1:
         return 0, 1, local
-    if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend is None:         # GF_DIST_BACKEND=gloo: several ranks on ONE GPU (smoke runs of the multi-rank path; RCCL refuses that)
+        backend = os.environ.get("GF_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     kw = {}
     if torch.cuda.is_available():           # every launcher enqueues on the CURRENT device's stream (ops._chk)
         torch.cuda.set_device(local % torch.cuda.device_count())
