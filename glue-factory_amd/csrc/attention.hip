@@ -91,8 +91,9 @@ template <typename T> struct RescaleThr { static constexpr float value = 0.f; };
 template <> struct RescaleThr<bf16_t> { static constexpr float value = 4.f; };   // P <= 2^4, log2 units
 
 template <typename T, int HD> struct StageRegs {
-    static constexpr int NK = 64 * Lay<T, HD>::CPR / 256;   // row-major chunks per thread
-    static constexpr int NV = 32 * Lay<T, HD>::CPR / 256;   // row pairs x chunks per thread
+    static constexpr int NKI = 64 * Lay<T, HD>::CPR, NVI = 32 * Lay<T, HD>::CPR;   // work items of a tile
+    static constexpr int NK = (NKI + 255) / 256;            // row-major chunks per thread
+    static constexpr int NV = (NVI + 255) / 256;            // row pairs x chunks per thread (bf16 at head_dim 32: half a round)
     u32x4 k[NK];
     u32x4 v0[NV], v1[NV];
 };
@@ -104,6 +105,7 @@ __device__ __forceinline__ void stage_load(StageRegs<T, HD>& rg, const T* kp, in
 #pragma unroll
     for (int i = 0; i < StageRegs<T, HD>::NK; ++i) {
         int c = threadIdx.x + 256 * i;
+        if (StageRegs<T, HD>::NKI % 256 && c >= StageRegs<T, HD>::NKI) continue;
         int r = c / L::CPR, cc = c % L::CPR;
         int gr = min(row0 + r, nmax - 1);
         rg.k[i] = *reinterpret_cast<const u32x4*>(kp + (int64_t)gr * kld + cc * L::VEC);
@@ -111,6 +113,7 @@ __device__ __forceinline__ void stage_load(StageRegs<T, HD>& rg, const T* kp, in
 #pragma unroll
     for (int i = 0; i < StageRegs<T, HD>::NV; ++i) {
         int it = threadIdx.x + 256 * i;
+        if (StageRegs<T, HD>::NVI % 256 && it >= StageRegs<T, HD>::NVI) continue;
         int cc = it % L::CPR, p = it / L::CPR;
         int r0 = min(row0 + 2 * p, nmax - 1), r1 = min(row0 + 2 * p + 1, nmax - 1);
         rg.v0[i] = *reinterpret_cast<const u32x4*>(vp + (int64_t)r0 * vld + cc * L::VEC);
@@ -125,12 +128,14 @@ __device__ __forceinline__ void stage_store(const StageRegs<T, HD>& rg, T* Ks, T
 #pragma unroll
     for (int i = 0; i < StageRegs<T, HD>::NK; ++i) {
         int c = threadIdx.x + 256 * i;
+        if (StageRegs<T, HD>::NKI % 256 && c >= StageRegs<T, HD>::NKI) continue;
         int r = c / L::CPR, cc = c % L::CPR;
         *reinterpret_cast<u32x4*>(Ks + r * L::LDR + cc * L::VEC) = rg.k[i];
     }
 #pragma unroll
     for (int i = 0; i < StageRegs<T, HD>::NV; ++i) {
         int it = threadIdx.x + 256 * i;
+        if (StageRegs<T, HD>::NVI % 256 && it >= StageRegs<T, HD>::NVI) continue;
         int cc = it % L::CPR, p = it / L::CPR;
         union { u32x4 u; T e[L::VEC]; } a, b;
         a.u = rg.v0[i];
@@ -280,7 +285,8 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_fwd_kernel(A
 // backward, part 1: dQ (and delta = rowsum(dO * O)); wave = 64 query rows, K/V tiles double-buffered
 // ===========================================================================================
 template <typename T, int HD> struct PairRegs {
-    static constexpr int N = 32 * Lay<T, HD>::CPR / 256;   // (row pair, chunk) items per thread
+    static constexpr int NI = 32 * Lay<T, HD>::CPR;         // (row pair, chunk) items of a tile
+    static constexpr int N = (NI + 255) / 256;              // ... per thread
     u32x4 a[N], b[N];
 };
 template <typename T, int HD>
@@ -289,6 +295,7 @@ __device__ __forceinline__ void pair_load(PairRegs<T, HD>& rg, const T* g, int64
 #pragma unroll
     for (int i = 0; i < PairRegs<T, HD>::N; ++i) {
         int it = threadIdx.x + 256 * i;
+        if (PairRegs<T, HD>::NI % 256 && it >= PairRegs<T, HD>::NI) continue;
         int cc = it % L::CPR, p = it / L::CPR;
         int r0 = min(row0 + 2 * p, nmax - 1), r1 = min(row0 + 2 * p + 1, nmax - 1);
         rg.a[i] = *reinterpret_cast<const u32x4*>(g + (int64_t)r0 * ld + cc * L::VEC);
@@ -302,6 +309,7 @@ __device__ __forceinline__ void pair_store(const PairRegs<T, HD>& rg, T* ldsR, T
 #pragma unroll
     for (int i = 0; i < PairRegs<T, HD>::N; ++i) {
         int it = threadIdx.x + 256 * i;
+        if (PairRegs<T, HD>::NI % 256 && it >= PairRegs<T, HD>::NI) continue;
         int cc = it % L::CPR, p = it / L::CPR;
         if (ROWM) {
             *reinterpret_cast<u32x4*>(ldsR + (2 * p) * L::LDR + cc * L::VEC) = rg.a[i];
@@ -321,6 +329,7 @@ __device__ __forceinline__ void pair_store(const PairRegs<T, HD>& rg, T* ldsR, T
     }
 }
 
+constexpr int ATTN_PLAIN_STATS = 0x100;      // internal flag (launch_bwd_generic): bf16 dQ kernel paired with the GENERIC dK/dV kernel
 template <typename T, int HD>
 __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dq_kernel(AttnParams p) {
     using L = Lay<T, HD>;
@@ -362,10 +371,10 @@ __global__ __launch_bounds__(256, sizeof(T) == 2 ? 2 : 1) void attn_bwd_dq_kerne
         const int64_t stat = ((int64_t)b * p.H + h) * p.Nq + qld;
         lse2[j] = p.lse[stat] * GF_LOG2E;
         if (qrow0 + 32 * j < p.Nq && hi == 0) {
-            if constexpr (sizeof(T) == 2) {      // what attn_bwd_dkv_bf16_kernel starts its accumulators from (attention_bwd3.hip)
+            if (sizeof(T) == 2 && !(p.flags & ATTN_PLAIN_STATS)) {   // what attn_bwd_dkv_bf16_kernel starts its accumulators from (attention_bwd3.hip)
                 p.delta[stat] = -lse2[j] / p.rr;
                 p.delta[(int64_t)p.B * p.H * p.Nq + stat] = -d;
-            } else {
+            } else {                             // the generic dK/dV kernel reads lse and delta as they are
                 p.delta[stat] = d;
             }
         }
@@ -1307,6 +1316,41 @@ template <typename T> int launch_bwd(const AttnParams& p, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
+// head_dim 32 / 128: the generic register-staged kernels (the LDS-DMA kernels above are specialised on 64-wide heads).  A capability
+// path, not a tuned one (at 128 the fragments of a row exceed the register budget and spill).
+constexpr size_t ATTN_LDS_MAX = 160 * 1024;
+template <typename T, int HD> int launch_fwd_generic(const AttnParams& p, hipStream_t st) {
+    const size_t lds = fwd_lds<T, HD>();
+    if (lds > ATTN_LDS_MAX) return GF_ERR_UNSUPPORTED;
+    if (int e = set_lds(attn_fwd_kernel<T, HD>, lds)) return e;
+    attn_fwd_kernel<T, HD><<<dim3(((p.Nq + 255) / 256) * p.H * p.B), dim3(256), lds, st>>>(p);
+    return (int)hipGetLastError();
+}
+template <typename T, int HD> int launch_bwd_generic(const AttnParams& p_, hipStream_t st) {
+    AttnParams p = p_;
+    p.flags |= ATTN_PLAIN_STATS;
+    const size_t l1 = dq_lds<T, HD>(), l2 = dkv_lds<T, HD>();
+    if (l1 > ATTN_LDS_MAX || l2 > ATTN_LDS_MAX) return GF_ERR_UNSUPPORTED;
+    if (int e = set_lds(attn_bwd_dq_kernel<T, HD>, l1)) return e;
+    attn_bwd_dq_kernel<T, HD><<<dim3(((p.Nq + 255) / 256) * p.H * p.B), dim3(256), l1, st>>>(p);
+    if (int e = (int)hipGetLastError()) return e;
+    if (int e = set_lds(attn_bwd_dkv_kernel<T, HD>, l2)) return e;
+    attn_bwd_dkv_kernel<T, HD><<<dim3(((p.Nk + 127) / 128) * p.H * p.B), dim3(256), l2, st>>>(p);
+    return (int)hipGetLastError();
+}
+template <typename T> int launch_fwd_any(const AttnParams& p, hipStream_t st, int D) {
+    if (D == 64) return launch_fwd<T>(p, st);
+    if (D == 32) return launch_fwd_generic<T, 32>(p, st);
+    if (D == 128) return launch_fwd_generic<T, 128>(p, st);
+    return GF_ERR_UNSUPPORTED;
+}
+template <typename T> int launch_bwd_any(const AttnParams& p, hipStream_t st, int D) {
+    if (D == 64) return launch_bwd<T>(p, st);
+    if (D == 32) return launch_bwd_generic<T, 32>(p, st);
+    if (D == 128) return launch_bwd_generic<T, 128>(p, st);
+    return GF_ERR_UNSUPPORTED;
+}
+
 bool bad_stride(const int64_t* s, int n, int align) {
     for (int i = 0; i < n; ++i)
         if (s[i] % align) return true;
@@ -1332,8 +1376,9 @@ extern "C" int gf_attn_fwd_ex(const void* q, const void* k, const void* v, void*
                               const int64_t* q_strides, const int64_t* k_strides,
                               const int64_t* v_strides, const int64_t* o_strides,
                               float scale, int dtype, int flags, float* o32, void* stream) {
-    if (D != 64) return GF_ERR_UNSUPPORTED;
+    if (D != 64 && D != 32 && D != 128) return GF_ERR_UNSUPPORTED;
     if (flags & ~GF_ATTN_SPLIT) return GF_ERR_UNSUPPORTED;
+    if (D != 64 && (flags & GF_ATTN_SPLIT) && dtype != GF_F32) return GF_ERR_UNSUPPORTED;   // split products: 64-wide heads only
     if (dtype == GF_F32) flags = 0;                                  // fp32 operands: nothing to split
     // the split products exist in the LDS-DMA bf16 kernels only (rows addressed through 32-bit buffer offsets)
     if ((flags & GF_ATTN_SPLIT) && !(kvdma_ok(Nk, k_strides[1]) && kvdma_ok(Nk, v_strides[1]))) return GF_ERR_UNSUPPORTED;
@@ -1353,8 +1398,8 @@ extern "C" int gf_attn_fwd_ex(const void* q, const void* k, const void* v, void*
     p.svb = v_strides[0]; p.svn = v_strides[1]; p.svh = v_strides[2];
     p.sob = o_strides[0]; p.son = o_strides[1]; p.soh = o_strides[2];
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == GF_F32) return launch_fwd<float>(p, st);
-    if (dtype == GF_BF16) return launch_fwd<bf16_t>(p, st);
+    if (dtype == GF_F32) return launch_fwd_any<float>(p, st, D);
+    if (dtype == GF_BF16) return launch_fwd_any<bf16_t>(p, st, D);
     return GF_ERR_DTYPE;
 }
 
@@ -1380,8 +1425,9 @@ extern "C" int gf_attn_bwd_acc(const void* q, const void* k, const void* v, cons
                                const int64_t* do_strides, const int64_t* dq_strides,
                                const int64_t* dk_strides, const int64_t* dv_strides,
                                float scale, int dtype, int flags, void* stream) {
-    if (D != 64) return GF_ERR_UNSUPPORTED;
+    if (D != 64 && D != 32 && D != 128) return GF_ERR_UNSUPPORTED;
     if (flags & ~7) return GF_ERR_UNSUPPORTED;
+    if (D != 64 && (flags & GF_ATTN_SPLIT) && dtype != GF_F32) return GF_ERR_UNSUPPORTED;
     if (dtype == GF_F32) flags &= ~GF_ATTN_SPLIT;                    // fp32 operands: nothing to split
     if ((flags & GF_ATTN_SPLIT) && !(kvdma_ok(Nk, k_strides[1]) && kvdma_ok(Nk, v_strides[1]))) return GF_ERR_UNSUPPORTED;
     if (B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0) return GF_ERR_SHAPE;
@@ -1405,8 +1451,8 @@ extern "C" int gf_attn_bwd_acc(const void* q, const void* k, const void* v, cons
     p.sdkb = dk_strides[0]; p.sdkn = dk_strides[1]; p.sdkh = dk_strides[2];
     p.sdvb = dv_strides[0]; p.sdvn = dv_strides[1]; p.sdvh = dv_strides[2];
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == GF_F32) return launch_bwd<float>(p, st);
-    if (dtype == GF_BF16) return launch_bwd<bf16_t>(p, st);
+    if (dtype == GF_F32) return launch_bwd_any<float>(p, st, D);
+    if (dtype == GF_BF16) return launch_bwd_any<bf16_t>(p, st, D);
     return GF_ERR_DTYPE;
 }
 

@@ -43,6 +43,7 @@ __global__ __launch_bounds__(256) void rotary_kernel(T* qkv, const T* yrot, cons
     const int npair = D / 2;
     for (int64_t tok = (int64_t)blockIdx.x * 4 + wave; tok < tokens; tok += (int64_t)gridDim.x * 4) {
         // generic in D: work items = 2 (q,k) * npair, strided over the 64 lanes
+        float carry = 0.f;
         for (int w = lane; w < 2 * npair; w += 64) {
             const int half = w / npair, i = w % npair;
             const f32x2 csv = *reinterpret_cast<const f32x2*>(cs + tok * D + 2 * i);
@@ -62,12 +63,14 @@ __global__ __launch_bounds__(256) void rotary_kernel(T* qkv, const T* yrot, cons
             if (WITH_DTHETA) {
                 // q and k halves of the same pair live in different lanes (or different w): atomics
                 // would be non-deterministic, so reduce through the other half explicitly.
-                // npair <= 32 -> lanes l and l+npair hold (q,i) and (k,i) when 2*npair <= 64.
+                // npair <= 32 -> lanes l and l+npair hold (q,i) and (k,i) when 2*npair <= 64;
+                // npair == 64 (head_dim 128): THIS lane visits (q, i) at w = lane and (k, i) at w = lane + 64.
                 float other = __shfl(acc, (lane + npair) & 63);
                 if (2 * npair <= 64) {
                     if (half == 0) dtheta[tok * npair + i] = acc + other;
                 } else {
-                    atomicAdd(&dtheta[tok * npair + i], acc);
+                    if (half == 0) carry = acc;
+                    else dtheta[tok * npair + i] = carry + acc;
                 }
             }
         }
@@ -424,7 +427,7 @@ extern "C" int gf_rotary_qk(void* qkv, const float* cs, int B, int N, int H, int
 extern "C" int gf_rotary_qk_bwd(void* dqkv, const void* qkv_rot, const float* cs, float* dtheta,
                                 int B, int N, int H, int D, int dtype, void* stream) {
     if (B <= 0 || N <= 0 || H <= 0 || D <= 0 || (D & 1)) return GF_ERR_SHAPE;
-    if (D > 64) return GF_ERR_UNSUPPORTED;  // keeps the q/k pair reduction inside one wave pass
+    if (D > 64 && D != 128) return GF_ERR_UNSUPPORTED;  // the q/k pair reduction stays inside one wave pass (<= 64) or one lane (128)
     if (dtype != GF_F32 && dtype != GF_BF16) return GF_ERR_DTYPE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     int64_t tokens = (int64_t)B * N;

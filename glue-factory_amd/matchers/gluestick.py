@@ -152,8 +152,8 @@ class GlueStick(BaseModel):
                           "lines_junc_idx1", "line_scores0", "line_scores1"]
 
     def _init(self, conf):
-        if conf.descriptor_dim != 256:
-            raise NotImplementedError("the HIP attention kernels are built for 4 heads of 64 channels")
+        if conf.descriptor_dim not in (128, 256, 512):
+            raise NotImplementedError("the HIP attention kernels exist for 4 heads of 64 channels (tuned) and of 32 / 128 (generic kernels)")
         if conf.attention_precision not in ("reference", "bf16"):
             raise ValueError(f"attention_precision: 'reference' or 'bf16', got {conf.attention_precision!r}")
         d = conf.descriptor_dim

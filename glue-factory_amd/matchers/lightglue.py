@@ -351,8 +351,8 @@ class LightGlue(nn.Module):
         super().__init__()
         self.conf = conf = Conf.merge(self.default_conf, conf or {})
         d, h, n = conf.descriptor_dim, conf.num_heads, conf.n_layers
-        if d % h or d // h != 64:
-            raise NotImplementedError("the HIP attention kernels are built for head_dim == 64")
+        if d % h or d // h not in (32, 64, 128):
+            raise NotImplementedError("the HIP attention kernels exist for head_dim 64 (tuned) and 32 / 128 (generic kernels)")
         self.input_proj = (nn.Linear(conf.input_dim, d, bias=True) if conf.input_dim != d
                            else nn.Identity())
         self.posenc = _PosEnc(2 + 2 * conf.add_scale_ori, d // h)

@@ -249,8 +249,8 @@ class SuperGlue(BaseModel):
                           "keypoint_scores0", "keypoint_scores1"]
 
     def _init(self, conf):
-        if conf.descriptor_dim != 256:
-            raise NotImplementedError("the HIP attention kernels are built for 4 heads of 64 channels")
+        if conf.descriptor_dim not in (128, 256, 512):
+            raise NotImplementedError("the HIP attention kernels exist for 4 heads of 64 channels (tuned) and of 32 / 128 (generic kernels)")
         self.kenc = KeypointEncoder(conf.descriptor_dim, conf.keypoint_encoder, conf.use_scores)
         self.gnn = AttentionalGNN(conf.descriptor_dim, conf.GNN_layers)
         self.final_proj = nn.Conv1d(conf.descriptor_dim, conf.descriptor_dim, kernel_size=1, bias=True)

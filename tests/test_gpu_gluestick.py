@@ -89,6 +89,35 @@ def test_gluestick_unequal_counts_and_bf16():
     assert err < 0.5
 
 
+def test_gluestick_other_descriptor_dim():
+    """descriptor_dim 128 = 4 heads of 32 channels (generic attention kernels, non-256 GEMM shapes): fp32 forward against the
+    oracle, then a bf16 train step with finite loss and gradients for every parameter."""
+    from glue_factory_amd.matchers.gluestick import GlueStick
+    from glue_factory_amd.synthetic import make_point_line_pairs, to_device
+    from oracle import gluestick_oracle as gso
+    names, dim = ["self", "cross"], 128
+    params = gso.init_params(dim, gnn_layers=2, seed=6)
+    data = make_point_line_pairs(2, 70, 20, dim=dim, size=(640, 480), seed=8)
+    odata = dict(data, image_size0=data["view0"]["image_size"], image_size1=data["view1"]["image_size"])
+    with torch.no_grad():
+        ref = gso.forward(params, odata, names, training=False)
+    model = GlueStick({"GNN_layers": names, "descriptor_dim": dim, "input_dim": dim}).cuda().eval()
+    model.load_state_dict(params)
+    cdata = to_device(data, "cuda")
+    with torch.no_grad():
+        pred = model(cdata)
+    torch.testing.assert_close(pred["log_assignment"].cpu(), ref["log_assignment"], rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(pred["line_log_assignment"].cpu(), ref["line_log_assignment"], rtol=1e-4, atol=1e-4)
+    model.train()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        pt = model(cdata)
+        losses, _ = model.loss(pt, {**pt, **cdata})
+    losses["total"].mean().backward()
+    assert torch.isfinite(losses["total"]).all()
+    for k, p_ in model.named_parameters():
+        assert p_.grad is not None and torch.isfinite(p_.grad).all(), k
+
+
 def test_gluestick_train_step_hipgraph_replay_equals_eager():
     """GlueStick (points + lines, HIP line layers and line head) captured as one hipGraph: replay == eager."""
     from glue_factory_amd.matchers.gluestick import GlueStick

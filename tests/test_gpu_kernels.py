@@ -25,9 +25,12 @@ def _tols(dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("B,H,Nq,Nk", [(2, 4, 128, 128), (1, 2, 100, 77), (2, 4, 300, 513), (1, 1, 1, 1)])
-def test_attention_fwd_bwd(dtype, B, H, Nq, Nk):
-    D = 64
+@pytest.mark.parametrize("B,H,Nq,Nk,D", [(2, 4, 128, 128, 64), (1, 2, 100, 77, 64), (2, 4, 300, 513, 64), (1, 1, 1, 1, 64),
+                                         # head_dim 32 / 128: the generic kernels (capability path)
+                                         (2, 4, 128, 128, 32), (1, 2, 100, 77, 32), (2, 2, 300, 513, 128), (1, 3, 65, 200, 128)])
+def test_attention_fwd_bwd(dtype, B, H, Nq, Nk, D):
+    if D == 128 and dtype == torch.float32:
+        pytest.skip("fp32 at head_dim 128 does not fit the LDS (GF_ERR_UNSUPPORTED, checked below)")
     g = torch.Generator().manual_seed(B * 1000 + Nq + Nk)
     q, k, v, do = (torch.randn(B, n, H, D, generator=g, dtype=torch.float64)
                    for n in (Nq, Nk, Nk, Nq))
@@ -50,6 +53,16 @@ def test_attention_fwd_bwd(dtype, B, H, Nq, Nk):
     _, lse = ops.attn_fwd_raw(qd.detach(), kd.detach(), vd.detach(), D ** -0.5)
     torch.testing.assert_close(lse.cpu().double(), lse_ref.detach(), rtol=1e-4,
                                atol=1e-4 if dtype == torch.float32 else 3e-2)
+
+
+def test_attention_head_dim_limits():
+    q = torch.zeros(1, 64, 2, 128, device=DEV, requires_grad=True)
+    o = ops.attention(q, q, q)                                 # fp32, head_dim 128: the forward fits the LDS ...
+    with pytest.raises(RuntimeError):
+        o.sum().backward()                                     # ... the backward's staging (208 KB) does not
+    q = torch.zeros(1, 64, 2, 48, device=DEV, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError):
+        ops.attn_fwd_raw(q, q, q, 0.1)                         # head_dim 48: no kernel
 
 
 def test_attention_strided_views_and_spike():

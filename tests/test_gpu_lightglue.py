@@ -94,6 +94,45 @@ def test_train_step_vs_oracle_fp32(n0, n1):
         torch.testing.assert_close(p.grad.cpu() / sc, ref / sc, rtol=2e-3, atol=2e-3, msg=lambda m: f"{k}: {m}")
 
 
+@pytest.mark.parametrize("dim,heads", [(128, 4), (256, 2)])
+@pytest.mark.parametrize("bf16", [False, True])
+def test_train_step_other_head_dims_vs_oracle(dim, heads, bf16):
+    """head_dim 32 (descriptor_dim 128 / 4 heads) and 128 (256 / 2): the generic attention kernels under the same model code --
+    fp32 against the oracle at 1e-4, bf16 with the bounds of the 64-wide configuration.  (fp32 at head_dim 128 does not fit the
+    LDS of the generic kernels: that combination raises from the library and is skipped here.)"""
+    from glue_factory_amd.matchers.lightglue import LightGlue
+    from glue_factory_amd.synthetic import make_pairs
+    if dim // heads == 128 and not bf16:
+        pytest.skip("fp32 at head_dim 128: GF_ERR_UNSUPPORTED (LDS), see tests/test_gpu_kernels.py::test_attention_head_dim_limits")
+    L = 2
+    params = lgo.init_params(L, dim, heads, seed=dim + heads)
+    data = make_pairs(2, 160, 131, dim=dim, size=(640, 480), seed=5)
+    odata = dict(data, image_size0=data["view0"]["image_size"], image_size1=data["view1"]["image_size"])
+    pred_o, loss_o, grads_o = lgo.train_step_grads(params, odata, L, heads)
+    model = LightGlue({"n_layers": L, "descriptor_dim": dim, "input_dim": dim, "num_heads": heads, "filter_threshold": 0.0})
+    res = model.load_state_dict(params, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    model = model.cuda().train()
+    cdata = _to_cuda(data)
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16):
+        pred = model(cdata)
+        losses, _ = model.loss(pred, {**pred, **cdata})
+    losses["total"].mean().backward()
+    tol = 0.1 if bf16 else 1e-4
+    torch.testing.assert_close(pred["log_assignment"].float().cpu(), pred_o["log_assignment"].detach(), rtol=tol, atol=tol)
+    for k, v in loss_o.items():
+        torch.testing.assert_close(losses[k].detach().float().cpu(), v.detach(), rtol=5e-3 if bf16 else 1e-4, atol=5e-3 if bf16 else 1e-4,
+                                   msg=lambda m: f"{k}: {m}")
+    worst = 0.0
+    for k, p in model.named_parameters():
+        ref = grads_o[k]
+        rel = float((p.grad.cpu().double() - ref.double()).norm() / ref.double().norm().clamp(min=1e-30))
+        if float(ref.norm()) > 1e-6:
+            worst = max(worst, rel)
+    print(f"LightGlue dim {dim} / {heads} heads ({'bf16' if bf16 else 'fp32'}): worst per-tensor gradient error {worst:.2e}")
+    assert worst < (0.05 if bf16 else 5e-4)
+
+
 def test_train_step_bf16_close_to_oracle():
     """perf mode (autocast bf16): same plumbing, looser numbers; reports the error."""
     from glue_factory_amd.synthetic import make_pairs

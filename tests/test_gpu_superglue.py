@@ -151,6 +151,35 @@ def test_superglue_unequal_counts_and_bf16():
     assert err < 0.5
 
 
+@pytest.mark.parametrize("dim", [128])
+def test_superglue_other_descriptor_dim(dim):
+    """descriptor_dim 128 = 4 heads of 32 channels: the generic attention kernels and the non-256 GEMM shapes under the same
+    module code; fp32 forward against the oracle, then a bf16 train step (finite loss and gradients for every parameter)."""
+    from glue_factory_amd.matchers.superglue import SuperGlue
+    from glue_factory_amd.synthetic import make_pairs, to_device
+    from oracle import superglue_oracle as sgo
+    names = ["self", "cross"]
+    params = sgo.init_params(dim, gnn_layers=2, seed=4)
+    data = make_pairs(2, 96, 80, dim=dim, size=(640, 480), seed=9)
+    odata = dict(data, image_size0=data["view0"]["image_size"], image_size1=data["view1"]["image_size"])
+    with torch.no_grad():
+        ref = sgo.forward(params, odata, names, 10, training=False)
+    model = SuperGlue({"GNN_layers": names, "num_sinkhorn_iterations": 10, "descriptor_dim": dim}).cuda().eval()
+    model.load_state_dict(params)
+    cdata = to_device(data, "cuda")
+    with torch.no_grad():
+        pred = model(cdata)
+    torch.testing.assert_close(pred["log_assignment"].cpu(), ref["log_assignment"], rtol=1e-4, atol=1e-4)
+    model.train()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        pt = model(cdata)
+        losses, _ = model.loss(pt, {**pt, **cdata})
+    losses["total"].mean().backward()
+    assert torch.isfinite(losses["total"]).all()
+    for k, p_ in model.named_parameters():
+        assert p_.grad is not None and torch.isfinite(p_.grad).all(), k
+
+
 def test_superglue_train_step_hipgraph_replay_equals_eager():
     """SuperGlue's loss gathers its positives through gt_assignment_col0 (no nonzero() scan, no host read), so the
     whole step captures: replay == kernel-by-kernel on changing batches, and fixed-length == dense-scan losses."""
