@@ -30,7 +30,7 @@ extern "C" {
 #define GF_DTYPE_F32 0
 #define GF_DTYPE_BF16 1
 
-#define GF_ERR_UNSUPPORTED (-1) /* e.g. head_dim != 64 */
+#define GF_ERR_UNSUPPORTED (-1) /* e.g. a head_dim outside {32, 64, 128} */
 #define GF_ERR_SHAPE (-2)
 #define GF_ERR_ALIGN (-3)
 #define GF_ERR_DTYPE (-4)
@@ -44,7 +44,8 @@ int gf_abi_version(void);
  * Replaces gluefactory/models/matchers/lightglue.py:97-128 (Attention), :161 (SelfBlock),
  * :203-216 (CrossBlock: call twice, (qk0,qk1,v1) and (qk1,qk0,v0)),
  * gluefactory_nonfree/superglue.py:112-116 and gluefactory/models/matchers/gluestick.py:524-529.
- * q [B,Nq,H,D], k/v [B,Nk,H,D], o [B,Nq,H,D] with strides {batch, token, head}; D == 64.
+ * q [B,Nq,H,D], k/v [B,Nk,H,D], o [B,Nq,H,D] with strides {batch, token, head}; D == 64 (the tuned LDS-DMA kernels) or
+ * D in {32, 128} (generic register-staged kernels; fp32 at 128: forward only, the backward's staging exceeds the LDS).
  * lse [B,H,Nq] = log sum_j exp(scale * q_i.k_j)  (saved for the backward). */
 int gf_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse,
                 int B, int H, int Nq, int Nk, int D,
