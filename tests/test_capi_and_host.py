@@ -99,8 +99,9 @@ def test_lightglue_conf_state_dict_and_no_cpu_fallback():
             "descriptors0": torch.rand(1, 8, 256), "descriptors1": torch.rand(1, 8, 256)}
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m(data)
+    assert LightGlue({"descriptor_dim": 128, "num_heads": 4, "n_layers": 1}).posenc.Wr.weight.shape == (16, 2)   # head_dim 32: generic kernels
     with pytest.raises(NotImplementedError):
-        LightGlue({"descriptor_dim": 128, "num_heads": 4})
+        LightGlue({"descriptor_dim": 192, "num_heads": 4})                                                       # head_dim 48: no kernel
 
 
 def test_fixed_length_positive_list_equals_nonzero():
