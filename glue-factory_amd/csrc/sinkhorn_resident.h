@@ -224,6 +224,12 @@ __global__ __launch_bounds__(256, 1) void skr_kernel(const SkrArgs a) {
 
     float ul = 0.f;                                        // forward: u of row `lane` (log2 units)
     f32x4 vkeep = splat4(0.f);                             // forward: this thread's finished columns of v
+    // backward: the iterates of the history that an iteration needs -- u^k of the row pass, v^k / v^{k-1} of the column
+    // phase -- are plain HBM loads; they are requested one phase ahead (u^{k-1} during iteration k, the v's in front of the
+    // row pass), not where they are used: with one wave per SIMD nothing else would hide their latency.
+    float u_next = 0.f;
+    if (BWD && lane < nrows && a.iters > 0)
+        u_next = a.u_hist[(size_t)(a.iters - 1) * a.ustride + (size_t)pair * g.R + gil];
     for (int it = 0; it < a.iters; ++it) {
         const int k = a.iters - it;                        // backward: reverse iteration index T .. 1
         f32x4 S[NSM];
@@ -231,10 +237,22 @@ __global__ __launch_bounds__(256, 1) void skr_kernel(const SkrArgs a) {
         for (int s_ = 0; s_ < NSM; ++s_) S[s_] = splat4(0.f);
         float st = 0.f, outl = 0.f;
         float u2l = 0.f, basel = 0.f;
+        f32x4 vp4 = splat4(0.f), vk4 = splat4(0.f);
         if (BWD) {
+            u2l = u_next * GF_LOG2E;
             if (lane < nrows) {
-                u2l = a.u_hist[(size_t)(k - 1) * a.ustride + (size_t)pair * g.R + gil] * GF_LOG2E;
+                if (k >= 2) u_next = a.u_hist[(size_t)(k - 2) * a.ustride + (size_t)pair * g.R + gil];
                 if (it == 0 && a.base_row) basel = a.base_row[(size_t)pair * g.R + gil];
+            }
+            if (grp == 0 && colact) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int j = 4 * q + c;
+                    if (j < g.C) {
+                        vk4[c] = a.v_hist[(size_t)(k - 1) * a.vstride + (size_t)pair * g.C + j];
+                        if (k >= 2) vp4[c] = a.v_hist[(size_t)(k - 2) * a.vstride + (size_t)pair * g.C + j];
+                    }
+                }
             }
         }
         const float t0 = misc[0], t1 = BWD ? misc[1] : 0.f;
@@ -301,8 +319,7 @@ __global__ __launch_bounds__(256, 1) void skr_kernel(const SkrArgs a) {
                 const int j = 4 * q + c;
                 if (j < g.C) {
                     if (BWD) {
-                        const float vp = k >= 2 ? a.v_hist[(size_t)(k - 2) * a.vstride + (size_t)pair * g.C + j] : 0.f;
-                        const float vk = a.v_hist[(size_t)(k - 1) * a.vstride + (size_t)pair * g.C + j];
+                        const float vp = vp4[c], vk = vk4[c];
                         const float vbn = -__expf(vp - vk + lnu(g, j)) * tot[c];
                         a.vbar_hist[(size_t)(k - 1) * a.vstride + (size_t)pair * g.C + j] = vbn;
                         oA[c] = (vp - lnu(g, j)) * GF_LOG2E;
