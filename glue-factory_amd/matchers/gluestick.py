@@ -156,6 +156,8 @@ class GlueStick(BaseModel):
             raise NotImplementedError("the HIP attention kernels exist for 4 heads of 64 channels (tuned) and of 32 / 128 (generic kernels)")
         if conf.attention_precision not in ("reference", "bf16"):
             raise ValueError(f"attention_precision: 'reference' or 'bf16', got {conf.attention_precision!r}")
+        if conf.descriptor_dim == 512 and conf.attention_precision == "reference":
+            raise NotImplementedError("head_dim 128 has no fp32 attention backward (LDS); use attention_precision: bf16")
         d = conf.descriptor_dim
         if conf.input_dim != d:
             self.input_proj = nn.Conv1d(conf.input_dim, d, kernel_size=1)

@@ -206,7 +206,11 @@ class AttentionalPropagation(nn.Module):
         # attention_fp32 (GlueStick, `attention_precision: reference`): the reference forces THIS attention to fp32 under mixed
         # precision (gluestick.py:18-22, 524-529 @AMP_CUSTOM_FWD_F32) -- scores, softmax and the weighted sum in fp32 on the
         # bf16-valued projections: the bf16 kernels with the softmax weights / score gradients split into hi + lo pairs
-        o = ops.attention_qkv(qkv, cross=cross, scale=scale, split=self.attention_fp32 and qkv.dtype != torch.float32)
+        split = self.attention_fp32 and qkv.dtype != torch.float32
+        if split and self.attn.dim != 64:      # no split instantiation for this head width: the reference's own form, the
+            o = ops.attention_qkv(qkv.float(), cross=cross, scale=scale).to(qkv.dtype)   # projections cast up to fp32
+        else:
+            o = ops.attention_qkv(qkv, cross=cross, scale=scale, split=split)
         pc = self.attn._pc
         first = None if pc is None else ops.folded_linear(pc[0], x.dtype, pc[1] + ".mlp0", self.mlp[0].weight, self.mlp[0].bias,
                                                           self.attn.merge.weight, self.attn.merge.bias)
@@ -220,7 +224,11 @@ class AttentionalPropagation(nn.Module):
         outs = []
         p0, p1 = self.attn.fused_projection(x0, premul=False)[0], self.attn.fused_projection(x1, premul=False)[0]
         for x, pq, ps in ((x0, p0, p1 if cross else p0), (x1, p1, p0 if cross else p1)):
-            o = ops.attention(pq[:, :, 0], ps[:, :, 1], ps[:, :, 2], split=self.attention_fp32 and pq.dtype != torch.float32)
+            split = self.attention_fp32 and pq.dtype != torch.float32
+            if split and self.attn.dim != 64:
+                o = ops.attention(pq[:, :, 0].float(), ps[:, :, 1].float(), ps[:, :, 2].float()).to(pq.dtype)
+            else:
+                o = ops.attention(pq[:, :, 0], ps[:, :, 1], ps[:, :, 2], split=split)
             msg = _conv_cl(o.reshape(x.shape), self.attn.merge, cols=self.attn._perm)
             outs.append(_mlp_cl(self.mlp, x, 1, x2=msg))
         return outs
