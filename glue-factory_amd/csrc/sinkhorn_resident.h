@@ -25,8 +25,8 @@
 // barrier = 3x the row pass; this form costs 2-3 us.  (Also measured: the finished column vectors as self-validating
 // tagged granules polled by every reader instead of the second barrier -- slower, 8.35 -> 9.84 ms forward at B = 32:
 // 8192 polling lanes per pair cost more than one counter.)  All workgroups are resident by construction (grid <= CU count,
-// one workgroup per CU by its LDS and register footprint); a wall-clock bound on every wait turns a scheduling
-// surprise into garbage output (caught by the parity tests) instead of a hung device.
+// one workgroup per CU by its LDS and register footprint); a bound on the polls of every wait (SKR_MAX_POLLS, > 1 s)
+// turns a scheduling surprise into garbage output (caught by the parity tests) instead of a hung device.
 constexpr int SKR_RR = 12;                 // rows of a wave that live in registers
 constexpr int SKR_MAX_BC = 16;             // pairs per launch (counter slots)
 constexpr int SKR_MAX_POLLS = 2000000;     // bound of every wait (a poll is a memory round trip, >= 0.5 us: > 1 s)
