@@ -21,6 +21,9 @@
 #ifndef GF_WRITE_SPLIT    // workgroups per column block of gf_assign_write (disjoint row ranges)
 #define GF_WRITE_SPLIT 4
 #endif
+#ifndef GF_WRITE_ABL      // timing probes of gf_assign_write only: 1 no MFMA, 2 no stores, 4 no exp
+#define GF_WRITE_ABL 0
+#endif
 #ifndef GF_BWD_SPLIT      // workgroups per column block of the dual-softmax backward (probe builds override it)
 #define GF_BWD_SPLIT 4
 #endif
@@ -357,7 +360,7 @@ __global__ __launch_bounds__(256) void assign_write_kernel(HeadParams p) {
             f32x16 s;
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[r] = 0.f;
-            mma_tile<T, D>(s, tile, kb * 32, of, l31, hi);
+            if (!(GF_WRITE_ABL & 1)) mma_tile<T, D>(s, tile, kb * 32, of, l31, hi);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 f32x4 b4 = *reinterpret_cast<const f32x4*>(vec0 + kb * 32 + 8 * g + 4 * hi);
@@ -366,8 +369,9 @@ __global__ __launch_bounds__(256) void assign_write_kernel(HeadParams p) {
                     int si = s0 + kb * 32 + 8 * g + 4 * hi + e;
                     if (si < p.Ns && orow < p.No) {
                         const float v = p.alpha * s[4 * g + e] + b4[e] + ocb;
-                        out[(int64_t)si * ldo + orow] = v;
-                        if (p.f0) esum += fast_exp2(v * GF_LOG2E);
+                        if (!(GF_WRITE_ABL & 2)) out[(int64_t)si * ldo + orow] = v;
+                        else if (v == 12345.678f) out[0] = v;
+                        if (p.f0 && !(GF_WRITE_ABL & 4)) esum += fast_exp2(v * GF_LOG2E);
                     }
                 }
             }
