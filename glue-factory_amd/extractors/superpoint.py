@@ -17,7 +17,8 @@ own top-k (``gf_topk_candidates``) and the descriptor sampler.  What differs fro
   * ``refinement_radius`` > 0: soft-argmax refinement of the keypoints on the pre-NMS score map (:92-108, :290-293);
   * ``legacy_sampling`` (the default): the original, slightly shifted descriptor sampling with ``align_corners=True``
     (:112-127) -- stock ``grid_sample``; ``legacy_sampling: false`` is the open variant's sampler without its +0.5 (:132-143);
-  * ``randomize_keypoints_training`` (multinomial keypoint sampling, :268-277) is not offered by the batched path and raises.
+  * ``randomize_keypoints_training`` (:268-277): in training mode the keypoints are drawn with probabilities proportional to
+    their scores (one batched ``torch.multinomial`` over the NMS candidate lists) instead of the k best.
 """
 from pathlib import Path
 
@@ -63,8 +64,6 @@ class SuperPoint(_SuperPointOpen):
     def _init(self, conf):
         if not (conf.has_detector and conf.has_descriptor and conf.sparse_outputs):
             raise NotImplementedError("glue_factory_amd.extractors.superpoint: sparse outputs of detector + descriptor only")
-        if conf.randomize_keypoints_training:
-            raise NotImplementedError("randomize_keypoints_training (multinomial keypoint sampling) is not offered by the batched path")
         self.stride = 8
         self.register_buffer("_gray", torch.tensor([0.299, 0.587, 0.114]).view(1, 3, 1, 1), persistent=False)
         c1, c2, c3, c4, c5 = 64, 64, 128, 128, 256
@@ -123,6 +122,22 @@ class SuperPoint(_SuperPointOpen):
         if not self.training and self.conf.max_num_keypoints_val is not None:
             k = self.conf.max_num_keypoints_val
         return None if k is None or k <= 0 else int(k)
+
+    def _sample_keypoints(self, cand, scores, k):
+        """``randomize_keypoints_training`` (superpoint.py:84-89, 273-282): in training mode the k keypoints are DRAWN without
+        replacement with probabilities proportional to their scores instead of taking the k best; an image with fewer than k
+        detections keeps them all.  Batched: one ``torch.multinomial`` over the NMS candidate lists; entries that are not
+        detections (score <= detection_threshold, empty slots) carry a weight of 1e-20, so they are only drawn once an image's
+        detections are exhausted -- and are then not `valid` and get padded / dropped exactly like the surplus of a top-k."""
+        if not (self.conf.randomize_keypoints_training and self.training):
+            return None
+        if cand is not None:
+            s, idx = cand[0], cand[1].long()
+        else:
+            s, idx = scores.reshape(scores.shape[0], -1), None
+        w = torch.where(s > self.conf.detection_threshold, s, torch.full_like(s, 1e-20))
+        j = torch.multinomial(w, min(k, w.shape[1]), replacement=False)
+        return s.gather(1, j), (j if idx is None else idx.gather(1, j))
 
     def _border_limits(self, data):
         """superpoint.py:236-244 removes the right / bottom border relative to `image_size` (images smaller than the batch

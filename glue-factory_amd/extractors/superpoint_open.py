@@ -347,7 +347,10 @@ class SuperPoint(BaseModel):
             keypoints = torch.stack(idx[::-1], -1).float()[None]
             kscores = scores[0][idx][None]
         else:
-            if cand is not None and k <= min(4096, cand[0].shape[1]):
+            picked = self._sample_keypoints(cand, scores, k)       # hook: None = the k highest scores
+            if picked is not None:
+                kscores, ind = picked
+            elif cand is not None and k <= min(4096, cand[0].shape[1]):
                 # own top-k over the candidate lists (csrc/topk.hip): sorted scores + pixel indices in one launch, and
                 # -- unlike torch.topk, whose memset nodes fault on the second replay of a captured graph -- capturable
                 from .. import lib as _lib
@@ -393,6 +396,9 @@ class SuperPoint(BaseModel):
     # ------------------------------------------------------------------ hooks of the post-processing (see superpoint.py)
     def _max_keypoints(self):
         return self.conf.max_num_keypoints
+
+    def _sample_keypoints(self, cand, scores, k):
+        return None
 
     def _border_limits(self, data):
         return None
