@@ -19,7 +19,8 @@ def test_nonfree_superpoint_surface():
                                                 "convPa", "convPb", "convDa", "convDb") for k in ("weight", "bias"))
     assert tuple(m.convPb.weight.shape) == (65, 256, 1, 1) and tuple(m.convDb.weight.shape) == (256, 256, 1, 1)
     assert m.conf.legacy_sampling and m.conf.max_num_keypoints_val is None and m.required_data_keys == ["image"]
+    assert SP({"randomize_keypoints_training": True}).conf.randomize_keypoints_training      # (GPU behaviour: test_gpu_extractor.py)
     with pytest.raises(NotImplementedError):
-        SP({"randomize_keypoints_training": True})
+        SP({"sparse_outputs": False})
     with pytest.raises(FileNotFoundError):
         SP({"weights": "/nonexistent/superpoint_v1.pth"})
