@@ -8,7 +8,7 @@
 //                            entries of the same table; gf_weight_grad_map sends their gradient back to the sources;
 //   gf_colsum_f32            deterministic column sums of an [R, C] fp32 matrix of per-block partials (LayerNorm
 //                            gamma / beta gradients: 36 reductions of [2048, 512] per step, 16 us each in torch);
-//   gf_small_dw              dW[o, k] = sum_m dy[m, o] x[m, k] for a tall dy [M, O] and a FEW input columns (K <= 4):
+//   gf_small_dw              dW[o, k] = sum_m dy[m, o] x[m, k] for a tall dy [M, O] and a FEW input columns (K <= 8):
 //                            the gradient of the Fourier positional encoding's Wr (lightglue.py:52-65; M = 131072,
 //                            O = 32, K = 2), which the library ran as a 0.4 ms skinny GEMM.
 #include "gf_common.h"
@@ -119,7 +119,7 @@ __global__ void colsum_stage2(const float* __restrict__ part2, float* __restrict
 }
 
 constexpr int SDW_BLOCKS = 256;
-// thread = (row slot g, output o); K <= 4 columns of x per row; partial sums per block, then colsum_stage-like finish
+// thread = (row slot g, output o); K <= 8 columns of x per row; partial sums per block, then colsum_stage-like finish
 template <int K>
 __global__ __launch_bounds__(256) void small_dw_stage1(const float* __restrict__ dy, const float* __restrict__ x,
                                                        float* __restrict__ part, int M, int O) {
@@ -186,15 +186,15 @@ extern "C" int gf_colsum_ws_floats(int G, int C) { return G * CS_CHUNKS * C; }
 
 extern "C" int gf_small_dw(const float* dy, const float* x, float* ws, float* dw, int M, int O, int K, void* stream) {
     if (M <= 0 || O <= 0 || K <= 0) return GF_ERR_SHAPE;
-    if (O > 256 || K > 4 || O * K > 256) return GF_ERR_UNSUPPORTED;
+    if (O > 256 || K > 8 || O * K > 256) return GF_ERR_UNSUPPORTED;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const size_t lds = (size_t)(256 / O) * O * K * sizeof(float);
+#define GF_SDW(K_) case K_: small_dw_stage1<K_><<<dim3(SDW_BLOCKS), dim3(256), lds, st>>>(dy, x, ws, M, O); break;
     switch (K) {
-        case 1: small_dw_stage1<1><<<dim3(SDW_BLOCKS), dim3(256), lds, st>>>(dy, x, ws, M, O); break;
-        case 2: small_dw_stage1<2><<<dim3(SDW_BLOCKS), dim3(256), lds, st>>>(dy, x, ws, M, O); break;
-        case 3: small_dw_stage1<3><<<dim3(SDW_BLOCKS), dim3(256), lds, st>>>(dy, x, ws, M, O); break;
-        default: small_dw_stage1<4><<<dim3(SDW_BLOCKS), dim3(256), lds, st>>>(dy, x, ws, M, O); break;
+        GF_SDW(1) GF_SDW(2) GF_SDW(3) GF_SDW(4) GF_SDW(5) GF_SDW(6) GF_SDW(7)
+        default: small_dw_stage1<8><<<dim3(SDW_BLOCKS), dim3(256), lds, st>>>(dy, x, ws, M, O); break;
     }
+#undef GF_SDW
     small_dw_stage2<<<dim3((O * K + 255) / 256), dim3(256), 0, st>>>(ws, dw, O * K);
     return (int)hipGetLastError();
 }

@@ -57,8 +57,8 @@ def _conv_cl(x, conv, rows=None, cols=None):
         w, b = w.index_select(0, rows), b.index_select(0, rows)
     if cols is not None:
         w = w.index_select(1, cols)
-    if w.shape[1] <= 4 and w.shape[0] * w.shape[1] <= 256 and x.dtype == torch.float32 and x.is_cuda:
-        # the keypoint / endpoint encoders' first layer (K = 2 .. 3 input columns, superglue.py:82-91): its weight gradient
+    if w.shape[1] <= 8 and w.shape[0] * w.shape[1] <= 256 and x.dtype == torch.float32 and x.is_cuda:
+        # the keypoint / endpoint encoders' first layer (K = 3 or 5 input columns, superglue.py:82-91, gluestick.py:489-521): its weight gradient
         # is a 1e5-deep reduction, not a GEMM (gf_small_dw)
         return ops.small_linear(x, w) + b
     if w.shape[0] % 8 or w.shape[1] % 8:

@@ -948,7 +948,7 @@ def colsum(x):
 
 
 class _SmallLinear(torch.autograd.Function):
-    """theta = x W^T for a tall fp32 x [M, K] with K <= 4 input columns (the Fourier positional encoding's Wr,
+    """theta = x W^T for a tall fp32 x [M, K] with K <= 8 input columns (the Fourier positional encoding's Wr,
     lightglue.py:52-65): the forward is the stock product (tiny), the weight gradient a dedicated reduction
     (gf_small_dw) instead of a skinny library GEMM over M = 131072 rows."""
 
@@ -964,7 +964,8 @@ class _SmallLinear(torch.autograd.Function):
         g2, x2 = g.reshape(-1, O).float().contiguous(), x.reshape(-1, K).float().contiguous()
         dx = g @ w if ctx.needs_input_grad[0] else None
         L = _lib.load()
-        if not g2.is_cuda or K > 4 or O * K > 256:
+        if not g2.is_cuda or K > 8 or O * K > 256:
+            _note_library_gemm(g2.shape[0], O, K, "fp32 (small_linear weight gradient)")
             return dx, (g2.t() @ x2).to(w.dtype)
         ws = torch.empty(L.gf_small_dw_ws_floats(O, K), dtype=torch.float32, device=g2.device)
         dw = torch.empty((O, K), dtype=torch.float32, device=g2.device)

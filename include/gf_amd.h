@@ -246,8 +246,8 @@ int gf_dense_assign_bwd(const float* raw, const float* r, const float* c, const 
  *   cross block (:196-221) -- are one entry per row block of the same output.
  * gf_weight_grad_map: the gradient of such a row block back to its parameter: out[perm[r]][cperm[c]] = g[r][c] rscale[r] scale.
  * gf_colsum_f32: out[g, c] = sum_r x[g, r, c] for fp32 x [G, R, C], deterministic (ws: gf_colsum_ws_floats(G, C) floats).
- * gf_small_dw:   dw[o, k] = sum_m dy[m, o] x[m, k], fp32, dy [M, O], x [M, K], K <= 4, O * K <= 256 (the gradient of
- *   lightglue.py:52-65 posenc.Wr); ws: gf_small_dw_ws_floats(O, K) floats. */
+ * gf_small_dw:   dw[o, k] = sum_m dy[m, o] x[m, k], fp32, dy [M, O], x [M, K], K <= 8, O * K <= 256 (the gradient of
+ *   lightglue.py:52-65 posenc.Wr, of the keypoint / line-endpoint encoders' first layer superglue.py:82-91, gluestick.py:489-521); ws: gf_small_dw_ws_floats(O, K) floats. */
 int gf_multi_cast_transpose(const void* table, int n_entries, int total_tiles, int dtype, void* stream);
 /* Folding a linear into its consumer (csrc/fold.hip): h = ffn.0(cat[x, out_proj(ctx)]) = [W0a | W0b Wo] cat[x, ctx] + (b0 + W0b bo)
  * (lightglue.py:131-163, :166-221 to_out; superglue.py:137-160 merge -> mlp.0) -- weights only, fp32 FMA arithmetic.

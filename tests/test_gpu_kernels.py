@@ -934,3 +934,24 @@ def test_cross_attention_fused_backward(B, N, H, scale):
     d = float((grads[True].float() - grads[False].float()).norm() / grads[False].float().norm())
     print(f"cross bwd {B}x{N}x{H}: fused vs two launches relative L2 difference {d:.2e}")
     assert d < 8e-3
+
+
+@pytest.mark.parametrize("M,O,K", [(131072, 32, 2), (65536, 32, 3), (70000, 32, 5), (4097, 16, 8), (100, 1, 1)])
+def test_small_linear_forward_and_weight_gradient(M, O, K):
+    """ops.small_linear (gf_small_dw): the K <= 8 column input linears of the positional / keypoint / line-endpoint encoders
+    (lightglue.py:52-65, superglue.py:82-91, gluestick.py:489-521) vs an fp64 product -- no library GEMM for K = 5 either."""
+    g = torch.Generator().manual_seed(M + O + K)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(O, K, generator=g)
+    dy = torch.randn(M, O, generator=g)
+    xd = x.to(DEV).requires_grad_(True)
+    wd = w.to(DEV).requires_grad_(True)
+    before = dict(ops.LIBRARY_GEMMS)
+    y = ops.small_linear(xd, wd)
+    (y * dy.to(DEV)).sum().backward()
+    assert dict(ops.LIBRARY_GEMMS) == before
+    torch.testing.assert_close(y.detach().cpu().double(), x.double() @ w.double().t(), rtol=1e-5, atol=1e-5)
+    ref_dw = dy.double().t() @ x.double()
+    sc = float(ref_dw.abs().max())
+    torch.testing.assert_close(wd.grad.cpu().double() / sc, ref_dw / sc, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(xd.grad.cpu().double(), dy.double() @ w.double(), rtol=1e-5, atol=1e-5)
