@@ -144,6 +144,19 @@ __global__ __launch_bounds__(256) void small_dw_stage1(const float* __restrict__
         part[(size_t)blockIdx.x * O * K + threadIdx.x] = s;
     }
 }
+// y[m, o] = sum_k x[m, k] w[o, k]  (K <= 8): the forward of the same input linears -- one thread per output, w in registers
+template <int K>
+__global__ __launch_bounds__(256) void small_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        float* __restrict__ y, size_t total, int O) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t m = i / O;
+        const int o = (int)(i - m * O);
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc = fmaf(x[m * K + k], w[o * K + k], acc);
+        y[i] = acc;
+    }
+}
 __global__ void small_dw_stage2(const float* __restrict__ part, float* __restrict__ dw, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -199,6 +212,21 @@ extern "C" int gf_small_dw(const float* dy, const float* x, float* ws, float* dw
     return (int)hipGetLastError();
 }
 extern "C" int gf_small_dw_ws_floats(int O, int K) { return SDW_BLOCKS * O * K; }
+
+extern "C" int gf_small_fwd(const float* x, const float* w, float* y, int M, int O, int K, void* stream) {
+    if (M <= 0 || O <= 0 || K <= 0) return GF_ERR_SHAPE;
+    if (K > 8) return GF_ERR_UNSUPPORTED;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const size_t total = (size_t)M * O;
+    const int nb = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+#define GF_SFW(K_) case K_: small_fwd_kernel<K_><<<dim3(nb), dim3(256), 0, st>>>(x, w, y, total, O); break;
+    switch (K) {
+        GF_SFW(1) GF_SFW(2) GF_SFW(3) GF_SFW(4) GF_SFW(5) GF_SFW(6) GF_SFW(7)
+        default: small_fwd_kernel<8><<<dim3(nb), dim3(256), 0, st>>>(x, w, y, total, O); break;
+    }
+#undef GF_SFW
+    return (int)hipGetLastError();
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // gf_multi_adam: the Adam update of EVERY parameter tensor of a model in a handful of launches (train.py:513

@@ -31,9 +31,11 @@ def warp_points(points, H, inverse=False, eps=1e-5):
     Hm = inv3x3(H) if inverse else H
     if Hm.dim() == 2:
         Hm = Hm[None]
-    ones = torch.ones_like(points[..., :1])
-    ph = torch.cat([points, ones], -1)
-    w = torch.einsum("bnj,bij->bni", ph, Hm)
+    # w_i = H_i0 x + H_i1 y + H_i2 as broadcast multiply-adds (not a [N,3] x [3,3] library product: exact fp32 in any
+    # autocast state, the same summation order as the reference's matmul of three terms, and kernel-only in a captured step)
+    x, y = points[..., 0:1], points[..., 1:2]
+    Hm = Hm[:, None]                                                    # [B,1,3,3]
+    w = Hm[..., 0] * x + Hm[..., 1] * y + Hm[..., 2]                    # [B,N,3]
     return w[..., :2] / (w[..., 2:] + eps)
 
 

@@ -955,14 +955,20 @@ class _SmallLinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w):
         ctx.save_for_backward(x, w)
-        return torch.nn.functional.linear(x, w)
+        O, K = w.shape
+        if not x.is_cuda or K > 8 or x.dtype != torch.float32 or w.dtype != torch.float32:
+            return torch.nn.functional.linear(x, w)
+        x2 = x.reshape(-1, K).contiguous()
+        y = torch.empty((x2.shape[0], O), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.load().gf_small_fwd(_p(x2), _p(w.contiguous()), _p(y), x2.shape[0], O, K, _stream()), "gf_small_fwd")
+        return y.view(*x.shape[:-1], O)
 
     @staticmethod
     def backward(ctx, g):
         x, w = ctx.saved_tensors
         O, K = w.shape
         g2, x2 = g.reshape(-1, O).float().contiguous(), x.reshape(-1, K).float().contiguous()
-        dx = g @ w if ctx.needs_input_grad[0] else None
+        dx = g @ w if ctx.needs_input_grad[0] else None       # (keypoints / scores carry no gradient on the train path)
         L = _lib.load()
         if not g2.is_cuda or K > 8 or O * K > 256:
             _note_library_gemm(g2.shape[0], O, K, "fp32 (small_linear weight gradient)")

@@ -36,7 +36,7 @@ extern "C" {
 #define GF_ERR_DTYPE (-4)
 
 /* ABI version; bumped on any signature or workspace-size change (2: gf_attn_bwd's delta workspace doubled; 3: line head + gf_bgemm; 4: smallops; 5: gf_attn_bwd_acc; 9: cast entries with leading dimensions, gf_fold_linear_*, double betas in gf_multi_adam; 10: gf_attn_fwd_ex / GF_ATTN_SPLIT, gf_topk_candidates). */
-#define GF_AMD_ABI_VERSION 11
+#define GF_AMD_ABI_VERSION 12
 int gf_abi_version(void);
 
 /* ---- multi-head attention over keypoints --------------------------------------------------
@@ -271,6 +271,8 @@ int gf_colsum_f32(const float* x, float* ws, float* out, int G, int R, int C, vo
 int gf_colsum_ws_floats(int G, int C);
 int gf_small_dw(const float* dy, const float* x, float* ws, float* dw, int M, int O, int K, void* stream);
 int gf_small_dw_ws_floats(int O, int K);
+/* the forward of the same linears: y[m, o] = sum_k x[m, k] w[o, k], fp32, K <= 8 */
+int gf_small_fwd(const float* x, const float* w, float* y, int M, int O, int K, void* stream);
 /* gf_multi_adam: the Adam update (torch.optim.Adam semantics, amsgrad = maximize = False; train.py:513) of every parameter
  * tensor in ceil(n_entries / 80) launches.  `table`: HOST array of n_entries records {float* p; const float* g; float* m;
  * float* v; long long n; int pad[2];} (gf_adam_entry_bytes() = 48) of DEVICE pointers; it travels by value in the kernel
