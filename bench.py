@@ -463,8 +463,8 @@ def make_stepper(args, model, local, allow_graph=True):
 def make_pipeline_step(args, rank, local):
     """Scope P through the product API: ``glue_factory_amd.pipeline.TwoViewPipeline`` (frozen SuperPoint-open extractor ->
     homography ground truth -> LightGlue) inside ``TrainStep`` -- forward, ground truth, loss, backward and the fused Adam
-    update of one step, captured as ONE hipGraph (the extractor's top-k is csrc/topk.hip: torch.topk's memset nodes made
-    such a graph fault on its second replay).  Inputs: 2 x batch synthetic IMG x IMG images resident in HBM."""
+    update of one step, captured as ONE hipGraph (the extractor's top-k is csrc/topk.hip: a captured extractor tail
+    with torch.topk in it faults on its second replay).  Inputs: 2 x batch synthetic IMG x IMG images resident in HBM."""
     from glue_factory_amd.pipeline import TwoViewPipeline
     torch.manual_seed(0)
     pipe = TwoViewPipeline({

@@ -1,11 +1,12 @@
 // gf_topk_candidates: the K best entries of each image's NMS candidate list, sorted by score (the `torch.topk(..., sorted=
 // True)` + index gather of superpoint_open.py:165-170 on the lists gf_nms_candidates wrote).
 //
-// Why an own kernel for a library-shaped op: torch.topk on ROCm 7.2 enqueues hipMemsetAsync nodes (counters of its
-// multi-block radix select), and a captured graph that contains them faults on its SECOND replay -- bisected with
-// tools/probe/capture_scope_p.py: `tail_nms` replays cleanly, `tail_topk` ("Memory access fault by GPU node") does not, the
-// convolutions and a bare memset + kernel graph (tools/probe/repro/graph_memset.hip) do.  This kernel uses no memset, no
-// global scratch and no atomics on global memory: ONE workgroup per image,
+// Why an own kernel for a library-shaped op: a captured graph of the extractor tail that contains torch.topk (ROCm 7.2,
+// torch 2.10) faults on its SECOND replay -- bisected with tools/probe/capture_scope_p.py: `tail_nms` replays cleanly,
+// `tail_topk` ("Memory access fault by GPU node") does not; still reproducible with the shipped library.  torch.topk is the
+// only op of the step that adds non-kernel nodes (four hipMemsetAsync on temporaries), but memset nodes alone do not
+// reproduce it (tools/probe/repro/): the defect sits below this code and is layout dependent (DESIGN.md section 4,
+// "hipGraph").  This kernel uses no memset, no global scratch and no atomics on global memory: ONE workgroup per image,
 //   1. radix select of the K-th largest key (4 passes of 8 bits, LDS histograms) over the non-negative scores -- negative
 //      scores are the lists' "unfilled slot" marker and rank below everything, in list order;
 //   2. ordered compaction (block scans in list order, so ties at the threshold are taken lowest position first:

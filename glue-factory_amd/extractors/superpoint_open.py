@@ -352,7 +352,7 @@ class SuperPoint(BaseModel):
                 kscores, ind = picked
             elif cand is not None and k <= min(4096, cand[0].shape[1]):
                 # own top-k over the candidate lists (csrc/topk.hip): sorted scores + pixel indices in one launch, and
-                # -- unlike torch.topk, whose memset nodes fault on the second replay of a captured graph -- capturable
+                # -- unlike torch.topk here, which faults on the second replay of a captured extractor tail -- safely capturable
                 from .. import lib as _lib
                 kscores = torch.empty((b, k), dtype=torch.float32, device=scores.device)
                 ind = torch.empty((b, k), dtype=torch.int64, device=scores.device)
