@@ -712,6 +712,21 @@ extern "C" int gf_sinkhorn_mode(int mode) {
     return prev;
 }
 
+// Host-only: the distribution the chip-resident path would use for this problem on a device of `ncu` compute units
+// (out[8] = pairs per launch, workgroups per pair, waves per pair, rows per wave, waves with one more row, float4 columns per
+// workgroup in the column phase, N / 256, LDS bytes).  Returns 1 and fills `out`, or 0 when the streaming kernels are used.
+extern "C" int gf_sinkhorn_plan(int B, int M, int N, int ncu, int backward, int64_t* out) {
+    if (B <= 0 || M <= 0 || N <= 0 || ncu <= 0 || out == nullptr) return GF_ERR_SHAPE;
+    const Geo g = make_geo(B, M, N);
+    SkrPlan d;
+    if (g.RB < 1 || skr_mode() == 0 || !skr_plan(g, B, ncu, backward != 0, d)) return 0;
+    const Ws w = carve(nullptr, g, 1);
+    if ((size_t)d.nw * d.bc > w.part_rows) return 0;
+    const int64_t v[8] = {d.bc, d.wpp, d.nw, d.base, d.extra, d.cs, d.nsm, (int64_t)d.lds};
+    for (int i = 0; i < 8; ++i) out[i] = v[i];
+    return 1;
+}
+
 extern "C" int64_t gf_sinkhorn_ws_bytes(int B, int M, int N, int iters) {
     if (B <= 0 || M <= 0 || N <= 0 || iters < 0) return GF_ERR_SHAPE;
     Geo g = make_geo(B, M, N);

@@ -36,7 +36,7 @@ extern "C" {
 #define GF_ERR_DTYPE (-4)
 
 /* ABI version; bumped on any signature or workspace-size change (2: gf_attn_bwd's delta workspace doubled; 3: line head + gf_bgemm; 4: smallops; 5: gf_attn_bwd_acc; 9: cast entries with leading dimensions, gf_fold_linear_*, double betas in gf_multi_adam; 10: gf_attn_fwd_ex / GF_ATTN_SPLIT, gf_topk_candidates). */
-#define GF_AMD_ABI_VERSION 12
+#define GF_AMD_ABI_VERSION 13
 int gf_abi_version(void);
 
 /* ---- multi-head attention over keypoints --------------------------------------------------
@@ -189,6 +189,10 @@ int gf_filter_matches(const float* max0, const int64_t* arg0, const int64_t* arg
  * gf_sinkhorn_mode(mode): 0 = streaming only, 1 = resident from 5 pairs per launch (default), 2 = resident whenever the
  * problem fits; any other value only queries.  Returns the previous mode.  Process-wide, not thread-safe. */
 int gf_sinkhorn_mode(int mode);
+/* Host-only query (no device needed): the chip-resident distribution for this problem on a device of `ncu` compute units:
+ * out[8] = {pairs per launch, workgroups per pair, waves per pair, rows per wave, waves holding one more row, float4 columns
+ * per workgroup in the column phase, N / 256, dynamic LDS bytes}.  1 = resident path (out filled), 0 = streaming kernels. */
+int gf_sinkhorn_plan(int B, int M, int N, int ncu, int backward, int64_t* out);
 int64_t gf_sinkhorn_ws_bytes(int B, int M, int N, int iters);
 int gf_sinkhorn_fwd(const float* Z, float* out, float* u_hist, float* v_hist, void* ws,
                     int B, int M, int N, int iters, void* stream);

@@ -134,3 +134,41 @@ def test_precast_cache_follows_parameter_versions():
         ops.precast([w], torch.bfloat16, key="t")
         assert ops._lp(w, torch.bfloat16).dtype == torch.bfloat16
         assert id(w) not in ops._LP_CACHE
+
+
+def test_sinkhorn_resident_plan_is_consistent():
+    """gf_sinkhorn_plan (host-only): the distribution of the chip-resident Sinkhorn sweeps (csrc/sinkhorn_resident.h) over a
+    256-CU device -- every pair gets whole workgroups, every row a wave, the rows of a wave fit its registers + LDS share, the
+    column phase covers every float4 column, the LDS request stays inside the CU -- for the benchmarked geometry and around it."""
+    import ctypes
+    from glue_factory_amd import lib
+    L = lib.load()
+    out = (ctypes.c_int64 * 8)()
+    seen = 0
+    for B in (1, 4, 5, 7, 8, 9, 16, 20, 32, 33, 64):
+        for M in (255, 1000, 2048):
+            for N in (256, 512, 1024, 1280, 2048):
+                for bwd in (0, 1):
+                    ok = L.gf_sinkhorn_plan(B, M, N, 256, bwd, out)
+                    assert ok in (0, 1)
+                    if B < 5:
+                        assert ok == 0                                    # few pairs stay on the streaming kernels
+                    if not ok:
+                        continue
+                    seen += 1
+                    bc, wpp, nw, base, extra, cs, nsm, lds = (int(v) for v in out)
+                    R, nvec = M + 1, N // 4 + 1
+                    assert 5 <= bc <= min(B, 16) and wpp * bc <= 256 and nw == 4 * wpp and nsm == N // 256
+                    assert base * nw + extra == R and 0 <= extra < nw               # every row has exactly one wave
+                    assert base + (1 if extra else 0) <= 64                          # per-row scalars live one per lane
+                    assert cs * wpp >= nvec and cs <= 32                             # the column phase covers every column
+                    lds_rows = sum(max(0, base + (1 if w < extra else 0) - 12) for w in range(4))
+                    assert lds == ((2 if bwd else 1) * (N // 4) + 256) * 16 + 32 + lds_rows * (N // 4) * 16
+                    assert lds <= 160 * 1024 - 512
+                    # launches cover the batch with balanced chunks
+                    nch = -(-B // bc)
+                    assert (nch - 1) * bc < B <= nch * bc
+    assert seen > 50
+    assert L.gf_sinkhorn_plan(32, 2048, 2048, 256, 0, out) == 1 and tuple(out)[:5] == (8, 32, 128, 16, 1)
+    assert L.gf_sinkhorn_plan(32, 2048, 2050, 256, 0, out) == 0                      # N % 256 != 0: streaming
+    assert L.gf_sinkhorn_plan(32, 2048, 2304, 256, 0, out) == 0                      # N / 256 > 8
