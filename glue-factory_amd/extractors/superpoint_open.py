@@ -17,7 +17,6 @@ padded like the reference's ``pad_and_stack(mode="random_c")`` (uniform inside t
 keypoints' bounding box, score 0).  ``weights=None`` gives a seeded random initialisation
 (pretrained files cannot be downloaded on this target); a local path is loaded as usual.
 """
-import os
 from collections import OrderedDict
 from pathlib import Path
 

@@ -23,7 +23,6 @@ What runs where
 from pathlib import Path
 
 import torch
-import torch.nn.functional as F
 from torch import nn
 
 from .. import ops
