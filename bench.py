@@ -173,6 +173,10 @@ def roofline_attention(batch, n, dtype):
     if t_x is not None:
         cross.update({"launch_ms": round(t_x * 1e3, 4), "achieved": round(f_bwd / t_x / 1e12, 2),
                       "frac": round(f_bwd / t_x / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": _traffic("gf_attn_cross_bwd")})
+    if t_x is not None:     # the step's attention backward as a whole: L self layers on gf_attn_bwd + L cross layers on gf_attn_cross_bwd
+        cross["step_attention_backward"] = {
+            "what": "one self layer + one cross layer (the step runs L of each): algorithmic FLOPs over the sum of the two launches",
+            "achieved": round(2 * f_bwd / (t_bwd + t_x) / 1e12, 2), "frac": round(2 * f_bwd / (t_bwd + t_x) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4)}
     return {
         "bound": "mfma", "kernel": "gf_attn_bwd (attn_dq3_bf16_kernel + attn_bwd_dkv_bf16_kernel of one launch)",
         "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
