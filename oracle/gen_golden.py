@@ -396,15 +396,21 @@ def _la_digest(out, la, stride, prefix="train."):
     out[prefix + "rowmax"] = la[:, :-1, :-1].max(2).values.numpy()
 
 
-def gen_superglue_config(name, batch, n, iters, seed, stride=997):
+def gen_superglue_config(name, batch, n, iters, seed, stride=997, sharp=None):
     """BASELINE configs[3] through the REFERENCE SuperGlue itself: N=2048 keypoints per image, the full 18-layer
     GNN, 100 Sinkhorn iterations (B=1: the reference keeps ~10 GB of autograd state for the unrolled Sinkhorn).
-    Compact storage as for lightglue_n2048_l9: inputs / weights regenerated from the seed by the test."""
+    Compact storage as for lightglue_n2048_l9: inputs / weights regenerated from the seed by the test.
+    sharp=(damp, sharp, noise, unmatched): the decisive case of sgo.sharp_case (B=2, so the train-mode BatchNorm
+    statistics run over several pairs): every mutual-NN decision of the reference's own output -- matched or -1 -- is
+    taken by the stored margin, so the tests compare matches0/1 bit for bit, in fp32 and bf16."""
     from gluefactory_nonfree.superglue import SuperGlue
     from oracle import superglue_oracle as sgo
 
-    params = sgo.init_params(256, gnn_layers=18, seed=seed)
-    data = make_pairs(batch, n, dim=256, size=(1024, 1024), seed=seed + 1)
+    if sharp is None:
+        params = sgo.init_params(256, gnn_layers=18, seed=seed)
+        data = make_pairs(batch, n, dim=256, size=(1024, 1024), seed=seed + 1)
+    else:
+        params, data = sgo.sharp_case(batch, n, 18, seed, (1024, 1024), *sharp)
     data["view0"]["image"] = torch.zeros(batch, 1, 1024, 1024)
     data["view1"]["image"] = torch.zeros(batch, 1, 1024, 1024)
     model = SuperGlue({"weights": None, "num_sinkhorn_iterations": iters})
@@ -428,20 +434,33 @@ def gen_superglue_config(name, batch, n, iters, seed, stride=997):
     out["param_checksum"] = np.array([float(sum(v.double().abs().sum() for v in params.values()))])
     out["data_checksum"] = _data_checksum(data)
     out["meta"] = np.array([batch, n, 18, iters, seed, stride])
+    if sharp is not None:
+        out["sharp"] = np.array(sharp, dtype=np.float64)
+        out["margins"] = np.array([sgo.decisiveness(pred["log_assignment"].detach(), 0.2), sgo.decisiveness(pe["log_assignment"], 0.2)])
+        assert out["margins"].min() > 1.0, out["margins"]          # decisive in train AND eval mode
+        for m in (pred, pe):                                        # ... and the decisions are the constructed ones
+            assert (m["matches0"] == data["gt_matches0"]).all() and (m["matches1"] == data["gt_matches1"]).all()
+        print(name, "decision margins (train, eval)", out["margins"].tolist())
     np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
     print(name, "loss", losses["total"].tolist(), "matches", (pred["matches0"] > -1).sum(1).tolist())
 
 
-def gen_gluestick_config(name, batch, n_kpts, n_lines, seed, stride=997):
+def gen_gluestick_config(name, batch, n_kpts, n_lines, seed, stride=997, sharp=None):
     """BASELINE configs[4] through the REFERENCE GlueStick: 2048 keypoints + 512 lines (1024 junctions -> 3072 tokens
-    per image), default 9 x (self, cross) GNN with the line layers, B=1.  Compact storage."""
+    per image), default 9 x (self, cross) GNN with the line layers, B=1.  Compact storage.
+    sharp=(damp, sharp, noise, unmatched): the decisive case of gso.sharp_case (B=2: train-mode BatchNorm over several
+    pairs) -- points AND lines, matched and -1 -- for bit-exact matches0/1 and line_matches0/1 in fp32 and bf16."""
     from gluefactory.models.matchers.gluestick import GlueStick
     from glue_factory_amd.synthetic import make_point_line_pairs
     from oracle import gluestick_oracle as gso
+    from oracle import superglue_oracle as sgo
 
     gnn = ["self", "cross"] * 9
-    params = gso.init_params(256, gnn_layers=len(gnn), inter=None, seed=seed)
-    data = make_point_line_pairs(batch, n_kpts, n_lines, dim=256, size=(1024, 1024), seed=seed + 1)
+    if sharp is None:
+        params = gso.init_params(256, gnn_layers=len(gnn), inter=None, seed=seed)
+        data = make_point_line_pairs(batch, n_kpts, n_lines, dim=256, size=(1024, 1024), seed=seed + 1)
+    else:
+        params, data = gso.sharp_case(batch, n_kpts, n_lines, len(gnn), seed, (1024, 1024), *sharp)
     model = GlueStick({"weights": None})
     res = model.load_state_dict(params, strict=True)
     assert not res.missing_keys and not res.unexpected_keys
@@ -449,7 +468,8 @@ def gen_gluestick_config(name, batch, n_kpts, n_lines, seed, stride=997):
     model.eval()
     with torch.no_grad():
         pe = model(data)
-    out.update(_np({k: pe[k] for k in ("matches0", "matching_scores0", "line_matches0", "line_matching_scores0")}, "eval."))
+    mkeys = ("matches0", "matches1", "matching_scores0", "line_matches0", "line_matches1", "line_matching_scores0")
+    out.update(_np({k: pe[k] for k in mkeys}, "eval."))
     model.train()
     pred = model(data)
     losses, _ = model.loss(pred, {**pred, **data})
@@ -457,12 +477,21 @@ def gen_gluestick_config(name, batch, n_kpts, n_lines, seed, stride=997):
     _la_digest(out, pred["log_assignment"], stride)
     _la_digest(out, pred["line_log_assignment"], 97, "train.line_")
     out["train.raw_line_scores_sample"] = pred["raw_line_scores"].detach().flatten(1)[:, ::97].numpy()
-    out.update(_np({k: pred[k] for k in ("matches0", "matching_scores0", "line_matches0", "line_matching_scores0")}, "train."))
+    out.update(_np({k: pred[k] for k in mkeys}, "train."))
     out.update(_np({k: v for k, v in losses.items() if torch.is_tensor(v)}, "loss."))
     _grad_digest(out, [(k, p.grad) for k, p in model.named_parameters() if p.grad is not None])
     out["param_checksum"] = np.array([float(sum(v.double().abs().sum() for v in params.values()))])
     out["data_checksum"] = _data_checksum(data)
     out["meta"] = np.array([batch, n_kpts, n_lines, len(gnn), seed, stride])
+    if sharp is not None:
+        out["sharp"] = np.array(sharp, dtype=np.float64)
+        out["margins"] = np.array([sgo.decisiveness(m[k].detach(), 0.2) for m in (pred, pe)
+                                   for k in ("log_assignment", "line_log_assignment")])
+        assert out["margins"].min() > 1.0, out["margins"]          # decisive in train AND eval mode, points and lines
+        for m in (pred, pe):
+            for k in ("matches0", "matches1", "line_matches0", "line_matches1"):
+                assert (m[k] == data["gt_" + k]).all(), k
+        print(name, "decision margins (train points, lines, eval points, lines)", out["margins"].tolist())
     np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
     print(name, "loss", losses["total"].tolist(), "matches", (pred["matches0"] > -1).sum(1).tolist(),
           "line matches", (pred["line_matches0"] > -1).sum(1).tolist())
@@ -543,6 +572,10 @@ def main():
             "metrics": lambda: gen_metrics("metrics", seed=109),
             "superglue_config4": lambda: gen_superglue_config("superglue_config4", 1, 2048, 100, seed=113),
             "gluestick_config5": lambda: gen_gluestick_config("gluestick_config5", 1, 2048, 512, seed=127),
+            "superglue_sharp": lambda: gen_superglue_config("superglue_sharp", 2, 2048, 100, seed=151,
+                                                             sharp=(0.01, 16.0, 0.03, 0.125)),
+            "gluestick_sharp": lambda: gen_gluestick_config("gluestick_sharp", 2, 2048, 512, seed=157,
+                                                             sharp=(0.01, 16.0, 0.03, 0.125)),
             "gluestick_lineattn": lambda: gen_gluestick("gluestick_lineattn", batch=2, n_kpts=36, n_lines=14,
                                                         gnn=["self", "cross"] * 2, inter=[0], seed=43, line_attention=True),
         }
@@ -569,6 +602,8 @@ def main():
     gen_gluestick_config("gluestick_config5", 1, 2048, 512, seed=127)
     gen_gluestick("gluestick_lineattn", batch=2, n_kpts=36, n_lines=14, gnn=["self", "cross"] * 2, inter=[0], seed=43,
                   line_attention=True)
+    gen_superglue_config("superglue_sharp", 2, 2048, 100, seed=151, sharp=(0.01, 16.0, 0.03, 0.125))
+    gen_gluestick_config("gluestick_sharp", 2, 2048, 512, seed=157, sharp=(0.01, 16.0, 0.03, 0.125))
 
 
 if __name__ == "__main__":

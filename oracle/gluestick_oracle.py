@@ -224,3 +224,97 @@ def train_step_grads(p, data, layer_names, inter=None):
     losses["total"].mean().backward()
     grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaves.items()}
     return pred, losses, grads
+
+
+# --------------------------------------------------------------------------- sharpened case (bit-exact matches)
+def sharp_case(batch, n_kpts, n_lines, gnn_layers, seed, size=(1024, 1024), damp=0.01, sharp=16.0, noise=0.03,
+               unmatched=0.125, enc_damp=0.004, share_junctions=0.25):
+    """Seeded weights + a seeded point+line pair batch on which EVERY mutual-nearest-neighbour decision of
+    gluestick.py:321-376 -- points and lines -- is decisive (superglue_oracle.decisiveness), so matches0/1 and
+    line_matches0/1 can be compared bit for bit in fp32 and bf16.
+    Image 0: 2*n_lines junction slots + n_kpts keypoints; a fraction of the line endpoints re-uses an earlier junction
+    (shared nodes in the junction graph).  Image 1: the same junction graph under a permutation of the junction slots
+    and of the lines (half of the lines with their endpoints swapped: the `max(s00 + s11, s01 + s10)` of :352-357),
+    coordinates warped by a similarity, descriptors normalise(d + noise N(0, I)); the last `unmatched` fraction of
+    the lines (which never share a junction) and of the keypoints have FRESH counterparts in image 1 (coordinates and
+    descriptors) and must come out as -1, as do those lines' junction points.  The last convolution of both encoders,
+    of every propagation MLP and of every line-layer MLP is damped; final_proj / final_line_proj are `sharp * I + init`.
+    Returns (params, data) of CPU fp32 tensors incl. the point and line ground truth."""
+    p = init_params(256, gnn_layers=gnn_layers, inter=None, seed=seed)
+    for k in list(p):
+        if k.endswith("mlp.3.weight"):
+            p[k] = p[k] * damp
+        if k in ("kenc.encoder.12.weight", "lenc.encoder.12.weight"):
+            p[k] = p[k] * enc_damp
+        if k in ("final_proj.weight", "final_line_proj.weight"):
+            p[k] = p[k] + sharp * torch.eye(256)[:, :, None]
+    g = torch.Generator().manual_seed(seed + 1)
+    w, h = size
+    wh = torch.tensor([w, h], dtype=torch.float32)
+    nl, nj = n_lines, 2 * n_lines
+    nlm = nl - int(unmatched * nl)                 # matched lines: 0 .. nlm-1 (image-0 numbering)
+    nkm = n_kpts - int(unmatched * n_kpts)         # matched keypoints
+    a = math.radians(10.0)
+    c, s = math.cos(a) * 1.1, math.sin(a) * 1.1
+    ctr = wh / 2
+    rot = torch.tensor([[c, -s], [s, c]])
+    warp = lambda x: (x - ctr) @ rot.T + ctr + torch.tensor([15.0, -10.0])   # noqa: E731
+    unit = lambda *shape: F.normalize(torch.randn(*shape, 256, generator=g), dim=-1)   # noqa: E731
+    # ---- image 0
+    p0 = torch.rand(batch, nl, 2, generator=g) * (wh - 200) + 100
+    ang = torch.rand(batch, nl, generator=g) * 2 * math.pi
+    length = 15 + torch.rand(batch, nl, generator=g) * 60
+    lines0 = torch.stack([p0, p0 + length[..., None] * torch.stack([torch.cos(ang), torch.sin(ang)], -1)], 2)
+    idx0 = torch.arange(nj).reshape(1, nl, 2).repeat(batch, 1, 1)
+    lnum = torch.arange(nl)[None, :, None]
+    share = (torch.rand(batch, nl, 2, generator=g) < share_junctions) & (lnum >= 1) & (lnum < nlm)
+    share[:, :, 0] &= ~share[:, :, 1]              # at most one shared endpoint per line: no two lines on the same junction pair
+    prev = (torch.rand(batch, nl, 2, generator=g) * (2 * lnum)).long()                 # a junction slot of an EARLIER line
+    idx0 = torch.where(share, prev, idx0)
+    jc0 = lines0.reshape(batch, nj, 2).clone()
+    jd0 = unit(batch, nj)
+    kp0 = torch.rand(batch, n_kpts, 2, generator=g) * wh
+    kd0 = unit(batch, n_kpts)
+    # ---- image 1 in image-0 numbering, then permuted
+    lines1 = warp(lines0.reshape(batch, nj, 2)).reshape(batch, nl, 2, 2)
+    lines1[:, nlm:] = torch.rand(batch, nl - nlm, 2, 2, generator=g) * wh
+    jc1 = warp(jc0)
+    jd1 = F.normalize(jd0 + noise * torch.randn(batch, nj, 256, generator=g), dim=-1)
+    jc1[:, 2 * nlm:] = lines1[:, nlm:].reshape(batch, -1, 2)
+    jd1[:, 2 * nlm:] = unit(batch, nj - 2 * nlm)
+    kp1 = warp(kp0)
+    kd1 = F.normalize(kd0 + noise * torch.randn(batch, n_kpts, 256, generator=g), dim=-1)
+    kp1[:, nkm:] = torch.rand(batch, n_kpts - nkm, 2, generator=g) * wh
+    kd1[:, nkm:] = unit(batch, n_kpts - nkm)
+    lperm = torch.stack([torch.randperm(nl, generator=g) for _ in range(batch)])        # new line position <- old line
+    jperm = torch.stack([torch.randperm(nj, generator=g) for _ in range(batch)])        # new junction slot <- old slot
+    kperm = torch.stack([torch.randperm(n_kpts, generator=g) for _ in range(batch)])
+    linv, jinv, kinv = (torch.argsort(t, 1) for t in (lperm, jperm, kperm))             # old -> new
+    flip = torch.rand(batch, nl, generator=g) < 0.5                                     # (in new line order)
+    l1 = lines1.gather(1, lperm[:, :, None, None].expand(-1, -1, 2, 2))
+    i1 = jinv.gather(1, idx0.gather(1, lperm[:, :, None].expand(-1, -1, 2)).flatten(1)).reshape(batch, nl, 2)
+    l1 = torch.where(flip[:, :, None, None], l1.flip(2), l1)
+    i1 = torch.where(flip[:, :, None], i1.flip(2), i1)
+    g2 = lambda t, pm: t.gather(1, pm[..., None].expand(-1, -1, t.shape[-1]))            # noqa: E731
+    pts0 = torch.cat([jc0, kp0], 1)
+    pts1 = torch.cat([g2(jc1, jperm), g2(kp1, kperm)], 1)
+    des0 = torch.cat([jd0, kd0], 1)
+    des1 = torch.cat([g2(jd1, jperm), g2(kd1, kperm)], 1)
+    ar = lambda n: torch.arange(n)[None]                                                 # noqa: E731
+    m0 = torch.cat([torch.where(ar(nj) < 2 * nlm, jinv, -1), torch.where(ar(n_kpts) < nkm, kinv + nj, -1)], 1)
+    m1 = torch.cat([torch.where(jperm < 2 * nlm, jperm, -1), torch.where(kperm < nkm, kperm + nj, -1)], 1)
+    lm0 = torch.where(ar(nl) < nlm, linv, -1)
+    lm1 = torch.where(lperm < nlm, lperm, -1)
+    nt = nj + n_kpts
+    gt = torch.zeros(batch, nt, nt, dtype=torch.bool)
+    gt.scatter_(2, m0.clamp(min=0)[..., None], (m0 >= 0)[..., None])
+    gtl = torch.zeros(batch, nl, nl, dtype=torch.bool)
+    gtl.scatter_(2, lm0.clamp(min=0)[..., None], (lm0 >= 0)[..., None])
+    data = {"keypoints0": pts0, "keypoints1": pts1, "descriptors0": des0, "descriptors1": des1,
+            "keypoint_scores0": torch.rand(batch, nt, generator=g), "keypoint_scores1": torch.rand(batch, nt, generator=g),
+            "lines0": lines0, "lines1": l1, "lines_junc_idx0": idx0, "lines_junc_idx1": i1,
+            "line_scores0": torch.rand(batch, nl, generator=g), "line_scores1": torch.rand(batch, nl, generator=g),
+            "view0": {"image_size": wh[None].repeat(batch, 1)}, "view1": {"image_size": wh[None].repeat(batch, 1)},
+            "gt_assignment": gt, "gt_assignment_col0": m0.clone(), "gt_matches0": m0, "gt_matches1": m1,
+            "gt_line_assignment": gtl, "gt_line_assignment_col0": lm0.clone(), "gt_line_matches0": lm0, "gt_line_matches1": lm1}
+    return p, data

@@ -149,3 +149,67 @@ def train_step_grads(p, data, layer_names, iters):
     losses["total"].mean().backward()
     grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaves.items()}
     return pred, losses, grads
+
+
+# --------------------------------------------------------------------------- sharpened case (bit-exact matches)
+def sharp_case(batch, n, gnn_layers, seed, size=(1024, 1024), damp=0.01, sharp=16.0, noise=0.03, unmatched=0.125,
+               kenc_damp=0.004, bin_score=1.0):
+    """Seeded weights + a seeded pair batch on which EVERY mutual-nearest-neighbour decision of superglue.py:300-320 is
+    decisive (see `decisiveness`), so matches0/1 can be compared bit for bit, in fp32 and bf16: the first
+    (1 - unmatched) * n keypoints of image 1 are image 0's (warped by a similarity, then permuted) with descriptors
+    normalise(d0 + noise N(0, I)), the rest are fresh points that must come out as -1; the last convolution of the
+    keypoint encoder and of every propagation MLP (`mlp.3`) is damped so the residual stream stays close to the input
+    descriptors, and final_proj is `sharp * I + init`.  With the filter threshold at 0.2 a matched row's margin cannot exceed
+    -log 0.2 = 1.6 (its probability is at most 1); the defaults reach 1.5.  Returns (params, data) of CPU fp32 tensors."""
+    p = init_params(256, gnn_layers=gnn_layers, seed=seed)
+    last_kenc = max(int(k.split(".")[2]) for k in p if k.startswith("kenc.encoder.") and k.endswith(".weight") and p[k].dim() == 3)
+    for k in p:
+        if k.endswith("mlp.3.weight"):
+            p[k] = p[k] * damp
+    p[f"kenc.encoder.{last_kenc}.weight"] = p[f"kenc.encoder.{last_kenc}.weight"] * kenc_damp
+    p["bin_score"] = torch.tensor(float(bin_score))
+    p["final_proj.weight"] = p["final_proj.weight"] + sharp * torch.eye(256)[:, :, None]
+    g = torch.Generator().manual_seed(seed + 1)
+    w, h = size
+    wh = torch.tensor([w, h], dtype=torch.float32)
+    nm = n - int(unmatched * n)
+    kp0 = torch.rand(batch, n, 2, generator=g) * wh
+    a = math.radians(10.0)
+    c, s = math.cos(a) * 1.1, math.sin(a) * 1.1
+    ctr = wh / 2
+    rot = torch.tensor([[c, -s], [s, c]])
+    d0 = F.normalize(torch.randn(batch, n, 256, generator=g), dim=-1)
+    kp1 = (kp0 - ctr) @ rot.T + ctr + torch.tensor([15.0, -10.0])
+    d1 = F.normalize(d0 + noise * torch.randn(batch, n, 256, generator=g), dim=-1)
+    kp1[:, nm:] = torch.rand(batch, n - nm, 2, generator=g) * wh                         # fresh, unmatched points
+    d1[:, nm:] = F.normalize(torch.randn(batch, n - nm, 256, generator=g), dim=-1)
+    perm = torch.stack([torch.randperm(n, generator=g) for _ in range(batch)])          # new position j holds old perm[j]
+    kp1 = kp1.gather(1, perm[..., None].expand(-1, -1, 2))
+    d1 = d1.gather(1, perm[..., None].expand(-1, -1, 256))
+    inv = torch.argsort(perm, 1)                                                        # old index -> new position
+    m0 = torch.where(torch.arange(n)[None] < nm, inv, -1)                               # image-0 point i <-> old index i
+    m1 = torch.where(perm < nm, perm, -1)
+    gt = torch.zeros(batch, n, n, dtype=torch.bool)
+    gt.scatter_(2, m0.clamp(min=0)[..., None], (m0 >= 0)[..., None])
+    data = {"keypoints0": kp0, "keypoints1": kp1, "descriptors0": d0, "descriptors1": d1,
+            "keypoint_scores0": torch.rand(batch, n, generator=g), "keypoint_scores1": torch.rand(batch, n, generator=g),
+            "view0": {"image_size": wh[None].repeat(batch, 1)}, "view1": {"image_size": wh[None].repeat(batch, 1)},
+            "gt_assignment": gt, "gt_assignment_col0": m0.clone(), "gt_matches0": m0, "gt_matches1": m1}
+    return p, data
+
+
+def decisiveness(la, th):
+    """Smallest margin by which any row / column decision of the mutual-NN filter (superglue.py:300-320,
+    gluestick.py:321-334) on the log-assignment `la` [B,M+1,N+1] is taken: a row (column) either has its best core
+    entry BELOW log(th) by the margin (it is unmatched whatever its arg-max is), or its best entry beats the runner-up
+    AND log(th) by the margin.  Outputs computed from any `la'` with max |la' - la| < margin / 2 are identical."""
+    core = la[:, :-1, :-1]
+    lth = math.log(th) if th > 0 else -float("inf")
+    worst = float("inf")
+    for dim in (2, 1):
+        t = core.topk(2, dim=dim).values
+        t1, t2 = (t[..., 0], t[..., 1]) if dim == 2 else (t[:, 0], t[:, 1])
+        matched = torch.minimum(t1 - t2, t1 - lth)
+        unmatched = lth - t1
+        worst = min(worst, float(torch.maximum(matched, unmatched).min()))
+    return worst

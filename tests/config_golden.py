@@ -106,10 +106,13 @@ def sg_config_inputs(name="superglue_config4"):
     from oracle import superglue_oracle as sgo
     z = load_golden(name)
     batch, n, nl, iters, seed, _ = (int(v) for v in z["meta"])
-    params = sgo.init_params(256, gnn_layers=nl, seed=seed)
+    if "sharp" in z:        # the decisive case: every mutual-NN decision taken by z["margins"]
+        params, data = sgo.sharp_case(batch, n, nl, seed, (1024, 1024), *(float(v) for v in z["sharp"]))
+    else:
+        params = sgo.init_params(256, gnn_layers=nl, seed=seed)
+        data = make_pairs(batch, n, dim=256, size=(1024, 1024), seed=seed + 1)
     chk = float(sum(v.double().abs().sum() for v in params.values()))
     assert abs(chk - float(z["param_checksum"][0])) < 1e-9 * chk
-    data = make_pairs(batch, n, dim=256, size=(1024, 1024), seed=seed + 1)
     dchk = float(sum(v.double().abs().sum() for v in data.values() if torch.is_tensor(v) and v.is_floating_point()))
     assert abs(dchk - float(z["data_checksum"][0])) < 1e-9 * dchk
     return z, params, data, nl, iters
@@ -120,10 +123,13 @@ def gs_config_inputs(name="gluestick_config5"):
     from oracle import gluestick_oracle as gso
     z = load_golden(name)
     batch, n_kpts, n_lines, nl, seed, _ = (int(v) for v in z["meta"])
-    params = gso.init_params(256, gnn_layers=nl, inter=None, seed=seed)
+    if "sharp" in z:
+        params, data = gso.sharp_case(batch, n_kpts, n_lines, nl, seed, (1024, 1024), *(float(v) for v in z["sharp"]))
+    else:
+        params = gso.init_params(256, gnn_layers=nl, inter=None, seed=seed)
+        data = make_point_line_pairs(batch, n_kpts, n_lines, dim=256, size=(1024, 1024), seed=seed + 1)
     chk = float(sum(v.double().abs().sum() for v in params.values()))
     assert abs(chk - float(z["param_checksum"][0])) < 1e-9 * chk
-    data = make_point_line_pairs(batch, n_kpts, n_lines, dim=256, size=(1024, 1024), seed=seed + 1)
     dchk = float(sum(v.double().abs().sum() for v in data.values() if torch.is_tensor(v) and v.is_floating_point()))
     assert abs(dchk - float(z["data_checksum"][0])) < 1e-9 * dchk
     return z, params, data, nl
@@ -164,12 +170,13 @@ def grad_digest_errors(z, grads, sample=2048):
 def significant_grads(errs):
     """Drop the gradients that are analytically zero and hold only rounding noise in the reference too (a conv bias in
     front of a train-mode BatchNorm, key / value / merge biases that BatchNorm or the softmax cancels): those whose
-    reference norm is below 1e-4 of their own layer's weight-gradient norm."""
+    reference norm is below 1e-3 of their own layer's weight-gradient norm (the noise sits at 1e-7 .. 2e-4 of it: the
+    damped `*_sharp` cases have small weight gradients; a genuine bias gradient is of the order of its weight's)."""
     keep = {}
     for k, e in errs.items():
         if k.endswith(".bias"):
             w = errs.get(k[:-5] + ".weight")
-            if w is not None and e[2] < 1e-4 * w[2]:
+            if w is not None and e[2] < 1e-3 * w[2]:
                 continue
         keep[k] = e
     return keep

@@ -2,7 +2,14 @@
 GNN and 100 Sinkhorn iterations, and GlueStick with 2048 keypoints + 512 lines (3072 tokens per image), B=1, whole
 train step (forward + loss + backward) -- in fp32 against the reference-generated compact goldens at north_star's
 1e-4, and in bf16 (the dtype bench.py times for `other_configs`) with stated, measured bounds incl. per-tensor
-gradient error.  Goldens: tests/golden/superglue_config4.npz, gluestick_config5.npz (oracle/gen_golden.py)."""
+gradient error.  Goldens: tests/golden/superglue_config4.npz, gluestick_config5.npz (oracle/gen_golden.py).
+
+Round 5: the DECISIVE goldens superglue_sharp.npz / gluestick_sharp.npz (B=2, N=2048 [+ 512 lines], reference-generated
+from oracle/{superglue,gluestick}_oracle.sharp_case): every mutual-NN decision of superglue.py:300-320 and
+gluestick.py:321-376 -- matched or -1, points and lines -- is taken with a margin of >= 1.5 nats in the reference's own
+output, so matches0/1 and line_matches0/1 are compared with assert_array_equal in fp32 AND in bf16 (the mode bench.py
+times), in train mode (BatchNorm batch statistics over both pairs) and in eval mode; and train-mode-BatchNorm steps at
+B=4, N=2048 against the CPU oracle (superglue.py:70-79, gluestick.py:465-474)."""
 import numpy as np
 import pytest
 import torch
@@ -132,3 +139,117 @@ def test_gluestick_config5_bf16_train_step_bounds():
     _bf16_report("gluestick config5", z,
                  [("log_assignment", pred["log_assignment"], int(z["meta"][5]), "train."),
                   ("line_log_assignment", pred["line_log_assignment"], 97, "train.line_")], losses, grads, GS_BF16)
+
+
+# ------------------------------------------------------------------------------------------ decisive goldens (round 5)
+def _sharp_model(kind):
+    if kind == "superglue":
+        from glue_factory_amd.matchers.superglue import SuperGlue
+        z, params, data, nl, iters = sg_config_inputs("superglue_sharp")
+        model = SuperGlue({"num_sinkhorn_iterations": iters})
+    else:
+        from glue_factory_amd.matchers.gluestick import GlueStick
+        z, params, data, nl = gs_config_inputs("gluestick_sharp")
+        model = GlueStick({})
+    res = model.load_state_dict(params, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    assert float(z["margins"].min()) > 1.5          # nats, in the reference's own output (train and eval)
+    return z, model.cuda(), _cuda(data)
+
+
+_SHARP_KEYS = {"superglue": ("matches0", "matches1"), "gluestick": ("matches0", "matches1", "line_matches0", "line_matches1")}
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("kind", ["superglue", "gluestick"])
+def test_sharp_golden_integer_outputs_are_bit_exact(kind, bf16):
+    """matches0/1 (and line_matches0/1) equal to the reference's on 100 % of the rows and columns -- matched AND -1
+    entries -- in train mode (BatchNorm batch statistics over the B=2 batch) and eval mode; fp32 additionally holds the
+    log-assignment digest, every loss entry and the gradients to the reference."""
+    z, model, cdata = _sharp_model(kind)
+    model.train()
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16):
+        pred = model(cdata)
+        losses, _ = model.loss(pred, {**pred, **cdata})
+    losses["total"].mean().backward()
+    for k in _SHARP_KEYS[kind]:
+        got = pred[k].cpu().numpy()
+        assert (got == -1).any() and (got >= 0).any()
+        np.testing.assert_array_equal(got, z["train." + k], err_msg=f"{kind} train {k}")
+    stride = int(z["meta"][5])
+    items = [("log_assignment", pred["log_assignment"], stride, "train.")]
+    if kind == "gluestick":
+        items.append(("line_log_assignment", pred["line_log_assignment"], 97, "train.line_"))
+    worst = 0.0
+    for name, la, st, prefix in items:
+        mx, p99, mean = la_digest_error(z, la, st, prefix)
+        worst = max(worst, mx)
+        print(f"{kind} sharp {'bf16' if bf16 else 'fp32'} {name}: max|d| {mx:.2e} p99 {p99:.2e} mean {mean:.2e} "
+              f"(decision margin {float(z['margins'].min()):.2f})")
+    assert worst < 0.25 * float(z["margins"].min())       # the decisions cannot flip: |d| << margin / 2
+    if not bf16:
+        for name, la, st, prefix in items:
+            check_la_digest(z, la, st, prefix=prefix, tol=1e-4)
+        _check_losses(z, losses, 1e-4)
+        grads = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+        _fp32_grads(z, grads, norm_tol=1e-3, sample_tol=4e-3)
+    model.eval()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16):
+        pe = model(cdata)
+    for k in _SHARP_KEYS[kind]:
+        np.testing.assert_array_equal(pe[k].cpu().numpy(), z["eval." + k], err_msg=f"{kind} eval {k}")
+
+
+# ------------------------------------------------------------------------------ train-mode BatchNorm at B=4, N=2048
+def _oracle_vs_hip(tag, model, params, data, oracle_step, la_keys, bf16=False):
+    """One train step (BatchNorm on batch statistics) of the HIP module vs the CPU oracle on the same B=4 batch."""
+    model.load_state_dict(params, strict=True)
+    model = model.cuda().train()
+    cdata = _cuda(data)
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16):
+        pred = model(cdata)
+        losses, _ = model.loss(pred, {**pred, **cdata})
+    losses["total"].mean().backward()
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    odata = dict(data, image_size0=data["view0"]["image_size"], image_size1=data["view1"]["image_size"])
+    pred_o, loss_o, grads_o = oracle_step(params, odata)
+    for k in la_keys:
+        d = float((pred[k].detach().float().cpu() - pred_o[k].detach()).abs().max())
+        print(f"{tag}: max |d {k}| {d:.2e}")
+        assert d < 1e-4, (k, d)
+    for k, v in loss_o.items():
+        if torch.is_tensor(v) and k in losses:
+            np.testing.assert_allclose(losses[k].detach().float().cpu().numpy(), v.detach().numpy(), rtol=1e-4, atol=1e-4, err_msg=k)
+    errs = {}
+    for k, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        r = grads_o[k].double()
+        errs[k] = (0.0, float((p.grad.double().cpu() - r).norm() / r.norm().clamp(min=1e-30)), float(r.norm()))
+    sig = significant_grads(errs)
+    worst = max((e[1], k) for k, e in sig.items())
+    print(f"{tag}: worst relative gradient error {worst} over {len(sig)} tensors")
+    assert worst[0] < 4e-3, worst
+
+
+def test_superglue_train_mode_batchnorm_b4_n2048_vs_oracle():
+    from glue_factory_amd.matchers.superglue import SuperGlue
+    from glue_factory_amd.synthetic import make_pairs
+    from oracle import superglue_oracle as sgo
+    iters = 20          # (the B=4 oracle's unrolled Sinkhorn keeps 2 GB of autograd state per 20 iterations)
+    params = sgo.init_params(256, gnn_layers=18, seed=161)
+    data = make_pairs(4, 2048, dim=256, size=(1024, 1024), seed=162)
+    names = ["self", "cross"] * 9
+    _oracle_vs_hip("superglue B=4 N=2048 train-BN", SuperGlue({"num_sinkhorn_iterations": iters}), params, data,
+                   lambda p, d: sgo.train_step_grads(p, d, names, iters), ("log_assignment",))
+
+
+def test_gluestick_train_mode_batchnorm_b4_n2048_vs_oracle():
+    from glue_factory_amd.matchers.gluestick import GlueStick
+    from glue_factory_amd.synthetic import make_point_line_pairs
+    from oracle import gluestick_oracle as gso
+    params = gso.init_params(256, gnn_layers=18, inter=None, seed=163)
+    data = make_point_line_pairs(4, 2048, 512, dim=256, size=(1024, 1024), seed=164)
+    names = ["self", "cross"] * 9
+    _oracle_vs_hip("gluestick B=4 2048+512 train-BN", GlueStick({}), params, data,
+                   lambda p, d: gso.train_step_grads(p, d, names, inter=None), ("log_assignment", "line_log_assignment"))

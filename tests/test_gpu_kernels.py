@@ -363,6 +363,42 @@ def test_batch_norm_act(dtype, M, C, relu):
     assert int(bn.num_batches_tracked) == 1
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,C", [(131072, 32), (131072, 256), (131072, 512), (196608, 32), (196608, 256), (196608, 512)])
+def test_batch_norm_act_at_benchmarked_row_counts(dtype, M, C):
+    """Train-mode BatchNorm + ReLU at the row counts bench.py's `other_configs` run (SuperGlue: 64 images x 2048
+    keypoints = 131 072 rows, GlueStick: 64 x 3072 = 196 608; csrc/batchnorm.hip caps the statistics grid at 512
+    workgroups there, every thread strides over >= 2 row groups) against an fp64 torch BatchNorm1d
+    (superglue.py:70-79, gluestick.py:465-474); channel means up to 4x the spread (the statistics kernel forms
+    E[x^2] - E[x]^2 from fp32 sums: its relative variance error grows as eps * (1 + (mean / std)^2))."""
+    g = torch.Generator().manual_seed(M // 1024 + C)
+    x = (torch.randn(M, C, generator=g) * 0.7 + torch.linspace(-1.0, 2.8, C)).to(DEV, dtype)
+    dy = torch.randn(M, C, generator=g).to(DEV, dtype)
+    bn = torch.nn.BatchNorm1d(C).to(DEV)
+    with torch.no_grad():
+        bn.weight.copy_(1 + 0.2 * torch.randn(C, generator=g))
+        bn.bias.copy_(0.2 * torch.randn(C, generator=g))
+    ref = torch.nn.BatchNorm1d(C).to(DEV).double()
+    ref.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in bn.state_dict().items()})
+    bn.train(); ref.train()
+    xs = x.clone().requires_grad_(True)
+    y = ops.batch_norm_act(xs, bn, True)
+    (y * dy).sum().backward()
+    xr = x.detach().double().requires_grad_(True)
+    yr = torch.relu(ref(xr))
+    (yr * dy.double()).sum().backward()
+    tol = dict(rtol=2e-5, atol=2e-5) if dtype == torch.float32 else dict(rtol=1.6e-2, atol=1.6e-2)   # bf16: output rounding
+    torch.testing.assert_close(y.detach().double(), yr.detach(), **tol)
+    sc = xr.grad.abs().max().item()
+    torch.testing.assert_close(xs.grad.double() / sc, xr.grad / sc, **tol)
+    # the statistics themselves (fp32 sums of 131 072+ terms in both modes): tight, whatever the activation dtype
+    for name, a, b in (("dgamma", bn.weight.grad, ref.weight.grad), ("dbeta", bn.bias.grad, ref.bias.grad),
+                       ("running_mean", bn.running_mean, ref.running_mean), ("running_var", bn.running_var, ref.running_var)):
+        sc = b.abs().max().item()
+        stat_tol = 2e-5 if dtype == torch.float32 or name.startswith("running") else 4e-3
+        torch.testing.assert_close(a.double() / sc, b / sc, rtol=stat_tol, atol=stat_tol, msg=lambda m: f"{name}: {m}")
+
+
 def test_linear_cat_equals_linear_of_cat():
     g = torch.Generator().manual_seed(0)
     x1 = torch.randn(3, 50, 256, generator=g).to(DEV).requires_grad_(True)

@@ -167,15 +167,21 @@ def test_oracle_at_baseline_configs_matches_reference(name):
     print(name, "worst relative gradient-norm error", worst)
 
 
-def test_superglue_oracle_at_config4_matches_reference():
+@pytest.mark.parametrize("name", ["superglue_config4", "superglue_sharp"])
+def test_superglue_oracle_at_config4_matches_reference(name):
     """BASELINE configs[3] (N=2048, 18 GNN layers, 100 Sinkhorn iterations, B=1): the SuperGlue oracle's train step vs
-    the compact vectors the reference itself produced at that size."""
+    the compact vectors the reference itself produced at that size; superglue_sharp: the decisive B=2 case (train-mode
+    BatchNorm over two pairs, matches0/1 bit-exact incl. the -1 entries)."""
     from config_golden import check_la_digest, grad_digest_errors, sg_config_inputs, significant_grads
     from oracle import superglue_oracle as sgo
-    z, params, data, nl, iters = sg_config_inputs()
+    z, params, data, nl, iters = sg_config_inputs(name)
     odata = dict(data, image_size0=data["view0"]["image_size"], image_size1=data["view1"]["image_size"])
     pred, losses, grads = sgo.train_step_grads(params, odata, ["self", "cross"] * (nl // 2), iters)
     check_la_digest(z, pred["log_assignment"], int(z["meta"][5]), tol=1e-4)
+    if "sharp" in z:
+        assert sgo.decisiveness(pred["log_assignment"].detach(), 0.2) > 1.5
+        for k in ("matches0", "matches1"):
+            np.testing.assert_array_equal(pred[k].numpy(), z["train." + k])
     for k in [k[5:] for k in z if k.startswith("loss.")]:
         np.testing.assert_allclose(losses[k].detach().numpy(), z["loss." + k], **TOL, err_msg=k)
     errs = significant_grads(grad_digest_errors(z, grads))
@@ -183,15 +189,20 @@ def test_superglue_oracle_at_config4_matches_reference():
     assert worst[0] <= 2e-3, worst
 
 
-def test_gluestick_oracle_at_config5_matches_reference():
-    """BASELINE configs[4] (2048 keypoints + 512 lines, 9 x (self, cross) with line layers, B=1)."""
+@pytest.mark.parametrize("name", ["gluestick_config5", "gluestick_sharp"])
+def test_gluestick_oracle_at_config5_matches_reference(name):
+    """BASELINE configs[4] (2048 keypoints + 512 lines, 9 x (self, cross) with line layers, B=1); gluestick_sharp: the
+    decisive B=2 case (point and line matches bit-exact incl. the -1 entries)."""
     from config_golden import check_la_digest, grad_digest_errors, gs_config_inputs, significant_grads
     from oracle import gluestick_oracle as gso
-    z, params, data, nl = gs_config_inputs()
+    z, params, data, nl = gs_config_inputs(name)
     data = dict(data, image_size0=data["view0"]["image_size"], image_size1=data["view1"]["image_size"])
     pred, losses, grads = gso.train_step_grads(params, data, ["self", "cross"] * (nl // 2), inter=None)
     check_la_digest(z, pred["log_assignment"], int(z["meta"][5]), tol=1e-4)
     check_la_digest(z, pred["line_log_assignment"], 97, prefix="train.line_", tol=1e-4)
+    if "sharp" in z:
+        for k in ("matches0", "matches1", "line_matches0", "line_matches1"):
+            np.testing.assert_array_equal(pred[k].numpy(), z["train." + k])
     for k in [k[5:] for k in z if k.startswith("loss.")]:
         np.testing.assert_allclose(losses[k].detach().numpy(), z["loss." + k], **TOL, err_msg=k)
     errs = significant_grads(grad_digest_errors(z, grads))
