@@ -78,7 +78,15 @@ class SuperPoint(_SuperPointOpen):
             path = Path(conf.weights)
             if not path.exists():
                 raise FileNotFoundError(f"SuperPoint weights '{conf.weights}' not found locally (no network on this target)")
-            self.load_state_dict(torch.load(str(path), map_location="cpu"), strict=False)
+            # strict=False like the reference (superpoint.py:198-200) -- but a file that fits none of the layers must not
+            # silently leave the random initialisation in place
+            res = self.load_state_dict(torch.load(str(path), map_location="cpu"), strict=False)
+            if res.missing_keys or res.unexpected_keys:
+                import logging
+                logging.getLogger(__name__).warning("SuperPoint weights '%s': missing keys %s, unexpected keys %s",
+                                                    conf.weights, list(res.missing_keys), list(res.unexpected_keys))
+            if len(res.missing_keys) == len(self.state_dict()):
+                raise RuntimeError(f"SuperPoint weights '{conf.weights}' match none of the model's parameters")
 
     # ------------------------------------------------------------------ layout: the open variant's names, no BatchNorm
     def _layout(self):

@@ -75,7 +75,7 @@ class SuperPoint(BaseModel):
         "weights": None,
     }
     required_data_keys = ["image"]
-    batchable_views = True      # forward reads data["image"] only, image by image: a frozen instance may see both views at once
+    batchable_views = True      # forward works image by image on batched keys only (`image`, `image_size`): a frozen instance may see both views at once
 
     def _init(self, conf):
         self.stride = 2 ** (len(conf.channels) - 2)
@@ -345,6 +345,7 @@ class SuperPoint(BaseModel):
             idx = torch.where(scores[0] > conf.detection_threshold)
             keypoints = torch.stack(idx[::-1], -1).float()[None]
             kscores = scores[0][idx][None]
+            keypoints = self._refine(keypoints, dense_scores)      # (the non-free variant refines in every case, superpoint.py:290-293)
         else:
             picked = self._sample_keypoints(cand, scores, k)       # hook: None = the k highest scores
             if picked is not None:

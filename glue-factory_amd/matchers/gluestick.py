@@ -223,6 +223,9 @@ class GlueStick(BaseModel):
         return (scores, *self._filter(scores), raw)
 
     # ------------------------------------------------------------------ forward
+    # torch.compile(model) (gluefactory/train.py:332-333): the HIP path is opaque to dynamo -- ctypes launches inside
+    # autograd.Functions, host-side caches -- so forward / loss are one clean graph break and run eagerly
+    @torch.compiler.disable
     def _forward(self, data):
         dev = data["keypoints0"].device
         b = len(data["keypoints0"])
@@ -346,6 +349,7 @@ class GlueStick(BaseModel):
             losses[prefix + "bin_score"] = bin_score[None]
         return losses
 
+    @torch.compiler.disable
     def loss(self, pred, data):
         losses = {"total": 0}
         if not (data["keypoints0"].shape[1] == 0 or data["keypoints1"].shape[1] == 0):

@@ -393,6 +393,9 @@ class LightGlue(nn.Module):
             return torch.bfloat16
         return torch.float32
 
+    # torch.compile(model) (gluefactory/train.py:332-333): the HIP path is opaque to dynamo -- ctypes launches inside
+    # autograd.Functions, host-side caches -- so forward / loss are one clean graph break and run eagerly
+    @torch.compiler.disable
     def forward(self, data):
         for key in self.required_data_keys:
             assert key in data, f"Missing key {key} in data"
@@ -631,6 +634,7 @@ class LightGlue(nn.Module):
         return nll, {"assignment_nll": nll, "nll_pos": nll_pos, "nll_neg": nll_neg,
                      "num_matchable": gt["num_pos"], "num_unmatchable": (gt["n0"] + gt["n1"]) / 2.0}
 
+    @torch.compiler.disable
     def loss(self, pred, data):
         with torch.autocast(device_type="cuda", enabled=False):
             return self._loss(pred, data)

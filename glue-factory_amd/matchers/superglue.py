@@ -270,6 +270,9 @@ class SuperGlue(BaseModel):
                                         "(pretrained downloads need network access)")
             self.load_state_dict(torch.load(str(path), map_location="cpu"))
 
+    # torch.compile(model) (gluefactory/train.py:332-333): the HIP path is opaque to dynamo -- ctypes launches inside
+    # autograd.Functions, host-side caches -- so forward / loss are one clean graph break and run eagerly
+    @torch.compiler.disable
     def _forward(self, data):
         kpts0, kpts1 = data["keypoints0"], data["keypoints1"]
         if kpts0.shape[1] == 0 or kpts1.shape[1] == 0:
@@ -330,6 +333,7 @@ class SuperGlue(BaseModel):
         return {"sinkhorn_cost": Z[:, :-1, :-1], "log_assignment": scores, "matches0": m0, "matches1": m1,
                 "matching_scores0": ms0, "matching_scores1": ms1}
 
+    @torch.compiler.disable
     def loss(self, pred, data):
         la = pred["log_assignment"]
         neg0 = (data["gt_matches0"] == -1).float()

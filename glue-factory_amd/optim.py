@@ -72,17 +72,39 @@ class FusedAdam(torch.optim.Optimizer):
     def load_state_dict(self, state_dict):
         """Accepts our own checkpoints and torch.optim.Adam's (whatever its fused / capturable / foreach flags were and
         wherever torch.load mapped the tensors): moments go to the parameters' device, the step count into the group's
-        device scalar at the next step(), and the groups stay fused + capturable."""
+        device scalar at the next step(), and the groups stay fused + capturable.  Safe after TrainStep(graph=True) has
+        captured the step: device scalars and moment tensors that already exist keep their addresses and are overwritten in place."""
         for g in state_dict["param_groups"]:
             if g.get("amsgrad") or g.get("maximize"):
                 raise ValueError("FusedAdam: amsgrad / maximize checkpoints are not supported")
+        live = {p_: (st["exp_avg"], st["exp_avg_sq"]) for p_, st in self.state.items() if "exp_avg" in st}
         super().load_state_dict(state_dict)
+        for p_, olds in live.items():           # moments a captured step already points at take the loaded values IN PLACE
+            st = self.state.get(p_)
+            if st is not None and "exp_avg" in st:
+                for k, old in zip(("exp_avg", "exp_avg_sq"), olds):
+                    if old.shape == st[k].shape:
+                        old.copy_(st[k])
+                        st[k] = old
         foreign = ("amsgrad", "maximize", "foreach", "differentiable", "decoupled_weight_decay")
         for g in self.param_groups:
             g["fused"], g["capturable"] = True, True
             for k in foreign + tuple(k for k in g if k.startswith("_")):      # (older checkpoints of ours leaked _step_dev ...)
                 g.pop(k, None)
-        self._dev = {}
+        # the device scalars stay where they are -- a captured step (TrainStep(graph=True)) holds their addresses -- and
+        # take the loaded values IN PLACE: the step count at the next _init_group (state[p]["step"] is no longer the
+        # shared tensor), the learning rate here
+        for gi, g in enumerate(self.param_groups):
+            d = self._dev.get(gi)
+            if d is not None:
+                d["lr_host"] = float(g["lr"])
+                d["lr"].fill_(d["lr_host"])
+                steps = [self.state[p_].get("step") for p_ in g["params"] if p_ in self.state]
+                if steps:
+                    d["step"].copy_(torch.as_tensor(steps[0], dtype=torch.float32).reshape(()))
+                for p_ in g["params"]:
+                    if p_ in self.state:
+                        self.state[p_]["step"] = d["step"]
 
     def sync_lr(self):
         """Copy each group's (host-side, scheduler-owned) learning rate into its device scalar when it moved.  step() does

@@ -55,18 +55,45 @@ class TwoViewPipeline(BaseModel):
     def _extract_pair(self, data):
         """Both views' extractor outputs.  A FROZEN extractor (no trainable parameter, BatchNorm layers in eval mode) sees
         the two image batches as one call on their concatenation when they have the same shape -- per-image results are
-        what two calls give, every kernel launch covers 2B images -- otherwise view by view like the reference."""
+        what two calls give, every kernel launch covers 2B images -- otherwise view by view like the reference.
+        Every batched tensor key the two views share (`image_size`, which the non-free SuperPoint's border removal reads,
+        gluefactory_nonfree/superpoint.py:236-244) rides along in the concatenated call; a view key that cannot be
+        concatenated, a batch of one without a fixed keypoint count (variable-length outputs exist for b == 1 only), or
+        an extractor that refuses the batch falls back to the per-view calls."""
         v0, v1 = data["view0"], data["view1"]
         ext = getattr(self, "extractor", None)
-        batched = (ext is not None and getattr(ext, "batchable_views", False)      # (its forward reads data["image"] only)
+        batched = (ext is not None and getattr(ext, "batchable_views", False)
                    and not v0.get("cache") and not v1.get("cache") and "image" in v0 and "image" in v1
                    and v0["image"].shape == v1["image"].shape and v0["image"].is_cuda
                    and not any(p_.requires_grad for p_ in ext.parameters())
                    and not any(m.training for m in ext.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm)))
-        if not batched:
+        if batched:
+            b = v0["image"].shape[0]
+            conf = getattr(ext, "conf", {})
+            k = ext._max_keypoints() if hasattr(ext, "_max_keypoints") else conf.get("max_num_keypoints")
+            fixed_count = bool(conf.get("force_num_keypoints", False)) and (k or -1) > 0
+            batched = b > 1 or fixed_count
+        both = None
+        if batched:
+            both = {}
+            for k in set(v0) | set(v1):
+                a, c = v0.get(k), v1.get(k)
+                if k == "cache" or (a is None and c is None):
+                    continue
+                if (torch.is_tensor(a) and torch.is_tensor(c) and a.dim() > 0 and a.shape == c.shape and a.shape[0] == b
+                        and a.dtype == c.dtype):
+                    both[k] = torch.cat([a, c], 0)
+                elif not torch.is_tensor(a) and not torch.is_tensor(c) and a == c:
+                    both[k] = a                    # (names, scalars: identical in both views)
+                elif torch.is_tensor(a) or torch.is_tensor(c):
+                    both = None                    # a per-view tensor that cannot ride in one call: view by view
+                    break
+        if both is None:
             return self.extract_view(data, "0"), self.extract_view(data, "1")
-        b = v0["image"].shape[0]
-        out = self.extractor({"image": torch.cat([v0["image"], v1["image"]], 0)})
+        try:
+            out = self.extractor(both)
+        except ValueError:                          # ("different keypoint counts" ...: what two b-sized calls can still serve)
+            return self.extract_view(data, "0"), self.extract_view(data, "1")
         if not all(torch.is_tensor(t) and t.dim() > 0 and t.shape[0] == 2 * b for t in out.values()):
             return self.extract_view(data, "0"), self.extract_view(data, "1")      # (an extractor with non-batched outputs)
         return {k: t[:b] for k, t in out.items()}, {k: t[b:] for k, t in out.items()}

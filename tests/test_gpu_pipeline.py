@@ -183,3 +183,60 @@ def test_scope_p_replays_as_one_hipgraph_for_40_steps():
     torch.testing.assert_close(lg, le, rtol=2e-2, atol=2e-2)                          # bf16 steps, 43 updates apart at most
     # (parameters are not compared after 43 Adam updates: an entry whose gradient is rounding noise random-walks by +-lr per
     # step in either run; tests/test_gpu_optim.py::test_train_step_graph_with_fused_adam_matches_eager compares them after 6)
+
+
+def _nonfree_pipeline(**ext):
+    from glue_factory_amd.base_model import get_model
+    P = get_model("glue_factory_amd.pipeline")
+    conf = {"name": "extractors.superpoint", "detection_threshold": 0.0, "nms_radius": 3, "trainable": False,
+            "remove_borders": 4, **ext}
+    torch.manual_seed(7)
+    pipe = P({"extractor": conf})
+    pipe.extractor.convPb.weight.data.mul_(40.0)        # spread the detector logits of the random weights
+    return pipe.cuda().eval()
+
+
+def test_batched_extraction_carries_image_size_to_the_nonfree_extractor():
+    """Square-padded views (superpoint+lightglue_megadepth style): `image_size` is smaller than the tensor and the non-free
+    SuperPoint removes the border relative to it (gluefactory_nonfree/superpoint.py:236-244).  The pipeline's batched
+    two-view call must hand `image_size` through: equal to the per-view calls, no keypoint in the padding."""
+    from glue_factory_amd.synthetic import to_device
+    pipe = _nonfree_pipeline(max_num_keypoints=256, force_num_keypoints=True)
+    g = torch.Generator().manual_seed(3)
+    b, h, w = 2, 256, 256
+    img0, img1 = torch.rand(b, 1, h, w, generator=g), torch.rand(b, 1, h, w, generator=g)
+    size0 = torch.tensor([[200.0, 160.0], [256.0, 176.0]])
+    size1 = torch.tensor([[176.0, 256.0], [144.0, 208.0]])
+    data = to_device({"view0": {"image": img0, "image_size": size0}, "view1": {"image": img1, "image_size": size1}}, "cuda")
+    with torch.no_grad():
+        pred = pipe(data)
+        p0, p1 = pipe.extract_view(data, "0"), pipe.extract_view(data, "1")
+    for i, (pv, size) in enumerate(((p0, size0), (p1, size1))):
+        kp, sc = pred[f"keypoints{i}"], pred[f"keypoint_scores{i}"]
+        det = sc > 0                                    # (padding keypoints of force_num_keypoints are random)
+        assert int(det.sum()) > 100
+        lim = (size - 4).cuda()[:, None]
+        assert bool(((kp < lim) | ~det[..., None]).all()), "a detection in the border / padding beyond image_size"
+        same = det & (pv["keypoint_scores"] > 0)
+        torch.testing.assert_close(kp[same], pv["keypoints"][same])
+        torch.testing.assert_close(sc[same], pv["keypoint_scores"][same])
+        torch.testing.assert_close(pred[f"descriptors{i}"][same], pv["descriptors"][same])
+        assert bool((det == (pv["keypoint_scores"] > 0)).all())
+
+
+def test_batch_of_one_with_a_variable_keypoint_count_extracts_view_by_view():
+    """b == 1 eval of a frozen extractor with `max_num_keypoints: -1` / no force_num_keypoints (the non-free default):
+    variable-length outputs exist for b == 1 only, so the two views must not be glued into a batch of two."""
+    from glue_factory_amd.synthetic import to_device
+    g = torch.Generator().manual_seed(4)
+    data = to_device({"view0": {"image": torch.rand(1, 1, 128, 160, generator=g)},
+                      "view1": {"image": torch.rand(1, 1, 128, 160, generator=g)}}, "cuda")
+    for ext in ({"max_num_keypoints": -1, "detection_threshold": 0.02},
+                {"max_num_keypoints": 64, "force_num_keypoints": False, "detection_threshold": 0.02, "refinement_radius": 2}):
+        pipe = _nonfree_pipeline(**ext)
+        with torch.no_grad():
+            pred = pipe(data)
+            p0 = pipe.extract_view(data, "0")
+        assert pred["keypoints0"].shape[0] == 1 and pred["keypoints0"].shape[1] > 0
+        torch.testing.assert_close(pred["keypoints0"], p0["keypoints"])
+        torch.testing.assert_close(pred["descriptors0"], p0["descriptors"])

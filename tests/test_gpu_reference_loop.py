@@ -1,0 +1,159 @@
+"""The reference's train-loop statements driving the HIP matcher (gluefactory/train.py:332-333, 362-367, 465-517).
+
+The reference enables ``torch.amp.GradScaler`` for ANY ``--mixed_precision`` (bfloat16 included, train.py:362-367), so
+under ``python -m gluefactory.train ... --mp bfloat16`` the HIP backward receives gradients scaled by 65 536 and
+``scaler.step(optimizer)`` drives the optimiser; ``--compile`` wraps the model in ``torch.compile`` (train.py:332-333).
+``_reference_loop`` below restates the loop body of train.py:465-517 statement by statement (zero_grad, autocast
+forward, loss_fn, NaN check, scaler.scale(loss).backward(), unscale_ + clip_grad_norm_(error_if_nonfinite) + scaler.step
+inside the try / except, scaler.update, lr_scheduler.step) -- gluefactory.train itself cannot be imported here
+(tensorboard, cv2, h5py are absent), the model, loss_fn, optimiser and scaler objects are the real ones.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _model_and_data(kind="lightglue", batch=2, n=256):
+    from glue_factory_amd.synthetic import make_pairs, to_device
+    if kind == "lightglue":
+        from glue_factory_amd.matchers.lightglue import LightGlue
+        from oracle import lightglue_oracle as lgo
+        model = LightGlue({"n_layers": 3})
+        model.load_state_dict(lgo.init_params(3, 256, 4, seed=171), strict=True)
+    else:
+        from glue_factory_amd.matchers.superglue import SuperGlue
+        from oracle import superglue_oracle as sgo
+        model = SuperGlue({"num_sinkhorn_iterations": 20, "GNN_layers": ["self", "cross"] * 2})
+        model.load_state_dict(sgo.init_params(256, gnn_layers=4, seed=171), strict=True)
+    return model.cuda(), to_device(make_pairs(batch, n, dim=256, size=(640, 480), seed=172), "cuda")
+
+
+def _reference_loop(model, data, optimizer, scaler, clip_grad, iters, mp_dtype=torch.bfloat16, loss_fn=None):
+    """train.py:465-517, one epoch of `iters` identical batches."""
+    loss_fn = model.loss if loss_fn is None else loss_fn                                        # train.py:334
+    all_params = [p for p in model.parameters() if p.requires_grad]
+    lr_scheduler = torch.optim.lr_scheduler.MultiplicativeLR(optimizer, lambda it: 0.9)         # stands for train.py:373-378
+    totals = []
+    for it in range(iters):
+        model.train()
+        optimizer.zero_grad()
+        with torch.autocast(device_type="cuda", enabled=mp_dtype is not None, dtype=mp_dtype):
+            pred = model(data)
+            losses, _ = loss_fn(pred, {**pred, **data})
+            loss = torch.mean(losses["total"])
+        if torch.isnan(loss).any():
+            continue
+        do_backward = loss.requires_grad
+        assert do_backward
+        scaler.scale(loss).backward()
+        if clip_grad:
+            scaler.unscale_(optimizer)
+            try:
+                torch.nn.utils.clip_grad_norm_(all_params, max_norm=clip_grad, error_if_nonfinite=True)
+                scaler.step(optimizer)
+            except RuntimeError:
+                raise AssertionError("non-finite gradients in a healthy step")
+            scaler.update()
+        else:
+            scaler.step(optimizer)
+            scaler.update()
+        lr_scheduler.step()
+        totals.append(float(loss))
+    return totals
+
+
+def _make_opt(kind, params):
+    from glue_factory_amd.optim import FusedAdam
+    if kind == "fused":
+        return FusedAdam(params, lr=1e-3)
+    if kind == "torch_fused":
+        return torch.optim.Adam(params, lr=1e-3, fused=True)
+    return torch.optim.Adam(params, lr=1e-3)
+
+
+@pytest.mark.parametrize("clip_grad", [None, 1.0])
+@pytest.mark.parametrize("opt_kind", ["torch", "torch_fused", "fused"])
+@pytest.mark.parametrize("kind", ["lightglue", "superglue"])
+def test_grad_scaler_loop_equals_the_unscaled_loop(kind, opt_kind, clip_grad):
+    """scaler at its default 65 536 (a power of two: every product of the backward is scaled exactly) + unscale_ +
+    clip + scaler.step == the same loop with the scaler disabled, with torch.optim.Adam, its fused variant and FusedAdam."""
+    runs = []
+    for enabled in (True, False):
+        model, data = _model_and_data(kind)
+        opt = _make_opt(opt_kind, model.parameters())
+        scaler = torch.amp.GradScaler("cuda", enabled=enabled)
+        totals = _reference_loop(model, data, opt, scaler, clip_grad, iters=3)
+        if enabled:
+            assert scaler.get_scale() == 65536.0            # no step was skipped for "inf" gradients
+        runs.append((totals, [p.detach().clone() for p in model.parameters()], model))
+    (ta, pa, ma), (tb, pb, _) = runs
+    assert len(ta) == len(tb) == 3
+    for a, b in zip(ta, tb):
+        assert abs(a - b) <= 1e-5 * max(1.0, abs(b)), (ta, tb)
+    init = _model_and_data(kind)[0]
+    moved = 0.0
+    for (name, p0), a, b in zip(init.named_parameters(), pa, pb):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=2e-7, msg=lambda m: f"{name}: {m}")
+        moved = max(moved, float((a - p0).abs().max()))
+    assert moved > 1e-4                                      # the optimiser did step
+
+
+def test_grad_scaler_skips_the_step_on_an_overflow_and_recovers():
+    """A poisoned batch (inf descriptor) makes the scaled gradients non-finite: scaler.step must leave the parameters
+    untouched (FusedAdam's found_inf protocol) and halve the scale; the next healthy step updates again."""
+    from glue_factory_amd.optim import FusedAdam
+    model, data = _model_and_data("lightglue")
+    opt = FusedAdam(model.parameters(), lr=1e-3)
+    scaler = torch.amp.GradScaler("cuda")
+    before = [p.detach().clone() for p in model.parameters()]
+    bad = dict(data, descriptors0=data["descriptors0"].clone())
+    bad["descriptors0"][0, 0, 0] = float("inf")
+    model.train()
+    for batch, expect_update in ((bad, False), (data, True)):
+        opt.zero_grad()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            pred = model(batch)
+            losses, _ = model.loss(pred, {**pred, **batch})
+            loss = torch.mean(losses["total"])
+        scaler.scale(loss).backward()
+        scaler.step(opt)
+        scaler.update()
+        changed = any(not torch.equal(p, q) for p, q in zip(model.parameters(), before))
+        assert changed == expect_update
+        if not expect_update:
+            assert scaler.get_scale() == 32768.0
+            assert all(torch.isfinite(p).all() for p in model.parameters())
+
+
+@pytest.mark.parametrize("kind", ["lightglue", "superglue"])
+def test_torch_compile_of_the_model_trains_like_eager(kind):
+    """train.py:332-333 (`model = torch.compile(model, mode=...)`; loss_fn is bound to the uncompiled module's loss
+    one line later): the HIP forward / loss are a clean graph break (torch.compiler.disable), the compiled module
+    trains, and equals the eager run."""
+    import torch._dynamo
+    runs = []
+    for compiled in (False, True):
+        torch._dynamo.reset()
+        model, data = _model_and_data(kind)
+        loss_fn = model.loss
+        fwd = torch.compile(model) if compiled else model
+        opt = _make_opt("fused", model.parameters())
+        totals = []
+        for it in range(3):
+            fwd.train()
+            opt.zero_grad()
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                pred = fwd(data)
+                losses, _ = loss_fn(pred, {**pred, **data})
+                loss = torch.mean(losses["total"])
+            loss.backward()
+            opt.step()
+            totals.append(float(loss))
+        runs.append((totals, [p.detach().clone() for p in model.parameters()]))
+    (ta, pa), (tb, pb) = runs
+    assert ta[0] > 0 and len(ta) == 3
+    for a, b in zip(ta, tb):
+        assert abs(a - b) <= 1e-5 * max(1.0, abs(a)), (ta, tb)
+    for a, b in zip(pa, pb):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=2e-7)
