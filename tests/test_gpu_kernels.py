@@ -385,10 +385,16 @@ def test_batch_norm_act_at_benchmarked_row_counts(dtype, M, C):
     y = ops.batch_norm_act(xs, bn, True)
     (y * dy).sum().backward()
     xr = x.detach().double().requires_grad_(True)
-    yr = torch.relu(ref(xr))
-    (yr * dy.double()).sum().backward()
+    zr = ref(xr)
     tol = dict(rtol=2e-5, atol=2e-5) if dtype == torch.float32 else dict(rtol=1.6e-2, atol=1.6e-2)   # bf16: output rounding
-    torch.testing.assert_close(y.detach().double(), yr.detach(), **tol)
+    torch.testing.assert_close(y.detach().double(), torch.relu(zr).detach(), **tol)
+    # the ReLU gate is discontinuous: an element whose pre-activation is within rounding of 0 may be gated either way (a
+    # handful in 1e8 in fp32, and one of them moves a channel's dgamma by 3e-3).  The forward comparison above pins the
+    # gate up to that rounding; the backward is compared under the SAME gate (taken from the kernel's own output)
+    gate = y.detach() > 0
+    flipped = float((gate != (zr.detach() > 0)).float().mean())
+    assert flipped < (1e-6 if dtype == torch.float32 else 2e-2), flipped
+    (zr * gate * dy.double()).sum().backward()
     sc = xr.grad.abs().max().item()
     torch.testing.assert_close(xs.grad.double() / sc, xr.grad / sc, **tol)
     # the statistics themselves (fp32 sums of 131 072+ terms in both modes): tight, whatever the activation dtype
