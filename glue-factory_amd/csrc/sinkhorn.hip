@@ -706,20 +706,14 @@ Ws carve(void* ws, const Geo& g, int iters) {
 
 }  // namespace
 
-extern "C" int gf_sinkhorn_mode(int mode) {
-    const int prev = g_skr_mode;
-    if (mode >= 0 && mode <= 2) g_skr_mode = mode;
-    return prev;
-}
-
 // Host-only: the distribution the chip-resident path would use for this problem on a device of `ncu` compute units
 // (out[8] = pairs per launch, workgroups per pair, waves per pair, rows per wave, waves with one more row, float4 columns per
 // workgroup in the column phase, N / 256, LDS bytes).  Returns 1 and fills `out`, or 0 when the streaming kernels are used.
-extern "C" int gf_sinkhorn_plan(int B, int M, int N, int ncu, int backward, int64_t* out) {
-    if (B <= 0 || M <= 0 || N <= 0 || ncu <= 0 || out == nullptr) return GF_ERR_SHAPE;
+extern "C" int gf_sinkhorn_plan(int B, int M, int N, int ncu, int backward, int schedule, int64_t* out) {
+    if (B <= 0 || M <= 0 || N <= 0 || ncu <= 0 || out == nullptr || (schedule & 3) == 3) return GF_ERR_SHAPE;
     const Geo g = make_geo(B, M, N);
     SkrPlan d;
-    if (g.RB < 1 || skr_mode() == 0 || !skr_plan(g, B, ncu, backward != 0, d)) return 0;
+    if (g.RB < 1 || !skr_plan(g, B, ncu, backward != 0, schedule & 3, d)) return 0;
     const Ws w = carve(nullptr, g, 1);
     if ((size_t)d.nw * d.bc > w.part_rows) return 0;
     const int64_t v[8] = {d.bc, d.wpp, d.nw, d.base, d.extra, d.cs, d.nsm, (int64_t)d.lds};
@@ -735,16 +729,17 @@ extern "C" int64_t gf_sinkhorn_ws_bytes(int B, int M, int N, int iters) {
 }
 
 extern "C" int gf_sinkhorn_fwd(const float* Z, float* out, float* u_hist, float* v_hist, void* ws,
-                               int B, int M, int N, int iters, void* stream) {
-    if (B <= 0 || M <= 0 || N <= 0 || iters < 0) return GF_ERR_SHAPE;
+                               int B, int M, int N, int iters, int schedule, void* stream) {
+    if (B <= 0 || M <= 0 || N <= 0 || iters < 0 || (schedule & 3) == 3) return GF_ERR_SHAPE;
     Geo g = make_geo(B, M, N);
     if (g.RB < 1) return GF_ERR_UNSUPPORTED;
     if (reinterpret_cast<uintptr_t>(ws) & 15) return GF_ERR_ALIGN;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const Ws w = carve(ws, g, iters);
     SkrPlan rp;
-    const bool resident = g.fast && iters > 0 && skr_mode() != 0 && skr_plan(g, B, skr_cus(), false, rp) &&
+    const bool resident = g.fast && iters > 0 && skr_plan(g, B, skr_cus(), false, schedule & 3, rp) &&
                           (size_t)rp.nw * rp.bc <= w.part_rows;
+    const long long wait_ticks = resident ? skr_wait_ticks(schedule) : 0;
     const int ch = resident ? rp.bc : batch_chunk(g);
     const size_t zs = (size_t)g.R * g.C;
     const size_t lds = g.fast ? 0 : rows_lds(g, false);
@@ -765,7 +760,7 @@ extern "C" int gf_sinkhorn_fwd(const float* Z, float* out, float* u_hist, float*
                     ra.colA = w.a2p; ra.colB = w.vbp;                 // 16-byte aligned [B, Cp] scratch (free in the forward)
                     ra.u_hist = u_hist + (size_t)b0 * g.R; ra.v_hist = v_hist + (size_t)b0 * g.C;
                     ra.ustride = (size_t)B * g.R; ra.vstride = (size_t)B * g.C;
-                    ra.iters = iters; ra.d = rp; ra.d.bc = bc; ra.g = g;
+                    ra.iters = iters; ra.d = rp; ra.d.bc = bc; ra.g = g; ra.wait_ticks = wait_ticks;
                     int rc = skr_launch<false>(ra, st);
                     if (rc) return rc;
                 } else {
@@ -810,8 +805,8 @@ extern "C" int gf_sinkhorn_fwd(const float* Z, float* out, float* u_hist, float*
 
 extern "C" int gf_sinkhorn_bwd(const float* Z, const float* gout, const float* gsum_row, const float* gsum_col,
                                const float* u_hist, const float* v_hist, float* gZ, void* ws,
-                               int B, int M, int N, int iters, void* stream) {
-    if (B <= 0 || M <= 0 || N <= 0 || iters < 0) return GF_ERR_SHAPE;
+                               int B, int M, int N, int iters, int schedule, void* stream) {
+    if (B <= 0 || M <= 0 || N <= 0 || iters < 0 || (schedule & 3) == 3) return GF_ERR_SHAPE;
     Geo g = make_geo(B, M, N);
     if (g.RB < 1) return GF_ERR_UNSUPPORTED;
     if (reinterpret_cast<uintptr_t>(ws) & 15) return GF_ERR_ALIGN;
@@ -835,8 +830,9 @@ extern "C" int gf_sinkhorn_bwd(const float* Z, const float* gout, const float* g
     e = gf_copy_f32(vbar_hist + (size_t)iters * B * g.C, gsum_col, (size_t)B * g.C, st);
     if (e != hipSuccess) return (int)e;
     SkrPlan rp;
-    const bool resident = g.fast && skr_mode() != 0 && skr_plan(g, B, skr_cus(), true, rp) &&
+    const bool resident = g.fast && skr_plan(g, B, skr_cus(), true, schedule & 3, rp) &&
                           (size_t)rp.nw * rp.bc <= w.part_rows;
+    const long long wait_ticks = resident ? skr_wait_ticks(schedule) : 0;
     const int ch = resident ? rp.bc : batch_chunk(g);
     for (int b0 = 0; b0 < B; b0 += ch) {
         const int bc = (B - b0) < ch ? (B - b0) : ch;
@@ -856,7 +852,7 @@ extern "C" int gf_sinkhorn_bwd(const float* Z, const float* gout, const float* g
                 ra.base_row = gsum_row + (size_t)b0 * g.R;
                 ra.ubar_hist = ubar_hist + (size_t)b0 * g.R; ra.vbar_hist = vbar_hist + (size_t)b0 * g.C;
                 ra.ustride = (size_t)B * g.R; ra.vstride = (size_t)B * g.C;
-                ra.iters = iters; ra.d = rp; ra.d.bc = bc; ra.g = g;
+                ra.iters = iters; ra.d = rp; ra.d.bc = bc; ra.g = g; ra.wait_ticks = wait_ticks;
                 return skr_launch<true>(ra, st);
             }() : [&]() -> int {
 #define SKF_CALL_BWD(NSV) skf_bwd_launch<NSV>(w.zp, u_hist + (size_t)b0 * g.R, v_hist + (size_t)b0 * g.C,          \

@@ -24,12 +24,22 @@
 // first version used agent-scope release / acquire fences in every wave (`buffer_wbl2` + `buffer_inv`), 25 us per
 // barrier = 3x the row pass; this form costs 2-3 us.  (Also measured: the finished column vectors as self-validating
 // tagged granules polled by every reader instead of the second barrier -- slower, 8.35 -> 9.84 ms forward at B = 32:
-// 8192 polling lanes per pair cost more than one counter.)  All workgroups are resident by construction (grid <= CU count,
-// one workgroup per CU by its LDS and register footprint); a bound on the polls of every wait (SKR_MAX_POLLS, > 1 s)
-// turns a scheduling surprise into garbage output (caught by the parity tests) instead of a hung device.
+// 8192 polling lanes per pair cost more than one counter.)
+//
+// Co-residency and what happens without it.  The grid is <= the CU count and a workgroup fills a CU (LDS + registers), so
+// on an idle device all workgroups of a pair run at once.  They need NOT: a workgroup that finds its CU held by another
+// stream's kernel (an RCCL reduction, a second process) is simply dispatched later, and the resident ones poll until it
+// arrives -- no workgroup waits for one that can never be scheduled, because the kernels that hold CUs do not depend on this
+// one (no circular wait; grid <= CU count rules out waiting for a sibling that needs a poller's own CU).  Contention
+// therefore costs time, not correctness (tests/test_gpu_sinkhorn_safety.py holds 32 CUs for 30 ms under a launch and
+// compares bit for bit).  Every wait is still BOUNDED, in wall-clock time (the 100 MHz s_memrealtime counter; the bound is
+// an argument of the call, default 10 s): when it expires the pair is marked failed, its later waits are released, and at
+// the end of the kernel every wave of the pair overwrites its rows of the last iterate (forward: u^T, backward: ubar^1)
+// with NaN -- the pair's output / gradient is NaN in every row, the loss is NaN, and TrainStep's device-side skip flag
+// (train.py:477-480) drops the update.  Never a silently wrong number, never a hung device.
 constexpr int SKR_RR = 12;                 // rows of a wave that live in registers
-constexpr int SKR_MAX_BC = 16;             // pairs per launch (counter slots)
-constexpr int SKR_MAX_POLLS = 2000000;     // bound of every wait (a poll is a memory round trip, >= 0.5 us: > 1 s)
+constexpr int SKR_MAX_BC = 16;             // pairs per launch (counter slots; the failure flags follow them)
+constexpr unsigned SKR_DEFAULT_WAIT_MS = 10000;
 
 struct SkrPlan {
     int bc, wpp, nw, base, extra, cs, nsm;
@@ -39,7 +49,8 @@ struct SkrPlan {
 struct SkrArgs {
     const float* Zp;            // [bc, R, Cp] prescaled padded copy
     float* part;                // [bc, nw, Cp] per-wave column partials
-    unsigned* ctr;              // [SKR_MAX_BC] barrier counters, zeroed before the launch
+    unsigned* ctr;              // [2 SKR_MAX_BC]: barrier counters, then failure flags; zeroed before the launch
+    long long wait_ticks;       // bound of every wait in wall_clock64() ticks
     float* colA;                // [bc, Cp]  forward: running v (log2 units); backward: a2p
     float* colB;                // [bc, Cp]  backward: vbp
     float* u_hist;              // forward: written; backward: read           (chunk-offset, iteration stride ustride)
@@ -54,7 +65,7 @@ struct SkrArgs {
 };
 
 __global__ void skr_reset(unsigned* ctr) {
-    if (threadIdx.x < SKR_MAX_BC) ctr[threadIdx.x] = 0u;
+    if (threadIdx.x < 2 * SKR_MAX_BC) ctr[threadIdx.x] = 0u;
 }
 
 #ifndef SKR_ABL
@@ -69,17 +80,26 @@ __device__ __forceinline__ void skr_st(__amdgpu_buffer_rsrc_t r, unsigned byte_o
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(skr_u32x4, v), r, byte_off, 0, 17);
 }
 
-__device__ __forceinline__ void skr_barrier(unsigned* ctr, unsigned target) {
+__device__ __forceinline__ void skr_barrier(unsigned* ctr, unsigned target, long long wait_ticks) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's write-through stores have left the CU
     __syncthreads();
     if ((SKR_ABL & 4) == 0 && threadIdx.x == 0) {
         __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int polls = 0;
+        long long t0 = 0;
         while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(1);
-            if (++polls > SKR_MAX_POLLS) {                // release every later wait of this pair as well
-                __hip_atomic_fetch_add(ctr, 0x40000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
+            if ((++polls & 1023) == 0) {                  // (the clock is read every ~1 ms of polling only)
+                const long long now = wall_clock64();
+                if (t0 == 0) t0 = now;
+                else if (now - t0 > wait_ticks) {
+                    // expired: mark the pair failed FIRST (the returned value is waited for), then release this and
+                    // every later wait of the pair; whoever leaves a barrier after this sees the flag at the kernel's end
+                    const unsigned was = __hip_atomic_fetch_or(ctr + SKR_MAX_BC, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("" ::"v"(was) : "memory");
+                    __hip_atomic_fetch_add(ctr, 0x40000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
             }
         }
     }
@@ -302,7 +322,7 @@ __global__ __launch_bounds__(256, 1) void skr_kernel(const SkrArgs a) {
             f32x4 tl = {st, 0.f, 0.f, 0.f};
             skr_st(rpart, prow + 16u * N4, tl);
         }
-        skr_barrier(ctr, ++nbar * (unsigned)a.d.wpp);
+        skr_barrier(ctr, ++nbar * (unsigned)a.d.wpp, a.wait_ticks);
 
         // ---- column phase: this workgroup finishes float4 columns [wg cs, wg cs + cs)
         f32x4 acc = splat4(0.f);
@@ -335,30 +355,36 @@ __global__ __launch_bounds__(256, 1) void skr_kernel(const SkrArgs a) {
             skr_st(rcA, 16u * q, oA);
             if (BWD) skr_st(rcB, 16u * q, oB);
         }
-        skr_barrier(ctr, ++nbar * (unsigned)a.d.wpp);
+        skr_barrier(ctr, ++nbar * (unsigned)a.d.wpp, a.wait_ticks);
 
         if (it + 1 < a.iters) pull_columns();
     }
+    // a wait of this pair expired (see the header): poison the iterate the final passes read -- forward: u^T of this wave's
+    // rows (out = Z + u + v - norm), backward: ubar^1 (a column of the rank-2T factor P of dZ = G - E o (P Q^T))
+    if (a.iters > 0 && __hip_atomic_load(ctr + SKR_MAX_BC, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u && lane < nrows) {
+        const float qnan = __builtin_nanf("");
+        if (BWD) a.ubar_hist[(size_t)pair * g.R + gil] = qnan;
+        else a.u_hist[(size_t)(a.iters - 1) * a.ustride + (size_t)pair * g.R + gil] = qnan;
+    }
 }
 
-// gf_sinkhorn_mode: 0 = streaming kernels only, 1 (default) = resident from SKR_MIN_BC pairs per launch, 2 = resident
-// whenever the problem fits (tests: small batches too).  Measured on MI355X (tools/probe/time_sinkhorn.py, N = 2048, T = 100,
-// forward / backward ms, streaming -> resident): B = 32 10.81 / 12.18 -> 8.35 / 10.66, B = 8 3.05 / 3.45 -> 2.10 / 2.73,
+// `schedule` argument of gf_sinkhorn_fwd / _bwd / _plan, bits 0-1: 0 = streaming kernels only, 1 = resident from SKR_MIN_BC
+// pairs per launch, 2 = resident whenever the problem fits (tests: small batches too); bits 8-31: bound of every inter-
+// workgroup wait in milliseconds (0 = SKR_DEFAULT_WAIT_MS).  Measured on MI355X (tools/probe/time_sinkhorn.py, N = 2048,
+// T = 100, forward / backward ms, streaming -> resident): B = 32 10.81 / 12.18 -> 8.35 / 10.66, B = 8 3.05 / 3.45 -> 2.10 / 2.73,
 // B = 4 2.25 / 2.51 -> 2.64 / 3.12, B = 1 1.46 / 1.56 -> 5.92 / 6.11 (a pair spread over the whole chip pays a 256-workgroup
 // barrier and 1024 partial rows per iteration): few pairs stay on the streaming path.
 constexpr int SKR_MIN_BC = 5;
-int g_skr_mode = 1;
-int skr_mode() { return g_skr_mode; }
 
 // Distribution of B pairs over the chip, or false when the problem does not fit the resident layout
-bool skr_plan(const Geo& g, int B, int ncu, bool bwd, SkrPlan& d) {
-    if (!g.fast || g.N < 256 || g.N % 256 || g.N / 256 > 8 || g.C != g.N + 1) return false;
+bool skr_plan(const Geo& g, int B, int ncu, bool bwd, int mode, SkrPlan& d) {
+    if (mode == 0 || !g.fast || g.N < 256 || g.N % 256 || g.N / 256 > 8 || g.C != g.N + 1) return false;
     const int n4 = g.N / 4, nvec = n4 + 1;
     const int cap = batch_chunk(g);
     for (int top = B < SKR_MAX_BC ? B : SKR_MAX_BC; top >= 1; --top) {
         const int nch = (B + top - 1) / top, bc = (B + nch - 1) / nch;
         if (bc > cap) continue;
-        if (bc < SKR_MIN_BC && skr_mode() != 2) continue;
+        if (bc < SKR_MIN_BC && mode != 2) continue;
         const int wpp = ncu / bc;
         if (wpp < 1) continue;
         const int nw = 4 * wpp, base = g.R / nw, extra = g.R % nw;
@@ -383,6 +409,14 @@ int skr_cus() {                            // CU count of the CURRENT device (as
     if (hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) return 0;
     return v;
+}
+
+long long skr_wait_ticks(int schedule) {   // the call's wait bound in wall_clock64() ticks of the CURRENT device
+    const unsigned ms = ((unsigned)schedule >> 8) ? ((unsigned)schedule >> 8) : SKR_DEFAULT_WAIT_MS;
+    int dev = 0, khz = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz < 1) khz = 100000;
+    return (long long)ms * khz;
 }
 
 template <bool BWD> int skr_launch(const SkrArgs& a, hipStream_t st) {

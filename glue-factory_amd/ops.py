@@ -1338,14 +1338,13 @@ class _Sinkhorn(torch.autograd.Function):
     Z [B,M+1,N+1] (fp32).  Only the u/v iterates are kept for the backward."""
 
     @staticmethod
-    def forward(ctx, Z, iters):
+    def forward(ctx, Z, iters, schedule):
         _chk(Z)
         assert Z.dtype == torch.float32 and Z.dim() == 3
         Z = Z.contiguous()
         B, R, C = Z.shape
         M, N = R - 1, C - 1
         L = _lib.load()
-        _sinkhorn_mode(L)
         nbytes = L.gf_sinkhorn_ws_bytes(B, M, N, iters)
         if nbytes < 0:
             _lib.check(int(nbytes), "gf_sinkhorn_ws_bytes")
@@ -1353,10 +1352,10 @@ class _Sinkhorn(torch.autograd.Function):
         out = torch.empty_like(Z)
         uh = torch.empty((max(iters, 1), B, R), dtype=torch.float32, device=Z.device)
         vh = torch.empty((max(iters, 1), B, C), dtype=torch.float32, device=Z.device)
-        _lib.check(L.gf_sinkhorn_fwd(_p(Z), _p(out), _p(uh), _p(vh), _p(ws), B, M, N, iters, _stream()),
+        _lib.check(L.gf_sinkhorn_fwd(_p(Z), _p(out), _p(uh), _p(vh), _p(ws), B, M, N, iters, schedule, _stream()),
                    "gf_sinkhorn_fwd")
         ctx.save_for_backward(Z, uh, vh)
-        ctx.iters = iters
+        ctx.iters, ctx.schedule = iters, schedule
         return out
 
     @staticmethod
@@ -1366,25 +1365,34 @@ class _Sinkhorn(torch.autograd.Function):
         M, N = R - 1, C - 1
         G = G.float().contiguous()
         L = _lib.load()
-        _sinkhorn_mode(L)
         ws = torch.empty(int(L.gf_sinkhorn_ws_bytes(B, M, N, ctx.iters)), dtype=torch.uint8, device=Z.device)
         gZ = torch.empty_like(Z)
         known = _known_sums(G)                   # the fused NLL node hands over the sums of its sparse gradient
         gr, gc = known if known is not None else (G.sum(2).contiguous(), G.sum(1).contiguous())
         _lib.check(L.gf_sinkhorn_bwd(_p(Z), _p(G), _p(gr), _p(gc), _p(uh), _p(vh), _p(gZ), _p(ws),
-                                     B, M, N, ctx.iters, _stream()), "gf_sinkhorn_bwd")
-        return gZ, None
+                                     B, M, N, ctx.iters, ctx.schedule, _stream()), "gf_sinkhorn_bwd")
+        return gZ, None, None
 
 
-def _sinkhorn_mode(L):
-    """GF_SINKHORN_RESIDENT (host-side knob; the library itself reads no environment): 0 = streaming Sinkhorn kernels only,
-    1 = chip-resident sweeps from 5 pairs per launch (default), 2 = resident whenever the problem fits (csrc/sinkhorn_resident.h)."""
-    m = os.environ.get("GF_SINKHORN_RESIDENT", "1")
-    L.gf_sinkhorn_mode(int(m) if m in ("0", "1", "2") else 1)
+def sinkhorn_schedule(mode=None, wait_ms=None):
+    """The `schedule` argument of gf_sinkhorn_fwd / _bwd (include/gf_amd.h): mode 0 = streaming kernels only, 1 = chip-resident
+    sweeps from 5 pairs per launch (default), 2 = resident whenever the problem fits (csrc/sinkhorn_resident.h); wait_ms = bound
+    of every inter-workgroup wait of the resident kernel (default 10 s; a pair whose wait expires comes out as NaN).
+    Host-side knobs GF_SINKHORN_RESIDENT / GF_SINKHORN_WAIT_MS fill what the caller leaves open (the library itself reads no
+    environment and keeps no setting)."""
+    if mode is None:
+        m = os.environ.get("GF_SINKHORN_RESIDENT", "1")
+        mode = int(m) if m in ("0", "1", "2") else 1
+    if wait_ms is None:
+        w = os.environ.get("GF_SINKHORN_WAIT_MS", "0")
+        wait_ms = int(w) if w.isdigit() else 0
+    if mode not in (0, 1, 2) or not 0 <= wait_ms < (1 << 23):
+        raise ValueError("sinkhorn_schedule: mode in {0, 1, 2}, 0 <= wait_ms < 2^23")
+    return int(mode) | (int(wait_ms) << 8)
 
 
-def sinkhorn(Z, iters):
-    return _Sinkhorn.apply(Z, iters)
+def sinkhorn(Z, iters, schedule=None):
+    return _Sinkhorn.apply(Z, iters, sinkhorn_schedule() if schedule is None else int(schedule))
 
 
 # ------------------------------------------------------------------------------ BatchNorm1d (+ReLU)

@@ -7,7 +7,8 @@
  *
  * Conventions
  *  - Plain pointers to DEVICE memory owned by the caller (PyTorch's caching allocator in the
- *    shipped host code); the library allocates nothing and keeps no global state.
+ *    shipped host code); the library allocates nothing and keeps no global state (ABI 14: the
+ *    Sinkhorn schedule, the last process-wide setting, became an argument of the calls).
  *  - `stream` is a hipStream_t passed as void*; every call only enqueues kernels on it (no host
  *    synchronisation, hipGraph-capturable).
  *  - `dtype`: GF_DTYPE_F32 (exact fp32 MFMA, parity mode) or GF_DTYPE_BF16 (bf16 operands, fp32
@@ -35,9 +36,13 @@ extern "C" {
 #define GF_ERR_ALIGN (-3)
 #define GF_ERR_DTYPE (-4)
 
-/* ABI version; bumped on any signature or workspace-size change (2: gf_attn_bwd's delta workspace doubled; 3: line head + gf_bgemm; 4: smallops; 5: gf_attn_bwd_acc; 9: cast entries with leading dimensions, gf_fold_linear_*, double betas in gf_multi_adam; 10: gf_attn_fwd_ex / GF_ATTN_SPLIT, gf_topk_candidates). */
-#define GF_AMD_ABI_VERSION 13
+/* ABI version; bumped on any signature or workspace-size change (2: gf_attn_bwd's delta workspace doubled; 3: line head + gf_bgemm; 4: smallops; 5: gf_attn_bwd_acc; 9: cast entries with leading dimensions, gf_fold_linear_*, double betas in gf_multi_adam; 10: gf_attn_fwd_ex / GF_ATTN_SPLIT, gf_topk_candidates; 14: gf_sinkhorn_* take `schedule`, gf_sinkhorn_mode removed, gf_probe_hold_cus). */
+#define GF_AMD_ABI_VERSION 14
 int gf_abi_version(void);
+/* Diagnostics (tests/test_gpu_sinkhorn_safety.py): occupies `n_cus` compute units (one 150 KB-LDS workgroup each) for
+ * `milliseconds` (<= 5000) on `stream` -- the stand-in for "another stream's kernel holds part of the chip" (an RCCL
+ * reduction, a second process) under which the chip-resident Sinkhorn's bounded waits are tested. */
+int gf_probe_hold_cus(int n_cus, int milliseconds, void* stream);
 
 /* ---- multi-head attention over keypoints --------------------------------------------------
  * softmax(scale * q k^T) v, flash style (no N x N tensor in HBM).
@@ -186,21 +191,23 @@ int gf_filter_matches(const float* max0, const int64_t* arg0, const int64_t* arg
  * Two schedules of the same recurrence: streaming kernels (one sweep of Z per iteration, two launches each) and, for
  * N % 256 == 0, N <= 2048, chip-resident sweeps (a chunk of <= 8-16 pairs is loaded once and stays in registers + LDS for
  * all iterations, one persistent launch per chunk with per-pair workgroup barriers; csrc/sinkhorn_resident.h).
- * gf_sinkhorn_mode(mode): 0 = streaming only, 1 = resident from 5 pairs per launch (default), 2 = resident whenever the
- * problem fits; any other value only queries.  Returns the previous mode.  Process-wide, not thread-safe. */
-int gf_sinkhorn_mode(int mode);
+ * `schedule` (per call; the library keeps no setting): bits 0-1 = 0 streaming only, 1 resident from 5 pairs per launch (the host
+ * code's default), 2 resident whenever the problem fits; bits 8-31 = bound of every inter-workgroup wait of the resident
+ * kernel in milliseconds (0 = 10 000).  The resident kernel's workgroups need not be co-resident (a CU held by another
+ * stream's kernel only delays them); when a wait outlasts the bound, the pair's out / gZ is NaN in every row -- a loud,
+ * skippable failure (train.py:477-480), never a silently wrong number or a hung device.  Same `schedule` for fwd and bwd. */
 /* Host-only query (no device needed): the chip-resident distribution for this problem on a device of `ncu` compute units:
  * out[8] = {pairs per launch, workgroups per pair, waves per pair, rows per wave, waves holding one more row, float4 columns
  * per workgroup in the column phase, N / 256, dynamic LDS bytes}.  1 = resident path (out filled), 0 = streaming kernels. */
-int gf_sinkhorn_plan(int B, int M, int N, int ncu, int backward, int64_t* out);
+int gf_sinkhorn_plan(int B, int M, int N, int ncu, int backward, int schedule, int64_t* out);
 int64_t gf_sinkhorn_ws_bytes(int B, int M, int N, int iters);
 int gf_sinkhorn_fwd(const float* Z, float* out, float* u_hist, float* v_hist, void* ws,
-                    int B, int M, int N, int iters, void* stream);
+                    int B, int M, int N, int iters, int schedule, void* stream);
 /* Backward: gout [B,M+1,N+1] and its row / column sums gsum_row [B,M+1], gsum_col [B,N+1]
  * -> gZ [B,M+1,N+1] (the caller reduces the bin row/column/corner of gZ to d bin_score). */
 int gf_sinkhorn_bwd(const float* Z, const float* gout, const float* gsum_row, const float* gsum_col,
                     const float* u_hist, const float* v_hist, float* gZ, void* ws,
-                    int B, int M, int N, int iters, void* stream);
+                    int B, int M, int N, int iters, int schedule, void* stream);
 
 /* ---- GlueStick line message passing (gluestick.py:589-691): endpoints e = 0..E-1 (E = 2 Nl, partner e ^ 1) sit on
  * junctions idx[b, e] in [0, N).

@@ -149,7 +149,7 @@ def test_sinkhorn_resident_plan_is_consistent():
         for M in (255, 1000, 2048):
             for N in (256, 512, 1024, 1280, 2048):
                 for bwd in (0, 1):
-                    ok = L.gf_sinkhorn_plan(B, M, N, 256, bwd, out)
+                    ok = L.gf_sinkhorn_plan(B, M, N, 256, bwd, 1, out)
                     assert ok in (0, 1)
                     if B < 5:
                         assert ok == 0                                    # few pairs stay on the streaming kernels
@@ -169,6 +169,6 @@ def test_sinkhorn_resident_plan_is_consistent():
                     nch = -(-B // bc)
                     assert (nch - 1) * bc < B <= nch * bc
     assert seen > 50
-    assert L.gf_sinkhorn_plan(32, 2048, 2048, 256, 0, out) == 1 and tuple(out)[:5] == (8, 32, 128, 16, 1)
-    assert L.gf_sinkhorn_plan(32, 2048, 2050, 256, 0, out) == 0                      # N % 256 != 0: streaming
-    assert L.gf_sinkhorn_plan(32, 2048, 2304, 256, 0, out) == 0                      # N / 256 > 8
+    assert L.gf_sinkhorn_plan(32, 2048, 2048, 256, 0, 1, out) == 1 and tuple(out)[:5] == (8, 32, 128, 16, 1)
+    assert L.gf_sinkhorn_plan(32, 2048, 2050, 256, 0, 1, out) == 0                      # N % 256 != 0: streaming
+    assert L.gf_sinkhorn_plan(32, 2048, 2304, 256, 0, 1, out) == 0                      # N / 256 > 8
