@@ -87,7 +87,7 @@ def parse():
     ap.add_argument("--sinkhorn-iters", type=int, default=100)
     ap.add_argument("--no-graph", action="store_true", help="launch the step kernel by kernel instead of replaying a hipGraph")
     ap.add_argument("--matcher-only", action="store_true", help="skip the extractor: scope M becomes the only line")
-    ap.add_argument("--dp-graph", action="store_true", help="N > 1: capture the multi-rank step (bucketed RCCL all-reduces included) as a hipGraph")
+    ap.add_argument("--dp-graph", action="store_true", help="(accepted for compatibility; N > 1 always measures kernel-by-kernel first and then tries the captured step)")
     return ap.parse_args()
 
 
@@ -460,14 +460,12 @@ def build_matcher(args, rank, name, conf=None):
 
 
 def make_stepper(args, model, local, allow_graph=True):
+    """TrainStep around `model`.  One process: the whole step is captured once and replayed as a hipGraph.  Several ranks:
+    main() measures the step launched kernel by kernel FIRST (bucketed all-reduces overlapped from autograd hooks: plain
+    torch.distributed calls, the safe path) and then tries the CAPTURED bucket-reducer step (collectives inside the
+    hipGraph, RCCL only) under a watchdog -- `allow_graph` selects which of the two this stepper is."""
     from glue_factory_amd.train_step import TrainStep
-    import torch.distributed as dist_
-    single = not (dist_.is_available() and dist_.is_initialized() and dist_.get_world_size() > 1)
-    # one process: the whole matcher step is captured once and replayed as a hipGraph (TrainStep(graph=True)).  Several
-    # ranks: the bucket reducer's collectives are capturable on RCCL, but that path has never run on hardware (1-GPU
-    # test boxes), so the multi-rank capture is opt-in (--dp-graph) and the default launches the step kernel by kernel
-    # with the bucketed all-reduces overlapped from autograd hooks.
-    graph = (single or args.dp_graph) and allow_graph and not args.no_graph
+    graph = allow_graph and not args.no_graph
     # Adam as ONE table-driven launch per 80 tensors (glue_factory_amd.optim.FusedAdam = torch.optim.Adam's numbers;
     # torch's own fused kernel needs 7 launches and 0.5 ms for these 12 M parameters)
     from glue_factory_amd.optim import FusedAdam
@@ -476,7 +474,37 @@ def make_stepper(args, model, local, allow_graph=True):
                      graph=graph)
 
 
-def make_pipeline_step(args, rank, local):
+def scope_p_inputs(batch, rank):
+    """a batch of synthetic images ~U(0,1) [B,1,IMG,IMG], a homography per pair SAMPLED like the reference's
+    homography dataset does (corner perturbation of the full frame: datasets/homographies.py:37-44 ->
+    geometry/homography.py:40-67 sample_homography_corners; here
+    every corner moves by up to 12 % of the image side, seeded), and the second view = the first WARPED by it (bilinear,
+    zeros outside) -- generated here, outside every timed region, resident in HBM.  H_0to1 maps view0 pixels to view1."""
+    g = torch.Generator(device="cuda").manual_seed(7 + rank)
+    img0 = torch.rand(batch, 1, IMG, IMG, device="cuda", generator=g)
+    side = float(IMG)
+    src = torch.tensor([[0.0, 0.0], [side, 0.0], [side, side], [0.0, side]], device="cuda")[None].repeat(batch, 1, 1)
+    dst = src + (torch.rand(batch, 4, 2, device="cuda", generator=g) - 0.5) * 0.24 * side
+    # DLT: the 8 x 8 system of the four corner correspondences (fp64)
+    x, y, u, v = src[..., 0].double(), src[..., 1].double(), dst[..., 0].double(), dst[..., 1].double()
+    z, o = torch.zeros_like(x), torch.ones_like(x)
+    A = torch.cat([torch.stack([x, y, o, z, z, z, -u * x, -u * y], -1), torch.stack([z, z, z, x, y, o, -v * x, -v * y], -1)], 1)
+    h = torch.linalg.solve(A, torch.cat([u, v], 1)[..., None])[..., 0]
+    H = torch.cat([h, torch.ones(batch, 1, device="cuda", dtype=torch.float64)], 1).reshape(batch, 3, 3)
+    # view1(p1) = view0(H^-1 p1): sample view0 at the back-projected pixel centres
+    ys, xs = torch.meshgrid(torch.arange(IMG, device="cuda", dtype=torch.float64) + 0.5,
+                            torch.arange(IMG, device="cuda", dtype=torch.float64) + 0.5, indexing="ij")
+    p1 = torch.stack([xs, ys, torch.ones_like(xs)], -1).reshape(1, -1, 3)
+    p0 = p1 @ torch.linalg.inv(H).transpose(1, 2)
+    p0 = p0[..., :2] / p0[..., 2:]
+    grid = (p0 / side * 2 - 1).reshape(batch, IMG, IMG, 2).float()
+    img1 = torch.nn.functional.grid_sample(img0, grid, mode="bilinear", padding_mode="zeros", align_corners=False)
+    size = torch.tensor([[side, side]], device="cuda").repeat(batch, 1)
+    return {"view0": {"image": img0, "image_size": size}, "view1": {"image": img1.contiguous(), "image_size": size.clone()},
+            "H_0to1": H.float()}
+
+
+def make_pipeline_step(args, rank, local, graph=True):
     """Scope P through the product API: ``glue_factory_amd.pipeline.TwoViewPipeline`` (frozen SuperPoint-open extractor ->
     homography ground truth -> LightGlue) inside ``TrainStep`` -- forward, ground truth, loss, backward and the fused Adam
     update of one step, captured as ONE hipGraph (the extractor's top-k is csrc/topk.hip: a captured extractor tail
@@ -489,12 +517,8 @@ def make_pipeline_step(args, rank, local):
         "ground_truth": {"name": "matchers.homography_matcher", "th_positive": 3.0, "th_negative": 3.0, "with_reward": False},
         "matcher": {"name": "matchers.lightglue", "n_layers": args.layers, "filter_threshold": 0.1},
     }).cuda()
-    stepper = make_stepper(args, pipe, local, allow_graph=True)
-    g = torch.Generator(device="cuda").manual_seed(7 + rank)
-    img0 = torch.rand(args.batch, 1, IMG, IMG, device="cuda", generator=g)
-    size = torch.tensor([[float(IMG), float(IMG)]], device="cuda").repeat(args.batch, 1)
-    data = {"view0": {"image": img0, "image_size": size}, "view1": {"image": img0.roll(8, -1), "image_size": size.clone()},
-            "H_0to1": torch.tensor([[1.0, 0, 8], [0, 1, 0], [0, 0, 1]], device="cuda")[None].repeat(args.batch, 1, 1)}
+    stepper = make_stepper(args, pipe, local, allow_graph=graph)
+    data = scope_p_inputs(args.batch, rank)
     images = torch.cat([data["view0"]["image"], data["view1"]["image"]], 0)
     state = {"data": data}
 
@@ -580,6 +604,60 @@ def data_parallel_report(dist, rank, world, stepper):
     return out
 
 
+DP_GRAPH_TIMEOUT_S = 240.0
+
+
+class _Watchdog:
+    """N > 1 only: bounds the attempt to run the multi-rank step as a captured hipGraph.  On expiry rank 0 prints the line
+    it already has (the kernel-by-kernel numbers) and every rank leaves with exit code 0 -- a hung collective must not cost
+    the measurement that was already taken."""
+
+    def __init__(self, seconds, line):
+        import threading
+        self._line = line
+        self._t = threading.Timer(seconds, self._expire)
+        self._t.daemon = True
+        self._t.start()
+
+    def _expire(self):
+        if self._line is not None:
+            print(json.dumps(self._line), flush=True)
+        os._exit(0)
+
+    def cancel(self):
+        self._t.cancel()
+
+
+def build_line(args, world, matcher, pipe_res, dp_info, dp_modes, pairs):
+    """The ONE JSON line of the contract from what has been measured so far."""
+    extra = {}
+    if dp_info is not None:
+        extra["data_parallel"] = dict(dp_info, **({"step_launch_modes": dp_modes} if dp_modes else {}))
+    if pipe_res is None:
+        return {"metric": f"image-pairs/sec (train step) {args.model} matcher only", "n_gpus": world,
+                "warmup": args.warmup, "dtype": args.dtype, "data": "synthetic",
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "config": {"workload": f"{args.model} matcher train step, {args.batch} pairs/GPU, N={args.kpts}"},
+                **extra, **matcher}
+    p_dt, p_loss, p_stepper, _ = pipe_res
+    return {
+        "metric": "image-pairs/sec (train step) SP+LightGlue N=2048 d=256 L=9",
+        "value": round(pairs / p_dt, 2), "unit": "image-pairs/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(p_dt / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "configs[1]: SuperPoint + LightGlue train step -- frozen SuperPoint-open forward on 2x32 "
+                               f"synthetic {IMG}x{IMG} images resident in HBM (view1 = view0 warped by a sampled homography, SURVEY 8(d)(P); "
+                               "first block and the 64-channel 3x3 blocks as fused HIP "
+                               "kernels, library convolutions + fused HIP tails for the 128/256-channel blocks), homography "
+                               "ground truth (gf_gt_nn), LightGlue fwd + loss + bwd + fused Adam; glue_factory_amd.pipeline."
+                               "TwoViewPipeline inside TrainStep, the whole step "
+                               + ("replayed as ONE hipGraph" if p_stepper.graph else "launched kernel by kernel"),
+                   "pairs_per_gpu": args.batch, "global_batch": args.batch * world, "keypoints": args.kpts,
+                   "descriptor_dim": DIM, "layers": args.layers, "image_size": [IMG, IMG], "parallelism": f"dp{world}"},
+        "final_loss": round(p_loss, 4), "matcher_step": matcher, **extra}
+
+
 def self_spawn(args):
     """`python bench.py --gpus N` without a torchrun environment: launch N ranks of this file on one node."""
     with socket.socket() as s:
@@ -629,62 +707,83 @@ def main():
         torch.cuda.synchronize()
 
     model, cpu_data = build_matcher(args, rank, args.model)
-    stepper = make_stepper(args, model, local, allow_graph=True)
     data = to_device(cpu_data, "cuda")
-
-    def matcher_step():
-        return stepper(data)["total"].mean()
-
     headline_is_pipeline = args.model == "lightglue" and not args.matcher_only
-    m_dt, m_loss = timed_steps(matcher_step, args.warmup, args.steps, barrier, dist)
     pairs = args.batch * world * args.steps
-    matcher = {"value": round(pairs / m_dt, 2), "unit": "image-pairs/s", "ms_per_step": round(m_dt / args.steps * 1e3, 3),
-               "steps": args.steps,
-               "scope": "M: matcher train step (fwd + loss + bwd + Adam) on SuperPoint-shaped keypoint pairs resident in "
-                        "HBM (the reference's cached-feature training mode)",
-               "mfma_frac_step": round(pairs / m_dt * flops_per_pair_train(args.kpts, DIM, args.layers)
-                                       / world / (MFMA_BF16_PEAK_TFLOPS * 1e12), 4),
-               "final_loss": round(m_loss, 4)}
+
+    def matcher_entry(m_dt, m_loss, graphed):
+        return {"value": round(pairs / m_dt, 2), "unit": "image-pairs/s", "ms_per_step": round(m_dt / args.steps * 1e3, 3),
+                "steps": args.steps,
+                "scope": "M: matcher train step (fwd + loss + bwd + Adam) on SuperPoint-shaped keypoint pairs resident in "
+                         "HBM (the reference's cached-feature training mode)",
+                "launch": "one hipGraph replay per step" if graphed else "kernel by kernel",
+                "mfma_frac_step": round(pairs / m_dt * flops_per_pair_train(args.kpts, DIM, args.layers)
+                                        / world / (MFMA_BF16_PEAK_TFLOPS * 1e12), 4),
+                "final_loss": round(m_loss, 4)}
+
+    def measure(graph):
+        """(matcher entry, pipeline (dt, loss, stepper, extract) or None, data-parallel report or None) with every step
+        either launched kernel by kernel or replayed as one hipGraph."""
+        stepper = make_stepper(args, model, local, allow_graph=graph)
+        m_dt, m_loss = timed_steps(lambda: stepper(data)["total"].mean(), args.warmup, args.steps, barrier, dist)
+        m = matcher_entry(m_dt, m_loss, stepper.graph)
+        dp = data_parallel_report(dist, rank, world, stepper) if dist is not None else None
+        if not headline_is_pipeline:
+            stepper.close()
+            return m, None, dp
+        pipeline_step, extract, p_stepper = make_pipeline_step(args, rank, local, graph=graph)
+        pipeline_step()                               # MIOpen's convolution search happens here, outside any timing
+        p_dt, p_loss = timed_steps(pipeline_step, args.warmup, args.steps, barrier, dist)
+        stepper.close()
+        return m, (p_dt, p_loss, p_stepper, extract), dp
+
+    # ---- N = 1: the step is ONE hipGraph.  N > 1: kernel by kernel first (plain torch.distributed calls from autograd
+    # hooks: the path the CPU / single-GPU multi-process tests cover), then -- RCCL only -- the CAPTURED bucket-reducer step
+    # (collectives inside the hipGraph) under a watchdog: if the capture raises, the run falls back to the eager numbers; if
+    # it hangs (a collective inside a capture that one rank abandoned), every rank prints / exits on the eager numbers after
+    # DP_GRAPH_TIMEOUT_S instead of hanging the job.  When both work the line carries both and `value` is the better one.
+    dp_modes = None
+    if dist is None:
+        matcher, pipe_res, dp_info = measure(graph=True)
+    else:
+        matcher, pipe_res, dp_info = measure(graph=False)
+        dp_modes = {"eager": {"matcher_ms_per_step": matcher["ms_per_step"],
+                              **({"pipeline_ms_per_step": round(pipe_res[0] / args.steps * 1e3, 3)} if pipe_res else {})}}
+        try_graph = dist.get_backend() == "nccl" and not args.no_graph
+        if try_graph:
+            eager_line = build_line(args, world, matcher, pipe_res, dp_info, dict(dp_modes, graph={"status": "timed out"}), pairs)
+            dog = _Watchdog(DP_GRAPH_TIMEOUT_S, eager_line if rank == 0 else None)
+            try:
+                g_matcher, g_pipe, _ = measure(graph=True)
+                ok = torch.ones((), device="cuda")
+            except Exception as e:          # capture / replay error on this rank
+                g_matcher = g_pipe = None
+                ok = torch.zeros((), device="cuda")
+                dp_modes["graph"] = {"status": f"failed: {type(e).__name__}: {str(e)[:200]}"}
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)          # every rank must have replayed its graph
+            torch.cuda.synchronize()
+            dog.cancel()
+            if float(ok.item()) > 0:
+                dp_modes["graph"] = {"status": "ok", "matcher_ms_per_step": g_matcher["ms_per_step"],
+                                     **({"pipeline_ms_per_step": round(g_pipe[0] / args.steps * 1e3, 3)} if g_pipe else {})}
+                better = (g_pipe[0] < pipe_res[0]) if pipe_res else (g_matcher["ms_per_step"] < matcher["ms_per_step"])
+                if better:
+                    matcher, pipe_res = g_matcher, g_pipe
+            else:
+                dp_modes.setdefault("graph", {"status": "failed on another rank"})
+        else:
+            dp_modes["graph"] = {"status": "not attempted (" + ("--no-graph" if args.no_graph else
+                                                               f"{dist.get_backend()}: collectives are capturable on RCCL only") + ")"}
+    out = build_line(args, world, matcher, pipe_res, dp_info, dp_modes, pairs)
     if not headline_is_pipeline:
-        dp_m = data_parallel_report(dist, rank, world, stepper) if dist is not None else None
         if rank == 0:
-            print(json.dumps({"metric": f"image-pairs/sec (train step) {args.model} matcher only", "n_gpus": world,
-                              "warmup": args.warmup, "dtype": args.dtype, "data": "synthetic",
-                              "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                              "config": {"workload": f"{args.model} matcher train step, {args.batch} pairs/GPU, N={args.kpts}"},
-                              **({"data_parallel": dp_m} if dp_m is not None else {}), **matcher}), flush=True)
+            print(json.dumps(out), flush=True)
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
         return
-
-    dp_info = None
-    if dist is not None:
-        dp_info = data_parallel_report(dist, rank, world, stepper)
-    pipeline_step, extract, p_stepper = make_pipeline_step(args, rank, local)
-    pipeline_step()                                   # MIOpen's convolution search happens here, outside any timing
-    p_dt, p_loss = timed_steps(pipeline_step, args.warmup, args.steps, barrier, dist)
-    value = pairs / p_dt
-    t_ext = time_kernel(extract, iters=5, warm=1)
-    out = {
-        "metric": "image-pairs/sec (train step) SP+LightGlue N=2048 d=256 L=9",
-        "value": round(value, 2), "unit": "image-pairs/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(p_dt / args.steps * 1e3, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": "configs[1]: SuperPoint + LightGlue train step -- frozen SuperPoint-open forward on 2x32 "
-                               f"synthetic {IMG}x{IMG} images resident in HBM (first block and the 64-channel 3x3 blocks as fused HIP "
-                               "kernels, library convolutions + fused HIP tails for the 128/256-channel blocks), homography "
-                               "ground truth (gf_gt_nn), LightGlue fwd + loss + bwd + fused Adam; glue_factory_amd.pipeline."
-                               "TwoViewPipeline inside TrainStep, the whole step "
-                               + ("replayed as ONE hipGraph" if p_stepper.graph else "launched kernel by kernel"),
-                   "pairs_per_gpu": args.batch, "global_batch": args.batch * world, "keypoints": args.kpts,
-                   "descriptor_dim": DIM, "layers": args.layers, "image_size": [IMG, IMG], "parallelism": f"dp{world}"},
-        "extractor_ms": round(t_ext * 1e3, 2), "final_loss": round(p_loss, 4),
-        "matcher_step": matcher,
-    }
-    if dp_info is not None:
-        out["data_parallel"] = dp_info
+    p_stepper, extract = pipe_res[2], pipe_res[3]
+    out["extractor_ms"] = round(time_kernel(extract, iters=5, warm=1) * 1e3, 2)
     if rank == 0 and world == 1:
         if not args.no_roofline:
             try:
@@ -694,7 +793,7 @@ def main():
             except Exception as e:   # a secondary measurement must never cost the headline line
                 out.setdefault("roofline", {"error": f"{type(e).__name__}: {e}"})
         if not args.no_other_configs:
-            del stepper, model, data, p_stepper, pipeline_step, extract
+            del model, data, p_stepper, extract, pipe_res
             torch.cuda.empty_cache()
             oc = {}
             for name in ("superglue", "gluestick"):

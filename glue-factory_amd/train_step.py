@@ -16,7 +16,8 @@ bucket's last gradient exists (buckets follow the backward: assignment / confide
 runs under the transformer backward), on the process group's own stream.  Unlike DistributedDataParallel's C++ reducer
 this is a fixed sequence of kernels and collectives with no host decisions, i.e. it can be CAPTURED: with the
 ``nccl`` (= RCCL) backend ``graph=True`` replays the multi-rank step -- collectives included -- as one hipGraph.
-``reducer="ddp"`` keeps the stock wrapper (never captured) for comparison.
+``reducer="ddp"`` keeps the stock wrapper (never captured) for comparison; ``reducer="buckets_bound"`` pre-binds ``p.grad`` to the
+flat buffer (no per-bucket copy; see GradBuckets).
 
 The same code runs on CPU with the ``gloo`` backend for tests (any module with the
 forward/loss interface), and on GPUs with ``nccl`` (= RCCL on ROCm).
@@ -89,11 +90,18 @@ class GradBuckets:
       bucket order, so every rank issues the same sequence of collectives whatever order its autograd engine ran in;
     * ``finish()`` issues whatever is left (parameters that received no gradient contribute zeros), waits for the
       collectives (a stream dependency on NCCL/RCCL, not a host sync) and re-points ``p.grad`` at the flat views.
-    The loss is pre-divided by the world size, so SUM yields DDP's average."""
+    The loss is pre-divided by the world size, so SUM yields DDP's average.
 
-    def __init__(self, params, cap_mb=16, extra=1, group=None):
+    ``bind_grads`` (reducer="buckets_bound"): ``p.grad`` IS the flat view from ``start()`` on -- autograd accumulates into
+    the (zeroed) buffer in place and the per-bucket copy disappears.  Same numbers (tests/test_ddp_gloo.py,
+    tests/test_gpu_ddp.py run both).  NOT the default: the copy variant moves 2 x 47 MB per LightGlue step (one read of the
+    freshly produced gradients, one write of the flat buffer, ~25 us at 4 TB/s), the bound variant 4 x (zero fill + read
+    view + read gradient + write view), because autograd's AccumulateGrad adds into a defined ``.grad``."""
+
+    def __init__(self, params, cap_mb=16, extra=1, group=None, bind_grads=False):
         self.params = [p for p in params if p.requires_grad]
         self.group = group
+        self.bind_grads = bool(bind_grads)
         dev = self.params[0].device
         order = list(reversed(self.params))
         total = sum(p.numel() for p in order)
@@ -119,6 +127,16 @@ class GradBuckets:
     def start(self):
         self._count, self._next, self._work = [0] * len(self.buckets), 0, []
         self._active = True
+        if self.bind_grads:
+            self.flat[:self.flat.numel() - self.extra.numel()].zero_()
+            for p in self.params:
+                p.grad = self.views[p]
+
+    def close(self):
+        """Detach from the parameters (hooks removed): a second reducer may now own them."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks, self._active = [], False
 
     def _arrived(self, p):
         if not self._active:
@@ -132,8 +150,9 @@ class GradBuckets:
     def _launch(self, b):
         lo, hi, ps = self.buckets[b]
         have = [p for p in ps if p.grad is not None]
-        if len(have) != len(ps):
+        if len(have) != len(ps) and not self.bind_grads:
             self.flat[lo:hi - (self.extra.numel() if b == len(self.buckets) - 1 else 0)].zero_()
+        have = [p for p in have if p.grad.data_ptr() != self.views[p].data_ptr()]      # (bound gradients are already in place)
         if have:
             torch._foreach_copy_([self.views[p] for p in have], [p.grad for p in have])
         self._work.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
@@ -176,8 +195,11 @@ class TrainStep:
                 self.fwd_model = DDP(model, device_ids=device_ids, bucket_cap_mb=bucket_cap_mb,
                                      gradient_as_bucket_view=True,
                                      find_unused_parameters=find_unused_parameters)
+            elif reducer in ("buckets", "buckets_bound"):
+                self.buckets = GradBuckets(model.parameters(), cap_mb=bucket_cap_mb, extra=1,
+                                           bind_grads=reducer == "buckets_bound")
             else:
-                self.buckets = GradBuckets(model.parameters(), cap_mb=bucket_cap_mb, extra=1)
+                raise ValueError(f"TrainStep: unknown reducer {reducer!r} (buckets, buckets_bound, ddp)")
         p = next(model.parameters())
         self.device_type = p.device.type
         self.check_grads = check_grads
@@ -197,6 +219,12 @@ class TrainStep:
         self.graph_warmup = graph_warmup
         self._calls = 0
         self._g = None            # (shape signature, CUDAGraph, static inputs, static outputs)
+
+    def close(self):
+        """Release what the step holds on the model (gradient hooks of the bucket reducer, the captured graph)."""
+        if self.buckets is not None:
+            self.buckets.close()
+        self._g = None
 
     def _device_skip_supported(self):
         """Fused CUDA optimisers take a device-side ``found_inf`` flag (the GradScaler protocol): the update is
@@ -240,7 +268,9 @@ class TrainStep:
         static_in = _clone_tree(data)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # several ranks: RCCL's watchdog thread polls events while this thread captures -- only THIS thread's calls belong to
+        # (and may invalidate) the capture
+        with torch.cuda.graph(g, capture_error_mode="thread_local" if self.distributed else "global"):
             static_out = self._step(static_in)
         self._g = (sig, g, static_in, static_out)
 
