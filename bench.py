@@ -278,6 +278,31 @@ def roofline_extra(batch, n, dtype):
                       "achieved": round(byt / t / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                       "frac": round(byt / t / 1e9 / HBM_PEAK_GBS, 4), "traffic": _traffic("gemm_st_kernel"),
                       "launch_ms": round(t * 1e3, 4), "algorithmic_bytes_per_launch": byt}
+    # assignment-head similarity passes (csrc/assignment.hip; lightglue.py:256-290, 68-94): every pass recomputes the N x N
+    # similarity of a pair on MFMA (2 N^2 d FLOP) and reduces it on the fly -- no N x N tensor exists.  A LightGlue step runs
+    # 28 such forward passes (3 per layer: column LSE, row LSE + row arg-max, column arg-max; + the assignment write) and 18
+    # backward ones; DESIGN.md section 4 says why the three dependent forward passes are not two.
+    md = (torch.randn(2 * batch, n, 256, device="cuda", generator=g) * 0.5).to(dtype)
+    a_, b_ = md[:batch], md[batch:]
+    zb = torch.randn(batch, n, device="cuda", generator=g)
+    fl = 2.0 * batch * n * n * 256
+    t1 = time_kernel(lambda: ops.rows_lse(b_, a_), iters=20)
+    cl = ops.rows_lse(b_, a_)
+    v0 = torch.empty(batch, n, device="cuda")
+    a0 = torch.empty(batch, n, dtype=torch.int64, device="cuda")
+    r0 = torch.empty(batch, n, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    dt_code = 1 if dtype == torch.bfloat16 else 0
+    t2 = time_kernel(lambda: lib.gf_rows_lse_argmax(a_.data_ptr(), b_.data_ptr(), zb.data_ptr(), cl.data_ptr(), 2.0, r0.data_ptr(),
+                                                    v0.data_ptr(), a0.data_ptr(), batch, n, n, 256, dt_code, st), iters=20)
+    out["head_pass"] = {"bound": "mfma", "kernel": f"rows_lse_kernel / rows_lse_argmax_kernel (B={batch} pairs, {n} x {n} x 256)",
+                        "achieved": round(fl / t1 / 1e12, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(fl / t1 / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4), "launch_ms": round(t1 * 1e3, 4),
+                        "rows_lse_argmax": {"achieved": round(fl / t2 / 1e12, 1), "frac": round(fl / t2 / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                                            "launch_ms": round(t2 * 1e3, 4)},
+                        "traffic": _traffic("rows_lse_kernel"), "algorithmic_flop_per_launch": fl,
+                        "passes_per_lightglue_step": {"forward": 28, "backward": 18}}
+    del md, a_, b_
     if dtype == torch.bfloat16:
         # calibration, not a product kernel: what the vendor library's plain bf16 GEMM reaches on THIS box in THIS process
         # (the part clocks down under sustained MFMA load; DESIGN.md section 5 reads the attention fractions against it)
