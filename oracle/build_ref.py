@@ -26,7 +26,10 @@ TARGETS = ["gluefactory.models.matchers.lightglue", "gluefactory.models.utils.lo
            "gluefactory.models.utils.metrics", "gluefactory.models.base_model", "gluefactory.models",
            # the CALLERS of the plugin boundary (two_view_pipeline.py:70-113, triplet_pipeline.py:23-99): the GPU tests drive
            # the HIP matchers through the reference's own pipeline code (tests/test_gpu_reference_boundary.py)
-           "gluefactory.models.two_view_pipeline", "gluefactory.models.triplet_pipeline"]
+           "gluefactory.models.two_view_pipeline", "gluefactory.models.triplet_pipeline",
+           # the train loop itself (train.py:216-683: dataset -> loader -> autocast -> GradScaler -> clip -> optimiser ->
+           # scheduler -> validation -> checkpoint) driving the HIP matcher: tests/test_gpu_reference_train.py
+           "gluefactory.train"]
 
 
 def _closure(targets):

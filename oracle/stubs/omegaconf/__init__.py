@@ -20,8 +20,20 @@ class DictConfig(dict):
     def __init__(self, d=None):
         super().__init__()
         object.__setattr__(self, "_flags", {"struct": False, "readonly": False})
-        for k, v in (d or {}).items():
-            dict.__setitem__(self, k, _wrap(v))
+        for k in (d or {}):
+            dict.__setitem__(self, k, _wrap(dict.__getitem__(d, k)))
+
+    def items(self):                                   # (raw values: copying / merging must not trip over "???")
+        return [(k, dict.__getitem__(self, k)) for k in self]
+
+    def values(self):
+        return [dict.__getitem__(self, k) for k in self]
+
+    def __getitem__(self, k):
+        v = dict.__getitem__(self, k)
+        if isinstance(v, str) and v == "???":          # omegaconf's mandatory-value marker
+            raise MissingMandatoryValue(f"Missing mandatory value: {k}")
+        return v
 
     def __getattr__(self, k):
         try:
@@ -43,7 +55,10 @@ class DictConfig(dict):
         return DictConfig(copy.deepcopy(_unwrap(self)))
 
     def get(self, k, default=None):
-        return self[k] if k in self else default
+        if k not in self:
+            return default
+        v = dict.__getitem__(self, k)
+        return default if isinstance(v, str) and v == "???" else v
 
 
 def _wrap(v):
@@ -58,7 +73,7 @@ def _wrap(v):
 
 def _unwrap(v):
     if isinstance(v, dict):
-        return {k: _unwrap(x) for k, x in v.items()}
+        return {k: _unwrap(dict.__getitem__(v, k)) for k in v}
     if isinstance(v, (list, tuple)):
         return [_unwrap(x) for x in v]
     return v
@@ -66,9 +81,10 @@ def _unwrap(v):
 
 def _merge(a, b):
     out = DictConfig(_unwrap(a))
-    for k, v in b.items():
-        if k in out and isinstance(out[k], dict) and isinstance(v, dict):
-            dict.__setitem__(out, k, _merge(out[k], v))
+    for k in b:
+        v = dict.__getitem__(b, k)
+        if k in out and isinstance(dict.__getitem__(out, k), dict) and isinstance(v, dict):
+            dict.__setitem__(out, k, _merge(dict.__getitem__(out, k), v))
         else:
             if a._flags["struct"] and k not in out:
                 raise AttributeError(f"unknown key {k}")
