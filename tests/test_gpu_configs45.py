@@ -19,13 +19,16 @@ from config_golden import (check_la_digest, grad_digest_errors, gs_config_inputs
 
 pytestmark = pytest.mark.gpu
 
-# ---- stated bf16 bounds: about 2x what was measured on MI355X (round 3; the measured numbers are printed) ----
-# SuperGlue measured: log_assignment max 0.32 / p99 0.136 / mean 0.027, worst loss entry 3.8e-4, per-tensor gradient error
-# median 2.9 %, worst 9.5 % (gnn.layers.0.attn.proj.0.bias: the query bias, whose gradient is a sum of cancelling terms)
-SG_BF16 = {"la_max": 0.65, "la_p99": 0.28, "la_mean": 0.055, "loss_rel": 2e-3, "grad_rel": 0.20}
-# GlueStick measured: log_assignment max 0.40 / p99 0.22 / mean 0.044, lines 0.41 / 0.20 / 0.055, worst loss entry 4.2e-3,
-# per-tensor gradient error median 7.4 %, worst 20 % (lenc.encoder.4.bias, a 256-vector in front of the 18-layer GNN)
-GS_BF16 = {"la_max": 0.8, "la_p99": 0.4, "la_mean": 0.09, "loss_rel": 1e-2, "grad_rel": 0.35}
+# ---- stated bf16 bounds: 1.5 x the LARGER of the values measured on MI355X in rounds 3-5 (the tests print the measured ones) ----
+# SuperGlue measured (round 3 / round 5 box): log_assignment max 0.32 / 0.25, p99 0.136 / 0.132, mean 0.027 / 0.027, worst loss
+# entry 3.8e-4 / 2.9e-4, per-tensor gradient error median 2.9 % / 2.8 %, worst 9.5 % / 7.8 % (gnn.layers.0.attn.proj.0.bias:
+# the query bias, whose gradient is a sum of cancelling terms).  The reference's OWN mixed precision measures 1.71 / 0.43 /
+# 0.081 and 13.9 % against its fp32 run (profiles/r04_reference_amp_*.txt).
+SG_BF16 = {"la_max": 0.48, "la_p99": 0.21, "la_mean": 0.042, "loss_rel": 6e-4, "grad_rel": 0.145}
+# GlueStick measured: log_assignment max 0.40 / 0.36, p99 0.22 / 0.195, mean 0.044 / 0.041, lines 0.41 / 0.35, 0.20 / 0.18,
+# 0.055 / 0.055, worst loss entry 4.2e-3 / 3.3e-3, per-tensor gradient error median 7.4 % / 6.7 %, worst 20 % / 19 %
+# (lenc.encoder.4.bias / gnn.layers.3.update.attn.proj.0.bias); the reference's own AMP: 1.60 / 0.50 / 0.107 and 33 %.
+GS_BF16 = {"la_max": 0.62, "la_p99": 0.33, "la_mean": 0.083, "loss_rel": 6.5e-3, "grad_rel": 0.30}
 
 
 def _cuda(d):
