@@ -37,7 +37,7 @@ __device__ __forceinline__ void store8(float* p, const float (&x)[8]) {
 // qkv: [B*N, 3, H, D]; lane -> (half = q|k, pair i); loop over heads.
 template <typename T, bool INVERSE, bool WITH_DTHETA>
 __global__ __launch_bounds__(256) void rotary_kernel(T* qkv, const T* yrot, const float* cs, float* dtheta,
-                                                     int64_t tokens, int H, int D) {
+                                                     const float* dtheta_base, int64_t tokens, int H, int D) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int npair = D / 2;
@@ -67,10 +67,10 @@ __global__ __launch_bounds__(256) void rotary_kernel(T* qkv, const T* yrot, cons
                 // npair == 64 (head_dim 128): THIS lane visits (q, i) at w = lane and (k, i) at w = lane + 64.
                 float other = __shfl(acc, (lane + npair) & 63);
                 if (2 * npair <= 64) {
-                    if (half == 0) dtheta[tok * npair + i] = acc + other;
+                    if (half == 0) dtheta[tok * npair + i] = acc + other + (dtheta_base ? dtheta_base[tok * npair + i] : 0.f);
                 } else {
                     if (half == 0) carry = acc;
-                    else dtheta[tok * npair + i] = carry + acc;
+                    else dtheta[tok * npair + i] = carry + acc + (dtheta_base ? dtheta_base[tok * npair + i] : 0.f);
                 }
             }
         }
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void rotary_kernel(T* qkv, const T* yrot, cons
 // over the 2H lanes that share the same channel chunk (lane bits >= log2(D/8)).
 template <typename T, bool INVERSE, bool WITH_DTHETA>
 __global__ __launch_bounds__(256) void rotary_vec_kernel(T* qkv, const T* yrot, const float* cs, float* dtheta,
-                                                         int64_t tokens, int H, int D) {
+                                                         const float* dtheta_base, int64_t tokens, int H, int D) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int W = 2 * H * D / 8, cpd = D / 8;           // work items per token, chunks per head
     const bool active = lane < W;
@@ -117,6 +117,8 @@ __global__ __launch_bounds__(256) void rotary_vec_kernel(T* qkv, const T* yrot, 
                 for (int off = cpd; off < 64; off <<= 1) acc[i] += __shfl_xor(acc[i], off);
             if (lane < cpd) {
                 f32x4 v = {acc[0], acc[1], acc[2], acc[3]};
+                // the angles are shared by every layer: the running sum of the layers behind this one rides along
+                if (dtheta_base) v += *reinterpret_cast<const f32x4*>(dtheta_base + tok * (D / 2) + lane * 4);
                 *reinterpret_cast<f32x4*>(dtheta + tok * (D / 2) + lane * 4) = v;
             }
         }
@@ -412,7 +414,7 @@ extern "C" int gf_rotary_qk(void* qkv, const float* cs, int B, int N, int H, int
     int64_t tokens = (int64_t)B * N;
     int nb = (int)((tokens + 3) / 4 > 8192 ? 8192 : (tokens + 3) / 4);
     const bool vec = rotary_vec_ok(H, D);
-#define GF_ROT(K, T, INV) K<T, INV, false><<<nb, 256, 0, st>>>((T*)qkv, nullptr, cs, nullptr, tokens, H, D)
+#define GF_ROT(K, T, INV) K<T, INV, false><<<nb, 256, 0, st>>>((T*)qkv, nullptr, cs, nullptr, nullptr, tokens, H, D)
     if (dtype == GF_F32) {
         if (vec) { if (inverse) GF_ROT(rotary_vec_kernel, float, true); else GF_ROT(rotary_vec_kernel, float, false); }
         else { if (inverse) GF_ROT(rotary_kernel, float, true); else GF_ROT(rotary_kernel, float, false); }
@@ -424,7 +426,7 @@ extern "C" int gf_rotary_qk(void* qkv, const float* cs, int B, int N, int H, int
     return (int)hipGetLastError();
 }
 
-extern "C" int gf_rotary_qk_bwd(void* dqkv, const void* qkv_rot, const float* cs, float* dtheta,
+extern "C" int gf_rotary_qk_bwd(void* dqkv, const void* qkv_rot, const float* cs, float* dtheta, const float* dtheta_base,
                                 int B, int N, int H, int D, int dtype, void* stream) {
     if (B <= 0 || N <= 0 || H <= 0 || D <= 0 || (D & 1)) return GF_ERR_SHAPE;
     if (D > 64 && D != 128) return GF_ERR_UNSUPPORTED;  // the q/k pair reduction stays inside one wave pass (<= 64) or one lane (128)
@@ -433,7 +435,7 @@ extern "C" int gf_rotary_qk_bwd(void* dqkv, const void* qkv_rot, const float* cs
     int64_t tokens = (int64_t)B * N;
     int nb = (int)((tokens + 3) / 4 > 8192 ? 8192 : (tokens + 3) / 4);
     const bool vec = rotary_vec_ok(H, D);
-#define GF_ROTB(K, T) K<T, true, true><<<nb, 256, 0, st>>>((T*)dqkv, (const T*)qkv_rot, cs, dtheta, tokens, H, D)
+#define GF_ROTB(K, T) K<T, true, true><<<nb, 256, 0, st>>>((T*)dqkv, (const T*)qkv_rot, cs, dtheta, dtheta_base, tokens, H, D)
     if (dtype == GF_F32) { if (vec) GF_ROTB(rotary_vec_kernel, float); else GF_ROTB(rotary_kernel, float); }
     else { if (vec) GF_ROTB(rotary_vec_kernel, bf16_t); else GF_ROTB(rotary_kernel, bf16_t); }
 #undef GF_ROTB

@@ -468,10 +468,12 @@ __device__ __forceinline__ void dm_chunk(f32x16 (&acc)[2][2], f32x16 (&bacc)[2],
     }
 }
 
+// x: the X source of THIS k-tile, already offset to its first column; ldx: that source's row stride (two-source calls:
+// tiles left of K1 read x1, the others x2 -- the virtual concatenation [x1 | x2] is never built)
 template <bool BIAS>
-__device__ __forceinline__ void dm_body(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, float* __restrict__ pp,
-                                        float* __restrict__ bp, int M, int Nout, int K, int m_begin, int m_end, int tn,
-                                        int tk) {
+__device__ __forceinline__ void dm_body(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, int ldx,
+                                        float* __restrict__ pp, float* __restrict__ bp, int M, int Nout, int K, int m_begin,
+                                        int m_end, int tn, int tk) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const unsigned lds0 = (unsigned)(size_t)smem;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -482,7 +484,7 @@ __device__ __forceinline__ void dm_body(const bf16_t* __restrict__ dy, const bf1
     const int prow = lane >> 4, pphys = lane & 15;
     const int plog = pphys ^ ((prow & 3) << 2);
     const bf16_t* gA = dy + (int64_t)tn * 128 + plog * 8;
-    const bf16_t* gB = x + (int64_t)tk * 128 + plog * 8;
+    const bf16_t* gB = x + plog * 8;
     auto issue = [&](int c, int stage) {
         char* sb = smem + stage * DM_STAGE;
 #pragma unroll
@@ -490,7 +492,7 @@ __device__ __forceinline__ void dm_body(const bf16_t* __restrict__ dy, const bf1
             const int piece = 2 * wave + i;
             const int64_t row = min(m_begin + c * DM_ROWS + 4 * piece + prow, M - 1);
             __builtin_amdgcn_global_load_lds((dm_glb_void*)(gA + row * Nout), (dm_lds_void*)(sb + piece * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((dm_glb_void*)(gB + row * K), (dm_lds_void*)(sb + DM_TILE + piece * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((dm_glb_void*)(gB + row * ldx), (dm_lds_void*)(sb + DM_TILE + piece * 1024), 16, 0, 0);
         }
     };
     const int nchunk = (m_end - m_begin + DM_ROWS - 1) / DM_ROWS;
@@ -561,6 +563,7 @@ __device__ __forceinline__ void dm_body(const bf16_t* __restrict__ dy, const bf1
 }
 
 __global__ __launch_bounds__(256, 2) void linear_dw_dma_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                               const bf16_t* __restrict__ x2, int K1,
                                                                float* __restrict__ part, float* __restrict__ bpart,
                                                                int M, int Nout, int K, int rows_per_slice) {
     const int ntk = K / 128;
@@ -573,8 +576,14 @@ __global__ __launch_bounds__(256, 2) void linear_dw_dma_kernel(const bf16_t* __r
     if (m_begin >= M) return;
     float* pp = part + (int64_t)slice * Nout * K;
     float* bp = bpart + (int64_t)slice * Nout;
-    if (tk == 0) dm_body<true>(dy, x, pp, bp, M, Nout, K, m_begin, m_end, tn, tk);
-    else dm_body<false>(dy, x, pp, bp, M, Nout, K, m_begin, m_end, tn, tk);
+    const bf16_t* xs = x + (int64_t)tk * 128;
+    int ldx = K;
+    if (x2 != nullptr) {                         // x = [x1 (K1 columns) | x2 (K - K1 columns)], K1 % 128 == 0
+        if (tk * 128 < K1) { ldx = K1; }
+        else { xs = x2 + (int64_t)(tk * 128 - K1); ldx = K - K1; }
+    }
+    if (tk == 0) dm_body<true>(dy, xs, ldx, pp, bp, M, Nout, K, m_begin, m_end, tn, tk);
+    else dm_body<false>(dy, xs, ldx, pp, bp, M, Nout, K, m_begin, m_end, tn, tk);
 }
 
 // Sum of the per-slice partials.  A workgroup covers 64 float4 columns with FOUR slice groups (one per wave,
@@ -657,7 +666,8 @@ extern "C" int64_t gf_linear_dw_ws_bytes(int M, int Nout, int K) {
     return ((int64_t)p.nslice * Nout * K + (int64_t)p.nslice * Nout) * 4 + 256;
 }
 
-int launch_dw_tr(const void* dy, const void* x, float* dw, float* db, void* ws, int M, int Nout, int K, hipStream_t st) {
+int launch_dw_tr(const void* dy, const void* x, float* dw, float* db, void* ws, int M, int Nout, int K, hipStream_t st,
+                 const void* x2 = nullptr, int K1 = 0) {
     DwPlan p = plan(M, Nout, K);
     float* part = reinterpret_cast<float*>(ws);
     float* bpart = part + (int64_t)p.nslice * Nout * K;
@@ -667,13 +677,15 @@ int launch_dw_tr(const void* dy, const void* x, float* dw, float* db, void* ws, 
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)dlds);
         if (e2 != hipSuccess) return (int)e2;
         linear_dw_dma_kernel<<<dim3(p.ntile * ((p.nslice + 7) / 8) * 8), 256, dlds, st>>>(
-            reinterpret_cast<const bf16_t*>(dy), reinterpret_cast<const bf16_t*>(x), part, bpart, M, Nout, K, p.rows);
+            reinterpret_cast<const bf16_t*>(dy), reinterpret_cast<const bf16_t*>(x), reinterpret_cast<const bf16_t*>(x2), K1,
+            part, bpart, M, Nout, K, p.rows);
         if (int e3 = (int)hipGetLastError()) return e3;
         int64_t nw2 = (int64_t)Nout * K;
         const int nwb2 = (int)((nw2 / 4 + 63) / 64), nbb2 = db ? (Nout / 4 + 63) / 64 : 0;
         linear_dw_reduce<<<dim3(nwb2 + nbb2), 256, 0, st>>>(part, bpart, dw, db, p.nslice, nw2, Nout, nwb2);
         return (int)hipGetLastError();
     }
+    if (x2 != nullptr) return GF_ERR_UNSUPPORTED;          // (two sources: 128-multiple shapes only, checked by the caller)
     size_t lds = 4 * (size_t)TR_TILE * sizeof(bf16_t);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_dw_tr_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -684,6 +696,13 @@ int launch_dw_tr(const void* dy, const void* x, float* dw, float* db, void* ws, 
     const int nwb = (int)((nw / 4 + 63) / 64), nbb = db ? (Nout / 4 + 63) / 64 : 0;
     linear_dw_reduce<<<dim3(nwb + nbb), 256, 0, st>>>(part, bpart, dw, db, p.nslice, nw, Nout, nwb);
     return (int)hipGetLastError();
+}
+
+extern "C" int gf_linear_dw2(const void* dy, const void* x1, const void* x2, int K1, float* dw, float* db, void* ws,
+                             int M, int Nout, int K, int dtype, void* stream) {
+    if (M <= 0 || Nout <= 0 || K <= 0 || K1 <= 0 || K1 >= K) return GF_ERR_SHAPE;
+    if (dtype != GF_BF16 || Nout % 128 || K1 % 128 || (K - K1) % 128 || x1 == nullptr || x2 == nullptr) return GF_ERR_UNSUPPORTED;
+    return launch_dw_tr(dy, x1, dw, db, ws, M, Nout, K, reinterpret_cast<hipStream_t>(stream), x2, K1);
 }
 
 extern "C" int gf_linear_dw(const void* dy, const void* x, float* dw, float* db, void* ws,

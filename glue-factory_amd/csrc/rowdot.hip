@@ -13,7 +13,9 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 template <typename T>
 __global__ __launch_bounds__(256) void rowdot_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w, float bias,
-                                                         float* __restrict__ z, int64_t M, int C) {
+                                                         const float* __restrict__ bias_dev, float* __restrict__ z, int64_t M,
+                                                         int C) {
+    if (bias_dev != nullptr) bias += bias_dev[0];          // the module's bias parameter, read on the device (no host sync)
     constexpr int VEC = 16 / sizeof(T);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < M; row += (int64_t)gridDim.x * 4) {
@@ -90,16 +92,17 @@ template <typename T> int rd_check(int C) {
 
 extern "C" int gf_rowdot_nblk(int M) { return rd_blocks(M); }
 
-extern "C" int gf_rowdot_fwd(const void* x, const float* w, float bias, float* z, int M, int C, int dtype, void* stream) {
+extern "C" int gf_rowdot_fwd(const void* x, const float* w, float bias, const float* bias_dev, float* z, int M, int C,
+                             int dtype, void* stream) {
     if (M <= 0 || C <= 0) return GF_ERR_SHAPE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     int nb = (int)(((int64_t)M + 3) / 4 > 4096 ? 4096 : ((int64_t)M + 3) / 4);
     if (dtype == GF_F32) {
         if (int e = rd_check<float>(C)) return e;
-        rowdot_fwd_kernel<float><<<nb, 256, 0, st>>>(reinterpret_cast<const float*>(x), w, bias, z, M, C);
+        rowdot_fwd_kernel<float><<<nb, 256, 0, st>>>(reinterpret_cast<const float*>(x), w, bias, bias_dev, z, M, C);
     } else if (dtype == GF_BF16) {
         if (int e = rd_check<bf16_t>(C)) return e;
-        rowdot_fwd_kernel<bf16_t><<<nb, 256, 0, st>>>(reinterpret_cast<const bf16_t*>(x), w, bias, z, M, C);
+        rowdot_fwd_kernel<bf16_t><<<nb, 256, 0, st>>>(reinterpret_cast<const bf16_t*>(x), w, bias, bias_dev, z, M, C);
     } else return GF_ERR_DTYPE;
     return (int)hipGetLastError();
 }

@@ -63,6 +63,7 @@ SIGNATURES = {
     "gf_gemm": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _L, _L, _L, _I, _P],
     "gf_linear_dw_ws_bytes": [_I, _I, _I],
     "gf_linear_dw": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "gf_linear_dw2": [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P],
     "gf_bn_nblk": [_I],
     "gf_bn_stats": [_P, _P, _I, _I, _I, _P],
     "gf_bn_act_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
@@ -81,14 +82,14 @@ SIGNATURES = {
     "gf_detector_scores": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "gf_sample_descriptors": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "gf_rowdot_nblk": [_I],
-    "gf_rowdot_fwd": [_P, _P, _F, _P, _I, _I, _I, _P],
+    "gf_rowdot_fwd": [_P, _P, _F, _P, _P, _I, _I, _I, _P],
     "gf_rowdot_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "gf_rows_lse_argmax": [_P, _P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "gf_lg_loss_fwd": [_P] * 9 + [_L] + [_P] * 13 + [_I, _I, _I, _I, _I, _P],
     "gf_lg_loss_bwd_tokens": [_P] * 11 + [_L] + [_P] * 7 + [_I, _I, _I, _P],
     "gf_lg_loss_bwd_rows": [_P] * 5 + [_L] + [_P] * 3 + [_I, _I, _I, _I, _I, _P],
     "gf_rotary_qk": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
-    "gf_rotary_qk_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "gf_rotary_qk_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "gf_ln_gelu_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _F, _I, _P],
     "gf_ln_gelu_nblk": [_I],
     "gf_ln_gelu_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],

@@ -137,7 +137,7 @@ class SelfBlock(nn.Module):
         return (self.Wqkv.weight.index_select(0, self._perm) * self._rowscale[:, None],
                 self.Wqkv.bias.index_select(0, self._perm) * self._rowscale)
 
-    def forward(self, x, theta, cs, chain=None):
+    def forward(self, x, theta, cs, chain=None, theta_sum=None):
         b, n, d = x.shape
         w, bias = self._prepared(x.dtype)
         # x feeds the projection, the FFN input and the residual: one gradient chain, closed by the projection (a chain
@@ -147,10 +147,10 @@ class SelfBlock(nn.Module):
         if self.head_dim == 64 and ops.gemm_takes(d, 3 * d, x.dtype):     # q, k leave the GEMM already rotated (rotary epilogue: 64-wide heads)
             qkv = ops.linear(x, w, bias, rotary_cs=cs, rot_n=2 * d, chain=chain, chain_last=True)
             qkv = qkv.view(b, n, 3, self.heads, self.head_dim)
-            ctx = ops.self_attention_rotary(qkv, theta, cs, pre_rotated=True, scale=ops.LN2)      # [b,n,H,hd]
+            ctx = ops.self_attention_rotary(qkv, theta, cs, pre_rotated=True, scale=ops.LN2, theta_sum=theta_sum)      # [b,n,H,hd]
         else:
             qkv = ops.linear(x, w, bias, chain=chain, chain_last=True).view(b, n, 3, self.heads, self.head_dim)
-            ctx = ops.self_attention_rotary(qkv, theta, cs, scale=ops.LN2)
+            ctx = ops.self_attention_rotary(qkv, theta, cs, scale=ops.LN2, theta_sum=theta_sum)
         first = _folded_ffn0(self._pc, x.dtype, self.ffn, self.out_proj)
         if first is not None:          # out_proj lives inside ffn.0's weight: the FFN reads the attention context directly
             return _ffn(self.ffn, x, ctx.view(b, n, d), chain, first=first)
@@ -459,10 +459,12 @@ class LightGlue(nn.Module):
             # the self block's three consumers and, optionally, that output's loss heads (added in _loss_fused)
             grad = torch.is_grad_enabled() and self.training and x.is_cuda
             chains = []
+            # the L self blocks share the rotary angles: their gradient is summed inside the rotary-backward launches
+            tsum = ops.SharedGradSum(conf.n_layers) if grad and theta.requires_grad else None
             for i, layer in enumerate(self.transformers):
                 ch = ops.GradChain(3) if grad and x.requires_grad else None
                 chains.append(ch)
-                x = layer.self_attn(x, theta, cs, chain=ch)
+                x = layer.self_attn(x, theta, cs, chain=ch, theta_sum=tsum)
                 x = layer.cross_attn.forward_stacked(x, out=None if lbuf is None else lbuf[i])
                 if self.training or i == conf.n_layers - 1:
                     layer_x.append(x)

@@ -125,8 +125,9 @@ class _SelfAttentionRotary(torch.autograd.Function):
     they carry the gradient to posenc.Wr); cs [B,N,D] = interleaved (cos, sin) of theta."""
 
     @staticmethod
-    def forward(ctx, qkv, theta, cs, pre_rotated=False, scale=None):
+    def forward(ctx, qkv, theta, cs, pre_rotated=False, scale=None, theta_sum=None):
         _chk(qkv, cs)
+        ctx.theta_sum = theta_sum
         B, N, three, H, D = qkv.shape
         assert three == 3 and qkv.is_contiguous() and cs.is_contiguous() and cs.dtype == torch.float32
         L = _lib.load()
@@ -146,9 +147,34 @@ class _SelfAttentionRotary(torch.autograd.Function):
         attn_bwd_raw(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], o, do, lse,
                      dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2], ctx.scale)
         dtheta = torch.empty((B, N, D // 2), dtype=torch.float32, device=qkv.device)
-        _lib.check(_lib.load().gf_rotary_qk_bwd(_p(dqkv), _p(qkv), _p(cs), _p(dtheta), B, N, H, D,
+        ts = ctx.theta_sum
+        base = None if ts is None else ts.acc
+        _lib.check(_lib.load().gf_rotary_qk_bwd(_p(dqkv), _p(qkv), _p(cs), _p(dtheta), _p(base), B, N, H, D,
                                                 _dt(qkv), _stream()), "gf_rotary_qk_bwd")
-        return dqkv, dtheta.to(ctx.theta_dtype), None, None, None
+        if ts is not None:          # the layers share theta: only the LAST backward returns the (complete) sum
+            dtheta = ts.add(dtheta)
+            if dtheta is None:
+                return dqkv, None, None, None, None, None
+        return dqkv, dtheta.to(ctx.theta_dtype), None, None, None, None
+
+
+class SharedGradSum:
+    """Gradient of ONE tensor consumed by `consumers` nodes of the same kind (the rotary angles of LightGlue's L self
+    blocks): every node's backward kernel adds the running sum of the nodes that ran before it (`acc`, passed as the
+    kernel's base operand) and only the last one hands the total to autograd -- L - 1 elementwise adds fewer.  A backward
+    pass that does not visit all consumers would lose gradient, so the count is checked when the next forward re-arms it."""
+    __slots__ = ("acc", "got", "expected")
+
+    def __init__(self, consumers):
+        self.acc, self.got, self.expected = None, 0, int(consumers)
+
+    def add(self, g):
+        self.got += 1
+        if self.got < self.expected:
+            self.acc = g
+            return None
+        self.acc, self.got = None, 0
+        return g
 
 
 LN2 = 0.6931471805599453
@@ -161,8 +187,11 @@ def attn_premul(head_dim):
     return head_dim ** -0.5 * 1.4426950408889634
 
 
-def self_attention_rotary(qkv, theta, cs, pre_rotated=False, scale=None):
-    return _SelfAttentionRotary.apply(qkv, theta, cs, pre_rotated, scale)
+def self_attention_rotary(qkv, theta, cs, pre_rotated=False, scale=None, theta_sum=None):
+    """theta_sum: a SharedGradSum over all layers that share `theta` (None: every call returns its own angle gradient)."""
+    if theta_sum is not None and not (torch.is_grad_enabled() and theta.requires_grad):
+        theta_sum = None
+    return _SelfAttentionRotary.apply(qkv, theta, cs, pre_rotated, scale, theta_sum)
 
 
 class _CrossAttention(torch.autograd.Function):
@@ -834,9 +863,20 @@ class _LinearCat(torch.autograd.Function):
             c = x2.reshape(-1, k - k1)
             a = a if a.is_contiguous() else a.contiguous()
             c = c if c.is_contiguous() else c.contiguous()
-            dwa, db32 = _dw(dy2, a, nout, k1, ctx.bdtype is not None)
-            dwb, _ = _dw(dy2, c, nout, k - k1, False)
-            dw = torch.cat([dwa, dwb], 1).to(ctx.wdtype)
+            if a.dtype == torch.bfloat16 and nout % 128 == 0 and k1 % 128 == 0 and (k - k1) % 128 == 0:
+                # ONE launch over the virtual concatenation (gf_linear_dw2): dY streamed once, dw comes out whole
+                L = _lib.load()
+                m = a.shape[0]
+                ws = torch.empty(int(L.gf_linear_dw_ws_bytes(m, nout, k)), dtype=torch.uint8, device=a.device)
+                dw32 = torch.empty((nout, k), dtype=torch.float32, device=a.device)
+                db32 = torch.empty((nout,), dtype=torch.float32, device=a.device) if ctx.bdtype is not None else None
+                _lib.check(L.gf_linear_dw2(_p(dy2), _p(a), _p(c), k1, _p(dw32), _p(db32), _p(ws), m, nout, k, _dt(a),
+                                           _stream()), "gf_linear_dw2")
+                dw = dw32.to(ctx.wdtype)
+            else:
+                dwa, db32 = _dw(dy2, a, nout, k1, ctx.bdtype is not None)
+                dwb, _ = _dw(dy2, c, nout, k - k1, False)
+                dw = torch.cat([dwa, dwb], 1).to(ctx.wdtype)
             db = None if db32 is None else db32.to(ctx.bdtype)
         return dx1, dx2, dw, db, None
 
@@ -859,10 +899,9 @@ class _RowDot(torch.autograd.Function):
         M = x2.shape[0]
         w32 = w.reshape(-1).float().contiguous()
         z = torch.empty(M, dtype=torch.float32, device=x.device)
-        # the bias stays on the device (no .item() sync): added after the kernel
-        _lib.check(_lib.load().gf_rowdot_fwd(_p(x2), _p(w32), 0.0, _p(z), M, C, _dt(x2), _stream()), "gf_rowdot_fwd")
-        if b is not None:
-            z = z + b.float()
+        # the bias stays on the device (no .item() sync): the kernel reads the parameter itself
+        b32 = None if b is None else b.detach().reshape(-1).float()
+        _lib.check(_lib.load().gf_rowdot_fwd(_p(x2), _p(w32), 0.0, _p(b32), _p(z), M, C, _dt(x2), _stream()), "gf_rowdot_fwd")
         ctx.save_for_backward(x2, w32)
         ctx.meta = (x.shape, w.shape, w.dtype, None if b is None else b.dtype)
         return z.view(x.shape[:-1])

@@ -36,7 +36,7 @@ extern "C" {
 #define GF_ERR_ALIGN (-3)
 #define GF_ERR_DTYPE (-4)
 
-/* ABI version; bumped on any signature or workspace-size change (2: gf_attn_bwd's delta workspace doubled; 3: line head + gf_bgemm; 4: smallops; 5: gf_attn_bwd_acc; 9: cast entries with leading dimensions, gf_fold_linear_*, double betas in gf_multi_adam; 10: gf_attn_fwd_ex / GF_ATTN_SPLIT, gf_topk_candidates; 14: gf_sinkhorn_* take `schedule`, gf_sinkhorn_mode removed, gf_probe_hold_cus). */
+/* ABI version; bumped on any signature or workspace-size change (2: gf_attn_bwd's delta workspace doubled; 3: line head + gf_bgemm; 4: smallops; 5: gf_attn_bwd_acc; 9: cast entries with leading dimensions, gf_fold_linear_*, double betas in gf_multi_adam; 10: gf_attn_fwd_ex / GF_ATTN_SPLIT, gf_topk_candidates; 14: gf_sinkhorn_* take `schedule`, gf_sinkhorn_mode removed, gf_probe_hold_cus, gf_linear_dw2). */
 #define GF_AMD_ABI_VERSION 14
 int gf_abi_version(void);
 /* Diagnostics (tests/test_gpu_sinkhorn_safety.py): occupies `n_cus` compute units (one 150 KB-LDS workgroup each) for
@@ -325,6 +325,12 @@ int gf_gemm(const void* x0, const void* x1, const void* w, const float* bias, co
 int64_t gf_linear_dw_ws_bytes(int M, int Nout, int K);
 int gf_linear_dw(const void* dy, const void* x, float* dw, float* db, void* ws,
                  int M, int Nout, int K, int dtype, void* stream);
+/* gf_linear_dw2: the same for a TWO-SOURCE input x = [x1 | x2] (x1 [M, K1], x2 [M, K - K1], each contiguous) without building
+ * the concatenation -- the weight gradient of `ffn.0(cat[x, message])`, lightglue.py:140-148,196-221 -- in ONE launch: dY is
+ * streamed once instead of twice, dw [Nout, K] comes out whole (no cat of two halves).  bf16, Nout, K1 and K - K1 multiples
+ * of 128 (GF_ERR_UNSUPPORTED otherwise: call gf_linear_dw per source); workspace of gf_linear_dw_ws_bytes(M, Nout, K). */
+int gf_linear_dw2(const void* dy, const void* x1, const void* x2, int K1, float* dw, float* db, void* ws,
+                  int M, int Nout, int K, int dtype, void* stream);
 
 /* ---- BatchNorm1d (+ReLU) over channels-last activations [M, C] (training: batch statistics) ------
  * Replaces the Conv1d -> BatchNorm1d -> ReLU tails of superglue.py:70-79 / gluestick.py:465-474.
@@ -422,7 +428,8 @@ int gf_sample_descriptors(const void* map, const float* kpts, float* out, int B,
  * when dx != NULL (pass NULL for a detached input) and per-block
  * partials part [gf_rowdot_nblk(M)][C+1] whose column sums are (dw[0..C), db). */
 int gf_rowdot_nblk(int M);
-int gf_rowdot_fwd(const void* x, const float* w, float bias, float* z, int M, int C, int dtype, void* stream);
+int gf_rowdot_fwd(const void* x, const float* w, float bias, const float* bias_dev, float* z, int M, int C, int dtype,
+                  void* stream);      /* z = x w + bias + (bias_dev ? *bias_dev : 0): bias_dev = a DEVICE scalar (the nn.Linear bias) */
 int gf_rowdot_bwd(const void* x, const float* dz, const float* w, void* dx, const void* base, float* part,
                   int M, int C, int dtype, void* stream);
 
@@ -469,8 +476,10 @@ int gf_rotary_qk(void* qkv, const float* cs, int B, int N, int H, int D, int inv
 /* Backward of the rotation: dqkv holds the gradients w.r.t. the ROTATED q,k (first two thirds,
  * rotated back in place) and qkv_rot the rotated values saved by the forward;
  * dtheta [B,N,D/2] (fp32) receives the gradient w.r.t. the pair angles
- * sum_{q,k,heads} (g_odd * y_even - g_even * y_odd), which autograd carries to posenc.Wr. */
-int gf_rotary_qk_bwd(void* dqkv, const void* qkv_rot, const float* cs, float* dtheta,
+ * sum_{q,k,heads} (g_odd * y_even - g_even * y_odd), which autograd carries to posenc.Wr;
+ * dtheta_base (may be NULL, may alias dtheta): added to it -- the angles are shared by all L layers, so the running sum of
+ * the layers whose backward already ran rides in this launch instead of L - 1 separate adds. */
+int gf_rotary_qk_bwd(void* dqkv, const void* qkv_rot, const float* cs, float* dtheta, const float* dtheta_base,
                      int B, int N, int H, int D, int dtype, void* stream);
 /* LayerNorm(affine) + GELU(erf) over rows of x [R, C] (lightglue.py:143-148 ffn.1, ffn.2):
  * y = gelu(ln(x) * gamma + beta); saves mean / rstd [R] for the backward. */

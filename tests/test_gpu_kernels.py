@@ -306,6 +306,40 @@ def test_ops_reject_cpu_tensors():
         ops.attention(torch.zeros(1, 4, 1, 64), torch.zeros(1, 4, 1, 64), torch.zeros(1, 4, 1, 64))
 
 
+@pytest.mark.parametrize("M,Nout,K1,K2", [(5000, 512, 256, 256), (4133, 256, 128, 384), (131072, 512, 256, 256), (300, 128, 128, 128)])
+def test_linear_cat_weight_gradient_in_one_launch(M, Nout, K1, K2):
+    """gf_linear_dw2: the weight gradient of y = [x1 | x2] W^T + b over the virtual concatenation (ffn.0(cat[x, message]),
+    lightglue.py:140-148,196-221) in one launch == gf_linear_dw per source == fp64 autograd."""
+    import ctypes
+    from glue_factory_amd import lib as L_
+    g = torch.Generator().manual_seed(M + Nout)
+    x1 = torch.randn(M, K1, generator=g).to(DEV, torch.bfloat16).requires_grad_(True)
+    x2 = torch.randn(M, K2, generator=g).to(DEV, torch.bfloat16).requires_grad_(True)
+    w = (torch.randn(Nout, K1 + K2, generator=g) / (K1 + K2) ** 0.5).to(DEV).requires_grad_(True)
+    b = torch.randn(Nout, generator=g).to(DEV).requires_grad_(True)
+    dy = torch.randn(M, Nout, generator=g).to(DEV, torch.bfloat16)
+    y = ops.linear_cat(x1, x2, w, b)
+    (y * dy).sum().backward()
+    # the two single-source launches this replaces (bit-comparable: same kernel, same slices per k-tile? no -- the slice
+    # count follows the tile count; compared at fp32 rounding)
+    L = L_.load()
+    parts = []
+    for x in (x1, x2):
+        k = x.shape[1]
+        ws = torch.empty(int(L.gf_linear_dw_ws_bytes(M, Nout, k)), dtype=torch.uint8, device=DEV)
+        dwp = torch.empty(Nout, k, device=DEV)
+        dbp = torch.empty(Nout, device=DEV)
+        L_.check(L.gf_linear_dw(dy.data_ptr(), x.detach().data_ptr(), dwp.data_ptr(), dbp.data_ptr(), ws.data_ptr(), M, Nout, k, 1,
+                                torch.cuda.current_stream().cuda_stream), "gf_linear_dw")
+        parts.append((dwp, dbp))
+    sc = float(w.grad.abs().max())
+    torch.testing.assert_close(w.grad / sc, torch.cat([parts[0][0], parts[1][0]], 1) / sc, rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(b.grad, parts[0][1], rtol=2e-5, atol=2e-5 * float(b.grad.abs().max()))
+    ref_w = dy.double().t() @ torch.cat([x1.detach(), x2.detach()], 1).double()
+    torch.testing.assert_close(w.grad.double() / sc, ref_w / sc, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(b.grad.double(), dy.double().sum(0), rtol=1e-4, atol=1e-4 * float(b.grad.abs().max()))
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("M,Nout,K", [(1000, 256, 256), (4096, 768, 256), (777, 512, 512), (64, 8, 8), (5000, 264, 136)])
 def test_linear_dw(dtype, M, Nout, K):
