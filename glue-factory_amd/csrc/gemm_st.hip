@@ -38,10 +38,10 @@ constexpr int GS_TILE = 32768;                // bytes of one activation tile
 constexpr int GS_NSTAGE = GS_NSTAGE_, GS_PD = GS_NSTAGE - 1;   // stages, prefetch distance in tiles
 
 struct GsParams {
-    const bf16_t* x0; const bf16_t* x1; const bf16_t* w; const float* bias; const bf16_t* res; bf16_t* y;
+    const bf16_t* x0; const bf16_t* x1; const bf16_t* w; const float* bias; const bf16_t* res; const bf16_t* res2; bf16_t* y;
     const float* cs;          // [M, 64] (cos, sin) per channel pair of a 64-wide head (ROT kernels)
     int M, N;
-    int64_t ld0, ld1, ldw, ldr, ldy;
+    int64_t ld0, ld1, ldw, ldr, ldr2, ldy;
 };
 
 template <int OFF> __device__ __forceinline__ u32x4 gs_rd128(unsigned a) {
@@ -71,14 +71,16 @@ __device__ __forceinline__ void gs_swap(unsigned& a, unsigned& b) {
     a = r[0]; b = r[1];
 }
 
-// KF = K / 16 (16 or 32); TWO: the K columns come half from x0, half from x1; RES: + residual; ROT: rotary epilogue
-// (lightglue.py:42-49,159-160) on every channel of the launch, head dim 64
-template <int KF, bool TWO, bool RES, bool ROT>
+// KF = K / 16 (16 or 32); TWO: the K columns come half from x0, half from x1; RES: number of residual inputs (0, 1, or 2:
+// where a loss head's parked gradient meets a block's residual gradient, both ride in the input-gradient GEMM instead of
+// being added by a separate 3-pass kernel first); ROT: rotary epilogue (lightglue.py:42-49,159-160) on every channel of the
+// launch, head dim 64
+template <int KF, bool TWO, int RES, bool ROT>
 __global__ __launch_bounds__(512, 2) void gemm_st_kernel(GsParams p) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     constexpr int K = 16 * KF, ROWB = 2 * K, CPR = ROWB / 16;     // bytes / 16-byte chunks of one activation row
     constexpr int TR = GS_TILE / ROWB, NRB = TR / 32;             // rows, 32-row blocks per tile
-    constexpr int NR = (RES ? 2 * NRB : 0) + (ROT ? 4 * NRB : 0), NS = 2 * NRB;   // residual + (cos, sin) loads / stores per tile and wave
+    constexpr int NR = RES * 2 * NRB + (ROT ? 4 * NRB : 0), NS = 2 * NRB;   // residual + (cos, sin) loads / stores per tile and wave
     const unsigned lds0 = (unsigned)(size_t)smem;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
@@ -135,12 +137,18 @@ __global__ __launch_bounds__(512, 2) void gemm_st_kernel(GsParams p) {
         else gs_wait_vm<(GS_PD > 2 ? (GS_PD - 3) * 4 + 2 * PER : 0)>();
         __builtin_amdgcn_s_barrier();                             // ... everyone's pieces; the stage of tile i-1 is free
         __builtin_amdgcn_sched_barrier(0);
-        u32x4 rr[NRB][2];
-        if (RES) {
+        u32x4 rr[NRB][2], rq[NRB][2];
+        if (RES >= 1) {
 #pragma unroll
             for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) rr[rb][j] = gs_ld128(p.res + (row0 + 32 * rb + l31) * p.ldr + ycol + 16 * j);
+        }
+        if (RES == 2) {
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) rq[rb][j] = gs_ld128(p.res2 + (row0 + 32 * rb + l31) * p.ldr2 + ycol + 16 * j);
         }
         u32x4 cc[NRB][4];                                          // (cos, sin) of this lane's channel pairs, per register group
         if (ROT) {
@@ -212,15 +220,17 @@ __global__ __launch_bounds__(512, 2) void gemm_st_kernel(GsParams p) {
                         v[t][0] = o0; v[t][1] = o1; v[t][2] = o2; v[t][3] = o3;
                     }
                 }
-                if (RES) {
-                    gs_tie(rr[rb][j]);
-                    unsigned a0_ = rr[rb][j][0], a1_ = rr[rb][j][1], b0_ = rr[rb][j][2], b1_ = rr[rb][j][3];
+                auto add_res = [&](u32x4& src) {
+                    gs_tie(src);
+                    unsigned a0_ = src[0], a1_ = src[1], b0_ = src[2], b1_ = src[3];
                     gs_swap(a0_, b0_);                            // back to "4 channels of g0 / 4 of g1 per lane"
                     gs_swap(a1_, b1_);
                     const bf16x4 r0 = __builtin_bit_cast(bf16x4, u32x2{a0_, a1_}), r1 = __builtin_bit_cast(bf16x4, u32x2{b0_, b1_});
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { v[0][e] += (float)r0[e]; v[1][e] += (float)r1[e]; }
-                }
+                };
+                if (RES >= 1) add_res(rr[rb][j]);
+                if (RES == 2) add_res(rq[rb][j]);
                 const bf16x4 o0 = {(bf16_t)v[0][0], (bf16_t)v[0][1], (bf16_t)v[0][2], (bf16_t)v[0][3]};
                 const bf16x4 o1 = {(bf16_t)v[1][0], (bf16_t)v[1][1], (bf16_t)v[1][2], (bf16_t)v[1][3]};
                 const u32x2 p0 = __builtin_bit_cast(u32x2, o0), p1 = __builtin_bit_cast(u32x2, o1);
@@ -234,7 +244,7 @@ __global__ __launch_bounds__(512, 2) void gemm_st_kernel(GsParams p) {
     gs_wait_vm<0>();                                              // the re-fetched tail tiles and the last stores
 }
 
-template <int KF, bool TWO, bool RES, bool ROT = false>
+template <int KF, bool TWO, int RES, bool ROT = false>
 int gs_launch(const GsParams& p, hipStream_t st) {
     constexpr int TR = GS_TILE / (32 * KF);
     const size_t lds = (size_t)GS_NSTAGE * GS_TILE;
@@ -254,24 +264,28 @@ int gs_launch(const GsParams& p, hipStream_t st) {
 // Internal (not part of the C ABI): called by gf_gemm first; GF_ERR_UNSUPPORTED = "use the register-resident kernel".
 int gf_gemm_stream_try(const void* x0, const void* x1, const void* w, const float* bias, const void* res, void* y,
                        const float* cs, int rot_n, int M, int N, int K0, int K1, int64_t ld0, int64_t ld1, int64_t ldw,
-                       int64_t ldr, int64_t ldy, hipStream_t st) {
+                       int64_t ldr, int64_t ldy, hipStream_t st, const void* res2, int64_t ldr2) {
     const int K = K0 + K1;
     if ((K != 256 && K != 512) || N % 256 || M % 64 || (K1 && K1 != K0)) return GF_ERR_UNSUPPORTED;
     if (cs && (rot_n % 256 || rot_n <= 0 || rot_n > N || res || K1)) return GF_ERR_UNSUPPORTED;
+    if (res2 && (!res || cs)) return GF_ERR_UNSUPPORTED;
     GsParams p;
     p.x0 = static_cast<const bf16_t*>(x0); p.x1 = static_cast<const bf16_t*>(x1); p.w = static_cast<const bf16_t*>(w);
-    p.bias = bias; p.res = static_cast<const bf16_t*>(res); p.y = static_cast<bf16_t*>(y); p.cs = cs;
-    p.M = M; p.N = N; p.ld0 = ld0; p.ld1 = ld1; p.ldw = ldw; p.ldr = ldr; p.ldy = ldy;
+    p.bias = bias; p.res = static_cast<const bf16_t*>(res); p.res2 = static_cast<const bf16_t*>(res2);
+    p.y = static_cast<bf16_t*>(y); p.cs = cs;
+    p.M = M; p.N = N; p.ld0 = ld0; p.ld1 = ld1; p.ldw = ldw; p.ldr = ldr; p.ldr2 = ldr2; p.ldy = ldy;
     if (cs) {       // rotated channel groups first, the rest (the v third of a fused qkv projection) as a plain launch
         p.N = rot_n;
-        if (int e = K == 256 ? gs_launch<16, false, false, true>(p, st) : gs_launch<32, false, false, true>(p, st)) return e;
+        if (int e = K == 256 ? gs_launch<16, false, 0, true>(p, st) : gs_launch<32, false, 0, true>(p, st)) return e;
         if (N == rot_n) return 0;
         p.N = N - rot_n; p.w += (int64_t)rot_n * ldw; p.y += rot_n; p.cs = nullptr;
         if (p.bias) p.bias += rot_n;
-        return K == 256 ? gs_launch<16, false, false>(p, st) : gs_launch<32, false, false>(p, st);
+        return K == 256 ? gs_launch<16, false, 0>(p, st) : gs_launch<32, false, 0>(p, st);
     }
-#define GS_GO(KF) (K1 ? (res ? gs_launch<KF, true, true>(p, st) : gs_launch<KF, true, false>(p, st)) \
-                      : (res ? gs_launch<KF, false, true>(p, st) : gs_launch<KF, false, false>(p, st)))
+    if (res2) return K1 ? (K == 256 ? gs_launch<16, true, 2>(p, st) : gs_launch<32, true, 2>(p, st))
+                        : (K == 256 ? gs_launch<16, false, 2>(p, st) : gs_launch<32, false, 2>(p, st));
+#define GS_GO(KF) (K1 ? (res ? gs_launch<KF, true, 1>(p, st) : gs_launch<KF, true, 0>(p, st)) \
+                      : (res ? gs_launch<KF, false, 1>(p, st) : gs_launch<KF, false, 0>(p, st)))
     return K == 256 ? GS_GO(16) : GS_GO(32);
 #undef GS_GO
 }

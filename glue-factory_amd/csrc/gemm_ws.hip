@@ -373,7 +373,20 @@ extern "C" int gf_gemm_trace(unsigned long long* host, int n) {
 // gemm_st.hip: the streamed-activation kernel for the large regular shapes (returns GF_ERR_UNSUPPORTED for the rest)
 int gf_gemm_stream_try(const void* x0, const void* x1, const void* w, const float* bias, const void* res, void* y,
                        const float* cs, int rot_n, int M, int N, int K0, int K1, int64_t ld0, int64_t ld1, int64_t ldw,
-                       int64_t ldr, int64_t ldy, hipStream_t st);
+                       int64_t ldr, int64_t ldy, hipStream_t st, const void* res2 = nullptr, int64_t ldr2 = 0);
+
+// y = [x0 | x1] W^T + bias + res + res_b: gf_gemm with TWO residual inputs, streamed-activation kernel only (bf16,
+// K0 + K1 in {256, 512}, N % 256 == 0, M % 64 == 0, no rotary epilogue; GF_ERR_UNSUPPORTED otherwise: add one of the
+// residuals first and call gf_gemm)
+extern "C" int gf_gemm_res2(const void* x0, const void* x1, const void* w, const float* bias, const void* res, const void* res_b,
+                            void* y, int M, int N, int K0, int K1, int64_t ld0, int64_t ld1, int64_t ldw, int64_t ldr,
+                            int64_t ldr_b, int64_t ldy, int dtype, void* stream) {
+    if (M <= 0 || N <= 0 || K0 <= 0 || K1 < 0) return GF_ERR_SHAPE;
+    if (dtype != GF_BF16 || !res || !res_b || (K1 && !x1)) return GF_ERR_UNSUPPORTED;
+    if (ld0 % 8 || (K1 && ld1 % 8) || ldw % 8 || ldy % 8 || ldr % 8 || ldr_b % 8) return GF_ERR_ALIGN;
+    return gf_gemm_stream_try(x0, x1, w, bias, res, y, nullptr, 0, M, N, K0, K1, ld0, ld1, ldw, ldr, ldy,
+                              reinterpret_cast<hipStream_t>(stream), res_b, ldr_b);
+}
 
 extern "C" int gf_gemm(const void* x0, const void* x1, const void* w, const float* bias, const void* res, void* y,
                        const float* cs, int rot_n, int M, int N, int K0, int K1,

@@ -61,6 +61,7 @@ SIGNATURES = {
     "gf_small_dw_ws_floats": [_I, _I],
     "gf_small_fwd": [_P, _P, _P, _I, _I, _I, _P],
     "gf_gemm": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _L, _L, _L, _I, _P],
+    "gf_gemm_res2": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _L, _L, _L, _I, _P],
     "gf_linear_dw_ws_bytes": [_I, _I, _I],
     "gf_linear_dw": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "gf_linear_dw2": [_P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P],

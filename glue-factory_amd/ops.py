@@ -586,13 +586,35 @@ def _row_ok(t, dtype):
     return t.stride(1) == 1 and t.stride(0) % al == 0 and t.data_ptr() % 16 == 0
 
 
-def gemm(x2, wt, bias=None, res2=None, out=None, x2b=None, cs=None, rot_n=0):
-    """y [M,N] = [x2 | x2b] wt^T (+ bias) (+ res2), optional rotary epilogue; x2 / x2b / wt / res2 2-D with unit inner
-    stride, all in the compute dtype (bias: any float dtype).  ``out`` may alias ``res2``.  Returns y."""
+def gemm(x2, wt, bias=None, res2=None, out=None, x2b=None, cs=None, rot_n=0, res3=None):
+    """y [M,N] = [x2 | x2b] wt^T (+ bias) (+ res2) (+ res3), optional rotary epilogue; x2 / x2b / wt / res2 / res3 2-D with unit
+    inner stride, all in the compute dtype (bias: any float dtype).  ``out`` may alias ``res2``.  Returns y.
+    res3: a second residual, fused on the streamed kernel's shapes (gf_gemm_res2), added beforehand otherwise."""
     M, K0 = x2.shape
     N = wt.shape[0]
     dtype = x2.dtype
     K1 = 0 if x2b is None else x2b.shape[1]
+    if res3 is not None:
+        if res2 is None:
+            res2, res3 = res3, None
+        else:
+            if res3.dim() != 2:
+                res3 = res3.reshape(M, N)
+            fused = (dtype == torch.bfloat16 and cs is None and x2.is_cuda and wt.dtype == dtype and (K0 + K1) in (256, 512)
+                     and (K1 == 0 or K1 == K0) and N % 256 == 0 and M % 64 == 0 and res2.dtype == dtype and res3.dtype == dtype
+                     and all(_row_ok(t_, dtype) for t_ in (x2, wt, res2, res3) + ((x2b,) if x2b is not None else ())
+                             + ((out,) if out is not None else ())))
+            if fused:
+                y = torch.empty((M, N), dtype=dtype, device=x2.device) if out is None else out
+                b32 = None if bias is None else bias.detach().float().contiguous()
+                rc = _lib.load().gf_gemm_res2(_p(x2), _p(x2b), _p(wt), _p(b32), _p(res2), _p(res3), _p(y), M, N, K0, K1,
+                                              x2.stride(0), 0 if x2b is None else x2b.stride(0), wt.stride(0), res2.stride(0),
+                                              res3.stride(0), y.stride(0), _dt(x2), _stream())
+                if rc == 0:
+                    return y
+                if rc != -1:
+                    _lib.check(rc, "gf_gemm_res2")
+            res2, res3 = res2 + res3, None
     ok = (x2.is_cuda and dtype in _GEMM_KMAX and wt.dtype == dtype and N % 32 == 0 and _row_ok(x2, dtype)
           and _row_ok(wt, dtype) and (x2b is None or (x2b.dtype == dtype and _row_ok(x2b, dtype)))
           and (res2 is None or (res2.dtype == dtype and _row_ok(res2, dtype)))
@@ -700,10 +722,17 @@ class GradChain:
     gradient; the last one's input-gradient GEMM adds the parked sum in its residual epilogue and returns the total.
     The last consumer must be the one whose backward runs last -- true by data dependence for the transformer blocks
     (the projection's gradient needs the attention backward, which needs the FFN's) and checked by the counter."""
-    __slots__ = ("acc", "got", "expected", "closed")
+    __slots__ = ("acc", "got", "expected", "closed", "extra")
 
     def __init__(self, consumers):
         self.acc, self.got, self.expected, self.closed = None, 0, consumers - 1, False
+        # a second parked tensor that has not been added to `acc` yet: it rides as the SECOND residual of the next link's
+        # GEMM (gf_gemm_res2) -- the place where a loss head's gradient meets the block's residual gradient
+        self.extra = None
+
+    def pop_extra(self):
+        e, self.extra = self.extra, None
+        return e
 
     def park(self, g, counted=True):
         """counted=False: an OPTIONAL contribution (the per-layer loss heads of LightGlue, which exist only when the
@@ -718,6 +747,9 @@ class GradChain:
         if self.got != self.expected:
             raise RuntimeError(f"GradChain: {self.got} of {self.expected} contributions arrived before the last consumer")
         acc, self.acc, self.got, self.closed = self.acc, None, 0, True
+        extra = self.pop_extra()
+        if extra is not None:           # no link in between took it along: one explicit add after all
+            acc = extra if acc is None else acc + extra
         return acc
 
 
@@ -764,9 +796,12 @@ class _Linear(torch.autograd.Function):
         dres = dy if ctx.has_res and ctx.needs_input_grad[3] else None
         if dres is not None and ctx.res_chain is not None:       # first link of the residual tensor's chain
             d2 = _flat2(dres, nout)
-            if ctx.res_chain.acc is not None:      # optional contributions got here first (the previous output's loss heads)
-                d2 = d2 + ctx.res_chain.acc
-            ctx.res_chain.park(d2)
+            rc = ctx.res_chain
+            if rc.acc is not None:      # optional contributions got here first (the previous output's loss heads): they wait
+                if rc.extra is not None:                     # in `extra` for the next link's two-residual GEMM
+                    d2 = d2 + rc.pop_extra()
+                rc.extra = rc.acc
+            rc.park(d2)
             dres = None
         if ctx.needs_input_grad[0]:
             ch = ctx.chain
@@ -775,7 +810,7 @@ class _Linear(torch.autograd.Function):
             elif ctx.chain_last is True:
                 dx = gemm(dy2, _wt_t(wt), res2=ch.take()).view(x.shape)
             else:                                       # chain_last == "extra": an optional, uncounted contribution
-                ch.park(gemm(dy2, _wt_t(wt), res2=ch.acc), counted=ctx.chain_last != "extra")
+                ch.park(gemm(dy2, _wt_t(wt), res2=ch.acc, res3=ch.pop_extra()), counted=ctx.chain_last != "extra")
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             x2 = x.reshape(-1, k)
             if not x2.is_contiguous():
@@ -855,7 +890,7 @@ class _LinearCat(torch.autograd.Function):
             if ch is None:
                 dx1 = gemm(dy2, _wt_t(wt, 0, k1)).view(x1.shape)
             else:                                   # a middle link: the parked residual gradient rides in the epilogue
-                ch.park(gemm(dy2, _wt_t(wt, 0, k1), res2=ch.acc))
+                ch.park(gemm(dy2, _wt_t(wt, 0, k1), res2=ch.acc, res3=ch.pop_extra()))
         dx2 = gemm(dy2, _wt_t(wt, k1, wt.shape[1])).view(x2.shape) if ctx.needs_input_grad[1] else None
         dw = db = None
         if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
@@ -916,6 +951,9 @@ class _RowDot(torch.autograd.Function):
         dx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
         ch = ctx.chain if dx is not None else None
         base = None if ch is None else ch.acc           # the chain's running sum rides in this kernel (dx = base + dz w)
+        if ch is not None and ch.extra is not None:
+            e = ch.pop_extra()
+            base = e if base is None else base + e
         part = torch.empty((L.gf_rowdot_nblk(M), C + 1), dtype=torch.float32, device=x2.device)
         _lib.check(L.gf_rowdot_bwd(_p(x2), _p(dz), _p(w32), _p(dx), _p(base), _p(part), M, C, _dt(x2), _stream()),
                    "gf_rowdot_bwd")

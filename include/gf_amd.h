@@ -36,7 +36,7 @@ extern "C" {
 #define GF_ERR_ALIGN (-3)
 #define GF_ERR_DTYPE (-4)
 
-/* ABI version; bumped on any signature or workspace-size change (2: gf_attn_bwd's delta workspace doubled; 3: line head + gf_bgemm; 4: smallops; 5: gf_attn_bwd_acc; 9: cast entries with leading dimensions, gf_fold_linear_*, double betas in gf_multi_adam; 10: gf_attn_fwd_ex / GF_ATTN_SPLIT, gf_topk_candidates; 14: gf_sinkhorn_* take `schedule`, gf_sinkhorn_mode removed, gf_probe_hold_cus, gf_linear_dw2). */
+/* ABI version; bumped on any signature or workspace-size change (2: gf_attn_bwd's delta workspace doubled; 3: line head + gf_bgemm; 4: smallops; 5: gf_attn_bwd_acc; 9: cast entries with leading dimensions, gf_fold_linear_*, double betas in gf_multi_adam; 10: gf_attn_fwd_ex / GF_ATTN_SPLIT, gf_topk_candidates; 14: gf_sinkhorn_* take `schedule`, gf_sinkhorn_mode removed, gf_probe_hold_cus, gf_linear_dw2, gf_gemm_res2; gf_rowdot_fwd / gf_rotary_qk_bwd take a device bias / a base sum). */
 #define GF_AMD_ABI_VERSION 14
 int gf_abi_version(void);
 /* Diagnostics (tests/test_gpu_sinkhorn_safety.py): occupies `n_cus` compute units (one 150 KB-LDS workgroup each) for
@@ -316,6 +316,13 @@ int gf_bgemm(const void* a, const void* b, void* c, int batch, int M, int N, int
 int gf_gemm(const void* x0, const void* x1, const void* w, const float* bias, const void* res, void* y,
             const float* cs, int rot_n, int M, int N, int K0, int K1,
             int64_t ld0, int64_t ld1, int64_t ldw, int64_t ldr, int64_t ldy, int dtype, void* stream);
+/* gf_gemm_res2: the same with TWO residual inputs, y = [x0 | x1] W^T + bias + res + res_b -- the input-gradient GEMM at the
+ * point where a per-layer loss head's gradient and the block's residual gradient meet (autograd of lightglue.py:131-221 +
+ * :271-290): both ride in the epilogue instead of being added by a separate elementwise kernel first.  bf16, the streamed-
+ * activation kernel's shapes only (K0 + K1 in {256, 512}, N % 256 == 0, M % 64 == 0); GF_ERR_UNSUPPORTED otherwise. */
+int gf_gemm_res2(const void* x0, const void* x1, const void* w, const float* bias, const void* res, const void* res_b,
+                 void* y, int M, int N, int K0, int K1, int64_t ld0, int64_t ld1, int64_t ldw, int64_t ldr,
+                 int64_t ldr_b, int64_t ldy, int dtype, void* stream);
 
 /* ---- weight / bias gradient of a linear layer (autograd of every nn.Linear on the path,
  * lightglue.py:131-221, 271-290): dW[n][k] = sum_m dY[m][n] X[m][k], db[n] = sum_m dY[m][n]

@@ -306,6 +306,29 @@ def test_ops_reject_cpu_tensors():
         ops.attention(torch.zeros(1, 4, 1, 64), torch.zeros(1, 4, 1, 64), torch.zeros(1, 4, 1, 64))
 
 
+@pytest.mark.parametrize("M,N,K,two", [(4096, 256, 512, False), (8192, 256, 256, False), (4096, 512, 512, True), (64, 256, 256, False),
+                                       (1000, 256, 512, False)])
+def test_gemm_with_two_residuals(M, N, K, two):
+    """gf_gemm_res2: y = [x0 | x1] W^T + b + r1 + r2 in one launch (the input-gradient GEMM where a loss head's gradient meets
+    the block's residual gradient); shapes outside the streamed kernel (M % 64 != 0) take the explicit add -- same numbers."""
+    g = torch.Generator().manual_seed(M + N + K)
+    bf = torch.bfloat16
+    x = torch.randn(M, K, generator=g).to(DEV, bf)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV, bf)
+    b = torch.randn(N, generator=g).to(DEV)
+    r1 = torch.randn(M, N, generator=g).to(DEV, bf)
+    r2 = torch.randn(M, N, generator=g).to(DEV, bf)
+    if two:
+        y = ops.gemm(x[:, :K // 2].contiguous(), w, b, res2=r1, x2b=x[:, K // 2:].contiguous(), res3=r2)
+    else:
+        y = ops.gemm(x, w, b, res2=r1, res3=r2)
+    ref = x.double() @ w.double().t() + b.double() + r1.double() + r2.double()
+    torch.testing.assert_close(y.double(), ref, rtol=1.2e-2, atol=1.2e-2)
+    # one rounding of the fp32 sum: closer to the reference than "add the residuals in bf16 first"
+    two_step = ops.gemm(x, w, b, res2=(r1 + r2))
+    assert float((y.double() - ref).abs().mean()) <= float((two_step.double() - ref).abs().mean()) * 1.001
+
+
 @pytest.mark.parametrize("M,Nout,K1,K2", [(5000, 512, 256, 256), (4133, 256, 128, 384), (131072, 512, 256, 256), (300, 128, 128, 128)])
 def test_linear_cat_weight_gradient_in_one_launch(M, Nout, K1, K2):
     """gf_linear_dw2: the weight gradient of y = [x1 | x2] W^T + b over the virtual concatenation (ffn.0(cat[x, message]),
