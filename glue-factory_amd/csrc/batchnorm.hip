@@ -14,6 +14,10 @@ namespace {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef GF_BN_UNR
+#define GF_BN_UNR 8           // rows of a thread in flight in the statistics passes (probe builds override it)
+#endif
+
 int bn_blocks(int M) {
     int nb = (M + 255) / 256;
     return nb < 1 ? 1 : (nb > 512 ? 512 : nb);
@@ -44,7 +48,7 @@ __global__ __launch_bounds__(256) void bn_colsum_kernel(const T* __restrict__ x,
     if (rl < rows_per_iter) {
         // UNR rows of this thread in flight at once: with one 16-byte load per thread and iteration the kernel was latency-
         // bound at ~2 TB/s (512 workgroups x 4 KB)
-        constexpr int UNR = 4;
+        constexpr int UNR = GF_BN_UNR;
         const int64_t stride = (int64_t)gridDim.x * rows_per_iter;
         for (int64_t r0 = (int64_t)blockIdx.x * rows_per_iter + rl; r0 < M; r0 += UNR * stride) {
             union Chunk { u32x4 u; T e[VEC]; };

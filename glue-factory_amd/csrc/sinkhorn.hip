@@ -760,7 +760,7 @@ extern "C" int gf_sinkhorn_fwd(const float* Z, float* out, float* u_hist, float*
                     ra.colA = w.a2p; ra.colB = w.vbp;                 // 16-byte aligned [B, Cp] scratch (free in the forward)
                     ra.u_hist = u_hist + (size_t)b0 * g.R; ra.v_hist = v_hist + (size_t)b0 * g.C;
                     ra.ustride = (size_t)B * g.R; ra.vstride = (size_t)B * g.C;
-                    ra.iters = iters; ra.d = rp; ra.d.bc = bc; ra.g = g; ra.wait_ticks = wait_ticks;
+                    ra.iters = iters; ra.d = rp; ra.d.bc = bc; ra.g = g; ra.wait_ticks = wait_ticks; ra.safe_only = (schedule >> 2) & 1;
                     int rc = skr_launch<false>(ra, st);
                     if (rc) return rc;
                 } else {
@@ -852,7 +852,7 @@ extern "C" int gf_sinkhorn_bwd(const float* Z, const float* gout, const float* g
                 ra.base_row = gsum_row + (size_t)b0 * g.R;
                 ra.ubar_hist = ubar_hist + (size_t)b0 * g.R; ra.vbar_hist = vbar_hist + (size_t)b0 * g.C;
                 ra.ustride = (size_t)B * g.R; ra.vstride = (size_t)B * g.C;
-                ra.iters = iters; ra.d = rp; ra.d.bc = bc; ra.g = g; ra.wait_ticks = wait_ticks;
+                ra.iters = iters; ra.d = rp; ra.d.bc = bc; ra.g = g; ra.wait_ticks = wait_ticks; ra.safe_only = (schedule >> 2) & 1;
                 return skr_launch<true>(ra, st);
             }() : [&]() -> int {
 #define SKF_CALL_BWD(NSV) skf_bwd_launch<NSV>(w.zp, u_hist + (size_t)b0 * g.R, v_hist + (size_t)b0 * g.C,          \

@@ -49,7 +49,8 @@ struct SkrPlan {
 struct SkrArgs {
     const float* Zp;            // [bc, R, Cp] prescaled padded copy
     float* part;                // [bc, nw, Cp] per-wave column partials
-    unsigned* ctr;              // [2 SKR_MAX_BC]: barrier counters, then failure flags; zeroed before the launch
+    unsigned* ctr;              // [3 SKR_MAX_BC]: barrier counters, failure flags, XCD masks of the pairs; zeroed before the launch
+    int safe_only;              // 1: placement-independent (write-through) hand-offs even when a pair sits on one XCD
     long long wait_ticks;       // bound of every wait in wall_clock64() ticks
     float* colA;                // [bc, Cp]  forward: running v (log2 units); backward: a2p
     float* colB;                // [bc, Cp]  backward: vbp
@@ -65,7 +66,7 @@ struct SkrArgs {
 };
 
 __global__ void skr_reset(unsigned* ctr) {
-    if (threadIdx.x < 2 * SKR_MAX_BC) ctr[threadIdx.x] = 0u;
+    if (threadIdx.x < 3 * SKR_MAX_BC) ctr[threadIdx.x] = 0u;
 }
 
 #ifndef SKR_ABL
@@ -78,6 +79,16 @@ __device__ __forceinline__ f32x4 skr_ld(__amdgpu_buffer_rsrc_t r, unsigned byte_
 }
 __device__ __forceinline__ void skr_st(__amdgpu_buffer_rsrc_t r, unsigned byte_off, f32x4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(skr_u32x4, v), r, byte_off, 0, 17);
+}
+// Same-XCD hand-off.  When EVERY workgroup of a pair runs on one XCD -- established at run time from the hardware's XCC id,
+// never assumed (see skr_kernel) -- the pair's readers and writers share one L2: a PLAIN store keeps the published line in
+// that L2 (a write-through `sc0 sc1` store drops it: the reader then fetches it from the memory side at the cross-XCD
+// rate), the readers' `sc0 sc1` loads bypass their own L1 and are served from it, and the producer's `s_waitcnt vmcnt(0)`
+// before it arrives on the counter is the L2's acknowledgement.  Coherent by construction of the part (one L2 per XCD),
+// and roughly half the latency of the memory-side round trip in every hop of the hand-off chain.
+__device__ __forceinline__ void skr_pub(__amdgpu_buffer_rsrc_t r, unsigned byte_off, f32x4 v, bool same_xcd) {
+    if (same_xcd) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(skr_u32x4, v), r, byte_off, 0, 0);
+    else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(skr_u32x4, v), r, byte_off, 0, 17);
 }
 
 __device__ __forceinline__ void skr_barrier(unsigned* ctr, unsigned target, long long wait_ticks) {
@@ -198,6 +209,15 @@ __global__ __launch_bounds__(256, 1) void skr_kernel(const SkrArgs a) {
     f32x4* zw = zl + (size_t)lrow0 * N4;
     unsigned* ctr = a.ctr + pair;
     unsigned nbar = 0;
+    // which XCD am I on?  every workgroup ORs its XCC id into the pair's mask BEFORE it arrives at the first barrier (which,
+    // like everything of the first iteration, uses the placement-independent protocol); whoever leaves that barrier reads the
+    // COMPLETE mask, so all workgroups of the pair take the same decision: one bit set = one shared L2 = `same_xcd` hand-offs
+    bool same_xcd = false;
+    if (tid == 0) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        __hip_atomic_fetch_or(ctr + 2 * SKR_MAX_BC, 1u << (xcc & 15u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 
     // ---- one-time load of the wave's rows
     const float* zb = a.Zp + ((size_t)pair * g.R + row0) * g.Cp;
@@ -317,12 +337,16 @@ __global__ __launch_bounds__(256, 1) void skr_kernel(const SkrArgs a) {
         }
         ul = outl;
 #pragma unroll
-        for (int s_ = 0; s_ < NSM; ++s_) skr_st(rpart, prow + 16u * (lane + 64 * s_), S[s_]);
+        for (int s_ = 0; s_ < NSM; ++s_) skr_pub(rpart, prow + 16u * (lane + 64 * s_), S[s_], same_xcd);
         if (lane == 0) {
             f32x4 tl = {st, 0.f, 0.f, 0.f};
-            skr_st(rpart, prow + 16u * N4, tl);
+            skr_pub(rpart, prow + 16u * N4, tl, same_xcd);
         }
         skr_barrier(ctr, ++nbar * (unsigned)a.d.wpp, a.wait_ticks);
+        if (it == 0 && !a.safe_only) {
+            const unsigned mask = __hip_atomic_load(ctr + 2 * SKR_MAX_BC, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            same_xcd = __builtin_amdgcn_readfirstlane((int)(__builtin_popcount(mask) == 1)) != 0;
+        }
 
         // ---- column phase: this workgroup finishes float4 columns [wg cs, wg cs + cs)
         f32x4 acc = splat4(0.f);
@@ -352,8 +376,8 @@ __global__ __launch_bounds__(256, 1) void skr_kernel(const SkrArgs a) {
                 }
             }
             if (!BWD) vkeep = oA;
-            skr_st(rcA, 16u * q, oA);
-            if (BWD) skr_st(rcB, 16u * q, oB);
+            skr_pub(rcA, 16u * q, oA, same_xcd);
+            if (BWD) skr_pub(rcB, 16u * q, oB, same_xcd);
         }
         skr_barrier(ctr, ++nbar * (unsigned)a.d.wpp, a.wait_ticks);
 
@@ -369,7 +393,8 @@ __global__ __launch_bounds__(256, 1) void skr_kernel(const SkrArgs a) {
 }
 
 // `schedule` argument of gf_sinkhorn_fwd / _bwd / _plan, bits 0-1: 0 = streaming kernels only, 1 = resident from SKR_MIN_BC
-// pairs per launch, 2 = resident whenever the problem fits (tests: small batches too); bits 8-31: bound of every inter-
+// pairs per launch, 2 = resident whenever the problem fits (tests: small batches too); bit 2: placement-independent
+// (write-through) hand-offs only, i.e. no same-XCD fast path (A/B tests); bits 8-31: bound of every inter-
 // workgroup wait in milliseconds (0 = SKR_DEFAULT_WAIT_MS).  Measured on MI355X (tools/probe/time_sinkhorn.py, N = 2048,
 // T = 100, forward / backward ms, streaming -> resident): B = 32 10.81 / 12.18 -> 8.35 / 10.66, B = 8 3.05 / 3.45 -> 2.10 / 2.73,
 // B = 4 2.25 / 2.51 -> 2.64 / 3.12, B = 1 1.46 / 1.56 -> 5.92 / 6.11 (a pair spread over the whole chip pays a 256-workgroup

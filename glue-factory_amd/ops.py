@@ -1451,7 +1451,7 @@ class _Sinkhorn(torch.autograd.Function):
         return gZ, None, None
 
 
-def sinkhorn_schedule(mode=None, wait_ms=None):
+def sinkhorn_schedule(mode=None, wait_ms=None, safe_handoff=None):
     """The `schedule` argument of gf_sinkhorn_fwd / _bwd (include/gf_amd.h): mode 0 = streaming kernels only, 1 = chip-resident
     sweeps from 5 pairs per launch (default), 2 = resident whenever the problem fits (csrc/sinkhorn_resident.h); wait_ms = bound
     of every inter-workgroup wait of the resident kernel (default 10 s; a pair whose wait expires comes out as NaN).
@@ -1465,7 +1465,9 @@ def sinkhorn_schedule(mode=None, wait_ms=None):
         wait_ms = int(w) if w.isdigit() else 0
     if mode not in (0, 1, 2) or not 0 <= wait_ms < (1 << 23):
         raise ValueError("sinkhorn_schedule: mode in {0, 1, 2}, 0 <= wait_ms < 2^23")
-    return int(mode) | (int(wait_ms) << 8)
+    if safe_handoff is None:        # GF_SINKHORN_SAFE_HANDOFF=1: never take the same-XCD (shared-L2) hand-off path
+        safe_handoff = os.environ.get("GF_SINKHORN_SAFE_HANDOFF", "0") == "1"
+    return int(mode) | (4 if safe_handoff else 0) | (int(wait_ms) << 8)
 
 
 def sinkhorn(Z, iters, schedule=None):

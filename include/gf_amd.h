@@ -192,8 +192,9 @@ int gf_filter_matches(const float* max0, const int64_t* arg0, const int64_t* arg
  * N % 256 == 0, N <= 2048, chip-resident sweeps (a chunk of <= 8-16 pairs is loaded once and stays in registers + LDS for
  * all iterations, one persistent launch per chunk with per-pair workgroup barriers; csrc/sinkhorn_resident.h).
  * `schedule` (per call; the library keeps no setting): bits 0-1 = 0 streaming only, 1 resident from 5 pairs per launch (the host
- * code's default), 2 resident whenever the problem fits; bits 8-31 = bound of every inter-workgroup wait of the resident
- * kernel in milliseconds (0 = 10 000).  The resident kernel's workgroups need not be co-resident (a CU held by another
+ * code's default), 2 resident whenever the problem fits; bit 2 = placement-independent hand-offs only (the resident kernel
+ * otherwise publishes through the shared L2 when it FINDS all workgroups of a pair on one XCD at run time -- a speed path,
+ * same numbers); bits 8-31 = bound of every inter-workgroup wait of the resident kernel in milliseconds (0 = 10 000).  The resident kernel's workgroups need not be co-resident (a CU held by another
  * stream's kernel only delays them); when a wait outlasts the bound, the pair's out / gZ is NaN in every row -- a loud,
  * skippable failure (train.py:477-480), never a silently wrong number or a hung device.  Same `schedule` for fwd and bwd. */
 /* Host-only query (no device needed): the chip-resident distribution for this problem on a device of `ncu` compute units:

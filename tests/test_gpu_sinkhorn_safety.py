@@ -137,3 +137,37 @@ def test_train_step_skips_the_update_when_the_sweep_was_poisoned(monkeypatch):
     again = step(data)["total"]
     assert bool(torch.isfinite(again).all()) and step.skipped == 1
     assert any(not torch.equal(p, q) for p, q in zip(model.parameters(), before))
+
+
+def test_same_xcd_handoffs_equal_the_write_through_protocol_bit_for_bit():
+    """When the resident kernel FINDS every workgroup of a pair on one XCD (hardware XCC id, checked at run time) it
+    publishes partial rows / column vectors with plain stores through the shared L2 instead of writing them through to the
+    memory side -- same arithmetic, same order, so the result must be bit-identical to the placement-independent protocol
+    (schedule bit 2), run after run (a stale hand-off would show up as a run that differs), forward and backward, at the
+    benchmarked geometry (B = 32: four launches of 8 pairs, T = 100) and at B = 9 (launches of 5 + 4 pairs: mixed placement)."""
+    from glue_factory_amd import ops
+    for Bn, Tn, reps in ((32, 100, 6), (9, 30, 10)):
+        g = torch.Generator(device="cuda").manual_seed(Bn)
+        Z = torch.randn(Bn, N + 1, N + 1, device="cuda", generator=g) * 2
+        G = torch.randn(Bn, N + 1, N + 1, device="cuda", generator=g)
+
+        def run(schedule):
+            z = Z.clone().requires_grad_(True)
+            out = ops.sinkhorn(z, Tn, schedule=schedule)
+            (out * G).sum().backward()
+            return out.detach(), z.grad
+
+        ref_out, ref_g = run(ops.sinkhorn_schedule(1, safe_handoff=True))
+        assert bool(torch.isfinite(ref_out).all()) and bool(torch.isfinite(ref_g).all())
+        for _ in range(reps):
+            out, gz = run(ops.sinkhorn_schedule(1, safe_handoff=False))
+            assert torch.equal(out, ref_out) and torch.equal(gz, ref_g)
+        # ... and under an uneven load: a streaming kernel on another stream while the sweeps run
+        side = torch.cuda.Stream()
+        junk = torch.randn(64 * 1024 * 1024, device="cuda")
+        with torch.cuda.stream(side):
+            for _ in range(20):
+                junk = junk * 1.0001 + 0.5
+        out, gz = run(ops.sinkhorn_schedule(1, safe_handoff=False))
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref_out) and torch.equal(gz, ref_g)
