@@ -49,7 +49,7 @@ struct SkrPlan {
 struct SkrArgs {
     const float* Zp;            // [bc, R, Cp] prescaled padded copy
     float* part;                // [bc, nw, Cp] per-wave column partials
-    unsigned* ctr;              // [3 SKR_MAX_BC]: barrier counters, failure flags, XCD masks of the pairs; zeroed before the launch
+    unsigned* ctr;              // [4 SKR_MAX_BC]: barrier counters, failure flags, XCD masks, same-XCD counters; zeroed before the launch
     int safe_only;              // 1: placement-independent (write-through) hand-offs even when a pair sits on one XCD
     long long wait_ticks;       // bound of every wait in wall_clock64() ticks
     float* colA;                // [bc, Cp]  forward: running v (log2 units); backward: a2p
@@ -66,7 +66,7 @@ struct SkrArgs {
 };
 
 __global__ void skr_reset(unsigned* ctr) {
-    if (threadIdx.x < 3 * SKR_MAX_BC) ctr[threadIdx.x] = 0u;
+    if (threadIdx.x < 4 * SKR_MAX_BC) ctr[threadIdx.x] = 0u;
 }
 
 #ifndef SKR_ABL
@@ -91,14 +91,25 @@ __device__ __forceinline__ void skr_pub(__amdgpu_buffer_rsrc_t r, unsigned byte_
     else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(skr_u32x4, v), r, byte_off, 0, 17);
 }
 
-__device__ __forceinline__ void skr_barrier(unsigned* ctr, unsigned target, long long wait_ticks) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's write-through stores have left the CU
+// L1-bypassing load of one word (the poll of the same-XCD counter: a plain load could be served by this CU's L1 for ever)
+__device__ __forceinline__ unsigned skr_peek(const unsigned* p) {
+    unsigned v;
+    asm volatile("global_load_dword %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
+// same_xcd: the pair's own L2 is the meeting point -- the arrival is an L2 atomic (workgroup scope: not forced out to the
+// memory side) on a counter word that only ever sees this protocol (ctr + 3 SKR_MAX_BC), polled past the L1
+__device__ __forceinline__ void skr_barrier(unsigned* ctr, unsigned target, long long wait_ticks, bool same_xcd = false) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's published stores have left the CU
     __syncthreads();
     if ((SKR_ABL & 4) == 0 && threadIdx.x == 0) {
-        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned* c = same_xcd ? ctr + 3 * SKR_MAX_BC : ctr;
+        if (same_xcd) __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int polls = 0;
         long long t0 = 0;
-        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        while ((same_xcd ? skr_peek(c) : __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < target) {
             __builtin_amdgcn_s_sleep(1);
             if ((++polls & 1023) == 0) {                  // (the clock is read every ~1 ms of polling only)
                 const long long now = wall_clock64();
@@ -108,7 +119,8 @@ __device__ __forceinline__ void skr_barrier(unsigned* ctr, unsigned target, long
                     // every later wait of the pair; whoever leaves a barrier after this sees the flag at the kernel's end
                     const unsigned was = __hip_atomic_fetch_or(ctr + SKR_MAX_BC, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     asm volatile("" ::"v"(was) : "memory");
-                    __hip_atomic_fetch_add(ctr, 0x40000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (same_xcd) __hip_atomic_fetch_add(c, 0x40000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    else __hip_atomic_fetch_add(c, 0x40000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     break;
                 }
             }
@@ -208,7 +220,7 @@ __global__ __launch_bounds__(256, 1) void skr_kernel(const SkrArgs a) {
     const int nreg = min(nrows, SKR_RR), nlds = nrows - nreg;
     f32x4* zw = zl + (size_t)lrow0 * N4;
     unsigned* ctr = a.ctr + pair;
-    unsigned nbar = 0;
+    unsigned nbar = 0, nbar2 = 0;                          // barriers passed on the agent-scope / the same-XCD counter
     // which XCD am I on?  every workgroup ORs its XCC id into the pair's mask BEFORE it arrives at the first barrier (which,
     // like everything of the first iteration, uses the placement-independent protocol); whoever leaves that barrier reads the
     // COMPLETE mask, so all workgroups of the pair take the same decision: one bit set = one shared L2 = `same_xcd` hand-offs
@@ -249,9 +261,24 @@ __global__ __launch_bounds__(256, 1) void skr_kernel(const SkrArgs a) {
 
     // the column vector(s) of the next row pass: LDS copy of the finished float4 columns + their dustbin entry
     auto pull_columns = [&]() {
-        for (int i = tid; i < N4; i += 256) {
-            vA[i] = skr_ld(rcA, 16u * i);
-            if (BWD) vB[i] = skr_ld(rcB, 16u * i);
+        // (all loads of a thread first, then the LDS writes: one round trip, not one per 256 columns)
+        constexpr int PC = (N4 + 255) / 256;
+        f32x4 pa[PC], pb[PC];
+#pragma unroll
+        for (int u = 0; u < PC; ++u) {
+            const int i = tid + 256 * u;
+            if (i < N4) {
+                pa[u] = skr_ld(rcA, 16u * i);
+                if (BWD) pb[u] = skr_ld(rcB, 16u * i);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < PC; ++u) {
+            const int i = tid + 256 * u;
+            if (i < N4) {
+                vA[i] = pa[u];
+                if (BWD) vB[i] = pb[u];
+            }
         }
         if (tid == 0) {
             misc[0] = skr_ld(rcA, 16u * N4)[0];
@@ -342,7 +369,8 @@ __global__ __launch_bounds__(256, 1) void skr_kernel(const SkrArgs a) {
             f32x4 tl = {st, 0.f, 0.f, 0.f};
             skr_pub(rpart, prow + 16u * N4, tl, same_xcd);
         }
-        skr_barrier(ctr, ++nbar * (unsigned)a.d.wpp, a.wait_ticks);
+        if (same_xcd) skr_barrier(ctr, ++nbar2 * (unsigned)a.d.wpp, a.wait_ticks, true);
+        else skr_barrier(ctr, ++nbar * (unsigned)a.d.wpp, a.wait_ticks);
         if (it == 0 && !a.safe_only) {
             const unsigned mask = __hip_atomic_load(ctr + 2 * SKR_MAX_BC, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             same_xcd = __builtin_amdgcn_readfirstlane((int)(__builtin_popcount(mask) == 1)) != 0;
@@ -350,8 +378,19 @@ __global__ __launch_bounds__(256, 1) void skr_kernel(const SkrArgs a) {
 
         // ---- column phase: this workgroup finishes float4 columns [wg cs, wg cs + cs)
         f32x4 acc = splat4(0.f);
-        if (colact && !(SKR_ABL & 16))
-            for (int w = grp; w < a.d.nw; w += 8) acc += skr_ld(rpart, (unsigned)w * rowb + 16u * q);
+        if (colact && !(SKR_ABL & 16)) {
+            // eight partial rows in flight per thread (the loop of single loads waited for every one of them: a chain of
+            // nw / 8 dependent round trips); summed in the same fixed order
+            int w = grp;
+            for (; w + 56 < a.d.nw; w += 64) {
+                f32x4 x[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) x[u] = skr_ld(rpart, (unsigned)(w + 8 * u) * rowb + 16u * q);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += x[u];
+            }
+            for (; w < a.d.nw; w += 8) acc += skr_ld(rpart, (unsigned)w * rowb + 16u * q);
+        }
         red[grp * 32 + ql] = acc;
         __syncthreads();
         if (grp == 0 && colact) {
@@ -379,7 +418,8 @@ __global__ __launch_bounds__(256, 1) void skr_kernel(const SkrArgs a) {
             skr_pub(rcA, 16u * q, oA, same_xcd);
             if (BWD) skr_pub(rcB, 16u * q, oB, same_xcd);
         }
-        skr_barrier(ctr, ++nbar * (unsigned)a.d.wpp, a.wait_ticks);
+        if (same_xcd) skr_barrier(ctr, ++nbar2 * (unsigned)a.d.wpp, a.wait_ticks, true);
+        else skr_barrier(ctr, ++nbar * (unsigned)a.d.wpp, a.wait_ticks);
 
         if (it + 1 < a.iters) pull_columns();
     }
