@@ -172,6 +172,18 @@ __device__ __forceinline__ void bn_block_sums(const float* __restrict__ part, in
     float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
     if (c < C) {
         int k = kg;
+        // eight partial rows in flight per thread (the two-row loop below waits for its loads every time round: nblk / 16
+        // dependent round trips, which is ALL this kernel's time); same two chains per statistic, same order
+        for (; k + 56 < nblk; k += 64) {
+            float x0[8], x1[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                x0[u] = part[(int64_t)(k + 8 * u) * 2 * C + c];
+                x1[u] = part[(int64_t)(k + 8 * u) * 2 * C + C + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) { a0 += x0[u]; a1 += x1[u]; b0 += x0[u + 1]; b1 += x1[u + 1]; }
+        }
         for (; k + 8 < nblk; k += 16) {
             a0 += part[(int64_t)k * 2 * C + c];
             a1 += part[(int64_t)k * 2 * C + C + c];

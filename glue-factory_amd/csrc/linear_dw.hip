@@ -603,6 +603,15 @@ __global__ __launch_bounds__(256) void linear_dw_reduce(const float* __restrict_
     f32x4 a0 = {0, 0, 0, 0}, a1 = a0;
     if (j < ncol4) {
         int k = g;
+        // eight slices in flight per thread (a loop of load pairs waits for every pair: nslice / 8 dependent round trips in a
+        // kernel that is nothing but latency); same two chains, same order
+        for (; k + 28 < nslice; k += 32) {
+            f32x4 x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const f32x4*>(src + (int64_t)(k + 4 * u) * stride + 4 * j);
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) { a0 += x[u]; a1 += x[u + 1]; }
+        }
         for (; k + 4 < nslice; k += 8) {
             a0 += *reinterpret_cast<const f32x4*>(src + (int64_t)k * stride + 4 * j);
             a1 += *reinterpret_cast<const f32x4*>(src + (int64_t)(k + 4) * stride + 4 * j);

@@ -101,8 +101,17 @@ __global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ x
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
     const int per = (R + CS_CHUNKS - 1) / CS_CHUNKS, r0 = blockIdx.y * per, r1 = min(R, r0 + per);
     float s = 0.f;
-    if (c < C)
-        for (int r = r0 + w; r < r1; r += 4) s += x[(size_t)r * C + c];
+    if (c < C) {
+        int r = r0 + w;
+        for (; r + 28 < r1; r += 32) {            // eight rows in flight (a loop of single loads is a chain of round trips)
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = x[(size_t)(r + 4 * u) * C + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; r < r1; r += 4) s += x[(size_t)r * C + c];
+    }
     sm[w][threadIdx.x & 63] = s;
     __syncthreads();
     if (w == 0 && c < C) part2[(size_t)blockIdx.y * C + c] = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
