@@ -333,7 +333,6 @@ def test_gemm_with_two_residuals(M, N, K, two):
 def test_linear_cat_weight_gradient_in_one_launch(M, Nout, K1, K2):
     """gf_linear_dw2: the weight gradient of y = [x1 | x2] W^T + b over the virtual concatenation (ffn.0(cat[x, message]),
     lightglue.py:140-148,196-221) in one launch == gf_linear_dw per source == fp64 autograd."""
-    import ctypes
     from glue_factory_amd import lib as L_
     g = torch.Generator().manual_seed(M + Nout)
     x1 = torch.randn(M, K1, generator=g).to(DEV, torch.bfloat16).requires_grad_(True)
