@@ -157,3 +157,23 @@ def test_torch_compile_of_the_model_trains_like_eager(kind):
         assert abs(a - b) <= 1e-5 * max(1.0, abs(a)), (ta, tb)
     for a, b in zip(pa, pb):
         torch.testing.assert_close(a, b, rtol=1e-5, atol=2e-7)
+
+
+def test_float16_mixed_precision_runs_the_hip_path_in_bf16():
+    """`--mp float16` (train.py:368-375): the matchers read autocast as "use the low-precision path" and compute in bf16
+    whatever the autocast dtype is (there are no fp16 kernels; bf16 has the wider exponent), outputs stay fp32; the
+    GradScaler-driven loop works unchanged (no overflow skips, finite losses, parameters move)."""
+    model, data = _model_and_data("lightglue")
+    opt = _make_opt("torch", model.parameters())
+    scaler = torch.amp.GradScaler("cuda", enabled=True)
+    before = [p.detach().clone() for p in model.parameters()]
+    totals = _reference_loop(model, data, opt, scaler, clip_grad=1.0, iters=3, mp_dtype=torch.float16)
+    assert len(totals) == 3 and all(0.0 < t < 50.0 for t in totals) and scaler.get_scale() == 65536.0
+    assert any(not torch.equal(p, q) for p, q in zip(model.parameters(), before))
+    with torch.autocast("cuda", dtype=torch.float16):
+        pred = model(data)
+    assert pred["log_assignment"].dtype == torch.float32
+    # same numbers as under bfloat16 autocast: the autocast dtype does not select the arithmetic
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        pred_bf = model(data)
+    torch.testing.assert_close(pred["log_assignment"], pred_bf["log_assignment"], rtol=0, atol=0)
