@@ -85,6 +85,8 @@ SIGNATURES = {
     "gf_rowdot_nblk": [_I],
     "gf_rowdot_fwd": [_P, _P, _F, _P, _P, _I, _I, _I, _P],
     "gf_rowdot_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "gf_rowdot2_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "gf_rowdot2_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "gf_rows_lse_argmax": [_P, _P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "gf_lg_loss_fwd": [_P] * 9 + [_L] + [_P] * 13 + [_I, _I, _I, _I, _I, _P],
     "gf_lg_loss_bwd_tokens": [_P] * 11 + [_L] + [_P] * 7 + [_I, _I, _I, _P],

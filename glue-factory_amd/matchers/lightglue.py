@@ -664,6 +664,7 @@ class LightGlue(nn.Module):
             x = layer_x[i]
             la = self.log_assignment[i]
             fh = priv["final_head"] if i == L - 1 else None
+            t, t_done = None, False
             if fh is not None:           # the forward pass already projected the last layer
                 md, z, rc = fh["md"], fh["z"], (fh["r"], fh["c"])
             else:
@@ -671,9 +672,16 @@ class LightGlue(nn.Module):
                 ch = priv["layer_chain"][i]
                 w, bias = la.scaled_proj(x.dtype)
                 md = ops.linear(x, w, bias, chain=ch, chain_last="extra")
-                z = ops.rowdot(x, la.matchability.weight, la.matchability.bias, chain=ch, counted=False)
+                tok = self.token_confidence[i].token[0] if i < L - 1 else None
+                if tok is not None and x.is_cuda and x.shape[-1] % 8 == 0:
+                    # matchability and token-confidence logits of this layer's output with one read of it
+                    z, t = ops.rowdot2(x, la.matchability.weight, la.matchability.bias, tok.weight, tok.bias, chain=ch, counted=False)
+                    t_done = True
+                else:
+                    z = ops.rowdot(x, la.matchability.weight, la.matchability.bias, chain=ch, counted=False)
                 rc = None
-            t = self.token_confidence[i].logits(x) if i < L - 1 else None
+            if not t_done:
+                t = self.token_confidence[i].logits(x) if i < L - 1 else None
             accs.append(ops.lg_layer_loss(md, z, t, rc, gt["pos"], gt["neg0"], gt["neg1"], fin0, fin1))
         acc = torch.stack(accs)                                       # [L, B, 4]
         nll_pos = -acc[..., 0] / gt["num_pos"]

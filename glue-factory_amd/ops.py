@@ -966,6 +966,67 @@ class _RowDot(torch.autograd.Function):
         return (None if dx is None else dx.view(xshape)), dw, db, None, None
 
 
+class _RowDot2(torch.autograd.Function):
+    """(z0, z1) = (x w0^T + b0, x.detach() w1^T + b1) for two single-output heads on the same rows with ONE read of x
+    (gf_rowdot2_*): a LightGlue layer's matchability (differentiable w.r.t. x: the rank-1 term joins x's gradient chain) and
+    token-confidence logits (the reference feeds that head desc.detach(), lightglue.py:81-94)."""
+
+    @staticmethod
+    def forward(ctx, x, w0, b0, w1, b1, chain=None, counted=True):
+        ctx.chain, ctx.counted = chain, counted
+        C = x.shape[-1]
+        x2 = x.reshape(-1, C)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        M = x2.shape[0]
+        w0f, w1f = w0.reshape(-1).float().contiguous(), w1.reshape(-1).float().contiguous()
+        z0 = torch.empty(M, dtype=torch.float32, device=x.device)
+        z1 = torch.empty(M, dtype=torch.float32, device=x.device)
+        b0f = None if b0 is None else b0.detach().reshape(-1).float()
+        b1f = None if b1 is None else b1.detach().reshape(-1).float()
+        _lib.check(_lib.load().gf_rowdot2_fwd(_p(x2), _p(w0f), _p(w1f), _p(b0f), _p(b1f), _p(z0), _p(z1), M, C, _dt(x2),
+                                              _stream()), "gf_rowdot2_fwd")
+        ctx.save_for_backward(x2, w0f)
+        ctx.meta = (x.shape, w0.shape, w0.dtype, None if b0 is None else b0.dtype, w1.shape, w1.dtype,
+                    None if b1 is None else b1.dtype)
+        return z0.view(x.shape[:-1]), z1.view(x.shape[:-1])
+
+    @staticmethod
+    def backward(ctx, dz0, dz1):
+        x2, w0f = ctx.saved_tensors
+        xshape, w0shape, w0dt, b0dt, w1shape, w1dt, b1dt = ctx.meta
+        M, C = x2.shape
+        L = _lib.load()
+        dz0 = torch.zeros(M, dtype=torch.float32, device=x2.device) if dz0 is None else dz0.reshape(-1).float().contiguous()
+        dz1 = torch.zeros(M, dtype=torch.float32, device=x2.device) if dz1 is None else dz1.reshape(-1).float().contiguous()
+        dx = torch.empty_like(x2) if ctx.needs_input_grad[0] else None
+        ch = ctx.chain if dx is not None else None
+        base = None if ch is None else ch.acc
+        if ch is not None and ch.extra is not None:
+            e = ch.pop_extra()
+            base = e if base is None else base + e
+        part = torch.empty((L.gf_rowdot_nblk(M), 2, C + 1), dtype=torch.float32, device=x2.device)
+        _lib.check(L.gf_rowdot2_bwd(_p(x2), _p(dz0), _p(dz1), _p(w0f), _p(dx), _p(base), _p(part), M, C, _dt(x2), _stream()),
+                   "gf_rowdot2_bwd")
+        s = part.sum(0)                                        # [2, C + 1]: ONE reduction for both heads
+        dw0 = s[0, :C].reshape(w0shape).to(w0dt)
+        db0 = None if b0dt is None else s[0, C:].to(b0dt)
+        dw1 = s[1, :C].reshape(w1shape).to(w1dt)
+        db1 = None if b1dt is None else s[1, C:].to(b1dt)
+        if ch is not None:
+            ch.park(dx, counted=ctx.counted)
+            dx = None
+        return (None if dx is None else dx.view(xshape)), dw0, db0, dw1, db1, None, None
+
+
+def rowdot2(x, w0, b0, w1, b1, chain=None, counted=True):
+    """See _RowDot2.  ``chain``: GradChain of x (the input gradient of head 0 is parked there)."""
+    _chk(x)
+    if not x.requires_grad:
+        chain = None
+    return _RowDot2.apply(x, w0, b0, w1, b1, chain, counted)
+
+
 def rowdot(x, w, b=None, chain=None, counted=True):
     """``chain``: GradChain of x -- the input gradient is parked there (added to the chain's running sum inside the
     kernel) instead of being returned."""

@@ -36,7 +36,7 @@ extern "C" {
 #define GF_ERR_ALIGN (-3)
 #define GF_ERR_DTYPE (-4)
 
-/* ABI version; bumped on any signature or workspace-size change (2: gf_attn_bwd's delta workspace doubled; 3: line head + gf_bgemm; 4: smallops; 5: gf_attn_bwd_acc; 9: cast entries with leading dimensions, gf_fold_linear_*, double betas in gf_multi_adam; 10: gf_attn_fwd_ex / GF_ATTN_SPLIT, gf_topk_candidates; 14: gf_sinkhorn_* take `schedule`, gf_sinkhorn_mode removed, gf_probe_hold_cus, gf_linear_dw2, gf_gemm_res2; gf_rowdot_fwd / gf_rotary_qk_bwd take a device bias / a base sum). */
+/* ABI version; bumped on any signature or workspace-size change (2: gf_attn_bwd's delta workspace doubled; 3: line head + gf_bgemm; 4: smallops; 5: gf_attn_bwd_acc; 9: cast entries with leading dimensions, gf_fold_linear_*, double betas in gf_multi_adam; 10: gf_attn_fwd_ex / GF_ATTN_SPLIT, gf_topk_candidates; 14: gf_sinkhorn_* take `schedule`, gf_sinkhorn_mode removed, gf_probe_hold_cus, gf_linear_dw2, gf_gemm_res2, gf_rowdot2_*; gf_rowdot_fwd / gf_rotary_qk_bwd take a device bias / a base sum). */
 #define GF_AMD_ABI_VERSION 14
 int gf_abi_version(void);
 /* Diagnostics (tests/test_gpu_sinkhorn_safety.py): occupies `n_cus` compute units (one 150 KB-LDS workgroup each) for
@@ -440,6 +440,14 @@ int gf_rowdot_fwd(const void* x, const float* w, float bias, const float* bias_d
                   void* stream);      /* z = x w + bias + (bias_dev ? *bias_dev : 0): bias_dev = a DEVICE scalar (the nn.Linear bias) */
 int gf_rowdot_bwd(const void* x, const float* dz, const float* w, void* dx, const void* base, float* part,
                   int M, int C, int dtype, void* stream);
+/* gf_rowdot2_*: TWO single-output heads on the same rows -- a LightGlue layer's matchability and token-confidence logits
+ * (lightglue.py:275-276 / :285-286, :71) -- with one read of x: z0 = x w0 + *b0, z1 = x w1 + *b1 (b0 / b1: device scalars or
+ * NULL).  Backward: dx = base + dz0 * w0 (only head 0 sees the un-detached descriptors, lightglue.py:81-94; dx may be NULL)
+ * and per-block partials part [gf_rowdot_nblk(M)][2][C+1] whose column sums are (dw0, db0) and (dw1, db1). */
+int gf_rowdot2_fwd(const void* x, const float* w0, const float* w1, const float* b0, const float* b1, float* z0, float* z1,
+                   int M, int C, int dtype, void* stream);
+int gf_rowdot2_bwd(const void* x, const float* dz0, const float* dz1, const float* w0, void* dx, const void* base,
+                   float* part, int M, int C, int dtype, void* stream);
 
 /* ---- fused deep-supervision loss of one LightGlue layer (lightglue.py:598-657 `loss`,
  * utils/losses.py:6-73 NLL with dustbins on the non-zero weights, lightglue.py:81-94 token confidence).

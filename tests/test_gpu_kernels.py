@@ -306,6 +306,35 @@ def test_ops_reject_cpu_tensors():
         ops.attention(torch.zeros(1, 4, 1, 64), torch.zeros(1, 4, 1, 64), torch.zeros(1, 4, 1, 64))
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,C", [(1000, 256), (131072, 256), (37, 64)])
+def test_rowdot2_two_heads_one_read(dtype, M, C):
+    """gf_rowdot2: matchability + token-confidence logits of the same rows in one pass; head 0 differentiable w.r.t. x
+    (dx = dz0 w0), head 1 on x.detach() (lightglue.py:81-94, 275-276, 285-286) == two nn.Linear(dim, 1) in fp64."""
+    g = torch.Generator().manual_seed(M + C)
+    x = torch.randn(M, C, generator=g).to(DEV, dtype).requires_grad_(True)
+    w0 = (torch.randn(1, C, generator=g) / C ** 0.5).to(DEV).requires_grad_(True)
+    w1 = (torch.randn(1, C, generator=g) / C ** 0.5).to(DEV).requires_grad_(True)
+    b0 = torch.randn(1, generator=g).to(DEV).requires_grad_(True)
+    b1 = torch.randn(1, generator=g).to(DEV).requires_grad_(True)
+    g0 = torch.randn(M, generator=g).to(DEV)
+    g1 = torch.randn(M, generator=g).to(DEV)
+    z0, z1 = ops.rowdot2(x, w0, b0, w1, b1)
+    ((z0 * g0).sum() + (z1 * g1).sum()).backward()
+    xr = x.detach().double().requires_grad_(True)
+    w0r, w1r, b0r, b1r = (t.detach().double().requires_grad_(True) for t in (w0, w1, b0, b1))
+    z0r = (xr @ w0r.t()).squeeze(-1) + b0r
+    z1r = (xr.detach() @ w1r.t()).squeeze(-1) + b1r
+    ((z0r * g0.double()).sum() + (z1r * g1.double()).sum()).backward()
+    tol = dict(rtol=1e-5, atol=1e-5) if dtype == torch.float32 else dict(rtol=1e-2, atol=1e-2)
+    torch.testing.assert_close(z0.double(), z0r.detach(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(z1.double(), z1r.detach(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(x.grad.double(), xr.grad, **tol)
+    for a, r in ((w0.grad, w0r.grad), (w1.grad, w1r.grad), (b0.grad, b0r.grad), (b1.grad, b1r.grad)):
+        sc = float(r.abs().max())
+        torch.testing.assert_close(a.double() / sc, r / sc, rtol=1e-4, atol=1e-4)
+
+
 @pytest.mark.parametrize("M,N,K,two", [(4096, 256, 512, False), (8192, 256, 256, False), (4096, 512, 512, True), (64, 256, 256, False),
                                        (1000, 256, 512, False)])
 def test_gemm_with_two_residuals(M, N, K, two):
