@@ -94,6 +94,51 @@ def test_train_step_vs_oracle_fp32(n0, n1):
         torch.testing.assert_close(p.grad.cpu() / sc, ref / sc, rtol=2e-3, atol=2e-3, msg=lambda m: f"{k}: {m}")
 
 
+@pytest.mark.parametrize("bf16", [False, True])
+def test_train_step_large_ragged_keypoint_counts_vs_oracle(bf16):
+    """N0 = 2000, N1 = 1777 (neither a multiple of 64 nor equal): the non-EVEN attention instantiations, the
+    register-resident GEMM for M % 64 != 0, the ragged tiles of the head / loss kernels and the unstacked (two-image) layer
+    code AT benchmark-like sizes, where the small ragged cases above only touch a tile or two.  fp32 at 1e-4; bf16 with the
+    bounds of the N = 2048 configuration (tests/test_gpu_baseline_configs.py)."""
+    from glue_factory_amd.synthetic import make_pairs
+    L, n0, n1 = 2, 2000, 1777
+    params = lgo.init_params(L, 256, 4, seed=91)
+    data = make_pairs(1, n0, n1, dim=256, size=(1024, 1024), seed=92)
+    odata = dict(data, image_size0=data["view0"]["image_size"], image_size1=data["view1"]["image_size"])
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    pred_o, loss_o, grads_o = lgo.train_step_grads(params, odata, L, 4)
+    model = _model(params, L).train()
+    cdata = _to_cuda(data)
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16):
+        pred = model(cdata)
+        losses, _ = model.loss(pred, {**pred, **cdata})
+    losses["total"].mean().backward()
+    la, la_o = pred["log_assignment"].detach().float().cpu(), pred_o["log_assignment"].detach()
+    assert la.shape == (1, n0 + 1, n1 + 1)
+    if not bf16:
+        torch.testing.assert_close(la, la_o, rtol=1e-4, atol=1e-4)
+        ok = _margin_mask(la_o[:, :-1, :-1], 1e-3)
+        assert torch.equal(pred["matches0"].cpu()[ok], pred_o["matches0"][ok])
+        for k, v in loss_o.items():
+            torch.testing.assert_close(losses[k].detach().cpu(), v.detach(), rtol=1e-4, atol=1e-4, msg=lambda m: f"{k}: {m}")
+        for k, p in model.named_parameters():
+            ref = grads_o[k]
+            sc = max(ref.abs().max().item(), 1e-9)
+            torch.testing.assert_close(p.grad.cpu() / sc, ref / sc, rtol=2e-3, atol=2e-3, msg=lambda m: f"{k}: {m}")
+    else:
+        err = (la - la_o).abs()
+        print(f"ragged 2000 x 1777 bf16: max |d log_assignment| {float(err.max()):.3f} mean {float(err.mean()):.4f}")
+        assert float(err.max()) <= 0.05 and float(err.mean()) <= 0.008       # (measured 0.022 / 0.0034 at L = 2)
+        for k, v in loss_o.items():
+            torch.testing.assert_close(losses[k].detach().float().cpu(), v.detach(), rtol=5e-3, atol=5e-3, msg=lambda m: f"{k}: {m}")
+        worst = 0.0
+        for k, p in model.named_parameters():
+            ref = grads_o[k].double()
+            worst = max(worst, float((p.grad.double().cpu() - ref).norm() / ref.norm().clamp(min=1e-30)))
+        print(f"   worst per-parameter gradient error {worst:.4f}")
+        assert worst <= 0.035
+
+
 @pytest.mark.parametrize("dim,heads", [(128, 4), (256, 2)])
 @pytest.mark.parametrize("bf16", [False, True])
 def test_train_step_other_head_dims_vs_oracle(dim, heads, bf16):
