@@ -15,7 +15,7 @@ import sys
 
 tag, root = sys.argv[1], sys.argv[2]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KEEP = ("attn_", "assign_write", "sk_", "skf_", "skr_", "sinkhorn", "gemm_st", "conv3x3_c64")
+KEEP = ("attn_", "assign_write", "sk_", "skf_", "skr_", "sinkhorn", "gemm_st", "conv3x3_c64", "rows_lse", "head_bwd", "linear_dw", "ln_gelu_fwd")
 agg = collections.defaultdict(lambda: [0.0, 0])
 allrows = []
 for f in glob.glob(os.path.join(root, "pmc*", "**", "*counter_collection.csv"), recursive=True):
@@ -89,6 +89,9 @@ out = {"gf_attn_bwd": group(["attn_bwd", "attn_dq3"], "attn_dq3"), "attn_fwd_ker
        "gf_attn_cross_bwd": group(["attn_xbwd", "attn_stats"], "attn_xbwd"),
        "gemm_st_kernel": group(["gemm_st"], "gemm_st"), "conv3x3_c64_kernel": group(["conv3x3_c64"], "conv3x3_c64"),
        "assign_write_kernel": group(["assign_write"], "assign_write"),
+       "rows_lse_kernel": group(["rows_lse_kernel"], "rows_lse_kernel"), "head_bwd_bf16_kernel": group(["head_bwd_bf16"], "head_bwd_bf16"),
+       "linear_dw_dma_kernel": group(["linear_dw_dma", "linear_dw_reduce"], "linear_dw_dma"),
+       "ln_gelu_fwd_kernel": group(["ln_gelu_fwd"], "ln_gelu_fwd"),
        # N <= 2304: the register-resident "skf_" kernels (one launch = prescale + T iterations + final pass)
        "gf_sinkhorn_fwd": group(["sk_rows_fwd", "sk_cols_fwd", "sk_final_fwd", "sk_fwd", "skf_fwd_iter", "skf_cols_fwd", "skr_kernel<8, false>",
                                  "skr_reset"],
