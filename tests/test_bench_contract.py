@@ -58,3 +58,42 @@ def test_grad_chain_bookkeeping():
     ch.got = 1
     ch.park("a+b")
     assert ch.take() == "a+b" and ch.acc is None and ch.got == 0
+
+
+def test_multi_rank_watchdog_prints_the_eager_line_and_exits_cleanly():
+    """bench.py --gpus N: the attempt to run the multi-rank step as a captured hipGraph is bounded by a watchdog -- when it
+    expires (a hung collective), rank 0 prints the line it already has (the kernel-by-kernel numbers) and the process leaves
+    with exit code 0.  Simulated here: a subprocess arms the watchdog with a line and then blocks."""
+    import subprocess
+    import sys
+    code = (
+        "import importlib.util, json, sys, time\n"
+        f"spec = importlib.util.spec_from_file_location('bench_mod', {os.path.join(ROOT, 'bench.py')!r})\n"
+        "mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)\n"
+        "mod._Watchdog(0.5, {'metric': 'm', 'value': 1.0, 'data_parallel': {'step_launch_modes': {'graph': {'status': 'timed out'}}}})\n"
+        "time.sleep(60)\n"
+        "print('NOT REACHED')\n")
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr[-500:]
+    lines = [ln for ln in res.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and "NOT REACHED" not in res.stdout
+    d = json.loads(lines[0])
+    assert d["value"] == 1.0 and d["data_parallel"]["step_launch_modes"]["graph"]["status"] == "timed out"
+    # a cancelled watchdog never fires
+    code2 = code.replace("time.sleep(60)", "").replace("mod._Watchdog(0.5,", "w = mod._Watchdog(0.5,").replace("print('NOT REACHED')", "w.cancel(); time.sleep(1.0); print('done')")
+    res = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0 and res.stdout.strip().splitlines()[-1] == "done"
+
+
+def test_gradchain_second_residual_slot():
+    """GradChain.extra: a parked tensor that has not been added yet rides to the next link (gf_gemm_res2) or is folded in by take()."""
+    from glue_factory_amd import ops
+    ch = ops.GradChain(2)
+    ch.extra = 3.0
+    ch.park(4.0)
+    assert ch.take() == 7.0 and ch.extra is None
+    ch = ops.GradChain(2)
+    ch.extra = 3.0
+    assert ch.pop_extra() == 3.0 and ch.pop_extra() is None
+    s = ops.SharedGradSum(3)
+    assert s.add("g1") is None and s.acc == "g1" and s.add("g2") is None and s.add("g3") == "g3" and s.acc is None and s.got == 0
