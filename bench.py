@@ -328,8 +328,11 @@ def roofline_extra(batch, n, dtype):
                             "achieved": round(by4 / t4 / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": round(by4 / t4 / 1e9 / HBM_PEAK_GBS, 4), "launch_ms": round(t4 * 1e3, 4),
                             "traffic": _traffic("linear_dw_dma_kernel"), "algorithmic_bytes_per_launch": by4,
-                            "note": "the 16 output tiles of a slice re-read the dY / X panels through L2 (4x the HBM bytes): L2 -> LDS "
-                                    "traffic, not HBM, bounds it (DESIGN.md section 7)"}
+                            "mfma_frac": round(2.0 * M * 512 * 512 / t4 / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+                            "note": "256 FLOP per HBM byte: the shape sits AT the ridge of the (power-limited) roofline, so neither line alone "
+                                    "bounds it -- `mfma_frac` is the same launch against the MFMA peak (PMC: MFMA pipe 33 % busy); the 16 output "
+                                    "tiles of a slice also re-read the dY / X panels through L2 (1.1 GB L2 -> LDS per launch, 4x the HBM bytes; "
+                                    "DESIGN.md section 7)"}
         xl = torch.randn(M, 512, device="cuda", dtype=dtype, generator=g)
         gam, bet = torch.ones(512, device="cuda"), torch.zeros(512, device="cuda")
         with torch.no_grad():
