@@ -85,6 +85,51 @@ def gen_lightglue(name, batch, n0, n1, n_layers, dim, heads, seed, size, store_p
           "matches", (pred["matches0"] > -1).sum(1).tolist())
 
 
+def gen_lightglue_sift(name, batch, n0, n1, n_layers, seed):
+    """The reference LightGlue as `configs/sift+lightglue_*.yaml` set it up: 128-d input descriptors through `input_proj`
+    (lightglue.py:343-346) and `add_scale_ori: true` -- keypoint scale and orientation join the positional encoding
+    (lightglue.py:348-350, 426-443).  Inputs stored; weights regenerated from the seed (checksum)."""
+    params = lgo.init_params(n_layers, 256, 4, input_dim=128, seed=seed, pos_dim=4)
+    data = make_pairs(batch, n0, n1, dim=128, size=(640, 480), seed=seed + 1)
+    g = torch.Generator().manual_seed(seed + 2)
+    for i, n in (("0", n0), ("1", n1)):
+        data["scales" + i] = torch.rand(batch, n, generator=g) * 4 + 1          # SIFT-like scales (pixels) ...
+        data["oris" + i] = (torch.rand(batch, n, generator=g) * 2 - 1) * 3.14159  # ... and orientations (radians)
+    model = ref_lightglue_conf({"n_layers": n_layers, "descriptor_dim": 256, "input_dim": 128, "num_heads": 4,
+                                "add_scale_ori": True, "weights": None, "flash": False, "checkpointed": False,
+                                "filter_threshold": 0.0}, params)
+    out = {}
+    model.eval()
+    with torch.no_grad():
+        pe = model(data)
+    out.update(_np({k: pe[k] for k in ("matches0", "matches1", "matching_scores0", "log_assignment")}, "eval."))
+    model.train()
+    pred = model(data)
+    losses, _ = model.loss(pred, {**pred, **data})
+    losses["total"].mean().backward()
+    out.update(_np({k: pred[k] for k in ("matches0", "matches1", "matching_scores0", "log_assignment")}, "train."))
+    out.update(_np({k: v for k, v in losses.items() if torch.is_tensor(v)}, "loss."))
+    for k, prm in model.named_parameters():
+        out["gradnorm." + k] = np.array([float(prm.grad.double().norm())])
+        if prm.grad.numel() <= 2048:
+            out["grad." + k] = prm.grad.numpy()
+    out["param_checksum"] = np.array([float(sum(v.double().abs().sum() for v in params.values()))])
+    out.update(_np({k: v for k, v in data.items() if torch.is_tensor(v)}, "data."))
+    out["data.image_size0"] = data["view0"]["image_size"].numpy()
+    out["data.image_size1"] = data["view1"]["image_size"].numpy()
+    out["meta"] = np.array([batch, n0, n1, n_layers, seed])
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+    print(name, "total loss", losses["total"].tolist(), "matches", (pred["matches0"] > -1).sum(1).tolist())
+
+
+def ref_lightglue_conf(conf, params):
+    from gluefactory.models.matchers.lightglue import LightGlue
+    model = LightGlue(conf)
+    res = model.load_state_dict(params, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    return model
+
+
 def gen_superglue(name, batch, n0, n1, gnn, iters, seed):
     """Reference SuperGlue (weights=None, seeded state_dict shared with the oracle): eval and
     train-mode forward, loss values and gradient norms; plus a bare log_optimal_transport case."""
@@ -572,6 +617,7 @@ def main():
             "metrics": lambda: gen_metrics("metrics", seed=109),
             "superglue_config4": lambda: gen_superglue_config("superglue_config4", 1, 2048, 100, seed=113),
             "gluestick_config5": lambda: gen_gluestick_config("gluestick_config5", 1, 2048, 512, seed=127),
+            "lightglue_sift": lambda: gen_lightglue_sift("lightglue_sift", 2, 150, 121, 2, seed=191),
             "superglue_sharp": lambda: gen_superglue_config("superglue_sharp", 2, 2048, 100, seed=151,
                                                              sharp=(0.01, 16.0, 0.03, 0.125)),
             "gluestick_sharp": lambda: gen_gluestick_config("gluestick_sharp", 2, 2048, 512, seed=157,
@@ -602,6 +648,7 @@ def main():
     gen_gluestick_config("gluestick_config5", 1, 2048, 512, seed=127)
     gen_gluestick("gluestick_lineattn", batch=2, n_kpts=36, n_lines=14, gnn=["self", "cross"] * 2, inter=[0], seed=43,
                   line_attention=True)
+    gen_lightglue_sift("lightglue_sift", 2, 150, 121, 2, seed=191)
     gen_superglue_config("superglue_sharp", 2, 2048, 100, seed=151, sharp=(0.01, 16.0, 0.03, 0.125))
     gen_gluestick_config("gluestick_sharp", 2, 2048, 512, seed=157, sharp=(0.01, 16.0, 0.03, 0.125))
 

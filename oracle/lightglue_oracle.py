@@ -196,6 +196,10 @@ def forward(p, data, n_layers=9, heads=4, filter_threshold=0.0, training=True):
     """LightGlue forward without early-stop / pruning (training path and plain eval)."""
     k0 = normalize_keypoints(data["keypoints0"], data.get("image_size0"))
     k1 = normalize_keypoints(data["keypoints1"], data.get("image_size1"))
+    if p["posenc.Wr.weight"].shape[1] == 4:        # add_scale_ori (lightglue.py:426-443): (x, y, scale, orientation)
+        cat = lambda k, sc, o: torch.cat([k, sc if sc.dim() == 3 else sc[..., None], o if o.dim() == 3 else o[..., None]], -1)   # noqa: E731
+        k0 = cat(k0, data["scales0"], data["oris0"])
+        k1 = cat(k1, data["scales1"], data["oris1"])
     d0, d1 = data["descriptors0"], data["descriptors1"]
     if "input_proj.weight" in p:
         d0, d1 = (F.linear(d, p["input_proj.weight"], p["input_proj.bias"]) for d in (d0, d1))

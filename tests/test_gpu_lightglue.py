@@ -95,6 +95,58 @@ def test_train_step_vs_oracle_fp32(n0, n1):
 
 
 @pytest.mark.parametrize("bf16", [False, True])
+def test_sift_style_configuration_vs_reference_golden(bf16):
+    """configs/sift+lightglue_{homography,megadepth}.yaml: `input_dim: 128` (a 128 -> 256 `input_proj` in front of the
+    transformer, lightglue.py:343-346) and `add_scale_ori: true` (keypoint scale and orientation join the positional
+    encoding: posenc.Wr is [32, 4], lightglue.py:348-350, 426-443) -- eval and train step against the vectors the
+    reference produced (tests/golden/lightglue_sift.npz), fp32 at 1e-4, bf16 with the small-configuration bounds."""
+    from conftest import load_golden
+    z = load_golden("lightglue_sift")
+    batch, n0, n1, L, seed = (int(v) for v in z["meta"])
+    params = lgo.init_params(L, 256, 4, input_dim=128, seed=seed, pos_dim=4)
+    from glue_factory_amd.matchers.lightglue import LightGlue
+    model = LightGlue({"n_layers": L, "input_dim": 128, "add_scale_ori": True, "filter_threshold": 0.0})
+    res = model.load_state_dict(params, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys and model.posenc.Wr.weight.shape == (32, 4)
+    model = model.cuda()
+    data = {k[5:]: torch.from_numpy(z[k]).cuda() for k in z if k.startswith("data.") and "image_size" not in k}
+    data["view0"] = {"image_size": torch.from_numpy(z["data.image_size0"]).cuda()}
+    data["view1"] = {"image_size": torch.from_numpy(z["data.image_size1"]).cuda()}
+    model.eval()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16):
+        pe = model(data)
+    model.train()
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16):
+        pred = model(data)
+        losses, _ = model.loss(pred, {**pred, **data})
+    losses["total"].mean().backward()
+    la = pred["log_assignment"].detach().float().cpu().numpy()
+    if not bf16:
+        np.testing.assert_allclose(pe["log_assignment"].float().cpu().numpy(), z["eval.log_assignment"], rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(la, z["train.log_assignment"], rtol=1e-4, atol=1e-4)
+        ok = _margin_mask(torch.from_numpy(z["train.log_assignment"])[:, :-1, :-1], 1e-3).numpy()
+        np.testing.assert_array_equal(pred["matches0"].cpu().numpy()[ok], z["train.matches0"][ok])
+        for k in [k[5:] for k in z if k.startswith("loss.")]:
+            np.testing.assert_allclose(losses[k].detach().float().cpu().numpy(), z["loss." + k], rtol=1e-4, atol=1e-4, err_msg=k)
+        for k, p in model.named_parameters():
+            ref = float(z["gradnorm." + k][0])
+            assert abs(float(p.grad.double().norm()) - ref) <= 2e-3 * ref + 1e-7, (k, float(p.grad.norm()), ref)
+            if "grad." + k in z:
+                r = z["grad." + k]
+                sc = max(np.abs(r).max(), 1e-9)
+                np.testing.assert_allclose(p.grad.cpu().numpy() / sc, r / sc, rtol=1e-3, atol=1e-3, err_msg=k)
+    else:
+        err = np.abs(la - z["train.log_assignment"])
+        print(f"sift-style bf16: max |d log_assignment| {err.max():.3f} mean {err.mean():.4f}")
+        assert err.max() <= 0.04 and err.mean() <= 0.007          # (measured 0.021 / 0.0032)
+        for k in [k[5:] for k in z if k.startswith("loss.")]:
+            np.testing.assert_allclose(losses[k].detach().float().cpu().numpy(), z["loss." + k], rtol=6e-3, atol=6e-3, err_msg=k)
+        for k, p in model.named_parameters():
+            ref = float(z["gradnorm." + k][0])
+            assert abs(float(p.grad.double().norm()) - ref) <= 0.04 * ref + 1e-6, (k, float(p.grad.norm()), ref)
+
+
+@pytest.mark.parametrize("bf16", [False, True])
 def test_train_step_large_ragged_keypoint_counts_vs_oracle(bf16):
     """N0 = 2000, N1 = 1777 (neither a multiple of 64 nor equal): the non-EVEN attention instantiations, the
     register-resident GEMM for M % 64 != 0, the ragged tiles of the head / loss kernels and the unstacked (two-image) layer

@@ -208,3 +208,28 @@ def test_gluestick_oracle_at_config5_matches_reference(name):
     errs = significant_grads(grad_digest_errors(z, grads))
     worst = max((e[0], k) for k, e in errs.items())
     assert worst[0] <= 3e-3, worst
+
+
+# ----------------------------------------------------------------------------- LightGlue, SIFT-style configuration
+def _sift_inputs():
+    z = load_golden("lightglue_sift")
+    batch, n0, n1, L, seed = (int(v) for v in z["meta"])
+    params = lgo.init_params(L, 256, 4, input_dim=128, seed=seed, pos_dim=4)
+    chk = float(sum(v.double().abs().sum() for v in params.values()))
+    assert abs(chk - float(z["param_checksum"][0])) < 1e-9 * chk
+    data = {k[5:]: torch.from_numpy(z[k]) for k in z if k.startswith("data.")}
+    return z, params, data, L
+
+
+def test_lightglue_oracle_with_input_proj_and_scale_orientation_matches_reference():
+    """configs/sift+lightglue_*.yaml: input_dim 128 -> input_proj (lightglue.py:343-346), add_scale_ori (:348-350, 426-443)."""
+    z, params, data, L = _sift_inputs()
+    pred, losses, grads = lgo.train_step_grads(params, data, L, 4)
+    np.testing.assert_allclose(pred["log_assignment"].detach().numpy(), z["train.log_assignment"], **TOL)
+    np.testing.assert_array_equal(pred["matches0"].numpy(), z["train.matches0"])
+    for k in [k[5:] for k in z if k.startswith("loss.")]:
+        np.testing.assert_allclose(losses[k].detach().numpy(), z["loss." + k], **TOL, err_msg=k)
+    for k, g in grads.items():
+        ref = float(z["gradnorm." + k][0])
+        assert abs(float(g.double().norm()) - ref) <= 2e-3 * ref + 1e-6, k
+    assert "input_proj.weight" in grads and grads["posenc.Wr.weight"].shape == (32, 4)
