@@ -122,6 +122,44 @@ def gen_lightglue_sift(name, batch, n0, n1, n_layers, seed):
     print(name, "total loss", losses["total"].tolist(), "matches", (pred["matches0"] > -1).sum(1).tolist())
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# Configuration options and edge cases of SuperGlue / GlueStick that no other fixture touches (tests/golden/matcher_options.npz)
+def gen_matcher_options(name="matcher_options"):
+    from gluefactory.models.matchers.gluestick import GlueStick
+    from gluefactory_nonfree.superglue import SuperGlue
+    out = {}
+    from oracle.option_cases import option_cases
+    for cname, (kind, conf, params, data) in option_cases().items():
+        model = (SuperGlue if kind == "superglue" else GlueStick)(conf)
+        res = model.load_state_dict(params, strict=True)
+        assert not res.missing_keys and not res.unexpected_keys, (cname, res)
+        out[f"{cname}.param_checksum"] = np.array([float(sum(v.double().abs().sum() for v in params.values()))])
+        model.eval()
+        with torch.no_grad():
+            pe = model(data)
+        for k, v in pe.items():
+            if torch.is_tensor(v):
+                out[f"{cname}.eval.{k}"] = v.numpy()
+        if cname.endswith("_empty"):
+            continue
+        model.train()
+        pred = model(data)
+        losses = model.loss(pred, {**pred, **data})
+        losses = losses[0] if isinstance(losses, tuple) else losses
+        losses["total"].mean().backward()
+        for k in ("log_assignment", "line_log_assignment"):
+            if k in pred:
+                out[f"{cname}.train.{k}"] = pred[k].detach().numpy()
+        for k, v in losses.items():
+            if torch.is_tensor(v):
+                out[f"{cname}.loss.{k}"] = v.detach().numpy()
+        for k, prm in model.named_parameters():
+            if prm.grad is not None:
+                out[f"{cname}.gradnorm.{k}"] = np.array([float(prm.grad.double().norm())])
+        print(name, cname, "loss", losses["total"].tolist())
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+
+
 def ref_lightglue_conf(conf, params):
     from gluefactory.models.matchers.lightglue import LightGlue
     model = LightGlue(conf)
@@ -617,6 +655,7 @@ def main():
             "metrics": lambda: gen_metrics("metrics", seed=109),
             "superglue_config4": lambda: gen_superglue_config("superglue_config4", 1, 2048, 100, seed=113),
             "gluestick_config5": lambda: gen_gluestick_config("gluestick_config5", 1, 2048, 512, seed=127),
+            "matcher_options": lambda: gen_matcher_options(),
             "lightglue_sift": lambda: gen_lightglue_sift("lightglue_sift", 2, 150, 121, 2, seed=191),
             "superglue_sharp": lambda: gen_superglue_config("superglue_sharp", 2, 2048, 100, seed=151,
                                                              sharp=(0.01, 16.0, 0.03, 0.125)),
@@ -649,6 +688,7 @@ def main():
     gen_gluestick("gluestick_lineattn", batch=2, n_kpts=36, n_lines=14, gnn=["self", "cross"] * 2, inter=[0], seed=43,
                   line_attention=True)
     gen_lightglue_sift("lightglue_sift", 2, 150, 121, 2, seed=191)
+    gen_matcher_options()
     gen_superglue_config("superglue_sharp", 2, 2048, 100, seed=151, sharp=(0.01, 16.0, 0.03, 0.125))
     gen_gluestick_config("gluestick_sharp", 2, 2048, 512, seed=157, sharp=(0.01, 16.0, 0.03, 0.125))
 

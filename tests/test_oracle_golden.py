@@ -233,3 +233,27 @@ def test_lightglue_oracle_with_input_proj_and_scale_orientation_matches_referenc
         ref = float(z["gradnorm." + k][0])
         assert abs(float(g.double().norm()) - ref) <= 2e-3 * ref + 1e-6, k
     assert "input_proj.weight" in grads and grads["posenc.Wr.weight"].shape == (32, 4)
+
+
+def test_matcher_option_cases_regenerate_and_load_into_the_hip_modules():
+    """oracle/option_cases.py (inputs of tests/golden/matcher_options.npz): the seeded parameters regenerate to the stored
+    checksum and load STRICTLY into the product modules built from the same conf (the state_dict contract of
+    `use_scores: false`, a short `keypoint_encoder`, `input_dim: 128`); the zero-keypoint early returns need no GPU and
+    equal the reference's outputs (superglue.py:271-279, gluestick.py:163-195)."""
+    from glue_factory_amd.matchers.gluestick import GlueStick
+    from glue_factory_amd.matchers.superglue import SuperGlue
+    from oracle.option_cases import option_cases
+    z = load_golden("matcher_options")
+    for name, (kind, conf, params, data) in option_cases().items():
+        chk = float(sum(v.double().abs().sum() for v in params.values()))
+        assert abs(chk - float(z[f"{name}.param_checksum"][0])) < 1e-9 * chk
+        model = (SuperGlue if kind == "superglue" else GlueStick)(conf)
+        res = model.load_state_dict(params, strict=True)
+        assert not res.missing_keys and not res.unexpected_keys
+        if name.endswith("_empty"):
+            pred = model(data)
+            ref = {k[len(name) + 6:]: v for k, v in z.items() if k.startswith(name + ".eval.")}
+            assert set(pred) == set(ref)
+            for k, v in ref.items():
+                assert tuple(pred[k].shape) == v.shape and pred[k].dtype == torch.from_numpy(v).dtype, k
+                np.testing.assert_array_equal(pred[k].numpy(), v)
