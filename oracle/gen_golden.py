@@ -130,7 +130,8 @@ def gen_matcher_options(name="matcher_options"):
     out = {}
     from oracle.option_cases import option_cases
     for cname, (kind, conf, params, data) in option_cases().items():
-        model = (SuperGlue if kind == "superglue" else GlueStick)(conf)
+        from gluefactory.models.matchers.lightglue import LightGlue
+        model = {"superglue": SuperGlue, "gluestick": GlueStick, "lightglue": LightGlue}[kind](conf)
         res = model.load_state_dict(params, strict=True)
         assert not res.missing_keys and not res.unexpected_keys, (cname, res)
         out[f"{cname}.param_checksum"] = np.array([float(sum(v.double().abs().sum() for v in params.values()))])

@@ -63,4 +63,11 @@ def option_cases():
     d["lines0"], d["lines_junc_idx0"], d["line_scores0"] = d["lines0"][:, :0], d["lines_junc_idx0"][:, :0], d["line_scores0"][:, :0]
     cases["gs_empty"] = ("gluestick", {"weights": None, "GNN_layers": ["self", "cross"]},
                          gso.init_params(256, gnn_layers=2, inter=None, seed=208), d)
+    # LightGlue: deep-supervision weights `loss.gamma` (gamma^(L-i-1); gamma <= 0 selects i + 1) and `loss.nll_balancing`
+    # away from their defaults (lightglue.py:328-332, 598-628; gluefactory/models/utils/losses.py:9-46)
+    from oracle import lightglue_oracle as lgo
+    for cname, loss in (("lg_gamma07", {"gamma": 0.7, "fn": "nll", "nll_balancing": 0.3}),
+                        ("lg_gamma0", {"gamma": 0.0, "fn": "nll", "nll_balancing": 0.8})):
+        cases[cname] = ("lightglue", {"weights": None, "n_layers": 3, "flash": False, "filter_threshold": 0.0, "loss": loss},
+                        lgo.init_params(3, 256, 4, seed=211), make_pairs(2, 96, 80, dim=256, size=(320, 240), seed=212))
     return cases

@@ -241,13 +241,14 @@ def test_matcher_option_cases_regenerate_and_load_into_the_hip_modules():
     `use_scores: false`, a short `keypoint_encoder`, `input_dim: 128`); the zero-keypoint early returns need no GPU and
     equal the reference's outputs (superglue.py:271-279, gluestick.py:163-195)."""
     from glue_factory_amd.matchers.gluestick import GlueStick
+    from glue_factory_amd.matchers.lightglue import LightGlue
     from glue_factory_amd.matchers.superglue import SuperGlue
     from oracle.option_cases import option_cases
     z = load_golden("matcher_options")
     for name, (kind, conf, params, data) in option_cases().items():
         chk = float(sum(v.double().abs().sum() for v in params.values()))
         assert abs(chk - float(z[f"{name}.param_checksum"][0])) < 1e-9 * chk
-        model = (SuperGlue if kind == "superglue" else GlueStick)(conf)
+        model = {"superglue": SuperGlue, "gluestick": GlueStick, "lightglue": LightGlue}[kind](conf)
         res = model.load_state_dict(params, strict=True)
         assert not res.missing_keys and not res.unexpected_keys
         if name.endswith("_empty"):
