@@ -63,6 +63,22 @@ def option_cases():
     d["lines0"], d["lines_junc_idx0"], d["line_scores0"] = d["lines0"][:, :0], d["lines_junc_idx0"][:, :0], d["line_scores0"][:, :0]
     cases["gs_empty"] = ("gluestick", {"weights": None, "GNN_layers": ["self", "cross"]},
                          gso.init_params(256, gnn_layers=2, inter=None, seed=208), d)
+    # GlueStick: intermediate supervision after layer 1 with non-default loss weights (gluestick.py:39-43, 378-462), and
+    # `skip_init: true` -- which the reference's constructor never forwards to its GNN (gluestick.py:78-85: `skip` keeps its
+    # default False), so it must register NO `scaling` parameter and change nothing: the strict load below proves both sides agree
+    p = gso.init_params(256, gnn_layers=4, inter=[1], seed=213)
+    cases["gs_skipinit"] = ("gluestick", {"weights": None, "GNN_layers": ["self", "cross"] * 2, "skip_init": True,
+                                          "inter_supervision": [1], "filter_threshold": 0.0,
+                                          "loss": {"nll_weight": 0.5, "nll_balancing": 0.3, "inter_supervision": [0.2, 0.7]}},
+                            p, make_point_line_pairs(2, 40, 12, dim=256, size=(320, 240), seed=214))
+    # SuperGlue: `descriptor_dim: 128` (4 heads of 32 channels) and `loss.nll_balancing: 0.8` (superglue.py:222-233, 322-342)
+    d = make_pairs(2, 70, 64, dim=128, size=(320, 240), seed=216)
+    d["view0"]["image"] = torch.zeros(2, 1, 240, 320)        # the reference reads view["image"].shape unconditionally
+    d["view1"]["image"] = torch.zeros(2, 1, 240, 320)
+    cases["sg_dim128"] = ("superglue", {"weights": None, "descriptor_dim": 128, "keypoint_encoder": [32, 64],
+                                        "GNN_layers": ["self", "cross"], "num_sinkhorn_iterations": 20, "filter_threshold": 0.0,
+                                        "loss": {"nll_balancing": 0.8}},
+                          sgo.init_params(128, kenc_layers=(32, 64), gnn_layers=2, seed=215), d)
     # LightGlue: deep-supervision weights `loss.gamma` (gamma^(L-i-1); gamma <= 0 selects i + 1) and `loss.nll_balancing`
     # away from their defaults (lightglue.py:328-332, 598-628; gluefactory/models/utils/losses.py:9-46)
     from oracle import lightglue_oracle as lgo
