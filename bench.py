@@ -79,6 +79,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive companion measurement of scope P")
     ap.add_argument("--roofline-only", action="store_true", help="only run the roofline kernels (rocprofv3 target)")
     ap.add_argument("--micro", action="store_true", help="print per-kernel micro timings and exit")
     ap.add_argument("--model", default="lightglue", choices=["lightglue", "superglue", "gluestick"],
@@ -622,6 +623,91 @@ def timed_steps(step, warmup, steps, barrier, dist):
     return dt, float(loss.item())
 
 
+def pcie_inclusive(args, p_stepper, data):
+    """The same scope-P step with the batch arriving from HOST memory, the way the reference's loop receives it
+    (train.py:462-469: `batch_to_device(data, device, non_blocking=True)` on what the DataLoader's pinned-memory workers
+    produced): 2 x B float32 images + image sizes + H_0to1 per step over PCIe.  `serial`: the host-to-device copies are
+    enqueued on the step's stream in front of the replay (what the reference loop does).  `prefetched`: batch k + 1 is copied
+    by a second stream into one of two device staging sets while step k replays; the step then starts with a device-side
+    copy into the graph's input buffers.  A REPORTED companion of `value`, never `value` itself."""
+    def tree(fn, d):
+        return {k: tree(fn, v) if isinstance(v, dict) else (fn(v) if torch.is_tensor(v) else v) for k, v in d.items()}
+
+    def leaves(d):
+        for v in d.values():
+            if isinstance(v, dict):
+                yield from leaves(v)
+            elif torch.is_tensor(v):
+                yield v
+
+    def copy_tree(dst, src):
+        for k, v in src.items():
+            if isinstance(v, dict):
+                copy_tree(dst[k], v)
+            elif torch.is_tensor(v):
+                dst[k].copy_(v, non_blocking=True)
+
+    host = tree(lambda t: t.detach().cpu().pin_memory(), data)
+    nbytes = sum(t.numel() * t.element_size() for t in leaves(host))
+    steps = min(args.steps, 10)
+    cur = torch.cuda.current_stream()
+
+    def timed(step_k):
+        for k in range(2):
+            step_k(k)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(2, 2 + steps):
+            loss = step_k(k)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        if not torch.isfinite(loss["total"]).all().item():
+            raise RuntimeError("non-finite loss in the PCIe-inclusive step")
+        return dt
+
+    # the copies alone (the box's pinned host-to-device rate)
+    stage = [tree(torch.empty_like, data) for _ in range(2)]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        copy_tree(stage[0], host)
+    torch.cuda.synchronize()
+    h2d = (time.perf_counter() - t0) / 3
+    serial = timed(lambda k: p_stepper(host))
+    side = torch.cuda.Stream()
+    landed = [torch.cuda.Event() for _ in range(2)]
+    freed = [torch.cuda.Event() for _ in range(2)]
+    for e in freed:
+        e.record(cur)
+
+    def prefetch(i):
+        with torch.cuda.stream(side):
+            side.wait_event(freed[i])                # the step that read staging set i has copied it out
+            copy_tree(stage[i], host)
+            landed[i].record(side)
+
+    prefetch(0)
+
+    def step_prefetched(k):
+        i = k & 1
+        prefetch(1 - i)
+        cur.wait_event(landed[i])
+        out = p_stepper(stage[i])
+        freed[i].record(cur)
+        return out
+
+    pref = timed(step_prefetched)
+    torch.cuda.synchronize()
+
+    def entry(dt):
+        return {"ms_per_step": round(dt * 1e3, 3), "value": round(args.batch / dt, 2)}
+
+    return {"unit": "image-pairs/s", "host_bytes_per_step": nbytes, "h2d_ms": round(h2d * 1e3, 3),
+            "h2d_GBps": round(nbytes / h2d / 1e9, 1), "steps": steps, "serial": entry(serial), "prefetched": entry(pref),
+            "note": "scope P with the batch in pinned HOST memory (2 x B float32 images, sizes, H_0to1): copies on the step's "
+                    "stream / on a second stream under the previous step; never the headline value"}
+
+
 def other_config(args, name, local, conf=None):
     """BASELINE.json configs[3] / configs[4]: matcher train step of SuperGlue / GlueStick, inputs resident in HBM."""
     from glue_factory_amd.synthetic import to_device
@@ -865,6 +951,11 @@ def main():
                 out["roofline_extra"] = roofline_extra(args.batch, args.kpts, dtype)
             except Exception as e:   # a secondary measurement must never cost the headline line
                 out.setdefault("roofline", {"error": f"{type(e).__name__}: {e}"})
+        if not args.no_pcie:
+            try:
+                out["pcie_inclusive"] = pcie_inclusive(args, p_stepper, p_stepper.static_inputs())
+            except Exception as e:   # a secondary measurement must never cost the headline line
+                out["pcie_inclusive"] = {"error": f"{type(e).__name__}: {e}"}
         if not args.no_other_configs:
             del model, data, p_stepper, extract, pipe_res
             torch.cuda.empty_cache()

@@ -202,6 +202,7 @@ class TrainStep:
                 raise ValueError(f"TrainStep: unknown reducer {reducer!r} (buckets, buckets_bound, ddp)")
         p = next(model.parameters())
         self.device_type = p.device.type
+        self.device = p.device
         self.check_grads = check_grads
         self._skipped_host = 0
         self._skipped_dev = None
@@ -240,12 +241,16 @@ class TrainStep:
         return self._skipped_host + (int(self._skipped_dev.item()) if self._skipped_dev is not None else 0)
 
     def __call__(self, data):
+        """One train step.  ``data`` may live on the model's device or in (pinned) HOST memory, as a DataLoader hands it
+        over (the reference moves it first: train.py:462-469 batch_to_device(non_blocking=True)): host tensors are copied to
+        the device in stream order -- in replay mode straight into the captured graph's own input buffers, one
+        host-to-device copy per tensor and no device-side copy behind it."""
         self._calls += 1
         if not self.graph or self._calls <= self.graph_warmup:
-            return self._step(data)
+            return self._step(_to_device_tree(data, self.device))
         sig = _signature(data)
         if self._g is None or self._g[0] != sig:
-            self._capture(data, sig)
+            self._capture(_to_device_tree(data, self.device), sig)
         _, g, static_in, static_out = self._g
         _copy_into(static_in, data)
         sync_lr = getattr(self.optimizer, "sync_lr", None)
@@ -333,8 +338,18 @@ def _signature(data):
     if isinstance(data, dict):
         return tuple((k, _signature(v)) for k, v in sorted(data.items()))
     if torch.is_tensor(data):
-        return (tuple(data.shape), data.dtype, data.device)
+        return (tuple(data.shape), data.dtype)         # (not the device: a host batch replays the same graph)
     return None
+
+
+def _to_device_tree(data, device):
+    """`data` with every tensor that is not on `device` moved there (stream-ordered; pinned host memory copies
+    asynchronously); tensors already there are passed through, not copied."""
+    if isinstance(data, dict):
+        return {k: _to_device_tree(v, device) for k, v in data.items()}
+    if torch.is_tensor(data) and data.device != device:
+        return data.to(device, non_blocking=True)
+    return data
 
 
 def _clone_tree(data):

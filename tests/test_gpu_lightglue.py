@@ -355,6 +355,41 @@ def test_train_step_hipgraph_replay_equals_eager():
     torch.testing.assert_close(e0, e1, rtol=1e-4, atol=1e-4)
 
 
+def test_train_step_takes_batches_from_pinned_host_memory():
+    """A DataLoader hands the batch over in (pinned) host memory (the reference moves it with batch_to_device,
+    train.py:462-469).  TrainStep accepts it as it is -- eager steps move it, replays copy it straight into the captured
+    graph's input buffers, ONE graph for host and device batches alike -- and trains exactly as on device-resident batches."""
+    from glue_factory_amd.synthetic import make_pairs
+    from glue_factory_amd.train_step import TrainStep
+    L = 2
+    params = lgo.init_params(L, 256, 4, seed=23)
+    cpu_batches = [make_pairs(2, 256, dim=256, size=(640, 480), seed=50 + i) for i in range(6)]
+
+    def pin(d):
+        return {k: pin(v) if isinstance(v, dict) else (v.pin_memory() if torch.is_tensor(v) else v) for k, v in d.items()}
+
+    results = []
+    for source in ("device", "host", "mixed"):
+        model = _model(params, L).train()
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True, capturable=True)
+        step = TrainStep(model, opt, amp_dtype=torch.bfloat16, graph=True, graph_warmup=2)
+        losses, graphs = [], set()
+        for i, b in enumerate(cpu_batches):
+            host = source == "host" or (source == "mixed" and i % 2 == 1)
+            losses.append(step(pin(b) if host else _to_cuda(b))["total"].clone())
+            if step._g is not None:
+                graphs.add(id(step._g[1]))
+        assert len(graphs) == 1                      # captured once; host batches replay the same graph
+        assert all(t.is_cuda for t in step.static_inputs().values() if torch.is_tensor(t))
+        results.append((torch.stack(losses), [p.detach().clone() for p in model.parameters()]))
+    for (losses, ps), source in zip(results[1:], ("host", "mixed")):
+        print(f"{source} vs device batches: max loss difference {float((losses - results[0][0]).abs().max()):.2e}")
+        # (same tolerance as graph vs eager above: the loss accumulators are atomic sums; another batch's loss differs by >1e-2)
+        torch.testing.assert_close(losses, results[0][0], rtol=1e-5, atol=1e-5)
+        for a, b in zip(ps, results[0][1]):
+            torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
+
+
 def test_hipgraph_replays_with_eager_work_between_and_no_host_sync():
     """The benchmark's pipeline pattern: eager kernels (there: the extractor) queued between replays of the captured
     step, and no host synchronisation for dozens of steps.  Every replay's reported losses must equal the eager
