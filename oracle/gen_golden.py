@@ -282,6 +282,34 @@ def gen_superpoint(name, seed):
     print(name, "keypoints", tuple(pr["keypoints"].shape))
 
 
+def gen_superpoint_options(name, seed):
+    """Reference superpoint_open under the configurations of superpoint_option_cases(), seeded weights shared through a temp
+    state_dict file; the detector's last convolution is scaled so that the scores spread (random weights give 1/65 everywhere)."""
+    import tempfile
+    from gluefactory.models.extractors.superpoint_open import SuperPoint as RefSP
+    from glue_factory_amd.extractors.superpoint_open import SuperPoint
+    out = {"seed": np.array(seed)}
+    from oracle.option_cases import superpoint_option_cases
+    for cname, (conf, shape) in superpoint_option_cases().items():
+        torch.manual_seed(seed)
+        ours = SuperPoint(conf)
+        for prm in ours.detector[1].parameters():
+            if prm.ndim == 4:
+                prm.data.mul_(40.0)
+        with tempfile.TemporaryDirectory() as d:
+            path = os.path.join(d, "sp.pth")
+            torch.save(ours.state_dict(), path)
+            ref = RefSP({**conf, "weights": path}).eval()
+        g = torch.Generator().manual_seed(seed + 1)
+        image = torch.rand(*shape, generator=g)
+        with torch.no_grad():
+            pr = ref({"image": image})
+        out[f"{cname}.image"] = image.numpy()
+        out.update(_np(pr, cname + "."))
+        print(name, cname, {k: tuple(v.shape) for k, v in pr.items()})
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+
+
 def gen_superpoint_nonfree(name, seed):
     """Reference gluefactory_nonfree.superpoint (the MagicLeap-layout extractor the N=2048 LightGlue yaml names) on seeded
     random weights: the reference constructor downloads superpoint_v1.pth, so torch.hub is pointed at the state_dict of OUR
@@ -652,6 +680,7 @@ def main():
             "lightglue_sharp": lambda: gen_lightglue_config("lightglue_sharp", 1, 2048, 9, seed=131, size=(1024, 1024),
                                                              stride=997, sharp=(0.04, 11.0, 0.06)),
             "lightglue_adaptive": lambda: gen_lightglue_adaptive("lightglue_adaptive", 160, 200, 3, seed=107),
+            "superpoint_options": lambda: gen_superpoint_options("superpoint_options", seed=57),
             "superpoint_nonfree": lambda: gen_superpoint_nonfree("superpoint_nonfree", seed=53),
             "metrics": lambda: gen_metrics("metrics", seed=109),
             "superglue_config4": lambda: gen_superglue_config("superglue_config4", 1, 2048, 100, seed=113),
@@ -677,6 +706,7 @@ def main():
     gen_gt_lines("gt_lines", batch=2, n0=40, n1=36, seed=71)
     gen_superpoint("superpoint_open", seed=51)
     gen_superpoint_nonfree("superpoint_nonfree", seed=53)
+    gen_superpoint_options("superpoint_options", seed=57)
     gen_gluestick("gluestick_d256", batch=2, n_kpts=40, n_lines=12, gnn=["self", "cross"] * 2, inter=[0], seed=41)
     gen_superglue("superglue_d256", batch=2, n0=60, n1=52, gnn=["self", "cross"] * 2, iters=20, seed=31)
     gen_lightglue_config("lightglue_config1", 4, 512, 4, seed=101, size=(640, 480))

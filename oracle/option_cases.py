@@ -87,3 +87,14 @@ def option_cases():
         cases[cname] = ("lightglue", {"weights": None, "n_layers": 3, "flash": False, "filter_threshold": 0.0, "loss": loss},
                         lgo.init_params(3, 256, 4, seed=211), make_pairs(2, 96, 80, dim=256, size=(320, 240), seed=212))
     return cases
+
+
+def superpoint_option_cases():
+    """name -> (conf, image shape): superpoint_open configurations the main golden does not touch (superpoint_open.py:79-90,
+    150-207): no keypoint cap + a real detection threshold + dense outputs (batch of one, variable count), a cap without
+    padding, no border removal with a small NMS radius.  (A batch of several images WITHOUT force_num_keypoints is not a
+    reference configuration: superpoint_open.py:196-208 ends in `list.transpose`.)"""
+    return {"uncapped": ({"detection_threshold": 0.02, "dense_outputs": True}, (1, 1, 120, 160)),
+            "capped": ({"max_num_keypoints": 60, "detection_threshold": 0.02, "nms_radius": 3}, (1, 3, 96, 128)),
+            "noborder": ({"max_num_keypoints": 80, "force_num_keypoints": True, "detection_threshold": 0.0, "nms_radius": 2,
+                          "remove_borders": 0}, (2, 1, 96, 128))}
