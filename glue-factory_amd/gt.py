@@ -277,9 +277,9 @@ def _segments(lines):
     return lines
 
 
-def _close_point_counts(seg, pts, dist_th):
-    """count[b, a, c] = number of the sampled points pts[b, c, :, :] that lie within dist_th of segment seg[b, a]
-    and project onto it (the test of gt_generation.py:173-206, incl. its fp16-rounded segment length: the
+def _close_point_counts(seg, pts, dist_th, keep=None):
+    """count[b, a, c] = number of the sampled points pts[b, c, :, :] (of those flagged in keep[b, c, :], if given) that lie
+    within dist_th of segment seg[b, a] and project onto it (the test of gt_generation.py:173-206, incl. its fp16-rounded segment length: the
     direction is normalised by the half-precision norm, which the thresholds are sensitive to)."""
     d = seg[..., 2:] - seg[..., :2]
     length = torch.norm(d, dim=-1).half()                    # reference quirk, kept for identical labels
@@ -290,47 +290,30 @@ def _close_point_counts(seg, pts, dist_th):
     along = rel[..., 0] * u[..., None, None, 0] + rel[..., 1] * u[..., None, None, 1]
     perp = rel[..., 1] * u[..., None, None, 0] - rel[..., 0] * u[..., None, None, 1]
     inside = (along <= 0) & (along.abs() <= length[..., None, None])
-    return ((perp.abs() < dist_th) & inside).sum(-1)
+    close = (perp.abs() < dist_th) & inside
+    if keep is not None:
+        close = close & keep[:, None]
+    return close.sum(-1)
 
 
-@torch.no_grad()
-def gt_line_matches_from_homography(pred_lines0, pred_lines1, valid_lines0, valid_lines1, shape0, shape1, H,
-                                    npts=50, dist_th=5, overlap_th=0.2, min_visibility_th=0.2):
-    """Line ground truth under a homography (gluefactory/geometry/gt_generation.py:409-558): sample npts points
-    on every segment, warp them, count per segment pair how many warped samples fall on the other segment (both
-    ways), keep pairs whose two overlaps exceed overlap_th, solve the one-to-one assignment with the Hungarian
-    method on CPU (scipy, as the reference) and label the rest unmatched (-1) / ignored (-2, invalid lines).
-    Returns (assignment [B,L0,L1] bool, matches0 [B,L0], matches1 [B,L1])."""
+def _line_samples(seg, npts):
+    """npts points on every segment, end points included: [B,L,4] -> [B,L,npts,2] (gt_generation.py:164-170)."""
+    step = (seg[..., 2:4] - seg[..., :2]) / (npts - 1)
+    t = torch.arange(npts).to(seg)
+    return seg[..., None, :2] + t[:, None] * step[..., None, :]
+
+
+def _mostly_outside(p, w, h, min_visibility_th):
+    out = (p < 0).any(-1) | (p >= torch.tensor([w, h]).to(p)).any(-1)
+    return out.float().mean(-1) >= (1 - min_visibility_th)
+
+
+def _assign_lines(both, mask_close, unmatched0, unmatched1, ignore0, ignore1):
+    """The labelling both line ground truths end in (gt_generation.py:343-407, 502-558): one-to-one assignment that maximises
+    the product of the two close-point counts (Hungarian method on the CPU, scipy -- as the reference), positives = assigned
+    pairs that also pass `mask_close`; the rest unmatched (-1) or ignored (-2)."""
     from scipy.optimize import linear_sum_assignment
-    h0, w0 = shape0[-2:]
-    h1, w1 = shape1[-2:]
-    l0, l1 = _segments(pred_lines0.clone()), _segments(pred_lines1.clone())
-    b, n0, _ = l0.shape
-    n1 = l1.shape[1]
-    l0 = torch.min(torch.max(l0, torch.zeros_like(l0)), l0.new_tensor([w0 - 1, h0 - 1, w0 - 1, h0 - 1], dtype=torch.float))
-    l1 = torch.min(torch.max(l1, torch.zeros_like(l1)), l1.new_tensor([w1 - 1, h1 - 1, w1 - 1, h1 - 1], dtype=torch.float))
-
-    def samples(seg):                                        # [B,L,npts,2], end points included
-        step = (seg[..., 2:4] - seg[..., :2]) / (npts - 1)
-        t = torch.arange(npts).to(seg)
-        return seg[..., None, :2] + t[:, None] * step[..., None, :]
-
-    p0_in1 = warp_points(samples(l0).reshape(b, n0 * npts, 2), H, inverse=False).reshape(b, n0, npts, 2)
-    p1_in0 = warp_points(samples(l1).reshape(b, n1 * npts, 2), H, inverse=True).reshape(b, n1, npts, 2)
-
-    def mostly_outside(p, w, h):
-        out = (p < 0).any(-1) | (p >= torch.tensor([w, h]).to(p)).any(-1)
-        return out.float().mean(-1) >= (1 - min_visibility_th)
-
-    out_of0, out_of1 = mostly_outside(p1_in0, w0, h0), mostly_outside(p0_in1, w1, h1)   # [B,L1], [B,L0]
-    c0 = _close_point_counts(l0, p1_in0, dist_th)            # [B,L0,L1]
-    c1t = _close_point_counts(l1, p0_in1, dist_th).transpose(-1, -2)
-    both = c0 * c1t
-    mask_close = (c1t > npts * overlap_th) & (c0 > npts * overlap_th) & ~out_of0.unsqueeze(1) & ~out_of1.unsqueeze(-1)
-    unmatched0 = torch.all(~mask_close, dim=2) | out_of1
-    unmatched1 = torch.all(~mask_close, dim=1) | out_of0
-    ignore0, ignore1 = ~valid_lines0, ~valid_lines1
-
+    b, n0, n1 = both.shape
     cost = -both.clone()
     cost[unmatched0] = 1e6
     cost[ignore0] = 1e6
@@ -362,3 +345,81 @@ def gt_line_matches_from_homography(pred_lines0, pred_lines1, valid_lines0, vali
     m1[unmatched1] = UNMATCHED_FEATURE
     m1[ignore1] = IGNORE_FEATURE
     return positive, m0, m1
+
+
+@torch.no_grad()
+def gt_line_matches_from_homography(pred_lines0, pred_lines1, valid_lines0, valid_lines1, shape0, shape1, H,
+                                    npts=50, dist_th=5, overlap_th=0.2, min_visibility_th=0.2):
+    """Line ground truth under a homography (gluefactory/geometry/gt_generation.py:409-558): sample npts points
+    on every segment, warp them, count per segment pair how many warped samples fall on the other segment (both
+    ways), keep pairs whose two overlaps exceed overlap_th, solve the one-to-one assignment with the Hungarian
+    method on CPU (scipy, as the reference) and label the rest unmatched (-1) / ignored (-2, invalid lines).
+    Returns (assignment [B,L0,L1] bool, matches0 [B,L0], matches1 [B,L1])."""
+    h0, w0 = shape0[-2:]
+    h1, w1 = shape1[-2:]
+    l0, l1 = _segments(pred_lines0.clone()), _segments(pred_lines1.clone())
+    b, n0, _ = l0.shape
+    n1 = l1.shape[1]
+    l0 = torch.min(torch.max(l0, torch.zeros_like(l0)), l0.new_tensor([w0 - 1, h0 - 1, w0 - 1, h0 - 1], dtype=torch.float))
+    l1 = torch.min(torch.max(l1, torch.zeros_like(l1)), l1.new_tensor([w1 - 1, h1 - 1, w1 - 1, h1 - 1], dtype=torch.float))
+
+    p0_in1 = warp_points(_line_samples(l0, npts).reshape(b, n0 * npts, 2), H, inverse=False).reshape(b, n0, npts, 2)
+    p1_in0 = warp_points(_line_samples(l1, npts).reshape(b, n1 * npts, 2), H, inverse=True).reshape(b, n1, npts, 2)
+    out_of0 = _mostly_outside(p1_in0, w0, h0, min_visibility_th)                         # [B,L1]
+    out_of1 = _mostly_outside(p0_in1, w1, h1, min_visibility_th)                         # [B,L0]
+    c0 = _close_point_counts(l0, p1_in0, dist_th)            # [B,L0,L1]
+    c1t = _close_point_counts(l1, p0_in1, dist_th).transpose(-1, -2)
+    both = c0 * c1t
+    mask_close = (c1t > npts * overlap_th) & (c0 > npts * overlap_th) & ~out_of0.unsqueeze(1) & ~out_of1.unsqueeze(-1)
+    unmatched0 = torch.all(~mask_close, dim=2) | out_of1
+    unmatched1 = torch.all(~mask_close, dim=1) | out_of0
+    ignore0, ignore1 = ~valid_lines0, ~valid_lines1
+
+    return _assign_lines(both, mask_close, unmatched0, unmatched1, ignore0, ignore1)
+
+
+@torch.no_grad()
+def gt_line_matches_from_pose_depth(pred_lines0, pred_lines1, valid_lines0, valid_lines1, data, npts=50, dist_th=5,
+                                    overlap_th=0.2, min_visibility_th=0.5):
+    """Line ground truth from depth maps and the relative pose (gluefactory/geometry/gt_generation.py:207-407; the line
+    branch of depth_matcher.py:70-87): sample npts points on every segment (clamped into its depth map), lift them through
+    the sampled depth and reproject into the other view; a pair of segments is close when enough VISIBLE reprojected samples
+    of each fall on the other (more than overlap_th of that segment's visible samples); a segment whose reprojection is
+    mostly outside the other image, or that is close to nothing, is unmatched (-1); one with too few valid depth samples, or
+    flagged invalid, is ignored (-2).  Returns (assignment [B,L0,L1] bool, matches0 [B,L0], matches1 [B,L1]).
+    (The reference reads the inverse pose as `data.get(data["T_1to0"], data["T_0to1"].inv())`, i.e. always the inverse of
+    T_0to1: so does this.)"""
+    from .geometry import project, sample_depth
+    b, n0, n1 = pred_lines0.shape[0], pred_lines0.shape[1], pred_lines1.shape[1]
+    if n0 == 0 or n1 == 0:
+        dev = pred_lines0.device
+        return (torch.zeros((b, n0, n1), dtype=torch.bool, device=dev), torch.full((b, n0), -1, device=dev),
+                torch.full((b, n1), -1, device=dev))
+    l0, l1 = _segments(pred_lines0.clone()), _segments(pred_lines1.clone())
+    depth0, depth1 = data["view0"]["depth"], data["view1"]["depth"]
+    h0, w0 = depth0[0].shape
+    h1, w1 = depth1[0].shape
+    l0 = torch.min(torch.max(l0, torch.zeros_like(l0)), l0.new_tensor([w0 - 1, h0 - 1, w0 - 1, h0 - 1], dtype=torch.float))
+    l1 = torch.min(torch.max(l1, torch.zeros_like(l1)), l1.new_tensor([w1 - 1, h1 - 1, w1 - 1, h1 - 1], dtype=torch.float))
+    pts0 = _line_samples(l0, npts).reshape(b, n0 * npts, 2)
+    pts1 = _line_samples(l1, npts).reshape(b, n1 * npts, 2)
+    d0, valid0 = sample_depth(pts0, depth0)
+    d1, valid1 = sample_depth(pts1, depth1)
+    cam0, cam1, T_0to1 = data["view0"]["camera"], data["view1"]["camera"], data["T_0to1"]
+    p0_in1, visible0 = project(pts0, d0, depth1, cam0, cam1, T_0to1, valid0)
+    p1_in0, visible1 = project(pts1, d1, depth0, cam1, cam0, T_0to1.inv(), valid1)
+    h0, w0 = data["view0"]["image"].shape[-2:]
+    h1, w1 = data["view1"]["image"].shape[-2:]
+    p0_in1, p1_in0 = p0_in1.reshape(b, n0, npts, 2), p1_in0.reshape(b, n1, npts, 2)
+    out_of0 = _mostly_outside(p1_in0, w0, h0, min_visibility_th)                         # [B,L1]
+    out_of1 = _mostly_outside(p0_in1, w1, h1, min_visibility_th)                         # [B,L0]
+    vis0, vis1 = visible0.reshape(b, n0, npts), visible1.reshape(b, n1, npts)
+    c0 = _close_point_counts(l0, p1_in0, dist_th, vis1)                                  # [B,L0,L1]
+    c1t = _close_point_counts(l1, p0_in1, dist_th, vis0).transpose(-1, -2)
+    both = c0 * c1t
+    mask_close = (c1t > vis0.float().sum(-1)[:, :, None] * overlap_th) & (c0 > vis1.float().sum(-1)[:, None] * overlap_th)
+    unmatched0 = torch.all(~mask_close, dim=2) | out_of1
+    unmatched1 = torch.all(~mask_close, dim=1) | out_of0
+    ignore0 = (valid0.reshape(b, n0, npts).float().mean(-1) < min_visibility_th) | ~valid_lines0
+    ignore1 = (valid1.reshape(b, n1, npts).float().mean(-1) < min_visibility_th) | ~valid_lines1
+    return _assign_lines(both, mask_close, unmatched0, unmatched1, ignore0, ignore1)

@@ -407,6 +407,49 @@ def gen_gt_depth(name, batch, n0, n1, seed):
     np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
 
 
+def gen_gt_lines_depth(name, batch, n0, n1, seed):
+    """Reference gt_line_matches_from_pose_depth (gt_generation.py:207-407) on the seeded depth scene: segments of view 0,
+    view-1 segments = reprojected endpoints of a subset (+ noise) followed by random ones, a few lines flagged invalid, some
+    reaching over the depth hole (ignored) and some leaving the image (unmatched)."""
+    from gluefactory.geometry.depth import project, sample_depth
+    from gluefactory.geometry.gt_generation import gt_line_matches_from_pose_depth
+    from gluefactory.geometry.wrappers import Camera, Pose
+
+    sc = depth_scene(batch, 4, 4, seed)
+    h, w = sc["depth0"].shape[-2:]
+    cam0, cam1 = Camera(sc["camera0"]), Camera(sc["camera1"])
+    T = Pose.from_Rt(sc["R"], sc["t"])
+    g = torch.Generator().manual_seed(seed + 1)
+    wh = torch.tensor([w - 1.0, h - 1.0])
+    p = torch.rand(batch, n0, 2, generator=g) * (wh - 10) + 5
+    ang = torch.rand(batch, n0, generator=g) * 6.2832
+    ln = 8 + torch.rand(batch, n0, generator=g) * 30
+    q = p + ln[..., None] * torch.stack([torch.cos(ang), torch.sin(ang)], -1)
+    lines0 = torch.stack([p, q], 2)                                        # [B,L0,2,2] (may leave the image: clamped inside)
+    ends = lines0.reshape(batch, n0 * 2, 2).clamp(min=torch.zeros(2), max=wh)
+    d, v = sample_depth(ends, sc["depth0"])
+    proj, vis = project(ends, d, sc["depth1"], cam0, cam1, T, v)
+    proj = torch.nan_to_num(proj, nan=7.0).reshape(batch, n0, 2, 2)
+    nm = (2 * n1) // 3
+    lines1 = torch.rand(batch, n1, 2, 2, generator=g) * wh
+    lines1[:, :nm] = proj[:, :nm] + 0.8 * torch.randn(batch, nm, 2, 2, generator=g)
+    lines1 = lines1[:, torch.randperm(n1, generator=g)]
+    valid0 = torch.rand(batch, n0, generator=g) > 0.1
+    valid1 = torch.rand(batch, n1, generator=g) > 0.1
+    image = torch.zeros(batch, 1, h, w)
+    data = {"view0": {"camera": cam0, "depth": sc["depth0"], "image": image},
+            "view1": {"camera": cam1, "depth": sc["depth1"], "image": image}, "T_0to1": T, "T_1to0": T.inv()}
+    out = {"data.depth0": sc["depth0"].numpy(), "data.depth1": sc["depth1"].numpy(), "data.camera0": sc["camera0"].numpy(),
+           "data.camera1": sc["camera1"].numpy(), "data.R": sc["R"].numpy(), "data.t": sc["t"].numpy(),
+           "data.lines0": lines0.numpy(), "data.lines1": lines1.numpy(), "data.valid0": valid0.numpy(), "data.valid1": valid1.numpy()}
+    for tag, kw in (("default", {}), ("loose", {"npts": 30, "dist_th": 3, "overlap_th": 0.4, "min_visibility_th": 0.3})):
+        pos, m0, m1 = gt_line_matches_from_pose_depth(lines0, lines1, valid0, valid1, data, **kw)
+        out.update({f"{tag}.assignment": pos.numpy(), f"{tag}.matches0": m0.numpy(), f"{tag}.matches1": m1.numpy()})
+        print(name, tag, "positives", pos.sum((1, 2)).tolist(), "unmatched0", (m0 == -1).sum(1).tolist(),
+              "ignored0", (m0 == -2).sum(1).tolist(), "ignored1", (m1 == -2).sum(1).tolist())
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+
+
 def gen_gt_lines(name, batch, n0, n1, seed):
     from gluefactory.geometry.gt_generation import gt_line_matches_from_homography
     from gluefactory.geometry.homography import warp_points_torch
@@ -686,6 +729,7 @@ def main():
             "superglue_config4": lambda: gen_superglue_config("superglue_config4", 1, 2048, 100, seed=113),
             "gluestick_config5": lambda: gen_gluestick_config("gluestick_config5", 1, 2048, 512, seed=127),
             "matcher_options": lambda: gen_matcher_options(),
+            "gt_lines_depth": lambda: gen_gt_lines_depth("gt_lines_depth", batch=2, n0=40, n1=36, seed=73),
             "lightglue_sift": lambda: gen_lightglue_sift("lightglue_sift", 2, 150, 121, 2, seed=191),
             "superglue_sharp": lambda: gen_superglue_config("superglue_sharp", 2, 2048, 100, seed=151,
                                                              sharp=(0.01, 16.0, 0.03, 0.125)),
@@ -704,6 +748,7 @@ def main():
     gen_gt("gt_homography", batch=2, n0=96, n1=80, seed=5)
     gen_gt_depth("gt_depth", batch=2, n0=120, n1=100, seed=61)
     gen_gt_lines("gt_lines", batch=2, n0=40, n1=36, seed=71)
+    gen_gt_lines_depth("gt_lines_depth", batch=2, n0=40, n1=36, seed=73)
     gen_superpoint("superpoint_open", seed=51)
     gen_superpoint_nonfree("superpoint_nonfree", seed=53)
     gen_superpoint_options("superpoint_options", seed=57)
