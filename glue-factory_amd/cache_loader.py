@@ -4,7 +4,9 @@ plugin surface: ``two_view_pipeline`` puts a CacheLoader in the ``extractor`` sl
 
 Differences in HOW: the reference stores one HDF5 group per image (h5py is not available on this target);
 here a cache is a directory (or format string) of ``<name>.npz`` files, one per image, written by
-``export_features``.  Same keys, same scaling of ``keypoints*`` / ``lines*`` by the batch's ``scales``, same
+``export_features``.  A ``path`` that names a FILE is read as the reference's HDF5 export (one group per image name,
+nested groups as nested dicts, cache_loader.py:47-56, 98-105) when ``h5py`` is importable, so existing feature exports
+keep working where that package exists; without it the error says so.  Same keys, same scaling of ``keypoints*`` / ``lines*`` by the batch's ``scales``, same
 padding contract (``padding_fn`` + ``padding_length``: keypoints padded uniformly inside their bounding box,
 descriptors uniformly inside their value range, scores / scales / oris / depth with zeros), same collation.
 """
@@ -71,9 +73,27 @@ def _collate(preds):
     return out
 
 
+def _load_hdf5_group(path, name, keys):
+    """One image's group of a reference feature export (gluefactory/models/cache_loader.py:47-56 recursive_load)."""
+    try:
+        import h5py
+    except ImportError as e:
+        raise RuntimeError(f"{path} is a file, i.e. an HDF5 feature export of the reference; reading it needs the h5py package, "
+                           "which is not installed here.  Point `path` at a directory of <name>.npz files written by "
+                           "glue_factory_amd.cache_loader.export_features instead.") from e
+
+    def load(grp, ks):
+        return {k: torch.from_numpy(grp[k].__array__()) if isinstance(grp[k], h5py.Dataset) else load(grp[k], list(grp[k].keys()))
+                for k in ks}
+
+    with h5py.File(str(path), "r") as f:
+        grp = f[name]
+        return load(grp, keys if keys is not None else list(grp.keys()))
+
+
 class CacheLoader(BaseModel):
     default_conf = {
-        "path": "???",             # directory, may be a format string like exports/{scene}/
+        "path": "???",             # directory of .npz files (or an HDF5 file, needs h5py); may be a format string like exports/{scene}/
         "data_keys": None,         # load all keys
         "device": None,            # load to the same device as the batch
         "trainable": False,
@@ -106,9 +126,12 @@ class CacheLoader(BaseModel):
         preds = []
         for i, name in enumerate(data["name"]):
             root = self.conf.path.format(**{k: data[k][i] for k in var_names})
-            with np.load(os.path.join(root, f"{name}.npz")) as z:
-                keys = self.conf.data_keys if self.conf.data_keys is not None else list(z.keys())
-                pred = {k: torch.from_numpy(z[k]) for k in keys}
+            if os.path.isfile(root):
+                pred = _load_hdf5_group(root, name, self.conf.data_keys)
+            else:
+                with np.load(os.path.join(root, f"{name}.npz")) as z:
+                    keys = self.conf.data_keys if self.conf.data_keys is not None else list(z.keys())
+                    pred = {k: torch.from_numpy(z[k]) for k in keys}
             if self.numeric_dtype is not None:
                 pred = {k: v.to(self.numeric_dtype) if torch.is_floating_point(v) else v for k, v in pred.items()}
             pred = {k: v.to(device) for k, v in pred.items()}

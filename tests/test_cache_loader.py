@@ -122,3 +122,34 @@ def test_cache_loader_equals_reference_loader_on_the_same_files(tmp_path):
     assert set(ours) == set(ref)
     for k in ref:
         assert ours[k].dtype == ref[k].dtype and torch.equal(ours[k], ref[k]), k
+
+
+def test_cache_loader_reads_a_reference_hdf5_export_when_h5py_exists(tmp_path, monkeypatch):
+    """`path` naming a FILE = the reference's HDF5 layout (one group per image, cache_loader.py:98-105): read through
+    h5py when that package is importable (here: the stand-in of oracle/stubs, which serves the same arrays), with the
+    same scaling / padding / collation as the .npz directory; without h5py the error names the way out."""
+    import importlib
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    g = torch.Generator().manual_seed(6)
+    names, counts = ["x/a.jpg", "b"], (30, 21)
+    for n, k in zip(names, counts):
+        export_features(str(tmp_path), n, {"keypoints": torch.rand(k, 2, generator=g) * 100,
+                                           "keypoint_scores": torch.rand(k, generator=g),
+                                           "descriptors": torch.randn(k, 8, generator=g)})
+    (tmp_path / "features.h5").write_bytes(b"")
+    data = {"name": names, "scales": torch.tensor([[2.0, 2.0], [0.5, 0.5]])}
+    conf = {"path": str(tmp_path), "padding_fn": "pad_local_features", "padding_length": 32}
+    torch.manual_seed(0)
+    from_npz = CacheLoader(conf)(dict(data))
+    monkeypatch.setitem(sys.modules, "h5py", None)                       # "import h5py" raises ImportError
+    with pytest.raises(RuntimeError, match="needs the h5py package"):
+        CacheLoader({**conf, "path": str(tmp_path / "features.h5")})(dict(data))
+    monkeypatch.syspath_prepend(os.path.join(root, "oracle", "stubs"))
+    monkeypatch.delitem(sys.modules, "h5py")
+    importlib.invalidate_caches()
+    torch.manual_seed(0)
+    from_h5 = CacheLoader({**conf, "path": str(tmp_path / "features.h5")})(dict(data))
+    assert set(from_h5) == set(from_npz)
+    for k in from_npz:
+        assert torch.equal(from_h5[k], from_npz[k]), k
