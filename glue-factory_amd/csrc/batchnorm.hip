@@ -223,6 +223,22 @@ __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const float* __res
         run_var[c] = run_var[c] * (1.f - momentum) + v * (n / fmaxf(n - 1.f, 1.f)) * momentum;
     }
 }
+// The running statistics take the batch statistics of `sets` forward calls AGAIN (mvr = [sets][3][C]: mean, biased var, rstd
+// as bn_finalize_fwd_kernel wrote them), set after set -- what an activation-checkpointed reference does to its BatchNorm
+// buffers when the backward re-runs the forward (superglue.py:160-169, gluestick.py:724-757).
+__global__ __launch_bounds__(256) void bn_replay_running_kernel(const float* __restrict__ mvr, int sets, int C, float n, float momentum,
+                                                                float* __restrict__ run_mean, float* __restrict__ run_var) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float rm = run_mean[c], rv = run_var[c];
+    const float unbias = n / fmaxf(n - 1.f, 1.f);
+    for (int h = 0; h < sets; ++h) {
+        rm = rm * (1.f - momentum) + mvr[(size_t)(3 * h) * C + c] * momentum;
+        rv = rv * (1.f - momentum) + mvr[(size_t)(3 * h + 1) * C + c] * unbias * momentum;
+    }
+    run_mean[c] = rm;
+    run_var[c] = rv;
+}
 // bwd: part = (sum dz, sum dz * xhat) -> dbeta, dgamma (the sums) and m1 = sum dz / n, m2 = sum dz xhat / n
 __global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const float* __restrict__ part, int nblk, int C, float inv_n,
                                                               float* __restrict__ dbeta, float* __restrict__ dgamma,
@@ -284,6 +300,14 @@ extern "C" int gf_bn_finalize_fwd(const float* part, int nblk, int C, float n, f
     if ((run_mean == nullptr) != (run_var == nullptr)) return GF_ERR_SHAPE;
     bn_finalize_fwd_kernel<<<dim3((C + 31) / 32), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
         part, nblk, C, n, eps, momentum, mean, var, rstd, run_mean, run_var);
+    return (int)hipGetLastError();
+}
+
+extern "C" int gf_bn_replay_running(const float* mvr, int sets, int C, float n, float momentum, float* run_mean,
+                                    float* run_var, void* stream) {
+    if (sets <= 0 || C <= 0 || n <= 0.f || mvr == nullptr || run_mean == nullptr || run_var == nullptr) return GF_ERR_SHAPE;
+    bn_replay_running_kernel<<<dim3((C + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
+        mvr, sets, C, n, momentum, run_mean, run_var);
     return (int)hipGetLastError();
 }
 

@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgf_amd.so")
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 14      # == GF_AMD_ABI_VERSION in include/gf_amd.h (bumped with every signature / workspace change)
+ABI_VERSION = 15      # == GF_AMD_ABI_VERSION in include/gf_amd.h (bumped with every signature / workspace change)
 
 _c = ctypes
 _P, _I, _F, _L, _D = _c.c_void_p, _c.c_int, _c.c_float, _c.c_int64, _c.c_double
@@ -71,6 +71,7 @@ SIGNATURES = {
     "gf_bn_bwd_stats": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "gf_bn_bwd_dx": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "gf_bn_finalize_fwd": [_P, _I, _I, _F, _F, _F, _P, _P, _P, _P, _P, _P],
+    "gf_bn_replay_running": [_P, _I, _I, _F, _F, _P, _P, _P],
     "gf_bn_finalize_bwd": [_P, _I, _I, _F, _P, _P, _P, _P, _P],
     "gf_gt_nn": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "gf_bias_act_bn_nhwc": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],

@@ -77,6 +77,8 @@ class LineLayer(nn.Module):
     junction fused with the residual add, all on channels-last tensors; ``line_attention`` weighs the endpoints of a
     junction by a softmax over them (proj_node / proj_neigh, :623-639) instead of averaging."""
 
+    checkpointed_in_reference = False      # set per `checkpointed` (gluestick.py:741-757: see AttentionalPropagation)
+
     def __init__(self, feature_dim, line_attention=False):
         super().__init__()
         self.dim = feature_dim
@@ -98,14 +100,16 @@ class LineLayer(nn.Module):
             1, junc_idx, prob, reduce="sum", include_self=False)
         return prob / (denom.gather(1, junc_idx) + 1e-8)
 
-    def forward(self, ldesc, line_enc, junc_idx, halves, graph):
-        """ldesc [B',N,D], line_enc [B',2Nl,D], junc_idx [B',2Nl], graph = ops.line_graph(junc_idx, N)."""
+    def forward(self, ldesc, line_enc, junc_idx, halves, graph, replay_out=None):
+        """ldesc [B',N,D], line_enc [B',2Nl,D], junc_idx [B',2Nl], graph = ops.line_graph(junc_idx, N).
+        replay_out: see superglue._mlp_cl (two per-image calls of a checkpointed layer replay in call order)."""
         order, seg = graph
         # ldesc feeds the gather and the residual of the aggregation: one gradient chain (the sum happens in the gather's
         # segment-sum kernel instead of an autograd add over [B', N, D])
         chain = ops.GradChain(2) if ldesc.requires_grad and torch.is_grad_enabled() else None
         msg = ops.line_gather(ldesc, line_enc.to(ldesc.dtype), junc_idx, order, seg, chain=chain)
-        upd = _mlp_cl(self.mlp, msg, halves)
+        ck = self.checkpointed_in_reference and self.training
+        upd = _mlp_cl(self.mlp, msg, halves, replay=ck and replay_out is None, replay_out=replay_out if ck else None)
         if self.line_attention:
             upd = upd * self._attention(msg, ldesc, junc_idx, graph)[..., None].to(upd.dtype)
         return ops.line_aggregate(ldesc, upd, junc_idx, order, seg, mean=not self.line_attention, chain=chain)
@@ -179,6 +183,9 @@ class GlueStick(BaseModel):
                 self.layer2idx[layer] = i
         for layer in self.gnn.layers:
             layer.update.attention_fp32 = conf.attention_precision == "reference"
+            layer.update.checkpointed_in_reference = bool(conf.checkpointed)
+        for layer in self.gnn.line_layers:
+            layer.checkpointed_in_reference = bool(conf.checkpointed)
         self.register_parameter("bin_score", nn.Parameter(torch.tensor(1.0)))
         self.register_parameter("line_bin_score", nn.Parameter(torch.tensor(1.0)))
         if conf.weights:
@@ -288,8 +295,11 @@ class GlueStick(BaseModel):
                 xs = [xs[0] + d0 * layer.update.scaling, xs[1] + d1 * layer.update.scaling]
             if layer.type == "self" and have_lines:
                 for _ in range(self.gnn.num_line_iterations):
-                    xs = [self.gnn.line_layers[i // 2](x, le, ji, halves, gr)
+                    pending = [] if len(xs) > 1 else None        # two per-image calls: their replays run in call order from one node
+                    xs = [self.gnn.line_layers[i // 2](x, le, ji, halves, gr, replay_out=pending)
                           for x, le, ji, gr in zip(xs, lenc, jidx, graphs)]
+                    if pending:
+                        xs[0] = ops.replay_running_stats(xs[0], pending)
             if inter is not None and (i // 2) in inter and cross:
                 inter_desc[i // 2] = xs
         split = (lambda t: (t[0][:b], t[0][b:])) if stacked else (lambda t: (t[0], t[1]))

@@ -66,14 +66,17 @@ def _conv_cl(x, conv, rows=None, cols=None):
     return ops.linear(x, w, b)
 
 
-def _mlp_cl(seq, x, halves, x2=None, res=None, chain=None, first_wb=None):
+def _mlp_cl(seq, x, halves, x2=None, res=None, chain=None, first_wb=None, replay=False, replay_out=None):
     """Run an MLP Sequential (Conv1d / BatchNorm1d / ReLU) on channels-last x [B',N,C].
     BatchNorm (+ the ReLU that follows it) is one fused HIP pass pair, applied per image set
     (``halves`` = 2 when two images are stacked on the batch axis), reproducing the reference's
     one-call-per-image statistics and running-stat updates.  ``res``: added to the output inside the last
     convolution's GEMM epilogue; ``chain``: ops.GradChain of x (= res) for the first convolution and the residual.
     ``first_wb``: (weight, bias) replacing the first convolution's (the merge convolution folded into it: x2 is then the
-    attention output itself, AttentionalPropagation.forward)."""
+    attention output itself, AttentionalPropagation.forward).  ``replay``: the MLP sits inside an activation-checkpointed
+    block of the reference (its backward re-runs the forward in training mode), so the BatchNorm running statistics take
+    every update TWICE per step -- the second one is applied from our backward (ops.batch_norm_act_sets); with ``replay_out``
+    (a list) the replays are collected for ops.replay_running_stats instead (several calls, replayed in call order)."""
     layers = list(seq)
     i = 0
     if x2 is not None:      # first conv on cat[x, x2] without building the concatenation
@@ -98,7 +101,7 @@ def _mlp_cl(seq, x, halves, x2=None, res=None, chain=None, first_wb=None):
                 x = torch.relu(y) if relu else y
             else:
                 parts = x.reshape(halves, (b // halves) * n, c)
-                x = ops.batch_norm_act_sets(parts, layer, relu).reshape(b, n, c)
+                x = ops.batch_norm_act_sets(parts, layer, relu, replay=replay, stats_out=replay_out).reshape(b, n, c)
             i += int(relu)
         else:
             x = layer(x)
@@ -189,6 +192,11 @@ def derived_specs_of(model):
 
 class AttentionalPropagation(nn.Module):
     attention_fp32 = False      # GlueStick sets it per its `attention_precision` configuration
+    # SuperGlue's GNN wraps every layer in torch.utils.checkpoint while training (superglue.py:160-169): its backward re-runs the
+    # layer's forward in training mode, so the BatchNorm inside updates its running statistics TWICE per call.  To leave the
+    # same buffers behind (eval after training = the reference's), the second update is applied from our backward.
+    # GlueStick sets this per its `checkpointed` configuration (gluestick.py:724-757).
+    checkpointed_in_reference = True
 
     def __init__(self, num_dim, num_heads):
         super().__init__()
@@ -214,14 +222,19 @@ class AttentionalPropagation(nn.Module):
         pc = self.attn._pc
         first = None if pc is None else ops.folded_linear(pc[0], x.dtype, pc[1] + ".mlp0", self.mlp[0].weight, self.mlp[0].bias,
                                                           self.attn.merge.weight, self.attn.merge.bias)
+        replay = self.checkpointed_in_reference and self.training
         if first is not None:       # merge lives inside mlp.0's weight: the MLP reads the attention output directly
-            return _mlp_cl(self.mlp, x, halves, x2=o.view(b, n, d), res=x if residual else None, chain=chain, first_wb=first)
+            return _mlp_cl(self.mlp, x, halves, x2=o.view(b, n, d), res=x if residual else None, chain=chain, first_wb=first,
+                           replay=replay)
         msg = _conv_cl(o.view(b, n, d), self.attn.merge, cols=self.attn._perm)
-        return _mlp_cl(self.mlp, x, halves, x2=msg, res=x if residual else None, chain=chain)
+        return _mlp_cl(self.mlp, x, halves, x2=msg, res=x if residual else None, chain=chain, replay=replay)
 
     def forward_pair(self, x0, x1, cross):
         """Different keypoint counts: one projection per image, generic attention op."""
         outs = []
+        # (the reference's checkpoint re-runs image 0's call, then image 1's: the replays are collected and attached to ONE node,
+        # because the two calls' own autograd nodes run in the opposite order)
+        pending = [] if self.checkpointed_in_reference and self.training else None
         p0, p1 = self.attn.fused_projection(x0, premul=False)[0], self.attn.fused_projection(x1, premul=False)[0]
         for x, pq, ps in ((x0, p0, p1 if cross else p0), (x1, p1, p0 if cross else p1)):
             split = self.attention_fp32 and pq.dtype != torch.float32
@@ -230,7 +243,9 @@ class AttentionalPropagation(nn.Module):
             else:
                 o = ops.attention(pq[:, :, 0], ps[:, :, 1], ps[:, :, 2], split=split)
             msg = _conv_cl(o.reshape(x.shape), self.attn.merge, cols=self.attn._perm)
-            outs.append(_mlp_cl(self.mlp, x, 1, x2=msg))
+            outs.append(_mlp_cl(self.mlp, x, 1, x2=msg, replay_out=pending))
+        if pending:
+            outs[0] = ops.replay_running_stats(outs[0], pending)
         return outs
 
 

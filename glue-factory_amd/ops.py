@@ -1631,7 +1631,10 @@ class _BatchNormActSets(torch.autograd.Function):
     One node: no select / stack copies around the per-image calls, running statistics updated set after set."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, relu, run_mean, run_var, momentum):
+    def forward(ctx, x, gamma, beta, eps, relu, run_mean, run_var, momentum, replay=None):
+        """replay: None, or the module's num_batches_tracked buffer -- the BACKWARD then applies the H running-statistics
+        updates a second time (gf_bn_replay_running) and counts them, as an activation-checkpointed reference does when its
+        backward re-runs the forward in training mode (superglue.py:160-169; gluestick.py:724-757 with `checkpointed`)."""
         _chk(x)
         H, M, C = x.shape
         L = _lib.load()
@@ -1639,6 +1642,7 @@ class _BatchNormActSets(torch.autograd.Function):
         nblk = L.gf_bn_nblk(M)
         part = torch.empty((nblk, 2, C), dtype=torch.float32, device=x.device)
         mvr = torch.empty((H, 3, C), dtype=torch.float32, device=x.device)
+        ctx.replay = None if replay is None else (run_mean, run_var, replay, float(momentum))
         y = torch.empty_like(x)
         st, dt = _stream(), _dt(x)
         for h in range(H):
@@ -1650,10 +1654,11 @@ class _BatchNormActSets(torch.autograd.Function):
                                        int(relu), dt, st), "gf_bn_act_fwd")
         ctx.save_for_backward(x, mvr, g32, b32)
         ctx.cfg = (relu, gamma.dtype, beta.dtype)
-        return y
+        ctx.mark_non_differentiable(mvr)
+        return y, mvr
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _gmvr):
         x, mvr, g32, b32 = ctx.saved_tensors
         relu, gdt, bdt = ctx.cfg
         H, M, C = x.shape
@@ -1674,34 +1679,85 @@ class _BatchNormActSets(torch.autograd.Function):
             _lib.check(L.gf_bn_bwd_dx(_p(x[h]), _p(dy[h]), _p(mean), _p(rstd), _p(g32), _p(b32), _p(out[h, 2]),
                                       _p(out[h, 3]), _p(dx[h]), M, C, int(relu), dt, st), "gf_bn_bwd_dx")
         dbeta, dgamma = (out[0, 0], out[0, 1]) if H == 1 else (out[:, 0].sum(0), out[:, 1].sum(0))
-        return dx, dgamma.to(gdt), dbeta.to(bdt), None, None, None, None, None
+        if ctx.replay is not None:
+            run_mean, run_var, nbt, momentum = ctx.replay
+            _lib.check(L.gf_bn_replay_running(_p(mvr), H, C, float(M), momentum, _p(run_mean), _p(run_var), st),
+                       "gf_bn_replay_running")
+            nbt.add_(H)
+        return dx, dgamma.to(gdt), dbeta.to(bdt), None, None, None, None, None, None
 
 
-def batch_norm_act_sets(x, bn, relu=True):
+class _ReplayRunningStats(torch.autograd.Function):
+    """Identity on y whose BACKWARD gives BatchNorm modules' running statistics one more update from the forward's batch
+    statistics, group after group and set after set (the generic form of _BatchNormActSets' `replay`: single-set /
+    SyncBatchNorm / torch-fallback paths, and several module calls whose replays must run in CALL order although their
+    own autograd nodes run in reverse).  groups: [(bn module, [(mean, unbiased var), ...]), ...]."""
+
+    @staticmethod
+    def forward(ctx, y, groups):
+        ctx.groups = [(bn, [(m.detach(), v.detach()) for m, v in stats]) for bn, stats in groups]
+        return y.view_as(y)
+
+    @staticmethod
+    def backward(ctx, dy):
+        with torch.no_grad():
+            for bn, stats in ctx.groups:
+                for mean, unbiased in stats:
+                    bn.num_batches_tracked += 1
+                    mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+                    bn.running_mean.mul_(1 - mom).add_(mean.to(bn.running_mean.dtype), alpha=mom)
+                    bn.running_var.mul_(1 - mom).add_(unbiased.to(bn.running_var.dtype), alpha=mom)
+        return dy, None
+
+
+def replay_running_stats(y, groups):
+    """y, with the replays collected in ``groups`` (``stats_out`` of batch_norm_act_sets) attached to its backward."""
+    return _ReplayRunningStats.apply(y, groups) if groups else y
+
+
+def batch_norm_act_sets(x, bn, relu=True, replay=False, stats_out=None):
     """x [H,M,C]: ``batch_norm_act`` applied to each of the H sets in turn (set h sees the running statistics already
-    updated by set h-1, exactly like H consecutive module calls), as ONE autograd node where that is possible."""
+    updated by set h-1, exactly like H consecutive module calls), as ONE autograd node where that is possible.
+    ``replay``: the backward repeats the H running-statistics updates (see _BatchNormActSets.forward); with ``stats_out`` (a
+    list) the replay is NOT attached here: (bn, [(mean, unbiased var) per set]) is appended for replay_running_stats, which
+    lets a caller replay several calls in call order from one node."""
     assert x.dim() == 3
     if not x.is_contiguous():
         x = x.contiguous()
     import torch.distributed as dist
     sync = (isinstance(bn, torch.nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized()
             and dist.get_world_size() > 1)
+    want = (replay or stats_out is not None) and bn.training and bn.track_running_stats and torch.is_grad_enabled() and x.requires_grad
     if (bn.training and bn.track_running_stats and not sync and bn.momentum is not None
             and bn.running_mean.dtype == torch.float32 and bn.running_mean.is_contiguous()
             and bn.running_var.is_contiguous()):
-        y = _BatchNormActSets.apply(x, bn.weight, bn.bias, bn.eps, relu, bn.running_mean, bn.running_var,
-                                    float(bn.momentum))
+        in_node = want and stats_out is None
+        y, mvr = _BatchNormActSets.apply(x, bn.weight, bn.bias, bn.eps, relu, bn.running_mean, bn.running_var,
+                                         float(bn.momentum), bn.num_batches_tracked if in_node else None)
         with torch.no_grad():
             bn.num_batches_tracked += x.shape[0]
+        if want and stats_out is not None:
+            unb = x.shape[1] / max(x.shape[1] - 1.0, 1.0)
+            stats_out.append((bn, [(mvr[h, 0], mvr[h, 1] * unb) for h in range(x.shape[0])]))
         return y
-    return torch.stack([batch_norm_act(x[h], bn, relu) for h in range(x.shape[0])])
+    stats = [] if want else None
+    y = torch.stack([batch_norm_act(x[h], bn, relu, stats_out=stats) for h in range(x.shape[0])])
+    if not stats:
+        return y
+    if stats_out is not None:
+        stats_out.append((bn, stats))
+        return y
+    return _ReplayRunningStats.apply(y, [(bn, stats)])        # (one node: the sets replay in call order)
 
 
-def batch_norm_act(x, bn, relu=True):
+def batch_norm_act(x, bn, relu=True, replay=False, stats_out=None):
     """x [M,C] channels-last through ``bn`` (an nn.BatchNorm1d / SyncBatchNorm that owns the affine
     parameters and running statistics), then ReLU when ``relu``.  Training mode uses batch statistics
     (summed across ranks when ``bn`` was converted to SyncBatchNorm) and updates the running
-    statistics like torch (momentum, unbiased variance, num_batches_tracked); eval uses them."""
+    statistics like torch (momentum, unbiased variance, num_batches_tracked); eval uses them.
+    ``replay``: the backward repeats that update (the module sits inside an activation-checkpointed block of the
+    reference: see _BatchNormActSets.forward); ``stats_out``: a list that receives this call's (mean, unbiased var)
+    instead (batch_norm_act_sets replays several calls in order from one node)."""
     assert x.dim() == 2
     if not x.is_contiguous():
         x = x.contiguous()
@@ -1712,11 +1768,18 @@ def batch_norm_act(x, bn, relu=True):
         track = bn.training and bn.track_running_stats
         fused_running = (track and not sync and bn.momentum is not None and bn.running_mean.dtype == torch.float32
                          and bn.running_mean.is_contiguous() and bn.running_var.is_contiguous())
+        replay = replay and track and torch.is_grad_enabled() and x.requires_grad
         if fused_running:       # the finalize kernel updates the running statistics in place
-            y = _BatchNormAct.apply(x, bn.weight, bn.bias, None, None, bn.eps, True, relu, sync,
-                                    bn.running_mean, bn.running_var, float(bn.momentum))[0]
+            y, mean, var, _ = _BatchNormAct.apply(x, bn.weight, bn.bias, None, None, bn.eps, True, relu, sync,
+                                                  bn.running_mean, bn.running_var, float(bn.momentum))
             with torch.no_grad():
                 bn.num_batches_tracked += 1
+            if replay or stats_out is not None:
+                stat = (mean, var * (x.shape[0] / max(x.shape[0] - 1.0, 1.0)))
+                if stats_out is not None:
+                    stats_out.append(stat)
+                else:
+                    y = _ReplayRunningStats.apply(y, [(bn, [stat])])
             return y
         y, mean, var, n_t = _BatchNormAct.apply(x, bn.weight, bn.bias, None, None, bn.eps, True, relu, sync)
         if track:
@@ -1728,6 +1791,10 @@ def batch_norm_act(x, bn, relu=True):
                 unbiased = var * (n_t / (n_t - 1).clamp(min=1.0))
                 bn.running_mean.mul_(1 - mom).add_(mean.to(bn.running_mean.dtype), alpha=mom)
                 bn.running_var.mul_(1 - mom).add_(unbiased.to(bn.running_var.dtype), alpha=mom)
+            if stats_out is not None:
+                stats_out.append((mean, unbiased))
+            elif replay:
+                y = _ReplayRunningStats.apply(y, [(bn, [(mean, unbiased)])])
         return y
     rstd = torch.rsqrt(bn.running_var.float() + bn.eps)
     return _BatchNormAct.apply(x, bn.weight, bn.bias, bn.running_mean, rstd, bn.eps, False, relu, False)[0]

@@ -37,7 +37,7 @@ extern "C" {
 #define GF_ERR_DTYPE (-4)
 
 /* ABI version; bumped on any signature or workspace-size change (2: gf_attn_bwd's delta workspace doubled; 3: line head + gf_bgemm; 4: smallops; 5: gf_attn_bwd_acc; 9: cast entries with leading dimensions, gf_fold_linear_*, double betas in gf_multi_adam; 10: gf_attn_fwd_ex / GF_ATTN_SPLIT, gf_topk_candidates; 14: gf_sinkhorn_* take `schedule`, gf_sinkhorn_mode removed, gf_probe_hold_cus, gf_linear_dw2, gf_gemm_res2, gf_rowdot2_*; gf_rowdot_fwd / gf_rotary_qk_bwd take a device bias / a base sum). */
-#define GF_AMD_ABI_VERSION 14
+#define GF_AMD_ABI_VERSION 15
 int gf_abi_version(void);
 /* Diagnostics (tests/test_gpu_sinkhorn_safety.py): occupies `n_cus` compute units (one 150 KB-LDS workgroup each) for
  * `milliseconds` (<= 5000) on `stream` -- the stand-in for "another stream's kernel holds part of the chip" (an RCCL
@@ -367,6 +367,14 @@ int gf_bn_finalize_fwd(const float* part, int nblk, int C, float n, float eps, f
                        float* mean, float* var, float* rstd, float* run_mean, float* run_var, void* stream);
 int gf_bn_finalize_bwd(const float* part, int nblk, int C, float n, float* dbeta, float* dgamma,
                        float* m1, float* m2, void* stream);
+/* gf_bn_replay_running (ABI 15): the running statistics take the batch statistics of `sets` forward calls a SECOND time,
+ * set after set (mvr = [sets][3][C] rows mean / biased var / rstd as gf_bn_finalize_fwd wrote them, n rows per set).  The
+ * reference wraps its GNN layers in torch.utils.checkpoint while training (gluefactory_nonfree/superglue.py:160-169 always;
+ * gluefactory/models/matchers/gluestick.py:724-757 with `checkpointed: true`): the backward re-runs their forward in
+ * training mode, so every BatchNorm1d inside updates running_mean / running_var / num_batches_tracked twice per step.
+ * Launched from the backward of the fused BatchNorm op to leave the same buffers behind. */
+int gf_bn_replay_running(const float* mvr, int sets, int C, float n, float momentum, float* run_mean,
+                         float* run_var, void* stream);
 
 /* ---- ground-truth nearest neighbours under a homography (gluefactory/geometry/gt_generation.py:120-150)
  * For every point i of the "own" set [B,No,2] (own = its coordinates, own_warped = the same points

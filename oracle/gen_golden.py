@@ -157,6 +157,10 @@ def gen_matcher_options(name="matcher_options"):
         for k, prm in model.named_parameters():
             if prm.grad is not None:
                 out[f"{cname}.gradnorm.{k}"] = np.array([float(prm.grad.double().norm())])
+        # BatchNorm buffers AFTER the step (forward + backward): the reference's activation checkpointing re-runs the GNN
+        # layers' forward during the backward, so their running statistics have been updated twice per call by now
+        for k, buf in model.named_buffers():
+            out[f"{cname}.buffer.{k}"] = buf.detach().numpy().copy()
         print(name, cname, "loss", losses["total"].tolist())
     np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
 

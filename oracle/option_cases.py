@@ -71,6 +71,13 @@ def option_cases():
                                           "inter_supervision": [1], "filter_threshold": 0.0,
                                           "loss": {"nll_weight": 0.5, "nll_balancing": 0.3, "inter_supervision": [0.2, 0.7]}},
                             p, make_point_line_pairs(2, 40, 12, dim=256, size=(320, 240), seed=214))
+    # GlueStick: `checkpointed: true` (gluestick.py:724-757): same numbers as without, but the backward re-runs every GNN and
+    # line layer's forward in training mode -> their BatchNorm buffers take each update twice (the fixture stores the buffers
+    # after the step; "gs_skipinit" above is the un-checkpointed counterpart)
+    cases["gs_checkpointed"] = ("gluestick", {"weights": None, "GNN_layers": ["self", "cross"] * 2, "checkpointed": True,
+                                              "filter_threshold": 0.0},
+                                gso.init_params(256, gnn_layers=4, inter=None, seed=217),
+                                make_point_line_pairs(2, 40, 12, dim=256, size=(320, 240), seed=218))
     # SuperGlue: `descriptor_dim: 128` (4 heads of 32 channels) and `loss.nll_balancing: 0.8` (superglue.py:222-233, 322-342)
     d = make_pairs(2, 70, 64, dim=128, size=(320, 240), seed=216)
     d["view0"]["image"] = torch.zeros(2, 1, 240, 320)        # the reference reads view["image"].shape unconditionally

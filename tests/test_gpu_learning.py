@@ -1,70 +1,90 @@
-"""End to end: does the HIP LightGlue LEARN?  Parity tests pin every tensor of single steps to the reference; this one
-runs the thing the path exists for -- a few hundred optimiser steps (TrainStep: bf16 autocast, fused Adam, one hipGraph)
-on FRESH synthetic pairs every step (matched descriptors correlate at cos ~ 0.2, positions follow a similarity warp) -- and
-checks that it follows the learning curve of the UNMODIFIED reference module trained on the CPU on the very same batches from
-the very same initialisation, and ends where the reference ends on held-out pairs (loss, match precision, match recall).
-Wrong-but-finite gradients anywhere on the path fail this."""
+"""End to end: do the HIP matchers LEARN like the reference?  Parity tests pin every tensor of single steps to the
+reference; this one runs the thing the path exists for -- 300 optimiser steps (TrainStep: fused Adam, one hipGraph, bf16
+autocast or fp32) on FRESH synthetic pairs every step (matched descriptors correlate at cos ~ 0.2, positions follow a
+similarity warp; GlueStick: + line segments) -- and checks that the run follows the learning curve of the UNMODIFIED
+reference module trained on the CPU in fp32 on the very same batches from the very same initial parameters
+(tools/probe/ref_learning_curve.py, tests/learning_cases.py, profiles/r05e_learning_curve_reference_cpu.txt) and ends where
+the reference ends on held-out pairs (loss, match precision, match recall).  Wrong-but-finite gradients anywhere on the
+path -- attention, Sinkhorn, train-mode BatchNorm, line layers, loss heads, the fused optimiser -- fail this."""
 import pytest
 import torch
 
+import learning_cases as lc
+
 pytestmark = pytest.mark.gpu
 
+# the reference's runs: train loss at steps 50, 100, ..., 300; held-out (loss, precision, recall[, line precision, line recall])
+REF = {
+    "lightglue": {"trace": [5.812, 5.398, 4.639, 4.127, 3.868, 3.742], "before": [6.4633, 0.0, 0.0],
+                  "after": [1.9514, 0.7943, 0.4959]},
+    "superglue": {"trace": [1.735, 1.431, 1.292, 1.15, 1.15, 1.058], "before": [3.4872, 0.0, 0.0],
+                  "after": [3.3805, 0.4306, 0.0158]},
+}
 
-def _batch(seed, batch=8, n=256):
-    from glue_factory_amd.synthetic import make_pairs, to_device
-    return to_device(make_pairs(batch, n, dim=256, size=(640, 480), seed=seed), "cuda")
+
+def _model(kind):
+    from glue_factory_amd.matchers.gluestick import GlueStick
+    from glue_factory_amd.matchers.lightglue import LightGlue
+    from glue_factory_amd.matchers.superglue import SuperGlue
+    torch.manual_seed(0)
+    model = {"lightglue": LightGlue, "superglue": SuperGlue, "gluestick": GlueStick}[kind](lc.conf(kind))
+    params = lc.initial_params(kind)
+    if params is not None:
+        res = model.load_state_dict(params, strict=True)
+        assert not res.missing_keys and not res.unexpected_keys
+    return model.cuda()
 
 
-def _evaluate(model, seeds):
+def _batch(kind, seed):
+    from glue_factory_amd.synthetic import to_device
+    return to_device(lc.batch(kind, seed), "cuda")
+
+
+def _evaluate(kind, model, bf16):
     from glue_factory_amd.metrics import matcher_metrics
     model.eval()
-    loss, prec, rec = [], [], []
-    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
-        for s in seeds:
-            data = _batch(s)
+    rows = []
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16):
+        for s in lc.HELD_OUT:
+            data = _batch(kind, s)
             pred = model(data)
             losses, _ = model.loss(pred, {**pred, **data})
             m = matcher_metrics(pred, {**pred, **data})
-            loss.append(float(losses["total"].mean()))
-            prec.append(float(m["match_precision"].mean()))
-            rec.append(float(m["match_recall"].mean()))
-    n = len(seeds)
-    return sum(loss) / n, sum(prec) / n, sum(rec) / n
-
-
-# The UNMODIFIED reference module trained on the CPU in fp32 on the very same batches from the very same initialisation
-# (tools/probe/ref_learning_curve.py, profiles/r05e_learning_curve_reference_cpu.txt):
-REF_TRACE = [5.812, 5.398, 4.639, 4.127, 3.868, 3.742]          # train loss at steps 50, 100, ..., 300
-REF_BEFORE = (6.4633, 0.0, 0.0)                                   # held-out loss / precision / recall before training
-REF_AFTER = (1.9514, 0.7943, 0.4959)                              # ... after 300 steps
+            row = [float(losses["total"].mean()), float(m["match_precision"].mean()), float(m["match_recall"].mean())]
+            if kind == "gluestick":
+                ml = matcher_metrics(pred, {**pred, **data}, prefix="line_", prefix_gt="line_")
+                row += [float(ml["line_match_precision"].mean()), float(ml["line_match_recall"].mean())]
+            rows.append(row)
+    return [sum(v) / len(v) for v in zip(*rows)]
 
 
 @pytest.mark.parametrize("bf16", [True, False])
-def test_lightglue_learns_like_the_reference_on_fresh_synthetic_pairs(bf16):
-    from glue_factory_amd.matchers.lightglue import LightGlue
+@pytest.mark.parametrize("kind", sorted(REF))
+def test_matcher_learns_like_the_reference_on_fresh_synthetic_pairs(kind, bf16):
     from glue_factory_amd.optim import FusedAdam
     from glue_factory_amd.train_step import TrainStep
-    torch.manual_seed(0)
-    model = LightGlue({"n_layers": 3, "filter_threshold": 0.1}).cuda()
-    held_out = (9001, 9002, 9003)
-    loss0, prec0, rec0 = _evaluate(model, held_out)
-    assert abs(loss0 - REF_BEFORE[0]) < 2e-2 and rec0 == 0.0          # same initialisation as the reference's run
-    step = TrainStep(model, FusedAdam(model.parameters(), lr=1e-3), amp_dtype=torch.bfloat16 if bf16 else None,
+    ref = REF[kind]
+    model = _model(kind)
+    before = _evaluate(kind, model, bf16)
+    assert abs(before[0] - ref["before"][0]) < 3e-2 * max(1.0, ref["before"][0])       # same starting point as the reference's run
+    step = TrainStep(model, FusedAdam(model.parameters(), lr=lc.LR[kind]), amp_dtype=torch.bfloat16 if bf16 else None,
                      graph=True, graph_warmup=2)
     trace = []
-    for i in range(300):
-        out = step(_batch(1000 + i))
+    for i in range(lc.STEPS):
+        out = step(_batch(kind, 1000 + i))
         if i % 50 == 49:
             trace.append(round(float(out["total"].mean()), 3))
     assert step.skipped == 0
-    loss1, prec1, rec1 = _evaluate(model, held_out)
-    print(f"{'bf16' if bf16 else 'fp32'} train loss every 50 steps: {trace}   (reference, CPU fp32: {REF_TRACE})")
-    print(f"held-out pairs: loss {loss0:.3f} -> {loss1:.3f}, precision {prec0:.3f} -> {prec1:.3f}, recall {rec0:.3f} -> {rec1:.3f}"
-          f"   (reference: {REF_AFTER})")
+    after = _evaluate(kind, model, bf16)
+    tag = f"{kind} {'bf16' if bf16 else 'fp32'}"
+    print(f"{tag} train loss every 50 steps: {trace}   (reference, CPU fp32: {ref['trace']})")
+    print(f"{tag} held-out before {[round(v, 3) for v in before]} -> after {[round(v, 3) for v in after]}   (reference: {ref['after']})")
     # the same trajectory while rounding differences have not been amplified by the optimiser yet, the same place afterwards
-    assert abs(trace[0] - REF_TRACE[0]) < 0.02 and abs(trace[1] - REF_TRACE[1]) < 0.03
-    assert all(abs(a - b) < 0.25 for a, b in zip(trace, REF_TRACE))
-    # (measured on MI355X: bf16 1.817 / 0.791 / 0.558, fp32 2.064 / 0.771 / 0.442 -- 250 Adam steps amplify rounding-level differences
-    # into a few hundredths; the margins are several times that)
-    assert loss1 < REF_AFTER[0] + 0.4 and prec1 > REF_AFTER[1] - 0.15 and rec1 > REF_AFTER[2] - 0.15
+    # (measured on MI355X, LightGlue: bf16 1.817 / 0.791 / 0.558, fp32 2.064 / 0.771 / 0.442 -- 250 Adam steps amplify rounding-level
+    # differences into a few hundredths; the margins are several times that)
+    scale = max(1.0, ref["trace"][0])
+    assert abs(trace[0] - ref["trace"][0]) < 0.005 * scale and abs(trace[1] - ref["trace"][1]) < 0.01 * scale
+    assert all(abs(a - b) < 0.06 * scale for a, b in zip(trace, ref["trace"]))
+    assert after[0] < ref["after"][0] + 0.1 * scale
+    assert all(a > r - 0.15 for a, r in zip(after[1:], ref["after"][1:]))
     step.close()
