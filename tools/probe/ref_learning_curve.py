@@ -29,7 +29,7 @@ def main():
         from gluefactory.models.matchers.gluestick import GlueStick as Model
         extra = {"weights": None}
     torch.manual_seed(0)
-    torch.set_num_threads(16)
+    torch.set_num_threads(int(os.environ.get("GF_THREADS", "16")))
     model = Model({**lc.conf(kind), **extra})
     params = lc.initial_params(kind)
     if params is not None:
