@@ -64,8 +64,9 @@ def _evaluate(kind, model, bf16):
     return [sum(v) / len(v) for v in zip(*rows)]
 
 
-@pytest.mark.parametrize("bf16", [True, False])
-@pytest.mark.parametrize("kind", sorted(REF))
+# (SuperGlue in the benchmarked precision only: its fp32 run follows the reference the same way -- 1.735 1.431 1.29 1.151 1.138 1.034,
+# profiles/r05e_learning_curve_reference_cpu.txt -- and costs another minute of the suite)
+@pytest.mark.parametrize("kind,bf16", [("lightglue", True), ("lightglue", False), ("superglue", True)])
 def test_matcher_learns_like_the_reference_on_fresh_synthetic_pairs(kind, bf16):
     from glue_factory_amd.optim import FusedAdam
     from glue_factory_amd.train_step import TrainStep
