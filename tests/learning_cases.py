@@ -1,4 +1,4 @@
-"""Shared by tests/test_gpu_learning.py (HIP modules on the GPU) and tools/probe/ref_learning_curve.py (the unmodified
+"""Shared by tests/test_gpu_zz_learning.py (HIP modules on the GPU) and tools/probe/ref_learning_curve.py (the unmodified
 reference modules on the CPU): model configuration, seeded initial parameters and seeded batches of the learning-curve runs."""
 import torch
 

@@ -1,4 +1,4 @@
-"""Diagnosis of tests/test_gpu_learning.py for the BatchNorm matchers: (1) the reference's TRAINED state (saved by
+"""Diagnosis of tests/test_gpu_zz_learning.py for the BatchNorm matchers: (1) the reference's TRAINED state (saved by
 GF_SAVE_FINAL=... tools/probe/ref_learning_curve.py) loaded into the HIP module -> held-out eval must equal the reference's;
 (2) the HIP module trained here (graph and eager) -> its BatchNorm buffers against the reference's, layer by layer.
 python tools/probe/learn_diag.py superglue tools/probe/build/ref_sg_final.pt"""
@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: E402
 
 import learning_cases as lc  # noqa: E402
-import test_gpu_learning as tl  # noqa: E402
+import test_gpu_zz_learning as tl  # noqa: E402
 
 
 def main():

@@ -1,5 +1,5 @@
 """Build-container only: what separates a HIP-trained SuperGlue state from the reference's after the 300 steps of
-tests/test_gpu_learning.py?  Inputs: a HIP-trained state (tools/probe/learn_save_state.py on the GPU box) and two reference
+tests/test_gpu_zz_learning.py?  Inputs: a HIP-trained state (tools/probe/learn_save_state.py on the GPU box) and two reference
 states (GF_THREADS=3 / 5 GF_SAVE_FINAL=... tools/probe/ref_learning_curve.py superglue), all evaluated with the REFERENCE
 module on the CPU.  Prints (1) held-out loss in eval / train mode and with re-estimated BatchNorm statistics, (2) parameter /
 buffer hybrids, (3) drift-from-initialisation correlations HIP-vs-reference against reference-vs-reference.

@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: E402
 
 import learning_cases as lc  # noqa: E402
-import test_gpu_learning as tl  # noqa: E402
+import test_gpu_zz_learning as tl  # noqa: E402
 
 
 def main():

@@ -1,5 +1,5 @@
 """Build-container only: the UNMODIFIED reference matchers trained on the CPU (fp32, torch.optim.Adam, lr per tests/learning_cases.py) on the very
-batches tests/test_gpu_learning.py feeds the HIP modules (tests/learning_cases.py) -- the yardstick for that test.
+batches tests/test_gpu_zz_learning.py feeds the HIP modules (tests/learning_cases.py) -- the yardstick for that test.
 python tools/probe/ref_learning_curve.py lightglue|superglue|gluestick [steps]"""
 import os
 import sys
