@@ -97,3 +97,50 @@ def test_gradchain_second_residual_slot():
     assert ch.pop_extra() == 3.0 and ch.pop_extra() is None
     s = ops.SharedGradSum(3)
     assert s.add("g1") is None and s.acc == "g1" and s.add("g2") is None and s.add("g3") == "g3" and s.acc is None and s.got == 0
+
+
+def test_replay_node_leaves_the_buffers_a_checkpointed_reference_block_leaves():
+    """ops._ReplayRunningStats (the generic form of the BatchNorm replay: SyncBatchNorm / single-set / fallback paths) against
+    the real thing on the CPU: a BatchNorm1d called for image 0 and image 1 inside torch.utils.checkpoint, as
+    gluefactory_nonfree/superglue.py:160-169 does -- after the backward its running statistics hold the sequence
+    s0, s1, s0, s1 and num_batches_tracked == 4; a forward without a backward holds s0, s1."""
+    import copy
+    import torch
+    import torch.utils.checkpoint
+    from glue_factory_amd import ops
+    torch.manual_seed(0)
+    ref_bn = torch.nn.BatchNorm1d(6)
+    with torch.no_grad():
+        ref_bn.running_mean.normal_()
+        ref_bn.running_var.uniform_(0.5, 2.0)
+    our_bn = copy.deepcopy(ref_bn).train()
+    x0 = torch.randn(4, 6, 50, requires_grad=True)
+    x1 = (torch.randn(4, 6, 50) * 2 + 1).requires_grad_(True)
+    ref_bn.train()
+    y0, y1 = torch.utils.checkpoint.checkpoint(lambda a, b: (ref_bn(a), ref_bn(b)), x0, x1, preserve_rng_state=False,
+                                               use_reentrant=False)
+    assert int(ref_bn.num_batches_tracked) == 2
+    (y0.sum() + (y1 * y1).sum()).backward()
+    assert int(ref_bn.num_batches_tracked) == 4                 # the backward re-ran the block in training mode
+
+    def stats(x):
+        m = x.detach().mean((0, 2))
+        return m, x.detach().var((0, 2), unbiased=True)
+
+    def forward_update(x):      # what ops.batch_norm_act does around the HIP kernels: batch statistics, then the buffers by hand
+        y = torch.nn.functional.batch_norm(x, None, None, our_bn.weight, our_bn.bias, training=True, eps=our_bn.eps)
+        with torch.no_grad():
+            m, v = stats(x)
+            our_bn.num_batches_tracked += 1
+            our_bn.running_mean.mul_(1 - our_bn.momentum).add_(m, alpha=our_bn.momentum)
+            our_bn.running_var.mul_(1 - our_bn.momentum).add_(v, alpha=our_bn.momentum)
+        return y
+
+    z0, z1 = forward_update(x0), forward_update(x1)              # the two forward updates
+    z0 = ops.replay_running_stats(z0, [(our_bn, [stats(x0), stats(x1)])])
+    assert int(our_bn.num_batches_tracked) == 2
+    (z0.sum() + (z1 * z1).sum()).backward()
+    assert int(our_bn.num_batches_tracked) == 4
+    torch.testing.assert_close(our_bn.running_mean, ref_bn.running_mean, rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(our_bn.running_var, ref_bn.running_var, rtol=1e-6, atol=1e-7)
+    assert ops.replay_running_stats(z1, []) is z1                # nothing collected: no node
