@@ -29,6 +29,16 @@ REF = {
 }
 
 
+@pytest.fixture(autouse=True, scope="module")
+def _few_cpu_threads():
+    """The batches are generated on the CPU (seeded, the same tensors the reference's run saw); torch's CPU backend crawls on
+    small tensors when it spreads them over the GPU box's 256 hardware threads."""
+    n = torch.get_num_threads()
+    torch.set_num_threads(min(n, 8))
+    yield
+    torch.set_num_threads(n)
+
+
 def _model(kind):
     from glue_factory_amd.matchers.gluestick import GlueStick
     from glue_factory_amd.matchers.lightglue import LightGlue
