@@ -1,0 +1,175 @@
+"""Ground-truth generation against the REFERENCE ITSELF over a sweep of seeded scenes (build container only: skipped where
+/root/reference is absent).  tests/test_gt_golden.py pins one scene per function to committed vectors; here the four
+functions of gluefactory/geometry/gt_generation.py -- points / lines, from a homography / from depth + pose -- are called
+side by side with ours on fresh scenes (several seeds, sizes, thresholds; empty and single-element inputs) and every
+integer label must agree bit for bit.  Torch ops on the CPU on both sides; no kernels."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+REF = "/root/reference"
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "gluefactory")),
+                                reason="reference checkout not present (GPU box)")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def ref_path():
+    stubs = os.path.join(ROOT, "oracle", "stubs")
+    added = [p for p in (stubs, REF) if p not in sys.path]
+    sys.path[:0] = [stubs]
+    sys.path.append(REF)
+    yield
+    for p in added:
+        if p in sys.path:
+            sys.path.remove(p)
+
+
+def _labels(res):
+    """(assignment, matches0, matches1) of a point ground truth.  On an EMPTY keypoint set the reference returns this bare
+    tuple instead of its dict (gt_generation.py:17-26, 111-119) -- a shape its own callers cannot merge into `pred`; ours
+    returns the dict in every case, with the same three tensors."""
+    return res if isinstance(res, tuple) else (res["assignment"], res["matches0"], res["matches1"])
+
+
+def _scene(seed, batch, hw=(96, 128)):
+    """Smooth positive depth maps with holes, pinhole cameras, a small relative pose (plain tensors)."""
+    g = torch.Generator().manual_seed(seed)
+    h, w = hw
+    ys, xs = torch.meshgrid(torch.arange(h).float(), torch.arange(w).float(), indexing="ij")
+    depth = []
+    for v in range(2):
+        d = 4.0 + 0.6 * torch.sin(xs / 17.0 + v + seed) + 0.4 * torch.cos(ys / 11.0 - v) + 0.05 * torch.rand(batch, h, w, generator=g)
+        d[:, 20:30, 40:60] = 0.0
+        d[torch.rand(batch, h, w, generator=g) < 0.03] = 0.0
+        depth.append(d)
+    cam = torch.tensor([w, h, 100.0, 100.0, w / 2.0, h / 2.0]).repeat(batch, 1)
+    ang = 0.05 * (torch.rand(batch, 3, generator=g) - 0.5)
+    K = torch.zeros(batch, 3, 3)
+    K[:, 0, 1], K[:, 0, 2], K[:, 1, 2] = -ang[:, 2], ang[:, 1], -ang[:, 0]
+    R = torch.linalg.matrix_exp(K - K.transpose(1, 2))
+    t = 0.3 * (torch.rand(batch, 3, generator=g) - 0.5)
+    return depth, cam, R, t, g
+
+
+def _both_sides(depth, cam, R, t):
+    from gluefactory.geometry.wrappers import Camera as RefCamera, Pose as RefPose
+    from glue_factory_amd.geometry import Camera, Pose
+    image = torch.zeros(depth[0].shape[0], 1, *depth[0].shape[-2:])
+
+    def data(C, P):
+        T = P.from_Rt(R, t)
+        return {"view0": {"camera": C(cam), "depth": depth[0], "image": image},
+                "view1": {"camera": C(cam.clone()), "depth": depth[1], "image": image}, "T_0to1": T, "T_1to0": T.inv()}
+
+    return data(RefCamera, RefPose), data(Camera, Pose)
+
+
+@pytest.mark.parametrize("seed,batch,n0,n1", [(1, 2, 60, 50), (2, 3, 33, 70), (3, 1, 1, 5), (4, 2, 40, 0)])
+def test_point_ground_truth_from_depth_equals_the_reference(ref_path, seed, batch, n0, n1):
+    from gluefactory.geometry.depth import project, sample_depth
+    from gluefactory.geometry.gt_generation import gt_matches_from_pose_depth as ref_fn
+    from glue_factory_amd.gt import gt_matches_from_pose_depth
+    depth, cam, R, t, g = _scene(seed, batch)
+    rdata, odata = _both_sides(depth, cam, R, t)
+    kp0 = torch.rand(batch, n0, 2, generator=g) * torch.tensor([127.0, 95.0])
+    kp1 = torch.rand(batch, n1, 2, generator=g) * torch.tensor([127.0, 95.0])
+    if n1:
+        d0, v0 = sample_depth(kp0, depth[0])
+        proj, vis = project(kp0, d0, depth[1], rdata["view0"]["camera"], rdata["view1"]["camera"], rdata["T_0to1"], v0)
+        nm = min(n0, (2 * n1) // 3)
+        src = torch.nan_to_num(proj[:, :nm], nan=5.0) + 0.7 * torch.randn(batch, nm, 2, generator=g)
+        kp1[:, :nm] = torch.where(vis[:, :nm, None], src, kp1[:, :nm])
+    for kw in ({}, {"cc_th": 4.0}, {"epi_th": 1.0, "cc_th": 4.0}):
+        ref = ref_fn(kp0, kp1, rdata, pos_th=3.0, neg_th=5.0, **kw)
+        out = gt_matches_from_pose_depth(kp0, kp1, odata, pos_th=3.0, neg_th=5.0, **kw)
+        assert isinstance(out, dict)
+        for a, b in zip(_labels(out), _labels(ref)):
+            np.testing.assert_array_equal(a.numpy(), b.numpy(), err_msg=str(kw))
+
+
+@pytest.mark.parametrize("seed,batch,n0,n1", [(5, 2, 80, 64), (6, 3, 17, 90), (7, 1, 1, 1), (8, 2, 0, 12)])
+def test_point_ground_truth_from_a_homography_equals_the_reference(ref_path, seed, batch, n0, n1):
+    from gluefactory.geometry.gt_generation import gt_matches_from_homography as ref_fn
+    from glue_factory_amd.gt import gt_matches_from_homography, warp_points
+    g = torch.Generator().manual_seed(seed)
+    wh = torch.tensor([640.0, 480.0])
+    ang = 0.1 * seed
+    H = torch.tensor([[1.05 * np.cos(ang), -np.sin(ang), 12.0], [np.sin(ang), 0.95 * np.cos(ang), -7.0], [2e-5, -1e-5, 1.0]],
+                     dtype=torch.float32).repeat(batch, 1, 1)
+    kp0 = torch.rand(batch, n0, 2, generator=g) * wh
+    kp1 = torch.rand(batch, n1, 2, generator=g) * wh
+    nm = min(n0, n1) // 2
+    if nm:
+        kp1[:, :nm] = warp_points(kp0[:, :nm], H) + 1.2 * torch.randn(batch, nm, 2, generator=g)
+    for pos, neg in ((3.0, 6.0), (3.0, 3.0), (1.0, 8.0)):
+        ref = ref_fn(kp0, kp1, H, pos_th=pos, neg_th=neg)
+        out = gt_matches_from_homography(kp0, kp1, H, pos_th=pos, neg_th=neg)
+        assert isinstance(out, dict)
+        for a, b in zip(_labels(out), _labels(ref)):
+            np.testing.assert_array_equal(a.numpy(), b.numpy(), err_msg=f"{pos} {neg}")
+
+
+def _segments(g, batch, n, wh, margin=5.0):
+    p = torch.rand(batch, n, 2, generator=g) * (wh - 2 * margin) + margin
+    ang = torch.rand(batch, n, generator=g) * 6.2832
+    ln = 8 + torch.rand(batch, n, generator=g) * 30
+    return torch.stack([p, p + ln[..., None] * torch.stack([torch.cos(ang), torch.sin(ang)], -1)], 2)
+
+
+@pytest.mark.parametrize("seed,batch,n0,n1", [(9, 2, 30, 26), (10, 1, 12, 40), (11, 2, 5, 0)])
+def test_line_ground_truth_from_depth_equals_the_reference(ref_path, seed, batch, n0, n1):
+    from gluefactory.geometry.depth import project, sample_depth
+    from gluefactory.geometry.gt_generation import gt_line_matches_from_pose_depth as ref_fn
+    from glue_factory_amd.gt import gt_line_matches_from_pose_depth
+    depth, cam, R, t, g = _scene(seed, batch)
+    rdata, odata = _both_sides(depth, cam, R, t)
+    wh = torch.tensor([127.0, 95.0])
+    lines0 = _segments(g, batch, n0, wh)
+    lines1 = torch.rand(batch, n1, 2, 2, generator=g) * wh
+    if n1:
+        ends = lines0.reshape(batch, n0 * 2, 2).clamp(min=torch.zeros(2), max=wh)
+        d, v = sample_depth(ends, depth[0])
+        proj, _ = project(ends, d, depth[1], rdata["view0"]["camera"], rdata["view1"]["camera"], rdata["T_0to1"], v)
+        proj = torch.nan_to_num(proj, nan=7.0).reshape(batch, n0, 2, 2)
+        nm = min(n0, (2 * n1) // 3)
+        lines1[:, :nm] = proj[:, :nm] + 0.8 * torch.randn(batch, nm, 2, 2, generator=g)
+        lines1 = lines1[:, torch.randperm(n1, generator=g)]
+    valid0 = torch.rand(batch, n0, generator=g) > 0.1
+    valid1 = torch.rand(batch, n1, generator=g) > 0.1
+    for kw in ({}, {"npts": 30, "dist_th": 3, "overlap_th": 0.4, "min_visibility_th": 0.3}):
+        rp, r0, r1 = ref_fn(lines0, lines1, valid0, valid1, rdata, **kw)
+        op, o0, o1 = gt_line_matches_from_pose_depth(lines0, lines1, valid0, valid1, odata, **kw)
+        np.testing.assert_array_equal(op.numpy(), rp.numpy(), err_msg=str(kw))
+        np.testing.assert_array_equal(o0.numpy(), r0.numpy(), err_msg=str(kw))
+        np.testing.assert_array_equal(o1.numpy(), r1.numpy(), err_msg=str(kw))
+
+
+@pytest.mark.parametrize("seed,batch,n0,n1", [(12, 2, 36, 30), (13, 1, 9, 50), (14, 3, 20, 20)])
+def test_line_ground_truth_from_a_homography_equals_the_reference(ref_path, seed, batch, n0, n1):
+    from gluefactory.geometry.gt_generation import gt_line_matches_from_homography as ref_fn
+    from glue_factory_amd.gt import gt_line_matches_from_homography, warp_points
+    g = torch.Generator().manual_seed(seed)
+    w, h = 320, 240
+    wh = torch.tensor([w - 1.0, h - 1.0])
+    ang = 0.05 * (seed - 12)
+    H = torch.tensor([[1.02 * np.cos(ang), -np.sin(ang), 6.0], [np.sin(ang), 0.98 * np.cos(ang), -4.0], [1e-5, -2e-5, 1.0]],
+                     dtype=torch.float32).repeat(batch, 1, 1)
+    lines0 = torch.rand(batch, n0, 2, 2, generator=g) * wh
+    lines1 = torch.rand(batch, n1, 2, 2, generator=g) * wh
+    nm = min(n0, (2 * n1) // 3)
+    lines1[:, :nm] = warp_points(lines0[:, :nm].reshape(batch, nm * 2, 2), H).reshape(batch, nm, 2, 2) \
+        + 1.5 * torch.randn(batch, nm, 2, 2, generator=g)
+    lines1 = lines1[:, torch.randperm(n1, generator=g)]
+    valid0 = torch.rand(batch, n0, generator=g) > 0.1
+    valid1 = torch.rand(batch, n1, generator=g) > 0.1
+    shape = (batch, 1, h, w)
+    for kw in ({}, {"npts": 20, "dist_th": 3, "overlap_th": 0.5, "min_visibility_th": 0.5}):
+        rp, r0, r1 = ref_fn(lines0, lines1, valid0, valid1, shape, shape, H, **kw)
+        op, o0, o1 = gt_line_matches_from_homography(lines0, lines1, valid0, valid1, shape, shape, H, **kw)
+        np.testing.assert_array_equal(op.numpy(), rp.numpy(), err_msg=str(kw))
+        np.testing.assert_array_equal(o0.numpy(), r0.numpy(), err_msg=str(kw))
+        np.testing.assert_array_equal(o1.numpy(), r1.numpy(), err_msg=str(kw))
