@@ -173,3 +173,58 @@ def test_line_ground_truth_from_a_homography_equals_the_reference(ref_path, seed
         np.testing.assert_array_equal(op.numpy(), rp.numpy(), err_msg=str(kw))
         np.testing.assert_array_equal(o0.numpy(), r0.numpy(), err_msg=str(kw))
         np.testing.assert_array_equal(o1.numpy(), r1.numpy(), err_msg=str(kw))
+
+
+OURS_ONLY = {"assignment_col0", "line_assignment_col0"}     # fixed-length positive columns for the fused losses
+
+
+def _module_outputs_agree(out, ref):
+    assert set(ref) <= set(out) and set(out) - set(ref) <= OURS_ONLY, set(out) ^ set(ref)
+    for k, v in ref.items():
+        assert out[k].shape == v.shape and out[k].dtype == v.dtype, (k, out[k].shape, v.shape, out[k].dtype, v.dtype)
+        if v.is_floating_point():
+            torch.testing.assert_close(out[k], v, rtol=1e-4, atol=1e-4, equal_nan=True, msg=lambda m: f"{k}: {m}")
+        else:
+            assert torch.equal(out[k], v), k
+
+
+@pytest.mark.parametrize("use_points,use_lines", [(True, False), (False, True), (True, True)])
+def test_ground_truth_modules_equal_the_reference_modules(ref_path, use_points, use_lines):
+    """The plugin modules themselves (matchers/homography_matcher.py:8-66, matchers/depth_matcher.py:16-89), constructed by
+    either side's get_model from the same configuration: output keys, dtypes, shapes and values."""
+    from omegaconf import OmegaConf
+    from gluefactory.models import get_model as ref_get
+    from glue_factory_amd.base_model import get_model
+    from glue_factory_amd.gt import warp_points
+    g = torch.Generator().manual_seed(31)
+    batch, n, nl = 2, 40, 14
+    # ---- homography
+    conf = {"use_points": use_points, "use_lines": use_lines, "th_positive": 3.0, "th_negative": 4.0, "overlap_th": 0.3}
+    ref_m = ref_get("matchers.homography_matcher")(OmegaConf.create(conf))
+    our_m = get_model("matchers.homography_matcher")(conf)
+    assert set(ref_m.required_data_keys) == set(our_m.required_data_keys)
+    H = torch.tensor([[1.03, -0.05, 5.0], [0.04, 0.98, -3.0], [1e-5, 0.0, 1.0]]).repeat(batch, 1, 1)
+    wh = torch.tensor([319.0, 239.0])
+    kp0 = torch.rand(batch, n, 2, generator=g) * wh
+    kp1 = torch.rand(batch, n, 2, generator=g) * wh
+    kp1[:, :25] = warp_points(kp0[:, :25], H) + torch.randn(batch, 25, 2, generator=g)
+    lines0 = torch.rand(batch, nl, 2, 2, generator=g) * wh
+    lines1 = torch.rand(batch, nl, 2, 2, generator=g) * wh
+    lines1[:, :9] = warp_points(lines0[:, :9].reshape(batch, 18, 2), H).reshape(batch, 9, 2, 2)
+    img = torch.zeros(batch, 1, 240, 320)
+    data = {"H_0to1": H, "keypoints0": kp0, "keypoints1": kp1, "lines0": lines0, "lines1": lines1,
+            "valid_lines0": torch.rand(batch, nl, generator=g) > 0.1, "valid_lines1": torch.rand(batch, nl, generator=g) > 0.1,
+            "view0": {"image": img}, "view1": {"image": img}}
+    _module_outputs_agree(our_m(dict(data)), ref_m(dict(data)))
+    # ---- depth + pose
+    conf = {"use_points": use_points, "use_lines": use_lines, "th_positive": 3.0, "th_negative": 5.0, "th_consistency": 4.0}
+    ref_m = ref_get("matchers.depth_matcher")(OmegaConf.create(conf))
+    our_m = get_model("matchers.depth_matcher")(conf)
+    assert set(ref_m.required_data_keys) == set(our_m.required_data_keys)
+    depth, cam, R, t, g = _scene(32, batch)
+    rdata, odata = _both_sides(depth, cam, R, t)
+    wh = torch.tensor([127.0, 95.0])
+    extra = {"keypoints0": torch.rand(batch, n, 2, generator=g) * wh, "keypoints1": torch.rand(batch, n, 2, generator=g) * wh,
+             "lines0": _segments(g, batch, nl, wh), "lines1": _segments(g, batch, nl, wh),
+             "valid_lines0": torch.rand(batch, nl, generator=g) > 0.1, "valid_lines1": torch.rand(batch, nl, generator=g) > 0.1}
+    _module_outputs_agree(our_m({**odata, **extra}), ref_m({**rdata, **extra}))
