@@ -119,7 +119,17 @@ def _traffic(key):
     """Measured HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 (gfx950 half count) + WRITE_SIZE; collected by
     tools/collect_pmc.sh over `bench.py --roofline-only`, summarised into profiles/roofline_traffic.json).  NOT
     measured in this run: `traffic_source` in the JSON line names the collection it comes from."""
-    return _traffic_table().get(key, {}).get("hbm_bytes_per_launch")
+    t = _traffic_table()
+    if t.get("lib_sha", _sha_of_source(t)) != _lib_sha():        # counters of ANOTHER build say nothing about this one's kernels
+        return None
+    return t.get(key, {}).get("hbm_bytes_per_launch")
+
+
+def _sha_of_source(t):
+    """Tables written before `lib_sha` existed name the build inside `source` ("... sha1 <12 hex> ...")."""
+    src = t.get("source", "")
+    i = src.find("sha1 ")
+    return src[i + 5:i + 17] if i >= 0 else None
 
 
 def _lib_sha():
@@ -134,6 +144,8 @@ def _lib_sha():
 def _traffic_source():
     t = _traffic_table()
     src = t.get("source", "none") if t else "none (profiles/roofline_traffic.json missing)"
+    if t and t.get("lib_sha", _sha_of_source(t)) != _lib_sha():
+        src = "STALE, `traffic` withheld (null): " + src
     return f"{src}; this run: libgf_amd.so sha1 {_lib_sha()}"
 
 
@@ -620,6 +632,11 @@ def timed_steps(step, warmup, steps, barrier, dist):
     # a matching NLL on random-init weights sits around log(N) ~ 8-10 and can only go down from there
     if not torch.isfinite(loss.detach()).item() or not 0.0 <= float(loss.item()) < 100.0:
         raise RuntimeError(f"implausible loss in the benchmark step: {float(loss.item())}")
+    # every product of a timed configuration must have run on the hand-written kernels: a shape that fell through to the
+    # vendor library (ops.gemm counts them) makes the number a measurement of something else -- fail, do not warn
+    from glue_factory_amd import ops
+    if ops.LIBRARY_GEMMS:
+        raise SystemExit(f"bench.py: products left the HIP path for the vendor library during a timed configuration: {ops.LIBRARY_GEMMS}")
     return dt, float(loss.item())
 
 

@@ -1,36 +1,4 @@
-// ABI bookkeeping for libgf_amd.so (include/gf_amd.h) + one diagnostics entry.
-#include <hip/hip_runtime.h>
-
+// ABI bookkeeping for libgf_amd.so (include/gf_amd.h).
 #include "gf_amd.h"
 
 extern "C" int gf_abi_version(void) { return GF_AMD_ABI_VERSION; }
-
-namespace {
-// A workgroup that claims (nearly) all of a CU's LDS -- so no other LDS-heavy workgroup shares the CU -- and spins on the
-// constant-rate wall clock until `ticks` have passed.
-__global__ __launch_bounds__(256) void hold_cus_kernel(long long ticks, unsigned* sink) {
-    extern __shared__ unsigned held[];
-    const long long t0 = wall_clock64();
-    unsigned n = 0;
-    while (wall_clock64() - t0 < ticks && n < 16000000u) {      // (the count bounds the spin should the clock ever stand still)
-        __builtin_amdgcn_s_sleep(64);
-        ++n;
-    }
-    held[threadIdx.x] = n;
-    if (sink != nullptr && threadIdx.x == 0) sink[blockIdx.x] = held[0];
-}
-}  // namespace
-
-extern "C" int gf_probe_hold_cus(int n_cus, int milliseconds, void* stream) {
-    if (n_cus < 1 || n_cus > 1024 || milliseconds < 0 || milliseconds > 5000) return GF_ERR_SHAPE;
-    int dev = 0, khz = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz < 1) khz = 100000;
-    const int lds = 150 * 1024;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(hold_cus_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return (int)e;
-    hold_cus_kernel<<<dim3((unsigned)n_cus), 256, lds, reinterpret_cast<hipStream_t>(stream)>>>(
-        (long long)milliseconds * khz, nullptr);
-    return (int)hipGetLastError();
-}

@@ -17,6 +17,8 @@
 //   dZ_ij = G_ij - sum_k [ exp(Z_ij+u^k_i+v^k_j-log_nu_j) vbar^k_j + exp(Z_ij+u^k_i-log_mu_i+v^{k-1}_j) ubar^k_i ]
 // i.e. T passes of the same one-read shape plus one final pass; every exponent is <= 0 up to
 // rounding (Q, R are sub-stochastic), so no max-shift is needed in the reverse sweep.
+#include <atomic>
+
 #include "gf_common.h"
 #include "gf_amd.h"
 
@@ -740,6 +742,7 @@ extern "C" int gf_sinkhorn_fwd(const float* Z, float* out, float* u_hist, float*
     const bool resident = g.fast && iters > 0 && skr_plan(g, B, skr_cus(), false, schedule & 3, rp) &&
                           (size_t)rp.nw * rp.bc <= w.part_rows;
     const long long wait_ticks = resident ? skr_wait_ticks(schedule) : 0;
+    const bool same_xcd_ok = resident && skr_same_xcd_allowed();
     const int ch = resident ? rp.bc : batch_chunk(g);
     const size_t zs = (size_t)g.R * g.C;
     const size_t lds = g.fast ? 0 : rows_lds(g, false);
@@ -760,7 +763,7 @@ extern "C" int gf_sinkhorn_fwd(const float* Z, float* out, float* u_hist, float*
                     ra.colA = w.a2p; ra.colB = w.vbp;                 // 16-byte aligned [B, Cp] scratch (free in the forward)
                     ra.u_hist = u_hist + (size_t)b0 * g.R; ra.v_hist = v_hist + (size_t)b0 * g.C;
                     ra.ustride = (size_t)B * g.R; ra.vstride = (size_t)B * g.C;
-                    ra.iters = iters; ra.d = rp; ra.d.bc = bc; ra.g = g; ra.wait_ticks = wait_ticks; ra.safe_only = (schedule >> 2) & 1;
+                    ra.iters = iters; ra.d = rp; ra.d.bc = bc; ra.g = g; ra.wait_ticks = wait_ticks; ra.safe_only = ((schedule >> 2) & 1) || !same_xcd_ok;
                     int rc = skr_launch<false>(ra, st);
                     if (rc) return rc;
                 } else {
@@ -833,6 +836,7 @@ extern "C" int gf_sinkhorn_bwd(const float* Z, const float* gout, const float* g
     const bool resident = g.fast && skr_plan(g, B, skr_cus(), true, schedule & 3, rp) &&
                           (size_t)rp.nw * rp.bc <= w.part_rows;
     const long long wait_ticks = resident ? skr_wait_ticks(schedule) : 0;
+    const bool same_xcd_ok = resident && skr_same_xcd_allowed();
     const int ch = resident ? rp.bc : batch_chunk(g);
     for (int b0 = 0; b0 < B; b0 += ch) {
         const int bc = (B - b0) < ch ? (B - b0) : ch;
@@ -852,7 +856,7 @@ extern "C" int gf_sinkhorn_bwd(const float* Z, const float* gout, const float* g
                 ra.base_row = gsum_row + (size_t)b0 * g.R;
                 ra.ubar_hist = ubar_hist + (size_t)b0 * g.R; ra.vbar_hist = vbar_hist + (size_t)b0 * g.C;
                 ra.ustride = (size_t)B * g.R; ra.vstride = (size_t)B * g.C;
-                ra.iters = iters; ra.d = rp; ra.d.bc = bc; ra.g = g; ra.wait_ticks = wait_ticks; ra.safe_only = (schedule >> 2) & 1;
+                ra.iters = iters; ra.d = rp; ra.d.bc = bc; ra.g = g; ra.wait_ticks = wait_ticks; ra.safe_only = ((schedule >> 2) & 1) || !same_xcd_ok;
                 return skr_launch<true>(ra, st);
             }() : [&]() -> int {
 #define SKF_CALL_BWD(NSV) skf_bwd_launch<NSV>(w.zp, u_hist + (size_t)b0 * g.R, v_hist + (size_t)b0 * g.C,          \

@@ -37,6 +37,9 @@
 // the end of the kernel every wave of the pair overwrites its rows of the last iterate (forward: u^T, backward: ubar^1)
 // with NaN -- the pair's output / gradient is NaN in every row, the loss is NaN, and TrainStep's device-side skip flag
 // (train.py:477-480) drops the update.  Never a silently wrong number, never a hung device.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "sinkhorn_resident.h: the same-XCD hand-off is written against gfx950's cache hierarchy (see skr_same_xcd_allowed)"
+#endif
 constexpr int SKR_RR = 12;                 // rows of a wave that live in registers
 constexpr int SKR_MAX_BC = 16;             // pairs per launch (counter slots; the failure flags follow them)
 constexpr unsigned SKR_DEFAULT_WAIT_MS = 10000;
@@ -119,8 +122,10 @@ __device__ __forceinline__ void skr_barrier(unsigned* ctr, unsigned target, long
                     // every later wait of the pair; whoever leaves a barrier after this sees the flag at the kernel's end
                     const unsigned was = __hip_atomic_fetch_or(ctr + SKR_MAX_BC, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     asm volatile("" ::"v"(was) : "memory");
-                    if (same_xcd) __hip_atomic_fetch_add(c, 0x40000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    else __hip_atomic_fetch_add(c, 0x40000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    // BOTH counters: should a pair's workgroups ever disagree about the protocol (they cannot after the guard
+                    // behind the first barrier, but a release must not depend on that), nobody sits out a second full bound
+                    __hip_atomic_fetch_add(ctr, 0x40000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_fetch_add(ctr + 3 * SKR_MAX_BC, 0x40000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     break;
                 }
             }
@@ -372,8 +377,11 @@ __global__ __launch_bounds__(256, 1) void skr_kernel(const SkrArgs a) {
         if (same_xcd) skr_barrier(ctr, ++nbar2 * (unsigned)a.d.wpp, a.wait_ticks, true);
         else skr_barrier(ctr, ++nbar * (unsigned)a.d.wpp, a.wait_ticks);
         if (it == 0 && !a.safe_only) {
+            // (a pair whose FIRST barrier expired left it with an incomplete mask: it is poisoned anyway and stays on the
+            // placement-independent protocol, so its workgroups cannot split over the two counters)
             const unsigned mask = __hip_atomic_load(ctr + 2 * SKR_MAX_BC, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            same_xcd = __builtin_amdgcn_readfirstlane((int)(__builtin_popcount(mask) == 1)) != 0;
+            const unsigned failed = __hip_atomic_load(ctr + SKR_MAX_BC, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            same_xcd = __builtin_amdgcn_readfirstlane((int)(__builtin_popcount(mask) == 1 && failed == 0u)) != 0;
         }
 
         // ---- column phase: this workgroup finishes float4 columns [wg cs, wg cs + cs)
@@ -474,6 +482,29 @@ int skr_cus() {                            // CU count of the CURRENT device (as
     if (hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) return 0;
     return v;
+}
+
+// The same-XCD hand-off leans on how THIS part is built, not on the HSA memory model (workgroups of different CUs meeting
+// through plain stores and an L2-resident counter): one L2 per XCD that every CU of the XCD shares, atomics executed in
+// that L2, HW_REG_XCC_ID naming the XCD.  It is therefore enabled per architecture, at run time, and nowhere else: gfx950
+// (MI350X / MI355X; measured bit-identical to the write-through protocol, tests/test_gpu_sinkhorn_safety.py).  Any other
+// device -- and any failure to ask -- takes the placement-independent protocol.
+bool skr_same_xcd_allowed() {
+    // (an immutable fact about a device, remembered per device ordinal: 0 unknown, 1 yes, 2 no -- not a setting)
+    static std::atomic<int> known[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    int k = known[dev].load(std::memory_order_relaxed);
+    if (k == 0) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
+        const char* a = prop.gcnArchName;
+        const bool ok = a[0] == 'g' && a[1] == 'f' && a[2] == 'x' && a[3] == '9' && a[4] == '5' && a[5] == '0' &&
+                        (a[6] == 0 || a[6] == ':');
+        k = ok ? 1 : 2;
+        known[dev].store(k, std::memory_order_relaxed);
+    }
+    return k == 1;
 }
 
 long long skr_wait_ticks(int schedule) {   // the call's wait bound in wall_clock64() ticks of the CURRENT device

@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgf_amd.so")
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 15      # == GF_AMD_ABI_VERSION in include/gf_amd.h (bumped with every signature / workspace change)
+ABI_VERSION = 16      # == GF_AMD_ABI_VERSION in include/gf_amd.h (bumped with every signature / workspace change)
 
 _c = ctypes
 _P, _I, _F, _L, _D = _c.c_void_p, _c.c_int, _c.c_float, _c.c_int64, _c.c_double
@@ -32,7 +32,6 @@ SIGNATURES = {
     "gf_dual_softmax_bwd": [_P, _P, _P, _P, _P, _P, _P, _L, _F, _P, _I, _I, _I, _I, _I, _P],
     "gf_head_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "gf_filter_matches": [_P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _P],
-    "gf_probe_hold_cus": [_I, _I, _P],
     "gf_sinkhorn_plan": [_I, _I, _I, _I, _I, _I, _P],
     "gf_sinkhorn_ws_bytes": [_I, _I, _I, _I],
     "gf_sinkhorn_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],

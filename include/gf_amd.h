@@ -36,13 +36,9 @@ extern "C" {
 #define GF_ERR_ALIGN (-3)
 #define GF_ERR_DTYPE (-4)
 
-/* ABI version; bumped on any signature or workspace-size change (2: gf_attn_bwd's delta workspace doubled; 3: line head + gf_bgemm; 4: smallops; 5: gf_attn_bwd_acc; 9: cast entries with leading dimensions, gf_fold_linear_*, double betas in gf_multi_adam; 10: gf_attn_fwd_ex / GF_ATTN_SPLIT, gf_topk_candidates; 14: gf_sinkhorn_* take `schedule`, gf_sinkhorn_mode removed, gf_probe_hold_cus, gf_linear_dw2, gf_gemm_res2, gf_rowdot2_*; gf_rowdot_fwd / gf_rotary_qk_bwd take a device bias / a base sum). */
-#define GF_AMD_ABI_VERSION 15
+/* ABI version; bumped on any signature or workspace-size change (2: gf_attn_bwd's delta workspace doubled; 3: line head + gf_bgemm; 4: smallops; 5: gf_attn_bwd_acc; 9: cast entries with leading dimensions, gf_fold_linear_*, double betas in gf_multi_adam; 10: gf_attn_fwd_ex / GF_ATTN_SPLIT, gf_topk_candidates; 14: gf_sinkhorn_* take `schedule`, gf_sinkhorn_mode removed, gf_probe_hold_cus, gf_linear_dw2, gf_gemm_res2, gf_rowdot2_*; gf_rowdot_fwd / gf_rotary_qk_bwd take a device bias / a base sum; 16: the test diagnostic gf_probe_hold_cus left the product ABI for tests/csrc/gf_test_probe.hip). */
+#define GF_AMD_ABI_VERSION 16
 int gf_abi_version(void);
-/* Diagnostics (tests/test_gpu_sinkhorn_safety.py): occupies `n_cus` compute units (one 150 KB-LDS workgroup each) for
- * `milliseconds` (<= 5000) on `stream` -- the stand-in for "another stream's kernel holds part of the chip" (an RCCL
- * reduction, a second process) under which the chip-resident Sinkhorn's bounded waits are tested. */
-int gf_probe_hold_cus(int n_cus, int milliseconds, void* stream);
 
 /* ---- multi-head attention over keypoints --------------------------------------------------
  * softmax(scale * q k^T) v, flash style (no N x N tensor in HBM).

@@ -180,8 +180,8 @@ def filter_matches(scores, th):
     core = scores[:, :-1, :-1]
     max0, m0 = core.max(2)
     m1 = core.max(1).indices
-    ar0 = torch.arange(m0.shape[1])[None]
-    ar1 = torch.arange(m1.shape[1])[None]
+    ar0 = torch.arange(m0.shape[1], device=m0.device)[None]
+    ar1 = torch.arange(m1.shape[1], device=m1.device)[None]
     mutual0 = m1.gather(1, m0) == ar0
     mutual1 = m0.gather(1, m1) == ar1
     s0 = torch.where(mutual0, max0.exp(), max0.new_zeros(()))

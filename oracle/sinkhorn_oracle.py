@@ -22,8 +22,8 @@ def couplings(scores, alpha):
 
 def marginals(m, n, like):
     norm = -math.log(m + n)
-    log_mu = torch.full((m + 1,), norm, dtype=like.dtype)
-    log_nu = torch.full((n + 1,), norm, dtype=like.dtype)
+    log_mu = torch.full((m + 1,), norm, dtype=like.dtype, device=like.device)
+    log_nu = torch.full((n + 1,), norm, dtype=like.dtype, device=like.device)
     log_mu[-1] = math.log(n) + norm
     log_nu[-1] = math.log(m) + norm
     return log_mu, log_nu, norm
@@ -32,8 +32,8 @@ def marginals(m, n, like):
 def sinkhorn(Z, log_mu, log_nu, iters):
     """Returns (Z + u + v, u_hist [T,B,R], v_hist [T,B,C])."""
     b = Z.shape[0]
-    u = torch.zeros(b, Z.shape[1], dtype=Z.dtype)
-    v = torch.zeros(b, Z.shape[2], dtype=Z.dtype)
+    u = torch.zeros(b, Z.shape[1], dtype=Z.dtype, device=Z.device)
+    v = torch.zeros(b, Z.shape[2], dtype=Z.dtype, device=Z.device)
     uh, vh = [], []
     for _ in range(iters):
         u = log_mu[None] - torch.logsumexp(Z + v[:, None, :], dim=2)

@@ -185,3 +185,27 @@ def significant_grads(errs):
 def matches_agreement(m, ref):
     m = m.cpu().numpy() if torch.is_tensor(m) else m
     return float((m == ref).mean())
+
+
+def assert_disagreements_are_ties(la, m, ref, threshold, margin=1e-3):
+    """Integer outputs against a golden whose weights are RANDOM (no decisive margins): every row on which our match index
+    differs from the reference's must be a decision OUR OWN log-assignment rates a near-tie -- the row's top-2 gap, the top-2
+    gap of a candidate column (ours, the reference's, the row's arg-max: the mutual check), or the distance of a candidate's
+    probability from the filter threshold is below `margin` (10 x the 1e-4 the log-assignment itself is held to).  A
+    disagreement that is none of these fails.  Returns the number of (explained) disagreements."""
+    la = la.detach().float().cpu()
+    m = m.cpu().numpy() if torch.is_tensor(m) else m
+    core = la[:, :-1, :-1]
+    t2r = core.topk(2, dim=-1).values
+    gap_r = (t2r[..., 0] - t2r[..., 1]).numpy()
+    t2c = core.transpose(1, 2).topk(2, dim=-1).values
+    gap_c = (t2c[..., 0] - t2c[..., 1]).numpy()
+    arg_r = core.argmax(-1).numpy()
+    bad = np.argwhere(m != ref)
+    for b, i in bad:
+        cands = {int(arg_r[b, i])} | {int(j) for j in (m[b, i], ref[b, i]) if j >= 0}
+        ok = gap_r[b, i] < margin
+        for j in cands:
+            ok = ok or gap_c[b, j] < margin or abs(float(core[b, i, j].exp()) - threshold) < margin
+        assert ok, (int(b), int(i), int(m[b, i]), int(ref[b, i]), float(gap_r[b, i]), [float(gap_c[b, j]) for j in cands])
+    return len(bad)

@@ -16,6 +16,34 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run via gpurun)")
 
 
+PROBE_SRC = os.path.join(ROOT, "tests", "csrc", "gf_test_probe.hip")
+PROBE_LIB = os.path.join(ROOT, "tests", "libgf_test_probe.so")
+_probe = None
+
+
+def build_test_probe():
+    """tests/libgf_test_probe.so: TEST-ONLY kernels (a CU holder) that have no place in the product ABI.  Built in-tree by
+    __graft_entry__.build() (so it travels to the GPU box) and on demand here."""
+    import subprocess
+    if not os.path.exists(PROBE_LIB) or os.path.getmtime(PROBE_LIB) < os.path.getmtime(PROBE_SRC):
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", PROBE_SRC,
+                        "-o", PROBE_LIB], check=True, capture_output=True)
+    return PROBE_LIB
+
+
+def test_probe():
+    global _probe
+    if _probe is None:
+        import ctypes
+        _probe = ctypes.CDLL(build_test_probe())
+        _probe.gf_test_hold_cus.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        _probe.gf_test_hold_cus.restype = ctypes.c_int
+    return _probe
+
+
+test_probe.__test__ = False          # (a helper, not a test: keep pytest from collecting it where it is imported)
+
+
 def load_golden(name):
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
     return {k: z[k] for k in z.files}

@@ -14,8 +14,8 @@ import numpy as np
 import pytest
 import torch
 
-from config_golden import (check_la_digest, grad_digest_errors, gs_config_inputs, la_digest_error, matches_agreement,
-                           sg_config_inputs, significant_grads)
+from config_golden import (assert_disagreements_are_ties, check_la_digest, grad_digest_errors, gs_config_inputs,
+                           la_digest_error, sg_config_inputs, significant_grads)
 
 pytestmark = pytest.mark.gpu
 
@@ -109,9 +109,11 @@ def test_superglue_config4_fp32_train_step_vs_reference():
     check_la_digest(z, pred["log_assignment"], stride, tol=1e-4)
     np.testing.assert_allclose(pred["sinkhorn_cost"].detach().cpu().flatten(1)[:, ::stride].numpy(), z["train.cost_sample"],
                                rtol=1e-4, atol=1e-4)
-    agree = matches_agreement(pred["matches0"], z["train.matches0"])
-    print("superglue config4 fp32: matches0 agreement", agree)
-    assert agree >= 0.999
+    # random weights, no decisive margins (the sharp goldens below are the bit-exact ones): a row may differ from the
+    # reference's only where our own log-assignment rates the decision a near-tie
+    n = assert_disagreements_are_ties(pred["log_assignment"], pred["matches0"], z["train.matches0"], 0.2)
+    print("superglue config4 fp32: matches0 rows that differ from the reference's, all near-ties:", n)
+    assert n <= 2
     _check_losses(z, losses, 1e-4)
     _fp32_grads(z, grads, norm_tol=6e-4, sample_tol=2e-3)        # 2x the measured 3.1e-4 / 1.0e-3
 
@@ -129,10 +131,10 @@ def test_gluestick_config5_fp32_train_step_vs_reference():
     check_la_digest(z, pred["line_log_assignment"], 97, prefix="train.line_", tol=1e-4)
     np.testing.assert_allclose(pred["raw_line_scores"].detach().cpu().flatten(1)[:, ::97].numpy(),
                                z["train.raw_line_scores_sample"], rtol=1e-4, atol=1e-4)
-    for k in ("matches0", "line_matches0"):
-        agree = matches_agreement(pred[k], z["train." + k])
-        print("gluestick config5 fp32:", k, "agreement", agree)
-        assert agree >= 0.999
+    for k, la in (("matches0", "log_assignment"), ("line_matches0", "line_log_assignment")):
+        n = assert_disagreements_are_ties(pred[la], pred[k], z["train." + k], 0.2)
+        print("gluestick config5 fp32:", k, "rows that differ from the reference's, all near-ties:", n)
+        assert n <= 3
     _check_losses(z, losses, 1e-4)
     _fp32_grads(z, grads, norm_tol=3e-4, sample_tol=1.5e-3)      # 2x the measured 1.3e-4 / 7.3e-4
 

@@ -2,7 +2,7 @@
 
 Its workgroups hand partial column sums to each other through per-pair counters, so every workgroup of a pair has to
 run before any of them can finish an iteration.  On an idle device they all start at once; here another stream's kernel
-(`gf_probe_hold_cus`: one 150 KB-LDS workgroup per compute unit, the stand-in for an RCCL reduction or a second process)
+(`gf_test_hold_cus` of the test-only tests/libgf_test_probe.so: one 150 KB-LDS workgroup per compute unit, the stand-in for an RCCL reduction or a second process)
 holds 32 of the 256 CUs while the sweep is launched:
   * the 32 workgroups that find no CU are dispatched when the holder leaves; the result is BIT-IDENTICAL to the idle run
     (contention costs time, never correctness);
@@ -36,8 +36,9 @@ def _run(Z, G, schedule):
 
 
 def _hold(n_cus, ms, stream):
-    from glue_factory_amd import lib
-    lib.check(lib.load().gf_probe_hold_cus(n_cus, ms, stream.cuda_stream), "gf_probe_hold_cus")
+    from conftest import test_probe
+    rc = test_probe().gf_test_hold_cus(n_cus, ms, stream.cuda_stream)
+    assert rc == 0, f"gf_test_hold_cus -> {rc}"
 
 
 def _resident_here():

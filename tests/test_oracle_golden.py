@@ -182,6 +182,9 @@ def test_superglue_oracle_at_config4_matches_reference(name):
         assert sgo.decisiveness(pred["log_assignment"].detach(), 0.2) > 1.5
         for k in ("matches0", "matches1"):
             np.testing.assert_array_equal(pred[k].numpy(), z["train." + k])
+    else:       # random weights: rows may differ from the reference's only at decisions the log-assignment rates near-ties
+        from config_golden import assert_disagreements_are_ties
+        assert assert_disagreements_are_ties(pred["log_assignment"], pred["matches0"], z["train.matches0"], 0.2) <= 2
     for k in [k[5:] for k in z if k.startswith("loss.")]:
         np.testing.assert_allclose(losses[k].detach().numpy(), z["loss." + k], **TOL, err_msg=k)
     errs = significant_grads(grad_digest_errors(z, grads))
@@ -203,6 +206,10 @@ def test_gluestick_oracle_at_config5_matches_reference(name):
     if "sharp" in z:
         for k in ("matches0", "matches1", "line_matches0", "line_matches1"):
             np.testing.assert_array_equal(pred[k].numpy(), z["train." + k])
+    else:
+        from config_golden import assert_disagreements_are_ties
+        for k, la in (("matches0", "log_assignment"), ("line_matches0", "line_log_assignment")):
+            assert assert_disagreements_are_ties(pred[la], pred[k], z["train." + k], 0.2) <= 3
     for k in [k[5:] for k in z if k.startswith("loss.")]:
         np.testing.assert_allclose(losses[k].detach().numpy(), z["loss." + k], **TOL, err_msg=k)
     errs = significant_grads(grad_digest_errors(z, grads))

@@ -24,4 +24,5 @@ cd "$REPO"
 python tools/pmc_to_traffic.py "$TAG" "$OUT"
 # only gpurun_out/ travels back from the GPU box: hand the summaries over through it (copy them into profiles/ locally)
 mkdir -p "$REPO/gpurun_out/profiles"
-cp "$REPO/profiles/${TAG}_roofline_pmc.csv" "$REPO/profiles/${TAG}_roofline_kernel_stats.csv" "$REPO/profiles/roofline_traffic.json" "$REPO/gpurun_out/profiles/" 2>/dev/null
+cp "$REPO/profiles/${TAG}_roofline_pmc.csv" "$REPO/profiles/${TAG}_roofline_kernel_stats.csv" "$REPO/profiles/roofline_traffic.json" \
+   "$REPO/profiles/${TAG}_roofline_traffic.json" "$REPO/gpurun_out/profiles/" 2>/dev/null

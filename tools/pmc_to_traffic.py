@@ -106,5 +106,7 @@ try:      # (no git on the GPU box: the build is identified by the library it me
 except OSError:
     build = "unknown"
 out["source"] = f"tools/collect_pmc.sh {tag} (build {build}): rocprofv3 --pmc passes over `bench.py --roofline-only`"
+out["lib_sha"] = build.rsplit(" ", 1)[-1]          # bench.py reports `traffic` only when the running library is this one
 json.dump(out, open(os.path.join(ROOT, "profiles", "roofline_traffic.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_roofline_traffic.json"), "w"), indent=1)      # the per-tag record
 print(json.dumps(out, indent=1))

@@ -34,14 +34,24 @@ def main():
     params = lc.initial_params(kind)
     if params is not None:
         model.load_state_dict(params, strict=True)
+    dtype = getattr(torch, os.environ.get("GF_DTYPE", "float32"))      # float64: the anchor run of tools/probe/learn_anchor_report.py
+    model = model.to(dtype)
     opt = torch.optim.Adam(model.parameters(), lr=lc.LR[kind])
+    make_batch = lc.batch
+
+    def cast(o):
+        if isinstance(o, dict):
+            return {k: cast(v) for k, v in o.items()}
+        return o.to(dtype) if torch.is_tensor(o) and o.is_floating_point() else o
+
+    lc_batch = lambda kind, seed: cast(make_batch(kind, seed))   # noqa: E731
 
     def evaluate():
         model.eval()
         out = []
         with torch.no_grad():
             for s in lc.HELD_OUT:
-                data = lc.batch(kind, s)
+                data = lc_batch(kind, s)
                 pred = model(data)
                 losses = model.loss(pred, {**pred, **data})
                 losses = losses[0] if isinstance(losses, tuple) else losses
@@ -58,7 +68,7 @@ def main():
     trace = []
     for i in range(steps):
         model.train()
-        data = lc.batch(kind, 1000 + i)
+        data = lc_batch(kind, 1000 + i)
         opt.zero_grad()
         pred = model(data)
         losses = model.loss(pred, {**pred, **data})
