@@ -716,6 +716,70 @@ def gen_lightglue_adaptive(name, n0, n1, n_layers, seed):
     np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
 
 
+
+def gen_trained_state(name, kind, state_path, stride=101):
+    """Parity AT A TRAINED STATE (round-5 review, item 1a): every other golden pins the kernels at random-init weights; this one
+    takes the state a 300-step run of tests/learning_cases.py ENDS in -- sharp attention, BatchNorm statistics far from their
+    initial values, a grown bin_score -- and records the REFERENCE module's eval forward and train step (outputs, losses, every
+    gradient) on a held-out batch of that run.  `state_path`: a state_dict saved by tools/probe/ref_learning_curve.py (the
+    reference's own training run on the CPU) or tools/probe/learn_save_state.py (the HIP path's run on the MI355X).  The fixture
+    keeps the state as the seeded initial state + its drift rounded to bf16 (2 bytes per parameter), and the golden is generated AT
+    that reconstructed state, so both sides start from bit-identical parameters."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import learning_cases as lc
+    if kind == "superglue":
+        from gluefactory_nonfree.superglue import SuperGlue as Model
+    else:
+        from gluefactory.models.matchers.gluestick import GlueStick as Model
+    init = lc.initial_params(kind)
+    trained = torch.load(state_path, map_location="cpu")
+    out = {}
+    for k, v in init.items():
+        if v.is_floating_point():
+            out["delta." + k] = (trained[k].float() - v).to(torch.bfloat16).view(torch.int16).numpy().astype(np.uint16)
+        else:
+            out["state." + k] = trained[k].numpy()
+    state = lc.trained_state_from_delta(init, out)
+    data = lc.batch(kind, lc.HELD_OUT[0])
+    model = Model({**lc.conf(kind), "weights": None})
+    res = model.load_state_dict(state, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    lines = kind == "gluestick"
+    mkeys = ("matches0", "matches1", "matching_scores0") + (("line_matches0", "line_matches1", "line_matching_scores0") if lines else ())
+    model.eval()
+    with torch.no_grad():
+        pe = model(data)
+        le = model.loss(pe, {**pe, **data})
+        le = le[0] if isinstance(le, tuple) else le
+    out.update(_np({k: pe[k] for k in mkeys}, "eval."))
+    _la_digest(out, pe["log_assignment"], stride, "eval.")
+    out["eval.loss_total"] = le["total"].numpy()
+    if lines:
+        _la_digest(out, pe["line_log_assignment"], 7, "eval.line_")
+    model.train()
+    pred = model(data)
+    losses = model.loss(pred, {**pred, **data})
+    losses = losses[0] if isinstance(losses, tuple) else losses
+    losses["total"].mean().backward()
+    _la_digest(out, pred["log_assignment"], stride)
+    if lines:
+        _la_digest(out, pred["line_log_assignment"], 7, "train.line_")
+    out.update(_np({k: pred[k] for k in mkeys}, "train."))
+    out.update(_np({k: v for k, v in losses.items() if torch.is_tensor(v)}, "loss."))
+    _grad_digest(out, [(k, p.grad) for k, p in model.named_parameters() if p.grad is not None])
+    post = model.state_dict()           # BatchNorm buffers after the step (incl. the second update under the reference's checkpointing)
+    for k in post:
+        if "running_" in k:
+            out["post." + k] = post[k].numpy()
+    out["data_checksum"] = _data_checksum(data)
+    out["meta"] = np.array([lc.HELD_OUT[0], stride])
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+    sharp = float((pred["log_assignment"].detach()[:, :-1, :-1].max(2).values).exp().mean())
+    print(name, "eval loss", float(le["total"].mean()), "train-mode loss", float(losses["total"].mean()), "bin_score",
+          float(state["bin_score"]), "mean row-max probability", round(sharp, 3), "file MB",
+          round(os.path.getsize(os.path.join(GOLD, name + ".npz")) / 1e6, 2))
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     only = set(sys.argv[1:])
@@ -739,6 +803,9 @@ def main():
                                                              sharp=(0.01, 16.0, 0.03, 0.125)),
             "gluestick_sharp": lambda: gen_gluestick_config("gluestick_sharp", 2, 2048, 512, seed=157,
                                                              sharp=(0.01, 16.0, 0.03, 0.125)),
+            "superglue_trained_ref": lambda: gen_trained_state("superglue_trained_ref", "superglue", "tools/probe/build/ref_sg_t3.pt"),
+            "superglue_trained_hip": lambda: gen_trained_state("superglue_trained_hip", "superglue", "gpurun_out/learn/sg_hip_fp32.pt"),
+            "gluestick_trained_hip": lambda: gen_trained_state("gluestick_trained_hip", "gluestick", "gpurun_out/learn/gs_hip_fp32.pt"),
             "gluestick_lineattn": lambda: gen_gluestick("gluestick_lineattn", batch=2, n_kpts=36, n_lines=14,
                                                         gnn=["self", "cross"] * 2, inter=[0], seed=43, line_attention=True),
         }

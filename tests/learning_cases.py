@@ -1,5 +1,6 @@
 """Shared by tests/test_gpu_zz_learning.py (HIP modules on the GPU) and tools/probe/ref_learning_curve.py (the unmodified
 reference modules on the CPU): model configuration, seeded initial parameters and seeded batches of the learning-curve runs."""
+import numpy as np
 import torch
 
 STEPS, HELD_OUT = 300, (9001, 9002, 9003)
@@ -34,3 +35,15 @@ def batch(kind, seed):
         d["view0"]["image"] = torch.zeros(8, 1, 8, 8)
         d["view1"]["image"] = torch.zeros(8, 1, 8, 8)
     return d
+
+
+def trained_state_from_delta(init, z):
+    """The state a `*_trained` golden is taken at: initial state + the stored bf16 drift (exactly reproducible on both sides)."""
+    state = {}
+    for k, v in init.items():
+        if v.is_floating_point():
+            d = torch.from_numpy(z["delta." + k].astype(np.int16)).view(torch.bfloat16).reshape(v.shape)
+            state[k] = v + d.float()
+        else:
+            state[k] = torch.from_numpy(z["state." + k]).reshape(v.shape).to(v.dtype)
+    return state

@@ -18,14 +18,30 @@ pytestmark = pytest.mark.gpu
 REF = {
     "lightglue": {"trace": [5.812, 5.398, 4.639, 4.127, 3.868, 3.742], "before": [6.4633, 0.0, 0.0],
                   "after": [1.9514, 0.7943, 0.4959]},
-    # SuperGlue (4 GNN layers, 20 Sinkhorn iterations, lr 2e-4): the training curve is compared; the held-out numbers AFTER
-    # training are printed, not asserted -- they are taken in eval mode, i.e. through BatchNorm running statistics that lag
-    # 300 steps of moving activations: the reference's own eval loss (3.38) sits far from its training loss (1.06), and
-    # percent-level differences between two runs' parameters move it by factors (profiles/r05e_learning_curve_reference_cpu.txt).
-    # What CAN be pinned about those statistics is pinned exactly: the buffers after one step against the reference's
-    # (tests/test_gpu_matcher_options.py, incl. the double update under the reference's activation checkpointing).
+    # SuperGlue (4 GNN layers, 20 Sinkhorn iterations, lr 2e-4).  What is asserted after training, and why (round 6,
+    # profiles/r06_learning_anchor.txt -- the same run in SIX arithmetics, every end state evaluated by the reference module):
+    #   * the EVAL-mode held-out loss is NOT a reproducible quantity of this model family after 300 steps: the unmodified
+    #     reference lands at 2.5 ... 5.1 in fp32 depending on the thread count, at 7.78 in fp64 (two thread counts, and
+    #     bit-for-bit the same state from stock torch fp64 on the MI355X), stock PyTorch-ROCm fp32 on the MI355X at 21.3,
+    #     the HIP path at 17.3 (fp32) / 10.8 (bf16) -- printed, never asserted;
+    #   * in TRAINING mode (per-image batch statistics: what the loss is trained under) all six agree: 1.071 ... 1.080 held-out,
+    #     precision 0.746 ... 0.763, recall 0.653 ... 0.722 -- asserted against the fp64 anchor's values;
+    #   * the distance of the trained weights to the reference's own fp32 run (the `superglue_trained_ref` fixture), in units of
+    #     that run's drift from the initial state: HIP fp32 0.195, stock ROCm fp32 0.197, reference fp32 vs fp64 0.157, HIP
+    #     bf16 0.288 -- asserted.
     "superglue": {"trace": [1.735, 1.431, 1.292, 1.15, 1.15, 1.058], "before": [3.4872, 0.0, 0.0],
-                  "after": [3.3805, 0.4306, 0.0158], "assert_after": False},
+                  "after": [3.3805, 0.4306, 0.0158], "assert_after": False,
+                  "train_mode_after": [1.074, 0.76, 0.708], "trained_ref": "superglue_trained_ref",
+                  "max_distance": {False: 0.25, True: 0.36}},
+    # GlueStick (4 GNN layers + line layers, 192 keypoints + 32 lines, lr 2e-4): the optimisation is chaotic from step ~150 on
+    # -- the reference's own runs: 16 threads 6.593 6.296 5.523 4.617 3.516 3.075, 3 threads 6.593 6.298 5.523 3.951 4.391 4.617,
+    # fp64 6.592 6.299 5.645 4.281 3.633 3.996, any two end states ~0.8 of the drift apart (HIP fp32 vs fp64: 0.75) -- so only the
+    # first 100 steps are compared point by point; afterwards: it must have learnt what the reference's runs learn (held-out,
+    # reference runs: eval loss 3.04 / 3.99 / 3.95, precision 0.32 / 0.40 / 0.40, line precision 0.62 / 0.54 / 0.62; HIP fp32
+    # 3.12 / 0.37 / 0.59, bf16 7.55 / 0.39 / 0.49; training-mode held-out loss 3.34 (fp64), 3.46, HIP 2.83).
+    "gluestick": {"trace": [6.593, 6.296, 5.523, 4.617, 3.516, 3.075], "before": [8.3008, 0.0, 0.0, 0.0, 0.0],
+                  "after": [3.0362, 0.3219, 0.102, 0.6212, 0.4261], "assert_after": False, "chaotic_after": 2,
+                  "learnt": {"train_mode_loss_below": 4.6, "precision_above": 0.25, "line_precision_above": 0.35}},
 }
 
 
@@ -57,9 +73,11 @@ def _batch(kind, seed):
     return to_device(lc.batch(kind, seed), "cuda")
 
 
-def _evaluate(kind, model, bf16):
+def _evaluate(kind, model, bf16, mode="eval"):
+    """Held-out loss / precision / recall [/ line precision / line recall]; mode "train": through per-image batch statistics
+    (the BatchNorm models' training arithmetic; no_grad, but the running statistics move -- call it last)."""
     from glue_factory_amd.metrics import matcher_metrics
-    model.eval()
+    model.train() if mode == "train" else model.eval()
     rows = []
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16):
         for s in lc.HELD_OUT:
@@ -75,9 +93,21 @@ def _evaluate(kind, model, bf16):
     return [sum(v) / len(v) for v in zip(*rows)]
 
 
-# (SuperGlue in the benchmarked precision only: its fp32 run follows the reference the same way -- 1.735 1.431 1.29 1.151 1.138 1.034,
-# profiles/r05e_learning_curve_reference_cpu.txt -- and costs another minute of the suite)
-@pytest.mark.parametrize("kind,bf16", [("lightglue", True), ("lightglue", False), ("superglue", True)])
+def _distance_to(model, kind, fixture):
+    """|theta - theta_ref| / |theta_ref - theta_0| over the weight matrices, theta_ref = the reference's own trained state
+    (a `*_trained_ref` fixture), theta_0 the shared initial state."""
+    from conftest import load_golden
+    init = lc.initial_params(kind)
+    ref = lc.trained_state_from_delta(init, load_golden(fixture))
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    keys = [k for k in init if k.endswith(".weight") and init[k].ndim >= 2]
+    num = sum(float((sd[k] - ref[k]).double().pow(2).sum()) for k in keys) ** 0.5
+    den = sum(float((ref[k] - init[k]).double().pow(2).sum()) for k in keys) ** 0.5
+    return num / den
+
+
+@pytest.mark.parametrize("kind,bf16", [("lightglue", True), ("lightglue", False), ("superglue", True), ("superglue", False),
+                                       ("gluestick", True), ("gluestick", False)])
 def test_matcher_learns_like_the_reference_on_fresh_synthetic_pairs(kind, bf16):
     from glue_factory_amd.optim import FusedAdam
     from glue_factory_amd.train_step import TrainStep
@@ -102,8 +132,24 @@ def test_matcher_learns_like_the_reference_on_fresh_synthetic_pairs(kind, bf16):
     # differences into a few hundredths; the margins are several times that)
     scale = max(1.0, ref["trace"][0])
     assert abs(trace[0] - ref["trace"][0]) < 0.005 * scale and abs(trace[1] - ref["trace"][1]) < 0.01 * scale
-    assert all(abs(a - b) < 0.06 * scale for a, b in zip(trace, ref["trace"]))
+    n_cmp = ref.get("chaotic_after", len(trace))
+    assert all(abs(a - b) < 0.06 * scale for a, b in zip(trace[:n_cmp], ref["trace"][:n_cmp]))
+    assert all(t == t and t < ref["trace"][0] + 0.5 for t in trace) and trace[-1] < 0.8 * trace[0]
     if ref.get("assert_after", True):
         assert after[0] < ref["after"][0] + 0.15 * scale
         assert all(a > r - 0.2 for a, r in zip(after[1:], ref["after"][1:]))
+    if "trained_ref" in ref:
+        dist = _distance_to(model, kind, ref["trained_ref"])
+        print(f"{tag} distance of the trained weights to the reference's own trained state, in units of its drift: {dist:.3f}")
+        assert dist < ref["max_distance"][bf16], dist
+    if "train_mode_after" in ref or "learnt" in ref:
+        tm = _evaluate(kind, model, bf16, mode="train")
+        print(f"{tag} held-out in TRAINING mode (per-image batch statistics): {[round(v, 3) for v in tm]}   "
+              f"(fp64 anchor: {ref.get('train_mode_after')})")
+        if "train_mode_after" in ref:
+            r = ref["train_mode_after"]
+            assert abs(tm[0] - r[0]) < 0.04 * max(1.0, r[0]) and tm[1] > r[1] - 0.06 and tm[2] > r[2] - 0.09, tm
+        if "learnt" in ref:
+            b = ref["learnt"]
+            assert tm[0] < b["train_mode_loss_below"] and after[1] > b["precision_above"] and after[3] > b["line_precision_above"], (tm, after)
     step.close()

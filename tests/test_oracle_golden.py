@@ -265,3 +265,42 @@ def test_matcher_option_cases_regenerate_and_load_into_the_hip_modules():
             for k, v in ref.items():
                 assert tuple(pred[k].shape) == v.shape and pred[k].dtype == torch.from_numpy(v).dtype, k
                 np.testing.assert_array_equal(pred[k].numpy(), v)
+
+
+# ----------------------------------------------------------------------------- trained states (round 6)
+@pytest.mark.parametrize("name,kind", [("superglue_trained_ref", "superglue"), ("superglue_trained_hip", "superglue"),
+                                       ("gluestick_trained_hip", "gluestick")])
+def test_oracles_at_trained_states_match_reference(name, kind):
+    """The oracles held to the reference at the states 300-step runs of tests/learning_cases.py end in (the reference's own
+    run and the HIP path's runs; oracle/gen_golden.py::gen_trained_state) -- eval forward through the running statistics and
+    the train step: the GPU tests lean on the oracles at trained states too (tests/test_gpu_trained_state.py reads the same
+    fixtures directly)."""
+    import learning_cases as lc
+    from config_golden import check_la_digest, grad_digest_errors, significant_grads
+    z = load_golden(name)
+    state = lc.trained_state_from_delta(lc.initial_params(kind), z)
+    data = lc.batch(kind, int(z["meta"][0]))
+    data = dict(data, image_size0=data["view0"]["image_size"], image_size1=data["view1"]["image_size"])
+    stride = int(z["meta"][1])
+    names = lc.conf(kind)["GNN_layers"]
+    if kind == "superglue":
+        from oracle import superglue_oracle as mo
+        iters = lc.conf(kind)["num_sinkhorn_iterations"]
+        with torch.no_grad():
+            pe = mo.forward(state, data, names, iters, training=False)
+        pred, losses, grads = mo.train_step_grads(state, data, names, iters)
+    else:
+        from oracle import gluestick_oracle as mo
+        with torch.no_grad():
+            pe = mo.forward(state, data, names, training=False)
+        pred, losses, grads = mo.train_step_grads(state, data, names, inter=None)
+    check_la_digest(z, pe["log_assignment"], stride, prefix="eval.", tol=1e-4)
+    check_la_digest(z, pred["log_assignment"], stride, tol=1e-4)
+    if kind == "gluestick":
+        check_la_digest(z, pe["line_log_assignment"], 7, prefix="eval.line_", tol=1e-4)
+        check_la_digest(z, pred["line_log_assignment"], 7, prefix="train.line_", tol=1e-4)
+    for k in [k[5:] for k in z if k.startswith("loss.")]:
+        np.testing.assert_allclose(losses[k].detach().numpy(), z["loss." + k], **TOL, err_msg=k)
+    errs = significant_grads(grad_digest_errors(z, {k: g for k, g in grads.items() if "gradnorm." + k in z}))
+    worst = max((e[0], k) for k, e in errs.items())
+    assert worst[0] <= 2e-3, worst
