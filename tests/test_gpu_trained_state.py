@@ -86,10 +86,12 @@ def test_trained_state_fp32_train_step_vs_reference(name, kind):
     print(f"{name}: BatchNorm buffers after the step, worst relative difference {worst_b:.2e}")
 
 
-# bf16 bounds: 1.5 x the values measured on MI355X in round 6 (printed by the test; the random-init bounds of
-# tests/test_gpu_configs45.py for comparison: SuperGlue 0.48 / 0.21 / 0.042, GlueStick 0.62 / 0.33 / 0.083)
-BF16 = {"superglue_trained_ref": (1.0, 0.5, 0.15, 0.1), "superglue_trained_hip": (1.0, 0.5, 0.15, 0.1),
-        "gluestick_trained_hip": (1.0, 0.5, 0.15, 0.1)}
+# bf16 bounds: 1.5 x the values measured on MI355X in round 6 -- log_assignment max / p99 / mean |d|, total loss (relative), worst
+# per-tensor gradient-sample error: superglue_trained_ref 0.133 / 0.049 / 0.012, 9.5e-5, 5.1 %; superglue_trained_hip 0.115 / 0.051 /
+# 0.013, 1.3e-4, 7.7 %; gluestick_trained_hip 0.064 / 0.033 / 0.0087, 4.6e-4, 4.3 % -- i.e. SMALLER than at random weights (the
+# random-init bounds of tests/test_gpu_configs45.py: SuperGlue 0.48 / 0.21 / 0.042, 14.5 %; GlueStick 0.62 / 0.33 / 0.083, 30 %)
+BF16 = {"superglue_trained_ref": (0.20, 0.076, 0.019, 5e-4, 0.12), "superglue_trained_hip": (0.20, 0.076, 0.019, 5e-4, 0.12),
+        "gluestick_trained_hip": (0.10, 0.05, 0.013, 1.5e-3, 0.07)}
 
 
 @pytest.mark.parametrize("name,kind", CASES)
@@ -108,4 +110,4 @@ def test_trained_state_bf16_train_step_bounds(name, kind):
     print(f"{name} bf16: log_assignment max|d| {mx:.4f} p99 {p99:.4f} mean {mean:.4f}; total loss rel {rel:.2e}; "
           f"gradient-sample error median {rels[len(rels) // 2]:.4f} worst {max((e[1], k) for k, e in errs.items())}")
     b = BF16[name]
-    assert mx <= b[0] and p99 <= b[1] and mean <= b[2] and rel <= b[3], (mx, p99, mean, rel)
+    assert mx <= b[0] and p99 <= b[1] and mean <= b[2] and rel <= b[3] and max(rels) <= b[4], (mx, p99, mean, rel, max(rels))
