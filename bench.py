@@ -756,6 +756,10 @@ def data_parallel_report(dist, rank, world, stepper):
     dist.all_gather(seen, ids)
     out = {"ranks_seen": [int(t[0]) for t in seen], "devices": [int(t[1]) for t in seen], "backend": dist.get_backend(),
            "reducer": "buckets" if stepper.buckets is not None else "ddp"}
+    if getattr(stepper, "last_collectives", None):
+        # per step and rank: gradient-bucket all-reduces + SyncBatchNorm exchanges (one per BatchNorm call-site and direction for
+        # BOTH views: ops._BatchNormActSetsSync); LightGlue has no BatchNorm
+        out["collectives_per_step"] = stepper.last_collectives
     if stepper.buckets is not None:
         out["buckets"] = len(stepper.buckets.buckets)
         out["bucket_mbytes"] = [round((hi - lo) * 4 / 2 ** 20, 2) for lo, hi, _ in stepper.buckets.buckets]

@@ -253,9 +253,110 @@ __global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const float* __res
     m2[c] = s1 * inv_n;
 }
 
+
+// ---- SyncBatchNorm over several statistics sets with ONE exchange (superglue.py:70-79 called once per image, train.py:338):
+// the block sums of all `sets` calls are packed into one buffer -- [sets][2][C] sums, then the `sets` row counts -- which the
+// host all-reduces across ranks ONCE; the finalize kernels below read the reduced sums and the reduced counts from it.
+__global__ __launch_bounds__(256) void bn_pack_sums_kernel(const float* __restrict__ part, int sets, int nblk, int C, float n_local,
+                                                           float* __restrict__ packed, float* __restrict__ local) {
+    const int h = blockIdx.y;
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+    float s0, s1;
+    bn_block_sums(part + (size_t)h * nblk * 2 * C, nblk, C, c, s0, s1);
+    if (threadIdx.x == 0 && blockIdx.x == 0) packed[(size_t)sets * 2 * C + h] = n_local;
+    if (threadIdx.x >= 32 || c >= C) return;
+    packed[(size_t)(2 * h) * C + c] = s0;
+    packed[(size_t)(2 * h + 1) * C + c] = s1;
+    if (local) {
+        local[(size_t)(2 * h) * C + c] = s0;
+        local[(size_t)(2 * h + 1) * C + c] = s1;
+    }
+}
+// mean / biased var / rstd of every set from the (reduced) packed sums and counts; the running statistics take the sets'
+// updates one after the other, as `sets` consecutive module calls would apply them
+__global__ __launch_bounds__(256) void bn_finalize_sets_fwd_kernel(const float* __restrict__ packed, int sets, int C, float eps,
+                                                                   float momentum, float* __restrict__ mvr,
+                                                                   float* __restrict__ run_mean, float* __restrict__ run_var) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float rm = run_mean ? run_mean[c] : 0.f, rv = run_var ? run_var[c] : 0.f;
+    for (int h = 0; h < sets; ++h) {
+        const float n = packed[(size_t)sets * 2 * C + h];
+        const float m = packed[(size_t)(2 * h) * C + c] / n;
+        const float v = fmaxf(packed[(size_t)(2 * h + 1) * C + c] / n - m * m, 0.f);
+        mvr[(size_t)(3 * h) * C + c] = m;
+        mvr[(size_t)(3 * h + 1) * C + c] = v;
+        mvr[(size_t)(3 * h + 2) * C + c] = rsqrtf(v + eps);
+        rm = rm * (1.f - momentum) + m * momentum;
+        rv = rv * (1.f - momentum) + v * (n / fmaxf(n - 1.f, 1.f)) * momentum;
+    }
+    if (run_mean) {
+        run_mean[c] = rm;
+        run_var[c] = rv;
+    }
+}
+// m1 = sum dz / n, m2 = sum dz xhat / n of every set from the reduced packed sums and the forward's (global) counts
+__global__ __launch_bounds__(256) void bn_finalize_sets_bwd_kernel(const float* __restrict__ packed, const float* __restrict__ counts,
+                                                                   int sets, int C, float* __restrict__ m12) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    for (int h = 0; h < sets; ++h) {
+        const float inv_n = 1.f / counts[h];
+        m12[(size_t)(2 * h) * C + c] = packed[(size_t)(2 * h) * C + c] * inv_n;
+        m12[(size_t)(2 * h + 1) * C + c] = packed[(size_t)(2 * h + 1) * C + c] * inv_n;
+    }
+}
+// bn_replay_running_kernel with the row count of every set on the device (the global count of a SyncBatchNorm call)
+__global__ __launch_bounds__(256) void bn_replay_running_n_kernel(const float* __restrict__ mvr, const float* __restrict__ counts, int sets,
+                                                                  int C, float momentum, float* __restrict__ run_mean,
+                                                                  float* __restrict__ run_var) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float rm = run_mean[c], rv = run_var[c];
+    for (int h = 0; h < sets; ++h) {
+        const float n = counts[h];
+        rm = rm * (1.f - momentum) + mvr[(size_t)(3 * h) * C + c] * momentum;
+        rv = rv * (1.f - momentum) + mvr[(size_t)(3 * h + 1) * C + c] * (n / fmaxf(n - 1.f, 1.f)) * momentum;
+    }
+    run_mean[c] = rm;
+    run_var[c] = rv;
+}
+
 }  // namespace
 
 extern "C" int gf_bn_nblk(int M) { return bn_blocks(M); }
+
+extern "C" int gf_bn_pack_sums(const float* part, int sets, int nblk, int C, float n_local, float* packed, float* local_copy,
+                               void* stream) {
+    if (sets <= 0 || sets > 65535 || nblk <= 0 || C <= 0 || n_local < 0.f || part == nullptr || packed == nullptr) return GF_ERR_SHAPE;
+    bn_pack_sums_kernel<<<dim3((C + 31) / 32, sets), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
+        part, sets, nblk, C, n_local, packed, local_copy);
+    return (int)hipGetLastError();
+}
+
+extern "C" int gf_bn_finalize_sets_fwd(const float* packed, int sets, int C, float eps, float momentum, float* mvr,
+                                       float* run_mean, float* run_var, void* stream) {
+    if (sets <= 0 || C <= 0 || packed == nullptr || mvr == nullptr) return GF_ERR_SHAPE;
+    if ((run_mean == nullptr) != (run_var == nullptr)) return GF_ERR_SHAPE;
+    bn_finalize_sets_fwd_kernel<<<dim3((C + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
+        packed, sets, C, eps, momentum, mvr, run_mean, run_var);
+    return (int)hipGetLastError();
+}
+
+extern "C" int gf_bn_finalize_sets_bwd(const float* packed, const float* counts, int sets, int C, float* m12, void* stream) {
+    if (sets <= 0 || C <= 0 || packed == nullptr || counts == nullptr || m12 == nullptr) return GF_ERR_SHAPE;
+    bn_finalize_sets_bwd_kernel<<<dim3((C + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
+        packed, counts, sets, C, m12);
+    return (int)hipGetLastError();
+}
+
+extern "C" int gf_bn_replay_running_n(const float* mvr, const float* counts, int sets, int C, float momentum, float* run_mean,
+                                      float* run_var, void* stream) {
+    if (sets <= 0 || C <= 0 || mvr == nullptr || counts == nullptr || run_mean == nullptr || run_var == nullptr) return GF_ERR_SHAPE;
+    bn_replay_running_n_kernel<<<dim3((C + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
+        mvr, counts, sets, C, momentum, run_mean, run_var);
+    return (int)hipGetLastError();
+}
 
 extern "C" int gf_bn_stats(const void* x, float* part, int M, int C, int dtype, void* stream) {
     if (M <= 0 || C <= 0) return GF_ERR_SHAPE;

@@ -1687,6 +1687,84 @@ class _BatchNormActSets(torch.autograd.Function):
         return dx, dgamma.to(gdt), dbeta.to(bdt), None, None, None, None, None, None
 
 
+COLLECTIVES = {"syncbn": 0}       # collectives issued by the ops of this module (bench.py / tests count them per step)
+
+
+def _all_reduce_sum(t):
+    import torch.distributed as dist
+    COLLECTIVES["syncbn"] += 1
+    dist.all_reduce(t)
+
+
+class _BatchNormActSetsSync(torch.autograd.Function):
+    """_BatchNormActSets under SyncBatchNorm (train.py:338): the H statistics sets of a call -- both images through the SAME
+    BatchNorm module (superglue.py:70-79 via :276-283) -- share ONE all-reduce per direction instead of one per set: the block
+    sums of all sets are packed with their row counts (gf_bn_pack_sums), reduced across ranks, and the fused finalize kernels
+    read the reduced buffer (mean / var / rstd of every set + the running statistics, set after set; m1 / m2 in the backward).
+    Row counts may differ between ranks (they are reduced with the sums).  dgamma / dbeta stay LOCAL sums: the gradient reducer
+    averages parameter gradients across ranks."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, relu, run_mean, run_var, momentum, replay=None):
+        _chk(x)
+        H, M, C = x.shape
+        L = _lib.load()
+        g32, b32 = gamma.float().contiguous(), beta.float().contiguous()
+        nblk = L.gf_bn_nblk(M)
+        part = torch.empty((H, nblk, 2, C), dtype=torch.float32, device=x.device)
+        packed = torch.empty(H * 2 * C + H, dtype=torch.float32, device=x.device)
+        mvr = torch.empty((H, 3, C), dtype=torch.float32, device=x.device)
+        y = torch.empty_like(x)
+        st, dt = _stream(), _dt(x)
+        for h in range(H):
+            _lib.check(L.gf_bn_stats(_p(x[h]), _p(part[h]), M, C, dt, st), "gf_bn_stats")
+        _lib.check(L.gf_bn_pack_sums(_p(part), H, nblk, C, float(M), _p(packed), None, st), "gf_bn_pack_sums")
+        _all_reduce_sum(packed)                                   # ONE exchange for the H sets
+        _lib.check(L.gf_bn_finalize_sets_fwd(_p(packed), H, C, float(eps), float(momentum), _p(mvr), _p(run_mean), _p(run_var),
+                                             st), "gf_bn_finalize_sets_fwd")
+        counts = packed[H * 2 * C:]                               # the reduced row count of every set
+        for h in range(H):
+            _lib.check(L.gf_bn_act_fwd(_p(x[h]), _p(mvr[h, 0]), _p(mvr[h, 2]), _p(g32), _p(b32), _p(y[h]), M, C,
+                                       int(relu), dt, st), "gf_bn_act_fwd")
+        ctx.replay = None if replay is None else (run_mean, run_var, replay, float(momentum))
+        ctx.save_for_backward(x, mvr, g32, b32, counts)
+        ctx.cfg = (relu, gamma.dtype, beta.dtype)
+        ctx.mark_non_differentiable(mvr, counts)
+        return y, mvr, counts
+
+    @staticmethod
+    def backward(ctx, dy, _gmvr, _gc):
+        x, mvr, g32, b32, counts = ctx.saved_tensors
+        relu, gdt, bdt = ctx.cfg
+        H, M, C = x.shape
+        if not dy.is_contiguous():
+            dy = dy.contiguous()
+        L = _lib.load()
+        nblk = L.gf_bn_nblk(M)
+        part = torch.empty((H, nblk, 2, C), dtype=torch.float32, device=x.device)
+        packed = torch.empty(H * 2 * C + H, dtype=torch.float32, device=x.device)
+        local = torch.empty((H, 2, C), dtype=torch.float32, device=x.device)
+        m12 = torch.empty((H, 2, C), dtype=torch.float32, device=x.device)
+        dx = torch.empty_like(x)
+        st, dt = _stream(), _dt(x)
+        for h in range(H):
+            _lib.check(L.gf_bn_bwd_stats(_p(x[h]), _p(dy[h]), _p(mvr[h, 0]), _p(mvr[h, 2]), _p(g32), _p(b32), _p(part[h]), M, C,
+                                         int(relu), dt, st), "gf_bn_bwd_stats")
+        _lib.check(L.gf_bn_pack_sums(_p(part), H, nblk, C, 0.0, _p(packed), _p(local), st), "gf_bn_pack_sums")
+        _all_reduce_sum(packed)
+        _lib.check(L.gf_bn_finalize_sets_bwd(_p(packed), _p(counts), H, C, _p(m12), st), "gf_bn_finalize_sets_bwd")
+        for h in range(H):
+            _lib.check(L.gf_bn_bwd_dx(_p(x[h]), _p(dy[h]), _p(mvr[h, 0]), _p(mvr[h, 2]), _p(g32), _p(b32), _p(m12[h, 0]),
+                                      _p(m12[h, 1]), _p(dx[h]), M, C, int(relu), dt, st), "gf_bn_bwd_dx")
+        dbeta, dgamma = (local[0, 0], local[0, 1]) if H == 1 else (local[:, 0].sum(0), local[:, 1].sum(0))
+        if ctx.replay is not None:
+            run_mean, run_var, nbt, momentum = ctx.replay
+            _lib.check(L.gf_bn_replay_running_n(_p(mvr), _p(counts), H, C, momentum, _p(run_mean), _p(run_var), st),
+                       "gf_bn_replay_running_n")
+            nbt.add_(H)
+        return dx, dgamma.to(gdt), dbeta.to(bdt), None, None, None, None, None, None
+
+
 class _ReplayRunningStats(torch.autograd.Function):
     """Identity on y whose BACKWARD gives BatchNorm modules' running statistics one more update from the forward's batch
     statistics, group after group and set after set (the generic form of _BatchNormActSets' `replay`: single-set /
@@ -1728,17 +1806,25 @@ def batch_norm_act_sets(x, bn, relu=True, replay=False, stats_out=None):
     sync = (isinstance(bn, torch.nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized()
             and dist.get_world_size() > 1)
     want = (replay or stats_out is not None) and bn.training and bn.track_running_stats and torch.is_grad_enabled() and x.requires_grad
-    if (bn.training and bn.track_running_stats and not sync and bn.momentum is not None
+    if (bn.training and bn.track_running_stats and bn.momentum is not None
             and bn.running_mean.dtype == torch.float32 and bn.running_mean.is_contiguous()
             and bn.running_var.is_contiguous()):
         in_node = want and stats_out is None
-        y, mvr = _BatchNormActSets.apply(x, bn.weight, bn.bias, bn.eps, relu, bn.running_mean, bn.running_var,
-                                         float(bn.momentum), bn.num_batches_tracked if in_node else None)
+        if sync:        # one all-reduce per direction for the H sets, fused finalize kernels kept
+            y, mvr, counts = _BatchNormActSetsSync.apply(x, bn.weight, bn.bias, bn.eps, relu, bn.running_mean, bn.running_var,
+                                                         float(bn.momentum), bn.num_batches_tracked if in_node else None)
+        else:
+            y, mvr = _BatchNormActSets.apply(x, bn.weight, bn.bias, bn.eps, relu, bn.running_mean, bn.running_var,
+                                             float(bn.momentum), bn.num_batches_tracked if in_node else None)
+            counts = None
         with torch.no_grad():
             bn.num_batches_tracked += x.shape[0]
         if want and stats_out is not None:
-            unb = x.shape[1] / max(x.shape[1] - 1.0, 1.0)
-            stats_out.append((bn, [(mvr[h, 0], mvr[h, 1] * unb) for h in range(x.shape[0])]))
+            if counts is None:
+                unb = [x.shape[1] / max(x.shape[1] - 1.0, 1.0)] * x.shape[0]
+            else:
+                unb = [counts[h] / (counts[h] - 1.0).clamp(min=1.0) for h in range(x.shape[0])]
+            stats_out.append((bn, [(mvr[h, 0], mvr[h, 1] * unb[h]) for h in range(x.shape[0])]))
         return y
     stats = [] if want else None
     y = torch.stack([batch_norm_act(x[h], bn, relu, stats_out=stats) for h in range(x.shape[0])])

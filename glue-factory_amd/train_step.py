@@ -206,6 +206,7 @@ class TrainStep:
         self.check_grads = check_grads
         self._skipped_host = 0
         self._skipped_dev = None
+        self.last_collectives = None
         # hipGraph replay of the whole step (forward, loss, backward, optimiser): ~1200 launches per LightGlue step
         # leave a few per cent of the GPU idle between kernels when they are issued one by one.  Needs: single
         # process (no DDP hooks inside a capture), a fused + capturable optimiser, no host synchronisation in the
@@ -282,6 +283,8 @@ class TrainStep:
     def _step(self, data):
         self.model.train()
         self.optimizer.zero_grad(set_to_none=True)
+        from . import ops
+        bn0 = ops.COLLECTIVES["syncbn"]
         with torch.autocast(self.device_type, dtype=self.amp_dtype or torch.bfloat16,
                             enabled=self.amp_dtype is not None):
             pred = self.fwd_model(data)
@@ -305,10 +308,14 @@ class TrainStep:
             (loss / dist.get_world_size()).backward()
             self.buckets.finish()
             bad = (self.buckets.extra[0] > 0).float()
+            n_grad = len(self.buckets.buckets)
         else:
             if self.distributed:
                 dist.all_reduce(bad, op=dist.ReduceOp.MAX)
             loss.backward()
+            n_grad = None                      # (DistributedDataParallel issues its own bucket reductions + the flag's)
+        # collectives this step issued (eager call or capture): gradient buckets, SyncBatchNorm exchanges (ops.COLLECTIVES)
+        self.last_collectives = {"gradient_buckets": n_grad, "syncbn": ops.COLLECTIVES["syncbn"] - bn0}
         if self.clip_grad is not None:
             gn = torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.clip_grad)   # no host sync
             bad = torch.maximum(bad, (~torch.isfinite(gn)).float().reshape(()).to(bad.device))

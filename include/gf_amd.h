@@ -363,6 +363,21 @@ int gf_bn_finalize_fwd(const float* part, int nblk, int C, float n, float eps, f
                        float* mean, float* var, float* rstd, float* run_mean, float* run_var, void* stream);
 int gf_bn_finalize_bwd(const float* part, int nblk, int C, float n, float* dbeta, float* dgamma,
                        float* m1, float* m2, void* stream);
+/* SyncBatchNorm over several statistics sets with ONE exchange per direction (ABI 16; train.py:338 converts every BatchNorm1d of
+ * superglue.py:70-79 / gluestick.py:465-474, which the reference calls once per image): gf_bn_pack_sums reduces the block
+ * sums of `sets` gf_bn_stats / gf_bn_bwd_stats outputs (part = [sets][nblk][2][C]) into packed = [sets][2][C] sums followed by
+ * the `sets` row counts (n_local each) -- the ONE buffer the host all-reduces across ranks -- and, when local_copy is given, keeps
+ * the un-reduced sums ([sets][2][C]: the local dbeta / dgamma that DDP averages).  gf_bn_finalize_sets_fwd: mean / biased var /
+ * rstd of every set (mvr = [sets][3][C]) from the reduced buffer, the running statistics updated set after set with the
+ * reduced counts.  gf_bn_finalize_sets_bwd: m12 = [sets][2][C] = reduced sums / counts (counts: the forward's reduced counts).
+ * gf_bn_replay_running_n: gf_bn_replay_running with per-set device-side counts. */
+int gf_bn_pack_sums(const float* part, int sets, int nblk, int C, float n_local, float* packed, float* local_copy,
+                    void* stream);
+int gf_bn_finalize_sets_fwd(const float* packed, int sets, int C, float eps, float momentum, float* mvr,
+                            float* run_mean, float* run_var, void* stream);
+int gf_bn_finalize_sets_bwd(const float* packed, const float* counts, int sets, int C, float* m12, void* stream);
+int gf_bn_replay_running_n(const float* mvr, const float* counts, int sets, int C, float momentum, float* run_mean,
+                           float* run_var, void* stream);
 /* gf_bn_replay_running (ABI 15): the running statistics take the batch statistics of `sets` forward calls a SECOND time,
  * set after set (mvr = [sets][3][C] rows mean / biased var / rstd as gf_bn_finalize_fwd wrote them, n rows per set).  The
  * reference wraps its GNN layers in torch.utils.checkpoint while training (gluefactory_nonfree/superglue.py:160-169 always;

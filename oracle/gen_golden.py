@@ -803,7 +803,7 @@ def main():
                                                              sharp=(0.01, 16.0, 0.03, 0.125)),
             "gluestick_sharp": lambda: gen_gluestick_config("gluestick_sharp", 2, 2048, 512, seed=157,
                                                              sharp=(0.01, 16.0, 0.03, 0.125)),
-            "superglue_trained_ref": lambda: gen_trained_state("superglue_trained_ref", "superglue", "tools/probe/build/ref_sg_t3.pt"),
+            "superglue_trained_ref": lambda: gen_trained_state("superglue_trained_ref", "superglue", "gpurun_out/learn_ref/ref_sg_t3.pt"),
             "superglue_trained_hip": lambda: gen_trained_state("superglue_trained_hip", "superglue", "gpurun_out/learn/sg_hip_fp32.pt"),
             "gluestick_trained_hip": lambda: gen_trained_state("gluestick_trained_hip", "gluestick", "gpurun_out/learn/gs_hip_fp32.pt"),
             "gluestick_lineattn": lambda: gen_gluestick("gluestick_lineattn", batch=2, n_kpts=36, n_lines=14,

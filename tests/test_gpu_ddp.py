@@ -90,9 +90,79 @@ def _sg_worker(rank, world, lock, out):
     step(shard_batch(data, rank, world))
     torch.cuda.synchronize()
     if rank == 0:
-        torch.save({k: v.detach().cpu() for k, v in step.model.state_dict().items()}, out)
+        sd = {k: v.detach().cpu() for k, v in step.model.state_dict().items()}
+        sd["__collectives__"] = dict(step.last_collectives)
+        sd["__bn_modules__"] = sum(isinstance(m, torch.nn.SyncBatchNorm) for m in step.model.modules())
+        torch.save(sd, out)
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
+
+
+def _check_syncbn_run(got, model, data):
+    """`got`: rank 0's state after ONE data-parallel step of two ranks; against a single-process step on the whole batch --
+    parameters, BatchNorm running statistics (incl. the second update under the reference's activation checkpointing) and
+    num_batches_tracked -- plus the collective budget: ONE exchange per BatchNorm module and direction for both views."""
+    from glue_factory_amd.train_step import TrainStep
+    coll, n_bn = got.pop("__collectives__"), got.pop("__bn_modules__")
+    assert coll["syncbn"] == 2 * n_bn, (coll, n_bn)            # (the per-call form issued 2 sets x 2 directions per module)
+    assert coll["gradient_buckets"] is not None and coll["gradient_buckets"] <= 4
+    init = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    step = TrainStep(model, torch.optim.SGD(model.parameters(), lr=0.05), amp_dtype=None)
+    step(data)
+    checked = buffers = 0
+    for k, v in model.state_dict().items():
+        if not v.dtype.is_floating_point:
+            assert int(got[k]) == int(v), (k, int(got[k]), int(v))         # num_batches_tracked (2 sets, + 2 replayed)
+            continue
+        b, a = v.detach().cpu(), got[k]
+        sc = (b - init[k]).abs().max().item()
+        if sc < 1e-6:      # e.g. conv biases in front of a train-mode BatchNorm: the true gradient is exactly 0
+            continue
+        err = ((a - b) / sc).abs()
+        # the shards sum their fp32 partials in another order than the whole batch; isolated ReLU-boundary flips allowed
+        assert err.max() < 5e-2 and (err > 5e-3).float().mean() < 1e-2, (k, err.max().item())
+        checked += 1
+        buffers += int("running_" in k)
+    return checked, buffers
+
+
+def _gs_model_and_data():
+    from glue_factory_amd.matchers.gluestick import GlueStick
+    from glue_factory_amd.synthetic import make_point_line_pairs, to_device
+    torch.manual_seed(9)
+    model = GlueStick({"GNN_layers": ["self", "cross"], "checkpointed": True}).cuda().train()
+    data = to_device(make_point_line_pairs(B, 96, 16, dim=256, size=(640, 480), seed=10), "cuda")
+    return model, data
+
+
+def _gs_worker(rank, world, lock, out):
+    from glue_factory_amd.train_step import TrainStep, init_distributed, shard_batch
+    torch.cuda.set_device(0)
+    init_distributed("gloo", init_method="file://" + lock, rank=rank, world_size=world)
+    model, data = _gs_model_and_data()
+    step = TrainStep(model, torch.optim.SGD(model.parameters(), lr=0.05), amp_dtype=None, device_ids=[0])
+    step(shard_batch(data, rank, world))
+    torch.cuda.synchronize()
+    if rank == 0:
+        sd = {k: v.detach().cpu() for k, v in step.model.state_dict().items()}
+        sd["__collectives__"] = dict(step.last_collectives)
+        sd["__bn_modules__"] = sum(isinstance(m, torch.nn.SyncBatchNorm) for m in step.model.modules())
+        torch.save(sd, out)
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_gluestick_syncbn_equals_single_process():
+    """BASELINE configs[4]'s path (GlueStick, DDP + SyncBatchNorm, train.py:338) on two ranks, with `checkpointed` so that the
+    running statistics also take the REPLAYED update (gluestick.py:724-757) from the global counts: parameters, buffers and
+    num_batches_tracked equal the single-process step; collectives per step <= 2 x BatchNorm modules + gradient buckets."""
+    with tempfile.TemporaryDirectory() as d:
+        lock, out = os.path.join(d, "distributed_lock"), os.path.join(d, "out.pt")
+        mp.spawn(_gs_worker, args=(2, lock, out), nprocs=2, join=True)
+        got = torch.load(out)
+    model, data = _gs_model_and_data()
+    checked, buffers = _check_syncbn_run(got, model, data)
+    assert checked > 30 and buffers >= 10
 
 
 def test_two_rank_superglue_syncbn_equals_single_process():
@@ -104,19 +174,5 @@ def test_two_rank_superglue_syncbn_equals_single_process():
         mp.spawn(_sg_worker, args=(2, lock, out), nprocs=2, join=True)
         got = torch.load(out)
     model, data = _sg_model_and_data()
-    init = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-    step = TrainStep(model, torch.optim.SGD(model.parameters(), lr=0.05), amp_dtype=None)
-    step(data)
-    checked = 0
-    for k, v in model.state_dict().items():
-        if not v.dtype.is_floating_point:
-            continue
-        b, a = v.detach().cpu(), got[k]
-        sc = (b - init[k]).abs().max().item()
-        if sc < 1e-6:      # e.g. conv biases in front of a train-mode BatchNorm: the true gradient is exactly 0
-            continue
-        err = ((a - b) / sc).abs()
-        # the shards sum their fp32 partials in another order than the whole batch; isolated ReLU-boundary flips allowed
-        assert err.max() < 5e-2 and (err > 5e-3).float().mean() < 1e-2, (k, err.max().item())
-        checked += 1
-    assert checked > 20
+    checked, buffers = _check_syncbn_run(got, model, data)
+    assert checked > 20 and buffers >= 10
