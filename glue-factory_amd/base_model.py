@@ -136,3 +136,9 @@ def get_model(name):
         except AttributeError:
             continue
     raise RuntimeError(f"Model {name} not found in any of [{' '.join(tried)}]")
+
+
+class BatchedExtractionUnsupported(ValueError):
+    """Raised by an extractor that cannot serve THIS batch in one call (images with different keypoint counts, no keypoint
+    cap): pipeline.TwoViewPipeline falls back to one call per view on exactly this exception -- any other error of an
+    extractor propagates.  (A ValueError subclass: callers that caught ValueError keep working.)"""

@@ -227,9 +227,10 @@ __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const float* __res
 // as bn_finalize_fwd_kernel wrote them), set after set -- what an activation-checkpointed reference does to its BatchNorm
 // buffers when the backward re-runs the forward (superglue.py:160-169, gluestick.py:724-757).
 __global__ __launch_bounds__(256) void bn_replay_running_kernel(const float* __restrict__ mvr, int sets, int C, float n, float momentum,
-                                                                float* __restrict__ run_mean, float* __restrict__ run_var) {
+                                                                float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                                const float* __restrict__ skip) {
     const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    if (c >= C || (skip != nullptr && !(*skip == 0.f))) return;      // (a NaN flag skips too)
     float rm = run_mean[c], rv = run_var[c];
     const float unbias = n / fmaxf(n - 1.f, 1.f);
     for (int h = 0; h < sets; ++h) {
@@ -309,9 +310,9 @@ __global__ __launch_bounds__(256) void bn_finalize_sets_bwd_kernel(const float* 
 // bn_replay_running_kernel with the row count of every set on the device (the global count of a SyncBatchNorm call)
 __global__ __launch_bounds__(256) void bn_replay_running_n_kernel(const float* __restrict__ mvr, const float* __restrict__ counts, int sets,
                                                                   int C, float momentum, float* __restrict__ run_mean,
-                                                                  float* __restrict__ run_var) {
+                                                                  float* __restrict__ run_var, const float* __restrict__ skip) {
     const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    if (c >= C || (skip != nullptr && !(*skip == 0.f))) return;
     float rm = run_mean[c], rv = run_var[c];
     for (int h = 0; h < sets; ++h) {
         const float n = counts[h];
@@ -351,10 +352,10 @@ extern "C" int gf_bn_finalize_sets_bwd(const float* packed, const float* counts,
 }
 
 extern "C" int gf_bn_replay_running_n(const float* mvr, const float* counts, int sets, int C, float momentum, float* run_mean,
-                                      float* run_var, void* stream) {
+                                      float* run_var, const float* skip, void* stream) {
     if (sets <= 0 || C <= 0 || mvr == nullptr || counts == nullptr || run_mean == nullptr || run_var == nullptr) return GF_ERR_SHAPE;
     bn_replay_running_n_kernel<<<dim3((C + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
-        mvr, counts, sets, C, momentum, run_mean, run_var);
+        mvr, counts, sets, C, momentum, run_mean, run_var, skip);
     return (int)hipGetLastError();
 }
 
@@ -405,10 +406,10 @@ extern "C" int gf_bn_finalize_fwd(const float* part, int nblk, int C, float n, f
 }
 
 extern "C" int gf_bn_replay_running(const float* mvr, int sets, int C, float n, float momentum, float* run_mean,
-                                    float* run_var, void* stream) {
+                                    float* run_var, const float* skip, void* stream) {
     if (sets <= 0 || C <= 0 || n <= 0.f || mvr == nullptr || run_mean == nullptr || run_var == nullptr) return GF_ERR_SHAPE;
     bn_replay_running_kernel<<<dim3((C + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream)>>>(
-        mvr, sets, C, n, momentum, run_mean, run_var);
+        mvr, sets, C, n, momentum, run_mean, run_var, skip);
     return (int)hipGetLastError();
 }
 

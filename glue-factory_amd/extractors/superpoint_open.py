@@ -26,7 +26,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..base_model import BaseModel
+from ..base_model import BaseModel, BatchedExtractionUnsupported
 
 
 def sample_descriptors(keypoints, descriptors, s=8):
@@ -341,7 +341,7 @@ class SuperPoint(BaseModel):
                 scores = self._apply_limits(scores, limits)
         if k is None:
             if b != 1:
-                raise ValueError("max_num_keypoints is required for batched extraction")
+                raise BatchedExtractionUnsupported("max_num_keypoints is required for batched extraction")
             idx = torch.where(scores[0] > conf.detection_threshold)
             keypoints = torch.stack(idx[::-1], -1).float()[None]
             kscores = scores[0][idx][None]
@@ -386,7 +386,7 @@ class SuperPoint(BaseModel):
             elif b == 1:
                 keypoints, kscores = keypoints[:, valid[0]], kscores[:, valid[0]]
             elif not bool(valid.all()):
-                raise ValueError("images yield different keypoint counts: set force_num_keypoints")
+                raise BatchedExtractionUnsupported("images yield different keypoint counts: set force_num_keypoints")
         descriptors = self._sample(keypoints, desc_map, dense, fused, s)
         pred = {"keypoints": keypoints + 0.5, "keypoint_scores": kscores, "descriptors": descriptors}
         if conf.dense_outputs:

@@ -70,12 +70,12 @@ SIGNATURES = {
     "gf_bn_bwd_stats": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "gf_bn_bwd_dx": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "gf_bn_finalize_fwd": [_P, _I, _I, _F, _F, _F, _P, _P, _P, _P, _P, _P],
-    "gf_bn_replay_running": [_P, _I, _I, _F, _F, _P, _P, _P],
+    "gf_bn_replay_running": [_P, _I, _I, _F, _F, _P, _P, _P, _P],
     "gf_bn_finalize_bwd": [_P, _I, _I, _F, _P, _P, _P, _P, _P],
     "gf_bn_pack_sums": [_P, _I, _I, _I, _F, _P, _P, _P],
     "gf_bn_finalize_sets_fwd": [_P, _I, _I, _F, _F, _P, _P, _P, _P],
     "gf_bn_finalize_sets_bwd": [_P, _P, _I, _I, _P, _P],
-    "gf_bn_replay_running_n": [_P, _P, _I, _I, _F, _P, _P, _P],
+    "gf_bn_replay_running_n": [_P, _P, _I, _I, _F, _P, _P, _P, _P],
     "gf_gt_nn": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "gf_bias_act_bn_nhwc": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "gf_conv1_bias_act_bn": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],

@@ -162,11 +162,18 @@ class SharedGradSum:
     """Gradient of ONE tensor consumed by `consumers` nodes of the same kind (the rotary angles of LightGlue's L self
     blocks): every node's backward kernel adds the running sum of the nodes that ran before it (`acc`, passed as the
     kernel's base operand) and only the last one hands the total to autograd -- L - 1 elementwise adds fewer.  A backward
-    pass that does not visit all consumers would lose gradient, so the count is checked when the next forward re-arms it."""
-    __slots__ = ("acc", "got", "expected")
+    pass that does not visit all consumers (torch.autograd.grad on an intermediate layer, a loss on layer k < L - 1 only)
+    would silently drop the visited consumers' share: `check()` raises in that case; TrainStep calls `check_all()` after its
+    backward (callers that drive autograd themselves on a partial graph can do the same)."""
+    __slots__ = ("acc", "got", "expected", "__weakref__")
+    live = None           # the sums armed by the last forward (weak): TrainStep checks them after its backward
 
     def __init__(self, consumers):
+        import weakref
         self.acc, self.got, self.expected = None, 0, int(consumers)
+        if SharedGradSum.live is None:
+            SharedGradSum.live = weakref.WeakSet()
+        SharedGradSum.live.add(self)
 
     def add(self, g):
         self.got += 1
@@ -175,6 +182,18 @@ class SharedGradSum:
             return None
         self.acc, self.got = None, 0
         return g
+
+    def check(self):
+        if 0 < self.got < self.expected:
+            got = self.got
+            self.acc, self.got = None, 0
+            raise RuntimeError(f"SharedGradSum: the backward visited {got} of {self.expected} consumers of a shared tensor -- "
+                               "its gradient is incomplete (differentiate through all layers, or build the model without the shared sum)")
+
+    @classmethod
+    def check_all(cls):
+        for s_ in list(cls.live or ()):
+            s_.check()
 
 
 LN2 = 0.6931471805599453
@@ -1681,11 +1700,18 @@ class _BatchNormActSets(torch.autograd.Function):
         dbeta, dgamma = (out[0, 0], out[0, 1]) if H == 1 else (out[:, 0].sum(0), out[:, 1].sum(0))
         if ctx.replay is not None:
             run_mean, run_var, nbt, momentum = ctx.replay
-            _lib.check(L.gf_bn_replay_running(_p(mvr), H, C, float(M), momentum, _p(run_mean), _p(run_var), st),
+            gate = REPLAY_GATE
+            _lib.check(L.gf_bn_replay_running(_p(mvr), H, C, float(M), momentum, _p(run_mean), _p(run_var), _p(gate), st),
                        "gf_bn_replay_running")
-            nbt.add_(H)
+            nbt.add_(H if gate is None else (gate == 0).to(nbt.dtype) * H)
         return dx, dgamma.to(gdt), dbeta.to(bdt), None, None, None, None, None, None
 
+
+# The reference `continue`s BEFORE its backward when the loss is non-finite or not differentiable (train.py:477-488): the
+# activation-checkpointed blocks are then not re-run and their BatchNorm statistics take ONE update.  TrainStep always runs its
+# backward (the gradient reducer needs every rank's), so it parks its device-side "bad" flag here for the duration of the
+# backward and the replays below become no-ops on such a step (fp32 scalar tensor, non-zero = skip; None = always replay).
+REPLAY_GATE = None
 
 COLLECTIVES = {"syncbn": 0}       # collectives issued by the ops of this module (bench.py / tests count them per step)
 
@@ -1759,9 +1785,10 @@ class _BatchNormActSetsSync(torch.autograd.Function):
         dbeta, dgamma = (local[0, 0], local[0, 1]) if H == 1 else (local[:, 0].sum(0), local[:, 1].sum(0))
         if ctx.replay is not None:
             run_mean, run_var, nbt, momentum = ctx.replay
-            _lib.check(L.gf_bn_replay_running_n(_p(mvr), _p(counts), H, C, momentum, _p(run_mean), _p(run_var), st),
+            gate = REPLAY_GATE
+            _lib.check(L.gf_bn_replay_running_n(_p(mvr), _p(counts), H, C, momentum, _p(run_mean), _p(run_var), _p(gate), st),
                        "gf_bn_replay_running_n")
-            nbt.add_(H)
+            nbt.add_(H if gate is None else (gate == 0).to(nbt.dtype) * H)
         return dx, dgamma.to(gdt), dbeta.to(bdt), None, None, None, None, None, None
 
 
@@ -1778,13 +1805,22 @@ class _ReplayRunningStats(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        gate = REPLAY_GATE
         with torch.no_grad():
             for bn, stats in ctx.groups:
                 for mean, unbiased in stats:
-                    bn.num_batches_tracked += 1
-                    mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
-                    bn.running_mean.mul_(1 - mom).add_(mean.to(bn.running_mean.dtype), alpha=mom)
-                    bn.running_var.mul_(1 - mom).add_(unbiased.to(bn.running_var.dtype), alpha=mom)
+                    if gate is None:
+                        bn.num_batches_tracked += 1
+                        mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+                        bn.running_mean.mul_(1 - mom).add_(mean.to(bn.running_mean.dtype), alpha=mom)
+                        bn.running_var.mul_(1 - mom).add_(unbiased.to(bn.running_var.dtype), alpha=mom)
+                        continue
+                    go = (gate == 0)                              # device-side: a skipped step replays nothing
+                    bn.num_batches_tracked += go.to(bn.num_batches_tracked.dtype)
+                    mom = bn.momentum if bn.momentum is not None else 1.0 / bn.num_batches_tracked.clamp(min=1).float()
+                    rm, rv = bn.running_mean, bn.running_var
+                    rm.copy_(torch.where(go, rm * (1 - mom) + mean.to(rm.dtype) * mom, rm))
+                    rv.copy_(torch.where(go, rv * (1 - mom) + unbiased.to(rv.dtype) * mom, rv))
         return dy, None
 
 

@@ -11,7 +11,7 @@ Convention: ``matches0[i]`` is the index in image 1 matched to keypoint i of ima
 import torch
 from torch import nn
 
-from .base_model import BaseModel, get_model
+from .base_model import BaseModel, BatchedExtractionUnsupported, get_model
 from .conf import to_container
 
 _STAGES = ("extractor", "matcher", "filter", "solver", "ground_truth")
@@ -83,8 +83,13 @@ class TwoViewPipeline(BaseModel):
                 if (torch.is_tensor(a) and torch.is_tensor(c) and a.dim() > 0 and a.shape == c.shape and a.shape[0] == b
                         and a.dtype == c.dtype):
                     both[k] = torch.cat([a, c], 0)
-                elif not torch.is_tensor(a) and not torch.is_tensor(c) and a == c:
-                    both[k] = a                    # (names, scalars: identical in both views)
+                elif not torch.is_tensor(a) and not torch.is_tensor(c):
+                    try:                           # (names, scalars: ride along when identical in both views; anything whose
+                        same = bool(a == c)        # comparison is not a plain truth value -- arrays, lists of tensors -- is dropped)
+                    except (ValueError, RuntimeError, TypeError):
+                        same = False
+                    if same:
+                        both[k] = a
                 elif torch.is_tensor(a) or torch.is_tensor(c):
                     both = None                    # a per-view tensor that cannot ride in one call: view by view
                     break
@@ -92,7 +97,8 @@ class TwoViewPipeline(BaseModel):
             return self.extract_view(data, "0"), self.extract_view(data, "1")
         try:
             out = self.extractor(both)
-        except ValueError:                          # ("different keypoint counts" ...: what two b-sized calls can still serve)
+        except BatchedExtractionUnsupported:        # ("different keypoint counts" ...: what two b-sized calls can still serve;
+                                                    # any other extractor error propagates)
             return self.extract_view(data, "0"), self.extract_view(data, "1")
         if not all(torch.is_tensor(t) and t.dim() > 0 and t.shape[0] == 2 * b for t in out.values()):
             return self.extract_view(data, "0"), self.extract_view(data, "1")      # (an extractor with non-batched outputs)

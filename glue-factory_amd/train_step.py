@@ -300,20 +300,29 @@ class TrainStep:
             bad = bad + 1.0
             # keep the autograd graph (and the reduction hooks) alive with an exactly-zero contribution
             loss = loss.detach() + sum((p.sum() * 0.0 for p in self.model.parameters() if p.requires_grad))
-        if self.buckets is not None:
-            # the flag rides in the last gradient bucket (SUM over ranks > 0 <=> bad on some rank): no collective of its
-            # own and nothing on the critical path in front of the backward
-            self.buckets.start()
-            self.buckets.extra.copy_(bad.reshape(1))
-            (loss / dist.get_world_size()).backward()
-            self.buckets.finish()
-            bad = (self.buckets.extra[0] > 0).float()
-            n_grad = len(self.buckets.buckets)
-        else:
-            if self.distributed:
-                dist.all_reduce(bad, op=dist.ReduceOp.MAX)
-            loss.backward()
-            n_grad = None                      # (DistributedDataParallel issues its own bucket reductions + the flag's)
+        # ops.REPLAY_GATE: the BatchNorm replays of the backward (the reference's checkpoint recompute) do nothing on a step the
+        # reference would have skipped BEFORE its backward (train.py:477-488).  Bucket reducer: this rank's own flag -- the other
+        # ranks' arrive with the last bucket, after the backward; otherwise the flag is all-reduced first, like the reference's.
+        try:
+            if self.buckets is not None:
+                # the flag rides in the last gradient bucket (SUM over ranks > 0 <=> bad on some rank): no collective of its
+                # own and nothing on the critical path in front of the backward
+                self.buckets.start()
+                self.buckets.extra.copy_(bad.reshape(1))
+                ops.REPLAY_GATE = bad
+                (loss / dist.get_world_size()).backward()
+                self.buckets.finish()
+                bad = (self.buckets.extra[0] > 0).float()
+                n_grad = len(self.buckets.buckets)
+            else:
+                if self.distributed:
+                    dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+                ops.REPLAY_GATE = bad
+                loss.backward()
+                n_grad = None                      # (DistributedDataParallel issues its own bucket reductions + the flag's)
+        finally:
+            ops.REPLAY_GATE = None
+        ops.SharedGradSum.check_all()           # a backward that skipped consumers of a shared tensor raises instead of losing gradient
         # collectives this step issued (eager call or capture): gradient buckets, SyncBatchNorm exchanges (ops.COLLECTIVES)
         self.last_collectives = {"gradient_buckets": n_grad, "syncbn": ops.COLLECTIVES["syncbn"] - bn0}
         if self.clip_grad is not None:

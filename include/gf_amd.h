@@ -377,15 +377,17 @@ int gf_bn_finalize_sets_fwd(const float* packed, int sets, int C, float eps, flo
                             float* run_mean, float* run_var, void* stream);
 int gf_bn_finalize_sets_bwd(const float* packed, const float* counts, int sets, int C, float* m12, void* stream);
 int gf_bn_replay_running_n(const float* mvr, const float* counts, int sets, int C, float momentum, float* run_mean,
-                           float* run_var, void* stream);
+                           float* run_var, const float* skip, void* stream);
 /* gf_bn_replay_running (ABI 15): the running statistics take the batch statistics of `sets` forward calls a SECOND time,
  * set after set (mvr = [sets][3][C] rows mean / biased var / rstd as gf_bn_finalize_fwd wrote them, n rows per set).  The
  * reference wraps its GNN layers in torch.utils.checkpoint while training (gluefactory_nonfree/superglue.py:160-169 always;
  * gluefactory/models/matchers/gluestick.py:724-757 with `checkpointed: true`): the backward re-runs their forward in
  * training mode, so every BatchNorm1d inside updates running_mean / running_var / num_batches_tracked twice per step.
- * Launched from the backward of the fused BatchNorm op to leave the same buffers behind. */
-int gf_bn_replay_running(const float* mvr, int sets, int C, float n, float momentum, float* run_mean,
-                         float* run_var, void* stream);
+ * Launched from the backward of the fused BatchNorm op to leave the same buffers behind.  `skip` (nullable): a device-side
+ * flag; when it is non-zero (or NaN) the launch leaves the buffers alone -- the reference `continue`s BEFORE its backward on
+ * a non-finite / non-differentiable loss (train.py:477-488), so such a step updates the statistics once, not twice. */
+int gf_bn_replay_running(const float* mvr, int sets, int C, float n, float momentum, float* run_mean, float* run_var,
+                         const float* skip, void* stream);
 
 /* ---- ground-truth nearest neighbours under a homography (gluefactory/geometry/gt_generation.py:120-150)
  * For every point i of the "own" set [B,No,2] (own = its coordinates, own_warped = the same points

@@ -265,3 +265,38 @@ def test_nll_node_gradient_and_sums_handed_to_sinkhorn():
     assert sums is not None
     torch.testing.assert_close(sums[0], G.sum(2))
     torch.testing.assert_close(sums[1], G.sum(1))
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_skipped_step_updates_batchnorm_statistics_once(graph):
+    """The reference `continue`s BEFORE its backward on a non-finite loss (train.py:477-480): the activation-checkpointed GNN
+    blocks are not re-run, so their BatchNorm buffers take ONE update on such a step (num_batches_tracked + 2: two images) and
+    two on a normal one (+ 4).  TrainStep always runs its backward; the replays are gated by the step's device-side flag
+    (ops.REPLAY_GATE, gf_bn_replay_running's `skip`) -- eager and inside a replayed hipGraph."""
+    from glue_factory_amd.matchers.superglue import SuperGlue
+    from glue_factory_amd.optim import FusedAdam
+    from glue_factory_amd.synthetic import make_pairs, to_device
+    from glue_factory_amd.train_step import TrainStep
+    torch.manual_seed(3)
+    model = SuperGlue({"GNN_layers": ["self", "cross"], "num_sinkhorn_iterations": 5}).cuda().train()
+    good = to_device(make_pairs(2, 128, dim=256, size=(640, 480), seed=21), "cuda")
+    bad = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in good.items()}
+    # a loss that is NaN although every activation is finite: a NaN among the ground-truth weights... the NLL reads the
+    # log-assignment at the positives only, so poison the couplings through ONE keypoint score instead -- and keep the
+    # statistics comparable by looking at the COUNTERS, which do not depend on the values
+    bad["keypoint_scores0"][0, 0] = float("nan")
+    step = TrainStep(model, FusedAdam(model.parameters(), lr=1e-4), amp_dtype=None, graph=graph, graph_warmup=2)
+    gnn_bn, kenc_bn = model.gnn.layers[0].mlp[1], model.kenc.encoder[1]
+    n_steps = 4 if graph else 1                  # (graph: two eager steps, the capture, one replay -- all on the good batch)
+    for _ in range(n_steps):
+        step(good)
+    torch.cuda.synchronize()
+    assert step.skipped == 0
+    g0, k0 = int(gnn_bn.num_batches_tracked), int(kenc_bn.num_batches_tracked)
+    assert g0 == 4 * n_steps and k0 == 2 * n_steps
+    step(bad)
+    torch.cuda.synchronize()
+    assert step.skipped == 1
+    assert int(kenc_bn.num_batches_tracked) == k0 + 2
+    assert int(gnn_bn.num_batches_tracked) == g0 + 2, "a skipped step must not replay the checkpointed blocks' update"
+    step.close()
