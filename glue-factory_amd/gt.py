@@ -388,7 +388,13 @@ def gt_line_matches_from_pose_depth(pred_lines0, pred_lines1, valid_lines0, vali
     mostly outside the other image, or that is close to nothing, is unmatched (-1); one with too few valid depth samples, or
     flagged invalid, is ignored (-2).  Returns (assignment [B,L0,L1] bool, matches0 [B,L0], matches1 [B,L1]).
     (The reference reads the inverse pose as `data.get(data["T_1to0"], data["T_0to1"].inv())`, i.e. always the inverse of
-    T_0to1: so does this.)"""
+    T_0to1: so does this.)
+    PARITY IS WITH THE REFERENCE'S CPU PATH (what tests/golden/gt_lines_depth.npz pins bit for bit).  On CUDA the reference
+    additionally rounds the centred samples and the rotation of its perpendicular-distance test to fp16
+    (gt_generation.py:193-195: `.half()` when `is_cuda`), so labels of segment pairs within fp16 rounding (~1e-3 relative) of
+    `dist_th` / of a segment end can differ from a reference run ON A GPU; only the segment length is kept fp16-rounded here, as
+    the reference's CPU path keeps it.  The reference's early return for inputs without elements is covered by the n0 == 0 /
+    n1 == 0 branch below."""
     from .geometry import project, sample_depth
     b, n0, n1 = pred_lines0.shape[0], pred_lines0.shape[1], pred_lines1.shape[1]
     if n0 == 0 or n1 == 0:
