@@ -628,6 +628,18 @@ constexpr int DKV_STATS = 2 * FT_TILE;                 // per wave: 16 lse | 16 
 constexpr int DKV_STAGE = 2 * FT_TILE + 1024;
 constexpr int DKV_NSTAGE = 3;
 
+// Timing probes only (tools/probe/attn_stall_table.sh; the shipped library builds with 0): what does the dK/dV loop cost
+// without ... 1 the exponentials, 2 the two output products (dV += P^T dO, dK += dS^T Q: 8 of the 16 MFMAs of a half tile),
+// 4 the DMA of the next tiles, 8 the hardware-transposed LDS reads of the output products' operands, 16 the row-major LDS
+// reads + statistics.  Results are wrong by construction.
+#ifndef GF_DKV_ABL
+#define GF_DKV_ABL 0
+#endif
+#if GF_DKV_ABL & 2
+#define GF_DKV_OUT_MMA(acc, a, b) do { const auto a_ = (a); const auto b_ = (b); asm volatile("" ::"v"(a_), "v"(b_)); } while (0)
+#else
+#define GF_DKV_OUT_MMA(acc, a, b) mma16(acc, a, b)
+#endif
 template <int QB, bool PRE, bool SPLIT, typename Mid>      // SPLIT: P and dS as hi + lo bf16 pairs (attention_fwd3.hip)
 __device__ __forceinline__ void dkv_half_tile(f32x16 (&dk)[2], f32x16 (&dv)[2], const bf16x8 (&kf)[4],
                                               const bf16x8 (&vf)[4], const unsigned (&aR)[4],
@@ -636,11 +648,15 @@ __device__ __forceinline__ void dkv_half_tile(f32x16 (&dk)[2], f32x16 (&dv)[2], 
     f32x4 l4[4], d4[4];
 #define GF_ST(g) l4[g] = __builtin_bit_cast(f32x4, lds_rd128<(2 * QB + (g >> 1)) * 256 + 32 * (g & 1)>(aS)); \
                  d4[g] = __builtin_bit_cast(f32x4, lds_rd128<(2 * QB + (g >> 1)) * 256 + 32 * (g & 1) + 64>(aS));
-    GF_ST(0) GF_ST(1) GF_ST(2) GF_ST(3)
+    if (!(GF_DKV_ABL & 16)) { GF_ST(0) GF_ST(1) GF_ST(2) GF_ST(3) }
+    else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { l4[g] = f32x4{0.f, 0.f, 0.f, 0.f}; d4[g] = l4[g]; }
+    }
 #undef GF_ST
     u32x4 qa[4], da[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) qa[s] = lds_rd128<QB * 4096>(aR[s]);
+    for (int s = 0; s < 4; ++s) qa[s] = (GF_DKV_ABL & 16) ? u32x4{0u, 0u, 0u, 0u} : lds_rd128<QB * 4096>(aR[s]);
     wait_lgkm<4>();
     f32x16 sa, dp;
 #pragma unroll
@@ -654,7 +670,7 @@ __device__ __forceinline__ void dkv_half_tile(f32x16 (&dk)[2], f32x16 (&dv)[2], 
         }
     }
 #pragma unroll
-    for (int s = 0; s < 4; ++s) da[s] = lds_rd128<FT_TILE + QB * 4096>(aR[s]);
+    for (int s = 0; s < 4; ++s) da[s] = (GF_DKV_ABL & 16) ? u32x4{0u, 0u, 0u, 0u} : lds_rd128<FT_TILE + QB * 4096>(aR[s]);
     wait_lgkm<4>();
 #pragma unroll
     for (int s = 0; s < 4; ++s) {                               // k-steps chained on ONE accumulator: switching
@@ -663,8 +679,8 @@ __device__ __forceinline__ void dkv_half_tile(f32x16 (&dk)[2], f32x16 (&dv)[2], 
     }
     // transposed operands: [t][db] -> rows 16t + 4hi + {0..3} (lo) and + 8 (hi half), columns db*32 + l31
     u32x2 dot[2][2][2], qt[2][2][2];
-#define GF_TR(dst, base, t, db) dst[t][db][0] = lds_rdtr<base + QB * 4096 + t * 2048>(aT[db]); \
-                                dst[t][db][1] = lds_rdtr<base + QB * 4096 + t * 2048 + 1024>(aT[2 + db]);
+#define GF_TR(dst, base, t, db) dst[t][db][0] = (GF_DKV_ABL & 8) ? u32x2{0u, 0u} : lds_rdtr<base + QB * 4096 + t * 2048>(aT[db]); \
+                                dst[t][db][1] = (GF_DKV_ABL & 8) ? u32x2{0u, 0u} : lds_rdtr<base + QB * 4096 + t * 2048 + 1024>(aT[2 + db]);
     GF_TR(dot, FT_TILE, 0, 0) GF_TR(dot, FT_TILE, 0, 1) GF_TR(dot, FT_TILE, 1, 0) GF_TR(dot, FT_TILE, 1, 1)
     wait_lgkm<8>();
 #pragma unroll
@@ -674,10 +690,10 @@ __device__ __forceinline__ void dkv_half_tile(f32x16 (&dk)[2], f32x16 (&dv)[2], 
     }
     GF_TR(qt, 0, 0, 0) GF_TR(qt, 0, 0, 1) GF_TR(qt, 0, 1, 0) GF_TR(qt, 0, 1, 1)
 #undef GF_TR
-    mid();                                                      // DMA issue rides in the VALU gap
+    if (!(GF_DKV_ABL & 4)) mid();                               // DMA issue rides in the VALU gap
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const float pr = fast_exp2(PRE ? sa[r] : sa[r] * c);
+        const float pr = (GF_DKV_ABL & 1) ? sa[r] : fast_exp2(PRE ? sa[r] : sa[r] * c);
         sa[r] = pr;
         dp[r] = pr * dp[r];                                     // dS overwrites dP
     }
@@ -692,15 +708,15 @@ __device__ __forceinline__ void dkv_half_tile(f32x16 (&dk)[2], f32x16 (&dv)[2], 
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
             tie(dot[0][db][0]); tie(dot[0][db][1]); tie(dot[1][db][0]); tie(dot[1][db][1]);
-            mma16(dv[db], as_frag(dot[0][db][0], dot[0][db][1]), pf0);
-            mma16(dv[db], as_frag(dot[1][db][0], dot[1][db][1]), pf1);
+            GF_DKV_OUT_MMA(dv[db], as_frag(dot[0][db][0], dot[0][db][1]), pf0);
+            GF_DKV_OUT_MMA(dv[db], as_frag(dot[1][db][0], dot[1][db][1]), pf1);
         }
         if (SPLIT) {
             const bf16x8 pl0 = cvt_frag_lo(sa, 0, pf0), pl1 = cvt_frag_lo(sa, 1, pf1);
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
-                mma16(dv[db], as_frag(dot[0][db][0], dot[0][db][1]), pl0);
-                mma16(dv[db], as_frag(dot[1][db][0], dot[1][db][1]), pl1);
+                GF_DKV_OUT_MMA(dv[db], as_frag(dot[0][db][0], dot[0][db][1]), pl0);
+                GF_DKV_OUT_MMA(dv[db], as_frag(dot[1][db][0], dot[1][db][1]), pl1);
             }
         }
     }
@@ -710,15 +726,15 @@ __device__ __forceinline__ void dkv_half_tile(f32x16 (&dk)[2], f32x16 (&dv)[2], 
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
             tie(qt[0][db][0]); tie(qt[0][db][1]); tie(qt[1][db][0]); tie(qt[1][db][1]);
-            mma16(dk[db], as_frag(qt[0][db][0], qt[0][db][1]), pf0);
-            mma16(dk[db], as_frag(qt[1][db][0], qt[1][db][1]), pf1);
+            GF_DKV_OUT_MMA(dk[db], as_frag(qt[0][db][0], qt[0][db][1]), pf0);
+            GF_DKV_OUT_MMA(dk[db], as_frag(qt[1][db][0], qt[1][db][1]), pf1);
         }
         if (SPLIT) {
             const bf16x8 pl0 = cvt_frag_lo(dp, 0, pf0), pl1 = cvt_frag_lo(dp, 1, pf1);
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
-                mma16(dk[db], as_frag(qt[0][db][0], qt[0][db][1]), pl0);
-                mma16(dk[db], as_frag(qt[1][db][0], qt[1][db][1]), pl1);
+                GF_DKV_OUT_MMA(dk[db], as_frag(qt[0][db][0], qt[0][db][1]), pl0);
+                GF_DKV_OUT_MMA(dk[db], as_frag(qt[1][db][0], qt[1][db][1]), pl1);
             }
         }
     }

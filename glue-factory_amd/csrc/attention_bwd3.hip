@@ -22,6 +22,17 @@
 namespace gfattn {
 namespace {
 
+// Timing probes only (tools/probe/attn_stall_table.sh; shipped: 0): the dQ loop without ... 1 the exponentials, 2 the dQ
+// product (4 of the 12 MFMAs of a half tile), 4 the DMA of the next tiles, 8 the hardware-transposed LDS reads (K^T), 16 the
+// row-major LDS reads (K, V).  Results are wrong by construction.
+#ifndef GF_DQ3_ABL
+#define GF_DQ3_ABL 0
+#endif
+#if GF_DQ3_ABL & 2
+#define GF_DQ3_OUT_MMA(acc, a, b) do { const auto a_ = (a); const auto b_ = (b); asm volatile("" ::"v"(a_), "v"(b_)); } while (0)
+#else
+#define GF_DQ3_OUT_MMA(acc, a, b) mma16(acc, a, b)
+#endif
 #ifndef DQ3_WPS
 #define DQ3_WPS 2          // workgroups per CU = waves per SIMD
 #endif
@@ -104,7 +115,8 @@ __global__ __launch_bounds__(256, DQ3_WPS) void attn_dq3_bf16_kernel(AttnParams 
         if (EVEN || t + 1 < nt) wait_vm<4>(); else wait_vm<0>();     // tile t landed (this wave's pieces)
         __builtin_amdgcn_s_barrier();                                // ... everyone's; the stage of tile t-1 is free
         __builtin_amdgcn_sched_barrier(0);
-        if (EVEN) dma.issue_full(min(t + 2, nt - 1), smem + (stage == 0 ? 2 : stage - 1) * FQ_STAGE + wave * 1024);
+        if (GF_DQ3_ABL & 4) {
+        } else if (EVEN) dma.issue_full(min(t + 2, nt - 1), smem + (stage == 0 ? 2 : stage - 1) * FQ_STAGE + wave * 1024);
         else if (t + 2 < nt) dma.issue(t + 2, smem + (stage == 0 ? 2 : stage - 1) * FQ_STAGE + wave * 1024);
         const bool ragged = !EVEN && t * 64 + 64 > p.Nk;
 
@@ -112,18 +124,19 @@ __global__ __launch_bounds__(256, DQ3_WPS) void attn_dq3_bf16_kernel(AttnParams 
         u32x2 kt[2][2][2];
         f32x16 s, dp;
 #define GF_DQ3_HALF(KB)                                                                                             \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) ka[i] = lds_rd128<KB * 4096>(aR[i]);                          \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) va[i] = lds_rd128<FT_TILE + KB * 4096>(aR[i]);                \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) ka[i] = (GF_DQ3_ABL & 16) ? u32x4{0u, 0u, 0u, 0u} : lds_rd128<KB * 4096>(aR[i]); \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) va[i] = (GF_DQ3_ABL & 16) ? u32x4{0u, 0u, 0u, 0u} : lds_rd128<FT_TILE + KB * 4096>(aR[i]); \
         wait_lgkm<4>();                                                                                             \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) tie(ka[i]);                                                   \
         s = mma16c(as_frag(ka[0]), qf[0], nlb);                              /* S^T[key][q] - lse (exponent units) */ \
         _Pragma("unroll") for (int i = 1; i < 4; ++i) mma16(s, as_frag(ka[i]), qf[i]);                              \
-        GF_FQ_TR(kt, 0, KB, 0, 0) GF_FQ_TR(kt, 0, KB, 0, 1) GF_FQ_TR(kt, 0, KB, 1, 0) GF_FQ_TR(kt, 0, KB, 1, 1)     \
+        if (GF_DQ3_ABL & 8) { _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) kt[i_ >> 2][(i_ >> 1) & 1][i_ & 1] = u32x2{0u, 0u}; }   \
+        else { GF_FQ_TR(kt, 0, KB, 0, 0) GF_FQ_TR(kt, 0, KB, 0, 1) GF_FQ_TR(kt, 0, KB, 1, 0) GF_FQ_TR(kt, 0, KB, 1, 1) }     \
         wait_lgkm<8>();                                                                                             \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) tie(va[i]);                                                   \
         dp = mma16c(as_frag(va[0]), dof[0], ndb);                            /* dP^T[key][q] - delta */             \
         _Pragma("unroll") for (int i = 1; i < 4; ++i) mma16(dp, as_frag(va[i]), dof[i]);                            \
-        _Pragma("unroll") for (int r = 0; r < 16; ++r) s[r] = fast_exp2(PRE ? s[r] : s[r] * rr) * dp[r];      /* dS */           \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) s[r] = ((GF_DQ3_ABL & 1) ? s[r] : fast_exp2(PRE ? s[r] : s[r] * rr)) * dp[r];      /* dS */           \
         if (ragged) {                                                        /* keys past Nk contribute nothing */   \
             _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                          \
                 if (t * 64 + KB * 32 + crow(r, hi) >= p.Nk) s[r] = 0.f;                                             \
@@ -133,14 +146,14 @@ __global__ __launch_bounds__(256, DQ3_WPS) void attn_dq3_bf16_kernel(AttnParams 
             wait_lgkm<0>();                                                                                         \
             _Pragma("unroll") for (int db = 0; db < 2; ++db) {                                                      \
                 tie(kt[0][db][0]); tie(kt[0][db][1]); tie(kt[1][db][0]); tie(kt[1][db][1]);                         \
-                mma16(dq[db], as_frag(kt[0][db][0], kt[0][db][1]), d0);      /* dQ^T[d][q] += K^T[d][key] dS */     \
-                mma16(dq[db], as_frag(kt[1][db][0], kt[1][db][1]), d1);                                             \
+                GF_DQ3_OUT_MMA(dq[db], as_frag(kt[0][db][0], kt[0][db][1]), d0);      /* dQ^T[d][q] += K^T[d][key] dS */     \
+                GF_DQ3_OUT_MMA(dq[db], as_frag(kt[1][db][0], kt[1][db][1]), d1);                                             \
             }                                                                                                       \
             if (SPLIT) {                                                                                            \
                 const bf16x8 e0 = cvt_frag_lo(s, 0, d0), e1 = cvt_frag_lo(s, 1, d1);                                \
                 _Pragma("unroll") for (int db = 0; db < 2; ++db) {                                                  \
-                    mma16(dq[db], as_frag(kt[0][db][0], kt[0][db][1]), e0);                                         \
-                    mma16(dq[db], as_frag(kt[1][db][0], kt[1][db][1]), e1);                                         \
+                    GF_DQ3_OUT_MMA(dq[db], as_frag(kt[0][db][0], kt[0][db][1]), e0);                                         \
+                    GF_DQ3_OUT_MMA(dq[db], as_frag(kt[1][db][0], kt[1][db][1]), e1);                                         \
                 }                                                                                                   \
             }                                                                                                       \
         }

@@ -225,7 +225,7 @@ def test_sinkhorn_config4_size_100_iterations():
     gerr = ((Zd.grad.cpu().double() - Zc.grad).abs().max() / sc).item()
     grel = _rel(Zd.grad, Zc.grad)
     print(f"sinkhorn N=2048 T=100: max|out - fp64| = {err:.2e}; max|dZ - fp64|/max|dZ| = {gerr:.2e}; relative L2 {grel:.2e}")
-    assert err < 2e-4 and gerr < 1e-3 and grel < 1e-3
+    assert err < 1e-4 and gerr < 1e-3 and grel < 1e-3          # (measured on MI355X: 9.4e-6 forward)
     # converged transport plan: both marginals hold
     P = out.detach().exp()
     torch.testing.assert_close(P[:, :-1, :].sum(2), torch.ones(1, M, device="cuda"), rtol=2e-3, atol=2e-3)
