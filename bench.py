@@ -538,6 +538,12 @@ def build_matcher(args, rank, name, conf=None):
     return model, cpu_data
 
 
+# GF_FORCE_DIST=1 python bench.py --gpus 1: the N > 1 code path (process group, gradient buckets, SyncBatchNorm exchange,
+# eager-then-captured measurement, data_parallel report) in a group of ONE rank over RCCL -- the smoke run of that path on a
+# single-GPU box (every collective is the identity; the line must equal the plain N = 1 one up to the launch mode).
+FORCE_DIST = os.environ.get("GF_FORCE_DIST") == "1"
+
+
 def make_stepper(args, model, local, allow_graph=True):
     """TrainStep around `model`.  One process: the whole step is captured once and replayed as a hipGraph.  Several ranks:
     main() measures the step launched kernel by kernel FIRST (bucketed all-reduces overlapped from autograd hooks: plain
@@ -550,7 +556,7 @@ def make_stepper(args, model, local, allow_graph=True):
     from glue_factory_amd.optim import FusedAdam
     opt = FusedAdam(model.parameters(), lr=1e-4)
     return TrainStep(model, opt, amp_dtype=torch.bfloat16 if args.dtype == "bf16" else None, device_ids=[local],
-                     graph=graph)
+                     graph=graph, force_distributed=FORCE_DIST)
 
 
 def scope_p_inputs(batch, rank):
@@ -872,7 +878,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     local = local % torch.cuda.device_count()        # (GF_DIST_BACKEND=gloo smoke runs put several ranks on one GPU)
     torch.cuda.set_device(local)
-    dist = dist_mod if world > 1 else None
+    dist = dist_mod if (world > 1 or FORCE_DIST) else None
     lib.load()
 
     def barrier():

@@ -1713,6 +1713,8 @@ class _BatchNormActSets(torch.autograd.Function):
 # backward and the replays below become no-ops on such a step (fp32 scalar tensor, non-zero = skip; None = always replay).
 REPLAY_GATE = None
 
+FORCE_SYNC_BN = False     # tests: take the SyncBatchNorm exchange in a one-rank group too (TrainStep(force_distributed=True))
+
 COLLECTIVES = {"syncbn": 0}       # collectives issued by the ops of this module (bench.py / tests count them per step)
 
 
@@ -1840,7 +1842,7 @@ def batch_norm_act_sets(x, bn, relu=True, replay=False, stats_out=None):
         x = x.contiguous()
     import torch.distributed as dist
     sync = (isinstance(bn, torch.nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized()
-            and dist.get_world_size() > 1)
+            and (dist.get_world_size() > 1 or FORCE_SYNC_BN))
     want = (replay or stats_out is not None) and bn.training and bn.track_running_stats and torch.is_grad_enabled() and x.requires_grad
     if (bn.training and bn.track_running_stats and bn.momentum is not None
             and bn.running_mean.dtype == torch.float32 and bn.running_mean.is_contiguous()
@@ -1886,7 +1888,7 @@ def batch_norm_act(x, bn, relu=True, replay=False, stats_out=None):
     if bn.training or not bn.track_running_stats:
         import torch.distributed as dist
         sync = (isinstance(bn, torch.nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized()
-                and dist.get_world_size() > 1)
+                and (dist.get_world_size() > 1 or FORCE_SYNC_BN))
         track = bn.training and bn.track_running_stats
         fused_running = (track and not sync and bn.momentum is not None and bn.running_mean.dtype == torch.float32
                          and bn.running_mean.is_contiguous() and bn.running_var.is_contiguous())

@@ -35,8 +35,8 @@ def init_distributed(backend=None, init_method=None, rank=None, world_size=None)
     world_size = int(os.environ.get("WORLD_SIZE", "1")) if world_size is None else world_size
     rank = int(os.environ.get("RANK", "0")) if rank is None else rank
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
-    if world_size == 1:
-        return 0, 1, local
+    if world_size == 1 and os.environ.get("GF_FORCE_DIST") != "1":      # GF_FORCE_DIST=1: a process group of ONE rank (smoke runs
+        return 0, 1, local                                              # of the RCCL path on a single-GPU box)
     if backend is None:         # GF_DIST_BACKEND=gloo: several ranks on ONE GPU (smoke runs of the multi-rank path; RCCL refuses that)
         backend = os.environ.get("GF_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     kw = {}
@@ -173,14 +173,21 @@ class TrainStep:
 
     def __init__(self, model, optimizer, amp_dtype=None, clip_grad=None, device_ids=None,
                  bucket_cap_mb=16, find_unused_parameters=False, check_grads=True, graph=False, graph_warmup=2,
-                 reducer="buckets"):
+                 reducer="buckets", force_distributed=False):
+        """force_distributed: take the multi-rank path (SyncBatchNorm conversion, gradient reducer, collectives) in a process
+        group of ONE rank too -- how the RCCL calls of that path are exercised on a single-GPU box (tests/test_gpu_rccl_one_rank.py);
+        every collective is then the identity, so the step must equal the plain single-process one."""
         self.model = model
         self.optimizer = optimizer
         self.amp_dtype = amp_dtype
         self.clip_grad = clip_grad
-        self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.distributed = (dist.is_available() and dist.is_initialized()
+                            and (dist.get_world_size() > 1 or bool(force_distributed)))
         self.fwd_model = model
         self.buckets = None
+        if force_distributed and self.distributed:
+            from . import ops as _ops
+            _ops.FORCE_SYNC_BN = True
         if self.distributed:
             # train.py:338: BatchNorm layers (SuperGlue / GlueStick MLPs) use global-batch statistics;
             # ops.batch_norm_act all-reduces its sums when it sees a SyncBatchNorm module.
