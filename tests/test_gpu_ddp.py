@@ -176,3 +176,63 @@ def test_two_rank_superglue_syncbn_equals_single_process():
     model, data = _sg_model_and_data()
     checked, buffers = _check_syncbn_run(got, model, data)
     assert checked > 20 and buffers >= 10
+
+
+def _uneven_worker(rank, world, lock, out):
+    """Ranks with DIFFERENT row counts (3 pairs / 1 pair): the packed SyncBatchNorm exchange reduces the counts with the sums."""
+    from glue_factory_amd import ops
+    from glue_factory_amd.train_step import init_distributed
+    torch.cuda.set_device(0)
+    init_distributed("gloo", init_method="file://" + lock, rank=rank, world_size=world)
+    torch.manual_seed(13)
+    bn = torch.nn.SyncBatchNorm(256).cuda().train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+    g = torch.Generator(device="cuda").manual_seed(14)
+    x = torch.randn(2, 4 * 96, 256, device="cuda", generator=g) * 2 + 0.5        # [views, 4 pairs x 96 rows, C]
+    dy = torch.randn(2, 4 * 96, 256, device="cuda", generator=g)
+    lo, hi = (0, 3 * 96) if rank == 0 else (3 * 96, 4 * 96)
+    xs = x[:, lo:hi].contiguous().requires_grad_(True)
+    y = ops.batch_norm_act_sets(xs, bn, relu=True, replay=True)
+    y.backward(dy[:, lo:hi].contiguous())
+    torch.cuda.synchronize()
+    torch.save({"y": y.detach().cpu(), "dx": xs.grad.cpu(), "rm": bn.running_mean.cpu(), "rv": bn.running_var.cpu(),
+                "nbt": int(bn.num_batches_tracked), "dg": bn.weight.grad.cpu(), "db": bn.bias.grad.cpu()}, out + str(rank))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_syncbn_exchange_with_unequal_row_counts_per_rank():
+    """Statistics, running buffers (incl. the replayed update) and the input gradient of a two-rank call with 288 / 96 rows per
+    view equal torch's BatchNorm1d on the 384 rows in one process; dgamma / dbeta are the LOCAL sums (the reducer averages them)."""
+    with tempfile.TemporaryDirectory() as d:
+        lock, out = os.path.join(d, "distributed_lock"), os.path.join(d, "out.pt")
+        mp.spawn(_uneven_worker, args=(2, lock, out), nprocs=2, join=True)
+        got = [torch.load(out + str(r)) for r in range(2)]
+    torch.manual_seed(13)
+    ref = torch.nn.BatchNorm1d(256).cuda().train()
+    with torch.no_grad():
+        ref.weight.uniform_(0.5, 1.5)
+        ref.bias.uniform_(-0.5, 0.5)
+    g = torch.Generator(device="cuda").manual_seed(14)
+    x = (torch.randn(2, 4 * 96, 256, device="cuda", generator=g) * 2 + 0.5).requires_grad_(True)
+    dy = torch.randn(2, 4 * 96, 256, device="cuda", generator=g)
+    ys = []
+    for h in range(2):                     # one module call per view, as the reference does -- twice (checkpoint recompute)
+        ys.append(torch.relu(ref(x[h])))
+    torch.stack(ys).backward(dy)
+    with torch.no_grad():
+        for h in range(2):
+            ref(x[h].detach())
+    y_ref, dx_ref = torch.stack(ys).detach().cpu(), x.grad.cpu()
+    y = torch.cat([got[0]["y"], got[1]["y"]], 1)
+    dx = torch.cat([got[0]["dx"], got[1]["dx"]], 1)
+    torch.testing.assert_close(y, y_ref, rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(dx, dx_ref, rtol=1e-4, atol=2e-5)
+    for r in range(2):
+        torch.testing.assert_close(got[r]["rm"], ref.running_mean.cpu(), rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(got[r]["rv"], ref.running_var.cpu(), rtol=1e-5, atol=1e-6)
+        assert got[r]["nbt"] == int(ref.num_batches_tracked) == 4
+    torch.testing.assert_close(got[0]["dg"] + got[1]["dg"], ref.weight.grad.cpu(), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(got[0]["db"] + got[1]["db"], ref.bias.grad.cpu(), rtol=1e-4, atol=1e-4)
