@@ -197,7 +197,10 @@ def test_sharp_golden_integer_outputs_are_bit_exact(kind, bf16):
             check_la_digest(z, la, st, prefix=prefix, tol=1e-4)
         _check_losses(z, losses, 1e-4)
         grads = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
-        # (measured: SuperGlue 4.5e-5 / 1.6e-3, GlueStick 3.0e-4 / 4.3e-3 -- the damped case has tiny gradients in front of 18 layers)
+        # (measured: SuperGlue 4.5e-5 / 1.6e-3, GlueStick 3.0e-4 / 4.3e-3 -- the damped case has tiny gradients in front of 18 layers.
+        # The yardstick for the 6.5e-3: the CPU oracle -- fp32 torch ops, the reference's own arithmetic family -- differs from the
+        # reference's golden by 2.98e-4 (norm) / 4.25e-3 (sample) on the SAME tensor, lenc.encoder.0.weight, at 8 and at 3 threads
+        # (round 6, tests/test_oracle_golden.py's inputs): the fp32 conditioning of this gradient, not a kernel error.)
         _fp32_grads(z, grads, norm_tol=6e-4, sample_tol=2.5e-3 if kind == "superglue" else 6.5e-3)
     model.eval()
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16):
