@@ -157,10 +157,14 @@ struct TileArg {
 };
 
 // lse[b, owner] = log sum_s exp(own . oth_s + sbias_s)
-template <typename T, int D, bool HAS_BIAS>
+// STORE (round 6, csrc/head_cache.hip): the pass also writes the raw scores once, in fp16, as S[b][streamed row][owner row]
+// (p.out; a half wave = 32 consecutive owner rows = 64 contiguous bytes) -- the later passes of the head stream that matrix
+// instead of recomputing it on the matrix cores.
+template <typename T, int D, bool HAS_BIAS, bool STORE = false>
 __global__ __launch_bounds__(256) void rows_lse_kernel(HeadParams p) {
     GF_HEAD_PROLOGUE(T, D)
     float m = GF_NEG_BIG, lsum = 0.f;
+    _Float16* sout = STORE ? reinterpret_cast<_Float16*>(p.out) + (int64_t)b * p.Ns * p.No + orow : nullptr;
     const float* sb = p.sbias ? p.sbias + (int64_t)b * p.Ns : nullptr;
     auto bias = [&](int si, float& v0, float& v1) {
         const float x = sb ? sb[min(si, p.Ns - 1)] * GF_LOG2E : 0.f;
@@ -178,6 +182,14 @@ __global__ __launch_bounds__(256) void rows_lse_kernel(HeadParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
             mma_tile<T, D>(s[kb], tile, kb * 32, of, l31, hi);
+            if (STORE && orow < p.No) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int srow = s0 + kb * 32 + 8 * (r >> 2) + 4 * hi + (r & 3);
+                    if (plain || srow < p.Ns)
+                        sout[(int64_t)srow * p.No] = (_Float16)fminf(fmaxf(s[kb][r], -65504.f), 65504.f);
+                }
+            }
             if (plain) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
@@ -481,7 +493,7 @@ template <typename K> int set_lds(K kern, size_t bytes) {
     return 0;
 }
 
-enum { K_LSE, K_ARGMAX, K_WRITE, K_BWD, K_LSEARG, K_ZNARG };
+enum { K_LSE, K_ARGMAX, K_WRITE, K_BWD, K_LSEARG, K_ZNARG, K_LSE_STORE };
 
 template <typename T, int D> int launch_td(int which, const HeadParams& p, hipStream_t st) {
     const int total = ((p.No + 127) / 128) * p.B * (p.nsplit > 1 ? p.nsplit : 1);
@@ -501,6 +513,10 @@ template <typename T, int D> int launch_td(int which, const HeadParams& p, hipSt
                 if (int e = set_lds(rows_lse_kernel<T, D, false>, lds)) return e;
                 rows_lse_kernel<T, D, false><<<dim3(total), dim3(256), lds, st>>>(p);
             }
+            return (int)hipGetLastError();
+        case K_LSE_STORE:
+            if (int e = set_lds(rows_lse_kernel<T, D, false, true>, lds)) return e;
+            rows_lse_kernel<T, D, false, true><<<dim3(total), dim3(256), lds, st>>>(p);
             return (int)hipGetLastError();
         case K_ARGMAX: GF_LAUNCH(rows_argmax_kernel)
         case K_WRITE: GF_LAUNCH(assign_write_kernel)
@@ -543,6 +559,14 @@ extern "C" int gf_rows_lse(const void* a, const void* b, const float* colbias, f
     HeadParams p = {};
     p.own = a; p.oth = b; p.B = B; p.No = M; p.Ns = N; p.sbias = colbias; p.f0 = lse;
     return launch(K_LSE, p, D, dtype, stream);
+}
+
+extern "C" int gf_rows_lse_cache(const void* a, const void* b, float* lse, void* s16,
+                                 int B, int M, int N, int D, int dtype, void* stream) {
+    if (s16 == nullptr || lse == nullptr) return GF_ERR_SHAPE;
+    HeadParams p = {};
+    p.own = a; p.oth = b; p.B = B; p.No = M; p.Ns = N; p.f0 = lse; p.out = s16;
+    return launch(K_LSE_STORE, p, D, dtype, stream);
 }
 
 extern "C" int gf_rows_argmax(const void* a, const void* b, const float* colbias, float alpha,
