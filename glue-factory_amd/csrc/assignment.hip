@@ -164,7 +164,11 @@ template <typename T, int D, bool HAS_BIAS, bool STORE = false>
 __global__ __launch_bounds__(256) void rows_lse_kernel(HeadParams p) {
     GF_HEAD_PROLOGUE(T, D)
     float m = GF_NEG_BIG, lsum = 0.f;
-    _Float16* sout = STORE ? reinterpret_cast<_Float16*>(p.out) + (int64_t)b * p.Ns * p.No + orow : nullptr;
+    // staging tile of the score store: [64 streamed rows][128 owner columns + 8] fp16 behind the stream buffers, so that the
+    // global stores are 16-byte rows of the WORKGROUP's 128 columns (2-byte stores per lane cost 141 us per pass: measured)
+    constexpr int SLD = 136;
+    _Float16* stg = reinterpret_cast<_Float16*>(vecs + 256);
+    _Float16* sout = STORE ? reinterpret_cast<_Float16*>(p.out) + (int64_t)b * p.Ns * p.No + ob * 128 : nullptr;
     const float* sb = p.sbias ? p.sbias + (int64_t)b * p.Ns : nullptr;
     auto bias = [&](int si, float& v0, float& v1) {
         const float x = sb ? sb[min(si, p.Ns - 1)] * GF_LOG2E : 0.f;
@@ -182,13 +186,11 @@ __global__ __launch_bounds__(256) void rows_lse_kernel(HeadParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
             mma_tile<T, D>(s[kb], tile, kb * 32, of, l31, hi);
-            if (STORE && orow < p.No) {
+            if (STORE) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int srow = s0 + kb * 32 + 8 * (r >> 2) + 4 * hi + (r & 3);
-                    if (plain || srow < p.Ns)
-                        sout[(int64_t)srow * p.No] = (_Float16)fminf(fmaxf(s[kb][r], -65504.f), 65504.f);
-                }
+                for (int r = 0; r < 16; ++r)
+                    stg[(kb * 32 + 8 * (r >> 2) + 4 * hi + (r & 3)) * SLD + wave * 32 + l31] =
+                        (_Float16)fminf(fmaxf(s[kb][r], -65504.f), 65504.f);
             }
             if (plain) {
 #pragma unroll
@@ -204,6 +206,16 @@ __global__ __launch_bounds__(256) void rows_lse_kernel(HeadParams p) {
                         mx = fmaxf(mx, x);
                     }
                 }
+            }
+        }
+        if (STORE) {
+            __syncthreads();                                       // the staging tile is complete (all four waves' columns)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int ch = threadIdx.x + 256 * q, row = ch >> 4, cc = ch & 15;
+                if (s0 + row < p.Ns && ob * 128 + cc * 8 < p.No)
+                    *reinterpret_cast<u32x4*>(sout + (int64_t)(s0 + row) * p.No + cc * 8) =
+                        *reinterpret_cast<const u32x4*>(stg + row * SLD + cc * 8);
             }
         }
         if (plain) mx *= GF_LOG2E;
@@ -514,10 +526,13 @@ template <typename T, int D> int launch_td(int which, const HeadParams& p, hipSt
                 rows_lse_kernel<T, D, false><<<dim3(total), dim3(256), lds, st>>>(p);
             }
             return (int)hipGetLastError();
-        case K_LSE_STORE:
-            if (int e = set_lds(rows_lse_kernel<T, D, false, true>, lds)) return e;
-            rows_lse_kernel<T, D, false, true><<<dim3(total), dim3(256), lds, st>>>(p);
+        case K_LSE_STORE: {
+            if (p.No % 8) return GF_ERR_UNSUPPORTED;              // 16-byte row pieces
+            const size_t lds2 = lds + 64 * 136 * 2;               // + the staging tile of the score store
+            if (int e = set_lds(rows_lse_kernel<T, D, false, true>, lds2)) return e;
+            rows_lse_kernel<T, D, false, true><<<dim3(total), dim3(256), lds2, st>>>(p);
             return (int)hipGetLastError();
+        }
         case K_ARGMAX: GF_LAUNCH(rows_argmax_kernel)
         case K_WRITE: GF_LAUNCH(assign_write_kernel)
         case K_BWD: GF_LAUNCH(dual_softmax_bwd_kernel)

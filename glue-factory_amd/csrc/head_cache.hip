@@ -27,73 +27,71 @@ __device__ __forceinline__ void better(float& v, int& i, float ov, int oi) {
     i = take ? oi : i;
 }
 
-// ---- rows: one wave per row, RPB rows per workgroup; N % 8 == 0
-constexpr int CR_RPB = 8;
-template <bool WITH_LSE>
+// ---- rows: a wave walks CR_RPW consecutive rows; its lanes keep the biases of THEIR columns (16-byte chunks lane + 64 u) in
+// registers for all of them, and the next row's chunks are in flight while a row is reduced.  N % 512 == 0, N <= 2048.
+constexpr int CR_RPW = 16, CR_RPB = 4 * CR_RPW;
+template <int NK, bool WITH_LSE>
 __global__ __launch_bounds__(256) void cached_rows_kernel(const _Float16* __restrict__ S, const float* __restrict__ bz,
                                                           const float* __restrict__ bn, float alpha, float* __restrict__ lse,
                                                           float* __restrict__ rowmax, int64_t* __restrict__ rowarg,
-                                                          int B, int M, int N) {
-    extern __shared__ __attribute__((aligned(16))) float bias[];          // [N]: logsigmoid(z_j) - n_j
+                                                          int B, int M) {
+    constexpr int N = NK * 512;
     const int nrb = (M + CR_RPB - 1) / CR_RPB;
     const int b = blockIdx.x / nrb, rb = blockIdx.x % nrb;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int j = threadIdx.x; j < N; j += 256) bias[j] = logsigmoid_f(bz[(int64_t)b * N + j]) - bn[(int64_t)b * N + j];
-    __syncthreads();
-    const int nch = N >> 3;                                               // 16-byte chunks per row
-    for (int rr = 0; rr < CR_RPB / 4; ++rr) {
-        const int row = rb * CR_RPB + wave * (CR_RPB / 4) + rr;
-        if (row >= M) break;
-        const h16x8* sp = reinterpret_cast<const h16x8*>(S + ((int64_t)b * M + row) * N);
-        float m = GF_NEG_BIG, lsum = 0.f, best = -INFINITY;
-        int bidx = 0x7fffffff;
-        for (int c0 = 0; c0 < nch; c0 += 256) {                           // four chunks of a lane in flight
-            h16x8 v[4];
+    float bias[NK][8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int c = c0 + lane + 64 * u;
-                v[u] = c < nch ? sp[c] : h16x8{0, 0, 0, 0, 0, 0, 0, 0};
-            }
+    for (int u = 0; u < NK; ++u)
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int c = c0 + lane + 64 * u;
-                if (c >= nch) continue;
-                const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + 8 * c);
-                const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias + 8 * c + 4);
-                float x[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) x[e] = (float)v[u][e];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float val = fmaf(alpha, x[e], e < 4 ? b0[e] : b1[e - 4]);
-                    const bool gt = val > best;                            // ascending j inside a lane: strict > keeps the lowest
-                    best = gt ? val : best;
-                    bidx = gt ? 8 * c + e : bidx;
-                }
-                if (WITH_LSE) {
-                    float mx = fmaxf(fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])), fmaxf(fmaxf(x[4], x[5]), fmaxf(x[6], x[7])));
-                    const float mnew = fmaxf(m, mx * GF_LOG2E);
-                    float ps = 0.f;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) ps += fast_exp2(fmaf(x[e], GF_LOG2E, -mnew));
-                    lsum = lsum * fast_exp2(m - mnew) + ps;
-                    m = mnew;
-                }
-            }
+        for (int e = 0; e < 8; ++e) {
+            const int64_t j = (int64_t)b * N + 8 * (lane + 64 * u) + e;
+            bias[u][e] = logsigmoid_f(bz[j]) - bn[j];
         }
+    const int row0 = rb * CR_RPB + wave * CR_RPW;
+    if (row0 >= M) return;
+    const int nrow = min(CR_RPW, M - row0);
+    const h16x8* sp = reinterpret_cast<const h16x8*>(S + ((int64_t)b * M + row0) * N);
+    h16x8 cur[NK], nxt[NK];
+#pragma unroll
+    for (int u = 0; u < NK; ++u) cur[u] = sp[lane + 64 * u];
+    for (int rr = 0; rr < nrow; ++rr) {
+        const h16x8* np = sp + (int64_t)min(rr + 1, nrow - 1) * (N / 8);
+#pragma unroll
+        for (int u = 0; u < NK; ++u) nxt[u] = np[lane + 64 * u];
+        float best = -INFINITY, mx = GF_NEG_BIG;
+        int bidx = 0x7fffffff;
+        float x[NK][8];
+#pragma unroll
+        for (int u = 0; u < NK; ++u)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                x[u][e] = (float)cur[u][e];
+                const float val = fmaf(alpha, x[u][e], bias[u][e]);
+                const bool gt = val > best;                                // ascending j inside a lane: strict > keeps the lowest
+                best = gt ? val : best;
+                bidx = gt ? 8 * (lane + 64 * u) + e : bidx;
+                if (WITH_LSE) mx = fmaxf(mx, x[u][e]);
+            }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) better(best, bidx, __shfl_xor(best, off), __shfl_xor(bidx, off));
         float tot = 0.f, mall = 0.f;
         if (WITH_LSE) {
-            mall = wave_allmax(m);
-            tot = wave_allsum(lsum * fast_exp2(m - mall));
+            mall = wave_allmax(mx) * GF_LOG2E;
+            float ps = 0.f;
+#pragma unroll
+            for (int u = 0; u < NK; ++u)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ps += fast_exp2(fmaf(x[u][e], GF_LOG2E, -mall));
+            tot = wave_allsum(ps);
         }
         if (lane == 0) {
-            const int64_t o = (int64_t)b * M + row;
+            const int64_t o = (int64_t)b * M + row0 + rr;
             rowmax[o] = best;
             rowarg[o] = bidx == 0x7fffffff ? 0 : bidx;
             if (WITH_LSE) lse[o] = (mall + fast_log2(tot)) * GF_LN2;
         }
+#pragma unroll
+        for (int u = 0; u < NK; ++u) cur[u] = nxt[u];
     }
 }
 
@@ -220,23 +218,21 @@ extern "C" int gf_cached_rows_lse_argmax(const void* s16, const float* bias_z, c
                                          float* rowmax, int64_t* rowarg, int B, int M, int N, void* stream) {
     if (B <= 0 || M <= 0 || N <= 0 || s16 == nullptr || bias_z == nullptr || bias_n == nullptr || rowmax == nullptr ||
         rowarg == nullptr) return GF_ERR_SHAPE;
-    if (N % 8 || (size_t)N * 4 > 160 * 1024 - 1024) return GF_ERR_UNSUPPORTED;
+    if (N % 512 || N > 2048) return GF_ERR_UNSUPPORTED;
     if (reinterpret_cast<uintptr_t>(s16) & 15) return GF_ERR_ALIGN;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int grid = B * ((M + CR_RPB - 1) / CR_RPB);
-    const size_t lds = (size_t)N * 4;
     const _Float16* S = reinterpret_cast<const _Float16*>(s16);
-    if (lse) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cached_rows_kernel<true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        cached_rows_kernel<true><<<dim3(grid), dim3(256), lds, st>>>(S, bias_z, bias_n, alpha, lse, rowmax, rowarg, B, M, N);
-    } else {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cached_rows_kernel<false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        cached_rows_kernel<false><<<dim3(grid), dim3(256), lds, st>>>(S, bias_z, bias_n, alpha, lse, rowmax, rowarg, B, M, N);
+#define GF_CR(NK_)                                                                                                        \
+    case NK_:                                                                                                             \
+        if (lse) cached_rows_kernel<NK_, true><<<dim3(grid), dim3(256), 0, st>>>(S, bias_z, bias_n, alpha, lse, rowmax, rowarg, B, M); \
+        else cached_rows_kernel<NK_, false><<<dim3(grid), dim3(256), 0, st>>>(S, bias_z, bias_n, alpha, lse, rowmax, rowarg, B, M);   \
+        break;
+    switch (N / 512) {
+        GF_CR(1) GF_CR(2) GF_CR(3) GF_CR(4)
+        default: return GF_ERR_UNSUPPORTED;
     }
+#undef GF_CR
     return (int)hipGetLastError();
 }
 
