@@ -157,31 +157,10 @@ struct TileArg {
 };
 
 // lse[b, owner] = log sum_s exp(own . oth_s + sbias_s)
-// STORE (round 6, csrc/head_cache.hip): the pass also writes the raw scores once, in fp16, as S[b][streamed row][owner row]
-// (p.out; a half wave = 32 consecutive owner rows = 64 contiguous bytes) -- the later passes of the head stream that matrix
-// instead of recomputing it on the matrix cores.
-template <typename T, int D, bool HAS_BIAS, bool STORE = false>
+template <typename T, int D, bool HAS_BIAS>
 __global__ __launch_bounds__(256) void rows_lse_kernel(HeadParams p) {
     GF_HEAD_PROLOGUE(T, D)
     float m = GF_NEG_BIG, lsum = 0.f;
-    // staging tile of the score store: [64 streamed rows][128 owner columns + 8] fp16 behind the stream buffers, so that the
-    // global stores are 16-byte rows of the WORKGROUP's 128 columns (2-byte stores per lane cost 141 us per pass: measured)
-    // Double buffered: a tile's scores are parked in front of the loop's ONE barrier and leave for HBM at the top of the next
-    // iteration -- no barrier of its own.
-    constexpr int SLD = 136;
-    _Float16* stg0 = reinterpret_cast<_Float16*>(vecs + 256);
-    _Float16* sout = STORE ? reinterpret_cast<_Float16*>(p.out) + (int64_t)b * p.Ns * p.No + ob * 128 : nullptr;
-    int sprev = -1, sbuf = 0;
-    auto flush = [&](int s0f, int buf) {
-        const _Float16* stg = stg0 + buf * 64 * SLD;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int ch = threadIdx.x + 256 * q, row = ch >> 4, cc = ch & 15;
-            if (s0f + row < p.Ns && ob * 128 + cc * 8 < p.No)
-                *reinterpret_cast<u32x4*>(sout + (int64_t)(s0f + row) * p.No + cc * 8) =
-                    *reinterpret_cast<const u32x4*>(stg + row * SLD + cc * 8);
-        }
-    };
     const float* sb = p.sbias ? p.sbias + (int64_t)b * p.Ns : nullptr;
     auto bias = [&](int si, float& v0, float& v1) {
         const float x = sb ? sb[min(si, p.Ns - 1)] * GF_LOG2E : 0.f;
@@ -191,11 +170,6 @@ __global__ __launch_bounds__(256) void rows_lse_kernel(HeadParams p) {
     auto body = [&](const T* tile, const float* vec0, const float*, int s0) {
         f32x16 s[2];
         float mx = GF_NEG_BIG;
-        if (STORE) {
-            if (sprev >= 0) flush(sprev, sbuf ^ 1);
-            sprev = s0;
-        }
-        _Float16* stg = stg0 + sbuf * 64 * SLD;
         // without a bias (LightGlue's double softmax) the scores stay RAW: the maximum is taken on them and log2(e) and the
         // shift ride in the fma in front of exp2 -- max3, fma, exp2, add = 3.5 instructions per score instead of 5
         const bool plain = !HAS_BIAS && s0 + 64 <= p.Ns;
@@ -204,12 +178,6 @@ __global__ __launch_bounds__(256) void rows_lse_kernel(HeadParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
             mma_tile<T, D>(s[kb], tile, kb * 32, of, l31, hi);
-            if (STORE) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    stg[(kb * 32 + 8 * (r >> 2) + 4 * hi + (r & 3)) * SLD + wave * 32 + l31] =
-                        (_Float16)fminf(fmaxf(s[kb][r], -65504.f), 65504.f);
-            }
             if (plain) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
@@ -226,7 +194,6 @@ __global__ __launch_bounds__(256) void rows_lse_kernel(HeadParams p) {
                 }
             }
         }
-        if (STORE) sbuf ^= 1;
         if (plain) mx *= GF_LOG2E;
         mx = fmaxf(mx, xhalf(mx));
         const float mnew = fmaxf(m, mx);
@@ -240,7 +207,6 @@ __global__ __launch_bounds__(256) void rows_lse_kernel(HeadParams p) {
         m = mnew;
     };
     stream_tiles<T, D>(tiles, vecs, othp, 0, p.Ns, p.Ns, bias, body);
-    if (STORE && sprev >= 0) flush(sprev, sbuf ^ 1);               // (stream_tiles ends on a barrier)
     lsum += xhalf(lsum);
     if (orow < p.No && hi == 0) p.f0[(int64_t)b * p.No + orow] = (m + fast_log2(lsum)) * GF_LN2;
 }
@@ -515,7 +481,7 @@ template <typename K> int set_lds(K kern, size_t bytes) {
     return 0;
 }
 
-enum { K_LSE, K_ARGMAX, K_WRITE, K_BWD, K_LSEARG, K_ZNARG, K_LSE_STORE };
+enum { K_LSE, K_ARGMAX, K_WRITE, K_BWD, K_LSEARG, K_ZNARG };
 
 template <typename T, int D> int launch_td(int which, const HeadParams& p, hipStream_t st) {
     const int total = ((p.No + 127) / 128) * p.B * (p.nsplit > 1 ? p.nsplit : 1);
@@ -536,13 +502,6 @@ template <typename T, int D> int launch_td(int which, const HeadParams& p, hipSt
                 rows_lse_kernel<T, D, false><<<dim3(total), dim3(256), lds, st>>>(p);
             }
             return (int)hipGetLastError();
-        case K_LSE_STORE: {
-            if (p.No % 8) return GF_ERR_UNSUPPORTED;              // 16-byte row pieces
-            const size_t lds2 = lds + 2 * 64 * 136 * 2;           // + the two staging tiles of the score store
-            if (int e = set_lds(rows_lse_kernel<T, D, false, true>, lds2)) return e;
-            rows_lse_kernel<T, D, false, true><<<dim3(total), dim3(256), lds2, st>>>(p);
-            return (int)hipGetLastError();
-        }
         case K_ARGMAX: GF_LAUNCH(rows_argmax_kernel)
         case K_WRITE: GF_LAUNCH(assign_write_kernel)
         case K_BWD: GF_LAUNCH(dual_softmax_bwd_kernel)
@@ -584,14 +543,6 @@ extern "C" int gf_rows_lse(const void* a, const void* b, const float* colbias, f
     HeadParams p = {};
     p.own = a; p.oth = b; p.B = B; p.No = M; p.Ns = N; p.sbias = colbias; p.f0 = lse;
     return launch(K_LSE, p, D, dtype, stream);
-}
-
-extern "C" int gf_rows_lse_cache(const void* a, const void* b, float* lse, void* s16,
-                                 int B, int M, int N, int D, int dtype, void* stream) {
-    if (s16 == nullptr || lse == nullptr) return GF_ERR_SHAPE;
-    HeadParams p = {};
-    p.own = a; p.oth = b; p.B = B; p.No = M; p.Ns = N; p.f0 = lse; p.out = s16;
-    return launch(K_LSE_STORE, p, D, dtype, stream);
 }
 
 extern "C" int gf_rows_argmax(const void* a, const void* b, const float* colbias, float alpha,

@@ -27,10 +27,6 @@ SIGNATURES = {
     "gf_attn_bwd_acc": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I,
                         _S, _S, _S, _S, _S, _S, _S, _S, _F, _I, _I, _P],
     "gf_rows_lse": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "gf_rows_lse_cache": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "gf_cached_rows_lse_argmax": [_P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _P],
-    "gf_cached_cols_ws_bytes": [_I, _I, _I],
-    "gf_cached_cols_argmax": [_P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _P],
     "gf_rows_argmax": [_P, _P, _P, _F, _P, _P, _I, _I, _I, _I, _I, _P],
     "gf_assign_write": [_P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _I, _I, _I, _I, _I, _P],
     "gf_dual_softmax_bwd": [_P, _P, _P, _P, _P, _P, _P, _L, _F, _P, _I, _I, _I, _I, _I, _P],
@@ -105,7 +101,7 @@ SIGNATURES = {
     "gf_ln_gelu_nblk": [_I],
     "gf_ln_gelu_bwd": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
 }
-_RESTYPE = {"gf_sinkhorn_ws_bytes": _c.c_int64, "gf_linear_dw_ws_bytes": _c.c_int64, "gf_cached_cols_ws_bytes": _c.c_int64}
+_RESTYPE = {"gf_sinkhorn_ws_bytes": _c.c_int64, "gf_linear_dw_ws_bytes": _c.c_int64}
 
 _lib = None
 

@@ -1268,9 +1268,6 @@ def dual_lse_stacked(md):
     return _DualLSEStacked.apply(md)
 
 
-HEAD_CACHE_ENABLED = True      # per-layer heads: stream a cached fp16 S in the dependent passes (tools/probe/ab_matcher.py --switch ops.HEAD_CACHE_ENABLED)
-
-
 class _LGLayerLoss(torch.autograd.Function):
     """Partial sums acc [B,4] of one layer's deep-supervision loss (gf_lg_loss_fwd) from the batch-stacked
     head inputs md [2B,N,D], z [2B,N] (matchability logits), t [2B,N] (token-confidence logits or None).
@@ -1286,18 +1283,8 @@ class _LGLayerLoss(torch.autograd.Function):
         B = B2 // 2
         a, b = md[:B], md[B:]
         z = z.float().contiguous()
-        # bf16 mode, N a multiple of 512 up to 2048: the first pass also writes S = a b^T once in fp16 and the two dependent
-        # passes stream it instead of recomputing it on the matrix cores (csrc/head_cache.hip): 3 MFMA passes -> 1
-        cached = (HEAD_CACHE_ENABLED and rc is None and md.dtype == torch.bfloat16 and N % 512 == 0 and N <= 2048
-                  and D in (64, 128, 256))
-        s16 = None
         if rc is None:
-            if cached:
-                s16 = torch.empty((B, N, N), dtype=torch.float16, device=md.device)
-                c = torch.empty((B, N), dtype=torch.float32, device=md.device)
-                _lib.check(lib.gf_rows_lse_cache(_p(b), _p(a), _p(c), _p(s16), B, N, N, D, _dt(md), _stream()), "gf_rows_lse_cache")
-            else:
-                c = rows_lse(b, a)
+            c = rows_lse(b, a)
             r = None
         else:
             r, c = (x.detach().float().contiguous() for x in rc)
@@ -1313,19 +1300,11 @@ class _LGLayerLoss(torch.autograd.Function):
             want_r = r is None
             if want_r:
                 r = st[2]
-            if s16 is not None:
-                _lib.check(lib.gf_cached_rows_lse_argmax(_p(s16), _p(z[B:]), _p(c), 2.0, _p(r) if want_r else None, _p(v0), _p(a0),
-                                                         B, N, N, _stream()), "gf_cached_rows_lse_argmax")
-                if t is not None:
-                    ws = torch.empty(int(lib.gf_cached_cols_ws_bytes(B, N, N)), dtype=torch.uint8, device=md.device)
-                    _lib.check(lib.gf_cached_cols_argmax(_p(s16), _p(z[:B]), _p(r), 2.0, _p(v1), _p(a1), _p(ws), B, N, N,
-                                                         _stream()), "gf_cached_cols_argmax")
-            else:
-                _lib.check(lib.gf_rows_lse_argmax(_p(a), _p(b), _p(z[B:]), _p(c), 2.0, _p(r) if want_r else None,
-                                                  _p(v0), _p(a0), B, N, N, D, _dt(md), _stream()), "gf_rows_lse_argmax")
-                if t is not None:
-                    _lib.check(lib.gf_rows_lse_argmax(_p(b), _p(a), _p(z[:B]), _p(r), 2.0, None, _p(v1), _p(a1),
-                                                      B, N, N, D, _dt(md), _stream()), "gf_rows_lse_argmax")
+            _lib.check(lib.gf_rows_lse_argmax(_p(a), _p(b), _p(z[B:]), _p(c), 2.0, _p(r) if want_r else None,
+                                              _p(v0), _p(a0), B, N, N, D, _dt(md), _stream()), "gf_rows_lse_argmax")
+            if t is not None:
+                _lib.check(lib.gf_rows_lse_argmax(_p(b), _p(a), _p(z[:B]), _p(r), 2.0, None, _p(v1), _p(a1),
+                                                  B, N, N, D, _dt(md), _stream()), "gf_rows_lse_argmax")
         if t is not None:
             t = t.float().contiguous()
             tgt = torch.empty((B2, N), dtype=torch.float32, device=md.device)

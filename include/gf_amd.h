@@ -135,23 +135,6 @@ int gf_rows_argmax(const void* a, const void* b, const float* colbias, float alp
 int gf_rows_lse_argmax(const void* a, const void* b, const float* bias_z, const float* bias_n,
                        float alpha, float* lse, float* rowmax, int64_t* rowarg,
                        int B, int M, int N, int D, int dtype, void* stream);
-/* ---- assignment-head statistics from a CACHED similarity matrix (ABI 16, csrc/head_cache.hip; bf16 mode of the per-layer
- * heads of lightglue.py:256-268 / :81-94).  gf_rows_lse_cache = gf_rows_lse (no column bias) that ALSO writes the raw scores
- * once in fp16: s16[b][n][m] = a_m . b_n for the M owner rows a and the N streamed rows b (so with a = image-1 rows and
- * b = image-0 rows the cache is S[b][i][j], i over image 0).  The two dependent passes that follow read it instead of
- * recomputing it on the matrix cores:
- *   gf_cached_rows_lse_argmax: per row i of s16 [B, M, N]: lse_i = log sum_j exp S_ij (lse may be null) and (max, arg max)_j
- *     of alpha S_ij + logsigmoid(bias_z_j) - bias_n_j         (= gf_rows_lse_argmax with the image-0 rows as owner);
- *   gf_cached_cols_argmax: per column j: (max, arg max)_i of alpha S_ij + logsigmoid(bias_z_i) - bias_n_i; needs
- *     gf_cached_cols_ws_bytes(B, M, N) bytes of 16-byte aligned workspace; N % 512 == 0, N <= 2048.
- * Ties go to the lowest index.  N % 8 == 0; other shapes: GF_ERR_UNSUPPORTED (callers keep the recomputing kernels). */
-int gf_rows_lse_cache(const void* a, const void* b, float* lse, void* s16, int B, int M, int N, int D, int dtype,
-                      void* stream);
-int gf_cached_rows_lse_argmax(const void* s16, const float* bias_z, const float* bias_n, float alpha, float* lse,
-                              float* rowmax, int64_t* rowarg, int B, int M, int N, void* stream);
-int64_t gf_cached_cols_ws_bytes(int B, int M, int N);
-int gf_cached_cols_argmax(const void* s16, const float* bias_z, const float* bias_n, float alpha, float* colmax,
-                          int64_t* colarg, void* ws, int B, int M, int N, void* stream);
 
 /* gf_assign_write: materialise the log assignment (lightglue.py:256-268)
  *   out[b,i,j] = alpha*S_ij + rowbias[b,i] + colbias[b,j]      i<M, j<N
