@@ -756,9 +756,10 @@ extern "C" int gf_sinkhorn_fwd(const float* Z, float* out, float* u_hist, float*
         if (g.fast) {
             if (iters > 0) {
                 const size_t nv4 = (size_t)bc * g.R * (g.Cp >> 2);
-                skf_prescale<<<dim3((unsigned)((nv4 + 255) / 256)), 256, 0, st>>>(Z + b0 * zs, w.zp, g, bc * g.R);
-                if (resident) {                       // the chunk stays on the chip for all iterations
-                    SkrArgs ra{};
+                if (!resident) skf_prescale<<<dim3((unsigned)((nv4 + 255) / 256)), 256, 0, st>>>(Z + b0 * zs, w.zp, g, bc * g.R);
+                if (resident) {                       // the chunk stays on the chip for all iterations; it is loaded from the
+                    SkrArgs ra{};                     // couplings themselves and writes `out` from its last iteration (round 6)
+                    ra.Zraw = Z + b0 * zs; ra.out = out + b0 * zs;
                     ra.Zp = w.zp; ra.part = w.part; ra.ctr = w.ctr;
                     ra.colA = w.a2p; ra.colB = w.vbp;                 // 16-byte aligned [B, Cp] scratch (free in the forward)
                     ra.u_hist = u_hist + (size_t)b0 * g.R; ra.v_hist = v_hist + (size_t)b0 * g.C;
@@ -798,7 +799,9 @@ extern "C" int gf_sinkhorn_fwd(const float* Z, float* out, float* u_hist, float*
                     v_hist + ((size_t)it * B + b0) * g.C, g);
             }
         }
-        // out = Z + u + v - norm with the final iterates (natural-log units = the last history entries)
+        // out = Z + u + v - norm with the final iterates (natural-log units = the last history entries); the resident kernel
+        // has written it already
+        if (!(g.fast && iters > 0 && resident))
         sk_final_fwd<<<dim3((g.C + 255) / 256, g.R, bc), 256, 0, st>>>(
             Z + b0 * zs, iters ? u_hist + ((size_t)(iters - 1) * B + b0) * g.R : nullptr,
             iters ? v_hist + ((size_t)(iters - 1) * B + b0) * g.C : nullptr, out + b0 * zs, g);

@@ -50,7 +50,10 @@ struct SkrPlan {
 };
 
 struct SkrArgs {
-    const float* Zp;            // [bc, R, Cp] prescaled padded copy
+    const float* Zraw;          // forward, round 6: the couplings themselves [bc, R, C] -- scaled by log2(e) while they are loaded,
+                                // rows only 4-byte aligned (C = N + 1): no pre-scaled padded copy is made for the resident forward
+    float* out;                 // forward, round 6: out = Z + u + v - norm written by the kernel's last iteration (null: not fused)
+    const float* Zp;            // backward: [bc, R, Cp] prescaled padded copy
     float* part;                // [bc, nw, Cp] per-wave column partials
     unsigned* ctr;              // [4 SKR_MAX_BC]: barrier counters, failure flags, XCD masks, same-XCD counters; zeroed before the launch
     int safe_only;              // 1: placement-independent (write-through) hand-offs even when a pair sits on one XCD
@@ -92,6 +95,18 @@ __device__ __forceinline__ void skr_st(__amdgpu_buffer_rsrc_t r, unsigned byte_o
 __device__ __forceinline__ void skr_pub(__amdgpu_buffer_rsrc_t r, unsigned byte_off, f32x4 v, bool same_xcd) {
     if (same_xcd) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(skr_u32x4, v), r, byte_off, 0, 0);
     else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(skr_u32x4, v), r, byte_off, 0, 17);
+}
+
+// 16 bytes at a 4-byte aligned address (rows of the [R, N + 1] couplings): one global_load / global_store_dwordx4
+struct __attribute__((packed, aligned(4))) SkrF4u { float v[4]; };
+__device__ __forceinline__ f32x4 skr_ldu(const float* p) {
+    const SkrF4u u = *reinterpret_cast<const SkrF4u*>(p);
+    return f32x4{u.v[0], u.v[1], u.v[2], u.v[3]};
+}
+__device__ __forceinline__ void skr_stu(float* p, f32x4 x) {
+    SkrF4u u;
+    u.v[0] = x[0]; u.v[1] = x[1]; u.v[2] = x[2]; u.v[3] = x[3];
+    *reinterpret_cast<SkrF4u*>(p) = u;
 }
 
 // L1-bypassing load of one word (the poll of the same-XCD counter: a plain load could be served by this CU's L1 for ever)
@@ -242,19 +257,26 @@ __global__ __launch_bounds__(256, 1) void skr_kernel(const SkrArgs a) {
         __hip_atomic_fetch_or(ctr + 2 * SKR_MAX_BC, 1u << (xcc & 15u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 
-    // ---- one-time load of the wave's rows
-    const float* zb = a.Zp + ((size_t)pair * g.R + row0) * g.Cp;
+    // ---- one-time load of the wave's rows.  Forward: straight from the couplings (scaled by log2 e here: no pre-scaled
+    // copy, 2 x 537 MB of traffic and a launch per chunk less); backward: from the padded pre-scaled copy.
+    const bool raw = !BWD && a.Zraw != nullptr;
+    const size_t zld = raw ? (size_t)g.C : (size_t)g.Cp;
+    const float* zb = (raw ? a.Zraw : a.Zp) + ((size_t)pair * g.R + row0) * zld;
+    const f32x4 zsc = splat4(raw ? GF_LOG2E : 1.f);
     f32x4 zr[SKR_RR][NSM];
 #pragma unroll
     for (int r = 0; r < SKR_RR; ++r)
 #pragma unroll
         for (int k = 0; k < NSM; ++k)
-            zr[r][k] = r < nreg ? *reinterpret_cast<const f32x4*>(zb + (size_t)r * g.Cp + 4 * (lane + 64 * k)) : splat4(0.f);
+            zr[r][k] = r < nreg ? (raw ? skr_ldu(zb + (size_t)r * zld + 4 * (lane + 64 * k))
+                                       : *reinterpret_cast<const f32x4*>(zb + (size_t)r * zld + 4 * (lane + 64 * k))) * zsc
+                                : splat4(0.f);
     for (int r = 0; r < nlds; ++r)
 #pragma unroll
         for (int k = 0; k < NSM; ++k)
-            zw[r * N4 + lane + 64 * k] = *reinterpret_cast<const f32x4*>(zb + (size_t)(SKR_RR + r) * g.Cp + 4 * (lane + 64 * k));
-    const float ztl = lane < nrows ? zb[(size_t)lane * g.Cp + 4 * N4] : 0.f;      // dustbin column of row `lane`
+            zw[r * N4 + lane + 64 * k] = (raw ? skr_ldu(zb + (size_t)(SKR_RR + r) * zld + 4 * (lane + 64 * k))
+                                              : *reinterpret_cast<const f32x4*>(zb + (size_t)(SKR_RR + r) * zld + 4 * (lane + 64 * k))) * zsc;
+    const float ztl = lane < nrows ? zb[(size_t)lane * zld + 4 * N4] * (raw ? GF_LOG2E : 1.f) : 0.f;      // dustbin column of row `lane`
     const int gil = row0 + lane;                                                  // the row this lane keeps scalars of
     const float lmu2l = lmu(g, gil) * GF_LOG2E;
 
@@ -435,7 +457,35 @@ __global__ __launch_bounds__(256, 1) void skr_kernel(const SkrArgs a) {
         if (same_xcd) skr_barrier(ctr, ++nbar2 * (unsigned)a.d.wpp, a.wait_ticks, true);
         else skr_barrier(ctr, ++nbar * (unsigned)a.d.wpp, a.wait_ticks);
 
-        if (it + 1 < a.iters) pull_columns();
+        if (it + 1 < a.iters || (!BWD && a.out != nullptr)) pull_columns();
+    }
+    // ---- forward, fused final pass: out = Z + u^T + v^T - norm from the resident rows, the wave's own u and the final column
+    // vector just pulled (all in log2 units until the last multiply) -- the couplings are not read a second time
+    if (!BWD && a.out != nullptr && a.iters > 0) {
+        const bool failed = __hip_atomic_load(ctr + SKR_MAX_BC, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+        const float qnan = __builtin_nanf("");
+        float* ob = a.out + ((size_t)pair * g.R + row0) * g.C;
+        const float vt = misc[0];
+        auto put_row = [&](const f32x4 (&z)[NSM], int r) {
+            const float ur = skr_lane(ul, r);
+            const f32x4 us = splat4(ur), ln2 = splat4(GF_LN2), nm = splat4(g.norm);
+#pragma unroll
+            for (int k = 0; k < NSM; ++k) {
+                f32x4 o = (z[k] + us + vA[lane + 64 * k]) * ln2 - nm;
+                if (failed) o = splat4(qnan);
+                skr_stu(ob + (size_t)r * g.C + 4 * (lane + 64 * k), o);
+            }
+        };
+#pragma unroll
+        for (int r = 0; r < SKR_RR; ++r)
+            if (r < nreg) put_row(zr[r], r);
+        for (int r = 0; r < nlds; ++r) {
+            f32x4 zz[NSM];
+#pragma unroll
+            for (int s_ = 0; s_ < NSM; ++s_) zz[s_] = zw[r * N4 + lane + 64 * s_];
+            put_row(zz, SKR_RR + r);
+        }
+        if (lane < nrows) ob[(size_t)lane * g.C + 4 * N4] = failed ? qnan : (ztl + ul + vt) * GF_LN2 - g.norm;
     }
     // a wait of this pair expired (see the header): poison the iterate the final passes read -- forward: u^T of this wave's
     // rows (out = Z + u + v - norm), backward: ubar^1 (a column of the rank-2T factor P of dZ = G - E o (P Q^T))
