@@ -845,14 +845,13 @@ extern "C" int gf_sinkhorn_bwd(const float* Z, const float* gout, const float* g
         const int bc = (B - b0) < ch ? (B - b0) : ch;
         if (g.fast) {
             const size_t nv4 = (size_t)bc * g.R * (g.Cp >> 2);
-            if (!resident) skf_prescale<<<dim3((unsigned)((nv4 + 255) / 256)), 256, 0, st>>>(Z + b0 * zs, w.zp, g, bc * g.R);
+            skf_prescale<<<dim3((unsigned)((nv4 + 255) / 256)), 256, 0, st>>>(Z + b0 * zs, w.zp, g, bc * g.R);
             const int ns = ((g.Cp >> 2) + 63) / 64;
             float* part = w.part + (size_t)b0 * g.nblk * g.Cp;
             int rc = resident ? [&]() -> int {
                 skf_bwd_prep<<<dim3((g.Cp + 255) / 256, bc), 256, 0, st>>>(
                     v_hist + ((size_t)(iters - 1) * B + b0) * g.C, gsum_col + (size_t)b0 * g.C, w.a2p, w.vbp, g);
                 SkrArgs ra{};
-                ra.Zraw = Z + b0 * zs;                // (the resident sweep scales the couplings as it loads them)
                 ra.Zp = w.zp; ra.part = w.part; ra.ctr = w.ctr;
                 ra.colA = w.a2p; ra.colB = w.vbp;
                 ra.u_hist = const_cast<float*>(u_hist) + (size_t)b0 * g.R;

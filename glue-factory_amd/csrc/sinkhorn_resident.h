@@ -50,10 +50,10 @@ struct SkrPlan {
 };
 
 struct SkrArgs {
-    const float* Zraw;          // round 6: the couplings themselves [bc, R, C] -- scaled by log2(e) while they are loaded, rows only
-                                // 4-byte aligned (C = N + 1): the resident sweeps need no pre-scaled padded copy
+    const float* Zraw;          // forward, round 6: the couplings themselves [bc, R, C] -- scaled by log2(e) while they are loaded,
+                                // rows only 4-byte aligned (C = N + 1): no pre-scaled padded copy is made for the resident forward
     float* out;                 // forward, round 6: out = Z + u + v - norm written by the kernel's last iteration (null: not fused)
-    const float* Zp;            // (Zraw == null) [bc, R, Cp] prescaled padded copy
+    const float* Zp;            // backward: [bc, R, Cp] prescaled padded copy
     float* part;                // [bc, nw, Cp] per-wave column partials
     unsigned* ctr;              // [4 SKR_MAX_BC]: barrier counters, failure flags, XCD masks, same-XCD counters; zeroed before the launch
     int safe_only;              // 1: placement-independent (write-through) hand-offs even when a pair sits on one XCD
@@ -257,9 +257,11 @@ __global__ __launch_bounds__(256, 1) void skr_kernel(const SkrArgs a) {
         __hip_atomic_fetch_or(ctr + 2 * SKR_MAX_BC, 1u << (xcc & 15u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 
-    // ---- one-time load of the wave's rows, straight from the couplings (scaled by log2 e here: no pre-scaled copy, 2 x 537 MB
-    // of traffic and a launch per chunk less in either direction)
-    const bool raw = a.Zraw != nullptr;
+    // ---- one-time load of the wave's rows.  Forward: straight from the couplings (scaled by log2 e here: no pre-scaled
+    // copy, 2 x 537 MB of traffic and a launch per chunk less); backward: from the padded pre-scaled copy.
+    // (forward only: measured in the backward too -- 7.91 -> 8.02 ms, the 4-byte aligned 16-byte loads cost more than the copy
+    // they replace when there is no fused final pass to pay for them)
+    const bool raw = !BWD && a.Zraw != nullptr;
     const size_t zld = raw ? (size_t)g.C : (size_t)g.Cp;
     const float* zb = (raw ? a.Zraw : a.Zp) + ((size_t)pair * g.R + row0) * zld;
     const f32x4 zsc = splat4(raw ? GF_LOG2E : 1.f);
