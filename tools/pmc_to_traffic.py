@@ -92,13 +92,13 @@ out = {"gf_attn_bwd": group(["attn_bwd", "attn_dq3"], "attn_dq3"), "attn_fwd_ker
        "rows_lse_kernel": group(["rows_lse_kernel"], "rows_lse_kernel"), "head_bwd_bf16_kernel": group(["head_bwd_bf16"], "head_bwd_bf16"),
        "linear_dw_dma_kernel": group(["linear_dw_dma", "linear_dw_reduce"], "linear_dw_dma"),
        "ln_gelu_fwd_kernel": group(["ln_gelu_fwd"], "ln_gelu_fwd"),
-       # N <= 2304: the register-resident "skf_" kernels (one launch = prescale + T iterations + final pass)
-       "gf_sinkhorn_fwd": group(["sk_rows_fwd", "sk_cols_fwd", "sk_final_fwd", "sk_fwd", "skf_fwd_iter", "skf_cols_fwd", "skr_kernel<8, false>",
-                                 "skr_reset"],
-                                "sk_final_fwd", half=["skf_prescale"], launches=SINKHORN_CALLS),
+       # chip-resident sweeps (round 6): the forward loads the couplings itself and writes `out` from its last iteration -- no
+       # prescale, no final pass; the backward keeps its pre-scaled copy (skf_prescale is the backward's alone now)
+       "gf_sinkhorn_fwd": group(["sk_rows_fwd", "sk_cols_fwd", "sk_final_fwd", "sk_fwd", "skf_fwd_iter", "skf_cols_fwd", "skr_kernel<8, false>"],
+                                "skr_kernel<8, false>", half=["skr_reset"], launches=SINKHORN_CALLS),
        "gf_sinkhorn_bwd": group(["sk_rows_bwd", "sk_cols_bwd", "sk_final_bwd", "sk_bwd", "skf_bwd_iter", "skf_cols_bwd",
-                                 "skf_bwd_prep", "skf_factors", "skf_final_bwd", "skr_kernel<8, true>"], "skf_final_bwd",
-                                half=["skf_prescale"], launches=SINKHORN_CALLS)}
+                                 "skf_bwd_prep", "skf_factors", "skf_final_bwd", "skr_kernel<8, true>", "skf_prescale"], "skf_final_bwd",
+                                half=["skr_reset"], launches=SINKHORN_CALLS)}
 out = {k: v for k, v in out.items() if v}
 import hashlib
 try:      # (no git on the GPU box: the build is identified by the library it measured)
