@@ -256,8 +256,10 @@ def roofline_hbm(batch, n, dtype, sinkhorn_iters=100):
             e.update({"bound": "hbm", "achieved": round(byt / t / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                       "frac": round(byt / t / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_launch": byt})
         return e
-    note = ("resident path: `frac` = exp2 evaluations per second / the transcendental peak (19.7 T/s); `traffic` (PMC) is ~2 sweeps of "
-            "the couplings per LAUNCH plus the write-through partial rows, not per iteration.  `hbm_accounting` keeps the figures of "
+    note = ("resident path: `frac` = exp2 evaluations per second / the transcendental peak (19.7 T/s); `traffic` (PMC) is per CALL, not per "
+            "iteration: forward = one read of the couplings + one write of the output (the resident kernel loads Z itself and writes `out` "
+            "from its last iteration) plus the published partial rows; backward = the pre-scaled copy, the rank-2T product's reads and the "
+            "partial rows.  `hbm_accounting` keeps the figures of "
             "a kernel that streams the couplings (one fp32 sweep per iteration; SURVEY 8(d) counts two) for comparison with earlier "
             "rounds -- an accounting figure, not a bound")
     out["sinkhorn_fwd"] = sk_entry("gf_sinkhorn_fwd", t)
