@@ -49,8 +49,15 @@ print("worker done", mode, losses)
 '''
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        return str(s_.getsockname()[1])
+
+
 def _run(mode, out):
-    env = dict(os.environ, GF_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+    env = dict(os.environ, GF_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port(), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     if mode == "rccl":
         env["GF_FORCE_DIST"] = "1"
@@ -83,7 +90,7 @@ def test_one_rank_rccl_step_with_captured_collectives_equals_the_plain_step():
 def test_bench_multi_rank_code_path_over_rccl_one_rank():
     """`bench.py --gpus N`'s N > 1 branch -- eager measurement first, the captured step under the watchdog, the data_parallel
     report with its measured all-reduce -- in a one-rank RCCL group (GF_FORCE_DIST=1)."""
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port(), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
                GF_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
                         "--matcher-only", "--batch", "4", "--kpts", "512", "--layers", "2"],
