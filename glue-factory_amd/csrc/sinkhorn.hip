@@ -577,34 +577,62 @@ __global__ __launch_bounds__(256) void skf_factors(const float* __restrict__ u_h
     }
 }
 
-// grid (ceil(C/64) * ceil(R/64), Bc), 256 threads: one wave = one 32 x 32 tile of the 64 x 64 block
+// grid (ceil(C/128) * ceil(R/128), Bc), 256 threads: one wave = a 64 x 64 block (2 x 2 MFMA tiles) of the workgroup's 128 x 128,
+// the factor fragments of the next k-step in flight under the current one's MFMAs.  (Round 6: was one 32 x 32 tile per wave with
+// the loads in front of their MFMAs -- ablations of that form: 0.97 of its 1.46 ms per step were the product, against 0.34 ms at
+// the exact-fp32 MFMA rate; prefetching took 0.15 ms off the call, sharing every fragment between two tiles another 0.12:
+// 7.96 -> 7.71 ms backward at B = 32, T = 100, bit-identical -- the summation order over k is unchanged.)
 __global__ __launch_bounds__(256) void skf_final_bwd(const float* __restrict__ Z, const float* __restrict__ G,
                                                      const float* __restrict__ P, const float* __restrict__ Q,
                                                      const float* __restrict__ uT, const float* __restrict__ vT,
                                                      float* __restrict__ gZ, int KP, Geo g) {
-    const int ncb = (g.C + 63) / 64;
+    const int ncb = (g.C + 127) / 128;
     const int b = blockIdx.y, rb = blockIdx.x / ncb, cb = blockIdx.x % ncb;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int i0 = rb * 64 + (wave >> 1) * 32, j0 = cb * 64 + (wave & 1) * 32;
+    const int i0 = rb * 128 + (wave >> 1) * 64, j0 = cb * 128 + (wave & 1) * 64;
     if (i0 >= g.R || j0 >= g.C) return;
-    const float* prow = P + ((size_t)b * g.R + min(i0 + l31, g.R - 1)) * KP + 8 * hi;
-    const float* qrow = Q + ((size_t)b * g.C + min(j0 + l31, g.C - 1)) * KP + 8 * hi;
-    f32x16 acc;
+    const float* prow[2];
+    const float* qrow[2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    for (int s_ = 0; s_ < KP; s_ += 16) mma32(acc, ld_frag8(prow + s_), ld_frag8(qrow + s_));
-    const int j = j0 + l31;
-    if (j >= g.C) return;
-    const float cj = vT[(size_t)b * g.C + j] - lnu(g, j);
+    for (int t = 0; t < 2; ++t) {
+        prow[t] = P + ((size_t)b * g.R + min(i0 + 32 * t + l31, g.R - 1)) * KP + 8 * hi;
+        qrow[t] = Q + ((size_t)b * g.C + min(j0 + 32 * t + l31, g.C - 1)) * KP + 8 * hi;
+    }
+    f32x16 acc[2][2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int i = i0 + crow(r, hi);
-        if (i < g.R) {
-            const size_t idx = ((size_t)b * g.R + i) * g.C + j;
-            const float E = __expf(Z[idx] + uT[(size_t)b * g.R + i] + cj);
-            gZ[idx] = G[idx] - E * acc[r];
-        }
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ti][tj][r] = 0.f;
+    Frag<float> p0 = ld_frag8(prow[0]), p1 = ld_frag8(prow[1]), q0 = ld_frag8(qrow[0]), q1 = ld_frag8(qrow[1]);
+    for (int s_ = 0; s_ < KP; s_ += 16) {
+        const int sn = min(s_ + 16, KP - 16);                       // (the last step re-fetches itself: no branch)
+        const Frag<float> p0n = ld_frag8(prow[0] + sn), p1n = ld_frag8(prow[1] + sn);
+        const Frag<float> q0n = ld_frag8(qrow[0] + sn), q1n = ld_frag8(qrow[1] + sn);
+        mma32(acc[0][0], p0, q0);
+        mma32(acc[0][1], p0, q1);
+        mma32(acc[1][0], p1, q0);
+        mma32(acc[1][1], p1, q1);
+        p0 = p0n; p1 = p1n; q0 = q0n; q1 = q1n;
+    }
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj) {
+        const int j = j0 + 32 * tj + l31;
+        if (j >= g.C) continue;
+        const float cj = vT[(size_t)b * g.C + j] - lnu(g, j);
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = i0 + 32 * ti + crow(r, hi);
+                if (i < g.R) {
+                    const size_t idx = ((size_t)b * g.R + i) * g.C + j;
+                    const float E = __expf(Z[idx] + uT[(size_t)b * g.R + i] + cj);
+                    gZ[idx] = G[idx] - E * acc[ti][tj][r];
+                }
+            }
     }
 }
 
@@ -892,7 +920,7 @@ extern "C" int gf_sinkhorn_bwd(const float* Z, const float* gout, const float* g
             skf_factors<<<dim3((max(g.R, g.C) + 255) / 256, iters, bc), 256, 0, st>>>(
                 u_hist + (size_t)b0 * g.R, v_hist + (size_t)b0 * g.C, ubar_hist + (size_t)b0 * g.R,
                 vbar_hist + (size_t)b0 * g.C, w.P, w.Q, iters, w.KP, (size_t)B * g.R, (size_t)B * g.C, g);
-            skf_final_bwd<<<dim3(((g.C + 63) / 64) * ((g.R + 63) / 64), bc), 256, 0, st>>>(
+            skf_final_bwd<<<dim3(((g.C + 127) / 128) * ((g.R + 127) / 128), bc), 256, 0, st>>>(
                 Z + b0 * zs, gout + b0 * zs, w.P, w.Q, u_hist + ((size_t)(iters - 1) * B + b0) * g.R,
                 v_hist + ((size_t)(iters - 1) * B + b0) * g.C, gZ + b0 * zs, w.KP, g);
         } else {
