@@ -64,12 +64,16 @@ def make_pairs(batch, n0, n1=None, dim=256, size=(1024, 1024), seed=0, frac_matc
     return data
 
 
-def to_device(data, device, non_blocking=True):
+def to_device(data, device, non_blocking=None):
     """Recursive .to(device) (the role of gluefactory/utils/tensor.py batch_to_device)."""
     if isinstance(data, dict):
         return {k: to_device(v, device, non_blocking) for k, v in data.items()}
     if torch.is_tensor(data):
-        return data.to(device, non_blocking=non_blocking)
+        # non_blocking=None: asynchronous only where that is safe -- pinned host memory or a device source.  An asynchronous
+        # copy from PAGEABLE host memory on ROCm reads the source AFTER the call returned: a batch that is freed or refilled
+        # right away (this module's own make_pairs loop) reaches the device corrupted now and then (round 6).
+        nb = (data.device.type != "cpu" or data.is_pinned()) if non_blocking is None else non_blocking
+        return data.to(device, non_blocking=nb)
     return data
 
 

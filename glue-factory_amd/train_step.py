@@ -371,8 +371,17 @@ def _to_device_tree(data, device):
     if isinstance(data, dict):
         return {k: _to_device_tree(v, device) for k, v in data.items()}
     if torch.is_tensor(data) and data.device != device:
-        return data.to(device, non_blocking=True)
+        return data.to(device, non_blocking=_async_ok(data))
     return data
+
+
+def _async_ok(src):
+    """May a copy FROM `src` be issued without waiting for it?  Device tensors: yes (stream-ordered).  Host tensors: only
+    PINNED ones -- torch's pinned allocator holds a pinned block until the copies recorded on it have run, whereas an
+    asynchronous copy from PAGEABLE memory on ROCm reads the source after the call returned: a caller that frees or refills
+    the batch afterwards (any Python loop that builds the next batch) corrupts the one in flight.  Found in round 6 as
+    run-to-run noise of the learning-curve test (tests/test_gpu_zz_learning.py fed pageable batches with non_blocking=True)."""
+    return src.device.type != "cpu" or src.is_pinned()
 
 
 def _clone_tree(data):
@@ -388,7 +397,7 @@ def _copy_into(static, data):
         if isinstance(v, dict):
             _copy_into(static[k], v)
         elif torch.is_tensor(v) and static[k] is not v:
-            static[k].copy_(v, non_blocking=True)
+            static[k].copy_(v, non_blocking=_async_ok(v))
 
 
 def reduce_losses(losses, dst=0):

@@ -70,7 +70,7 @@ def _model(kind):
 
 def _batch(kind, seed):
     from glue_factory_amd.synthetic import to_device
-    return to_device(lc.batch(kind, seed), "cuda")
+    return to_device(lc.batch(kind, seed), "cuda")      # (pageable host batches: copied synchronously, see synthetic.to_device)
 
 
 def _evaluate(kind, model, bf16, mode="eval"):
