@@ -173,8 +173,15 @@ class TrainStep:
 
     def __init__(self, model, optimizer, amp_dtype=None, clip_grad=None, device_ids=None,
                  bucket_cap_mb=16, find_unused_parameters=False, check_grads=True, graph=False, graph_warmup=2,
-                 reducer="buckets", force_distributed=False):
-        """force_distributed: take the multi-rank path (SyncBatchNorm conversion, gradient reducer, collectives) in a process
+                 reducer="buckets", force_distributed=False, deterministic_replay=False):
+        """deterministic_replay: wait for every hipGraph replay before returning.  A replayed step is bit-reproducible when it is
+        left alone, but on ROCm 7.2 what the HOST does while a replay is in flight can change its result at the rounding level --
+        measured (round 6, profiles/r06_graph_replay_determinism.txt): a blocking host-to-device copy from PAGEABLE memory
+        issued right after the replay was launched (any loop that builds and uploads the next batch) moves a SuperGlue /
+        GlueStick run off the eager run's numbers within a few steps (first in a parameter whose gradient is analytically
+        zero, which Adam amplifies), while the same loop launched kernel by kernel, or with this flag, reproduces the eager run
+        bit for bit.  Costs the overlap of host work with the step; the benchmark and training default leave it off.
+        force_distributed: take the multi-rank path (SyncBatchNorm conversion, gradient reducer, collectives) in a process
         group of ONE rank too -- how the RCCL calls of that path are exercised on a single-GPU box (tests/test_gpu_rccl_one_rank.py);
         every collective is then the identity, so the step must equal the plain single-process one."""
         self.model = model
@@ -214,6 +221,7 @@ class TrainStep:
         self._skipped_host = 0
         self._skipped_dev = None
         self.last_collectives = None
+        self.deterministic_replay = bool(deterministic_replay)
         # hipGraph replay of the whole step (forward, loss, backward, optimiser): ~1200 launches per LightGlue step
         # leave a few per cent of the GPU idle between kernels when they are issued one by one.  Needs: single
         # process (no DDP hooks inside a capture), a fused + capturable optimiser, no host synchronisation in the
@@ -265,6 +273,8 @@ class TrainStep:
         if sync_lr is not None:     # the reference steps its lr scheduler every iteration (train.py:517): the captured Adam
             sync_lr()               # reads a DEVICE scalar, refreshed here (a fill kernel in front of the replay, only on change)
         g.replay()
+        if self.deterministic_replay:       # see __init__: the host does nothing else while the replay runs
+            torch.cuda.current_stream().synchronize()
         from . import ops as _ops       # parameters changed behind the precast cache's back (no version bump)
         _ops.invalidate_precast()
         return static_out

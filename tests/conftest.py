@@ -38,6 +38,8 @@ def test_probe():
         _probe = ctypes.CDLL(build_test_probe())
         _probe.gf_test_hold_cus.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
         _probe.gf_test_hold_cus.restype = ctypes.c_int
+        _probe.gf_test_dirty_lds.argtypes = [ctypes.c_int, ctypes.c_uint, ctypes.c_void_p]
+        _probe.gf_test_dirty_lds.restype = ctypes.c_int
     return _probe
 
 

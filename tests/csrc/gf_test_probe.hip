@@ -34,3 +34,26 @@ extern "C" int gf_test_hold_cus(int n_cus, int milliseconds, void* stream) {
         (long long)milliseconds * khz, nullptr);
     return (int)hipGetLastError();
 }
+
+
+namespace {
+// fills a CU's whole LDS allocation (one 159 KB workgroup per CU) with a bit pattern and leaves: the next kernel on that CU finds it
+// there -- LDS is not cleared between kernels, so a kernel that reads shared memory it never wrote picks the pattern up
+__global__ __launch_bounds__(256) void dirty_lds_kernel(unsigned pattern, int words, unsigned* sink) {
+    extern __shared__ unsigned lds[];
+    for (int i = threadIdx.x; i < words; i += 256) lds[i] = pattern;
+    __syncthreads();
+    if (sink != nullptr && threadIdx.x == 0) sink[blockIdx.x] = lds[words - 1];
+}
+}  // namespace
+
+// every CU's LDS <- pattern (n_wg workgroups of 159 KB: one per CU when n_wg = the CU count, idle device)
+extern "C" int gf_test_dirty_lds(int n_wg, unsigned pattern, void* stream) {
+    if (n_wg < 1 || n_wg > 4096) return -1;
+    const int lds = 159 * 1024;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dirty_lds_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;
+    dirty_lds_kernel<<<dim3((unsigned)n_wg), 256, lds, reinterpret_cast<hipStream_t>(stream)>>>(pattern, lds / 4, nullptr);
+    return (int)hipGetLastError();
+}
