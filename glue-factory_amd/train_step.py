@@ -174,13 +174,13 @@ class TrainStep:
     def __init__(self, model, optimizer, amp_dtype=None, clip_grad=None, device_ids=None,
                  bucket_cap_mb=16, find_unused_parameters=False, check_grads=True, graph=False, graph_warmup=2,
                  reducer="buckets", force_distributed=False, deterministic_replay=False):
-        """deterministic_replay: wait for every hipGraph replay before returning.  A replayed step is bit-reproducible when it is
-        left alone, but on ROCm 7.2 what the HOST does while a replay is in flight can change its result at the rounding level --
-        measured (round 6, profiles/r06_graph_replay_determinism.txt): a blocking host-to-device copy from PAGEABLE memory
-        issued right after the replay was launched (any loop that builds and uploads the next batch) moves a SuperGlue /
-        GlueStick run off the eager run's numbers within a few steps (first in a parameter whose gradient is analytically
-        zero, which Adam amplifies), while the same loop launched kernel by kernel, or with this flag, reproduces the eager run
-        bit for bit.  Costs the overlap of host work with the step; the benchmark and training default leave it off.
+        """deterministic_replay: wait for every hipGraph replay before returning (the host then does nothing else while a
+        replay runs).  An option for loops that want that guarantee; it costs the overlap of host work with the step, the
+        benchmark and training default leave it off.  Background (profiles/r06_graph_replay_determinism.txt): the run-to-run
+        noise that prompted it turned out to be an asynchronous copy from PAGEABLE host memory racing with the loop that refilled
+        the batch (_async_ok below: asynchronous only from pinned memory); on the final tree replayed SuperGlue / GlueStick runs
+        are bit-reproducible over 300 steps under host-to-device copies, device copies, unrelated kernels, held CUs and dirtied
+        LDS alike, with and without this flag.
         force_distributed: take the multi-rank path (SyncBatchNorm conversion, gradient reducer, collectives) in a process
         group of ONE rank too -- how the RCCL calls of that path are exercised on a single-GPU box (tests/test_gpu_rccl_one_rank.py);
         every collective is then the identity, so the step must equal the plain single-process one."""

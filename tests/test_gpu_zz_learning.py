@@ -115,10 +115,10 @@ def test_matcher_learns_like_the_reference_on_fresh_synthetic_pairs(kind, bf16):
     model = _model(kind)
     before = _evaluate(kind, model, bf16)
     assert abs(before[0] - ref["before"][0]) < 3e-2 * max(1.0, ref["before"][0])       # same starting point as the reference's run
-    # deterministic_replay: this loop builds every batch on the CPU and uploads it from pageable memory while the previous
-    # replay may still be in flight -- which on ROCm 7.2 moves a replayed run off its own numbers at the rounding level
-    # (profiles/r06_graph_replay_determinism.txt); 300 chaotic steps turn that into run-to-run noise of the end state.  With
-    # the flag the run is bit-reproducible (and equal to the kernel-by-kernel run).
+    # deterministic_replay: this loop builds every batch on the CPU and uploads it while the previous replay may still be in
+    # flight; the host waits for every replay instead (belt and braces: on the final tree the run is bit-reproducible either
+    # way, profiles/r06_graph_replay_determinism.txt -- the noise this test once showed was an asynchronous copy from pageable
+    # memory, fixed in train_step._async_ok / synthetic.to_device).
     step = TrainStep(model, FusedAdam(model.parameters(), lr=lc.LR[kind]), amp_dtype=torch.bfloat16 if bf16 else None,
                      graph=True, graph_warmup=2, deterministic_replay=True)
     trace = []

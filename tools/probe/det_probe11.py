@@ -10,12 +10,14 @@ from glue_factory_amd.synthetic import to_device
 from glue_factory_amd.train_step import TrainStep
 kind, steps, nruns = "superglue", int(sys.argv[1]), int(sys.argv[2])
 noisy = os.environ.get("GF_SUB") == "h2d"
+det = os.environ.get("GF_DET") == "1"          # TrainStep(deterministic_replay=True): wait for every replay
 torch.set_num_threads(8)
 dev = [to_device(lc.batch(kind, 1000 + i), "cuda") for i in range(steps)]
 pre_cpu = torch.randn(8, 256, 256); pre_dev = torch.zeros(8, 256, 256, device="cuda")
 def run(noise):
     model = tl._model(kind)
-    step = TrainStep(model, FusedAdam(model.parameters(), lr=lc.LR[kind]), amp_dtype=torch.bfloat16, graph=True, graph_warmup=2)
+    step = TrainStep(model, FusedAdam(model.parameters(), lr=lc.LR[kind]), amp_dtype=torch.bfloat16, graph=True, graph_warmup=2,
+                     deterministic_replay=det)
     rec = []
     for i in range(steps):
         if noise: pre_dev.copy_(pre_cpu)
