@@ -157,3 +157,32 @@ def test_matcher_learns_like_the_reference_on_fresh_synthetic_pairs(kind, bf16):
             b = ref["learnt"]
             assert tm[0] < b["train_mode_loss_below"] and after[1] > b["precision_above"] and after[3] > b["line_precision_above"], (tm, after)
     step.close()
+
+
+@pytest.mark.parametrize("kind", ["superglue", "gluestick"])
+def test_replayed_run_with_uploads_in_the_loop_is_bit_reproducible(kind):
+    """The loop every training script runs -- build the next batch on the CPU and upload it while the previous hipGraph replay may
+    still be in flight, no host wait anywhere -- must give the same numbers twice, bit for bit: nothing on the replayed path may
+    depend on timing (atomics in gradient paths, workgroup placement of the resident Sinkhorn, what the host does meanwhile:
+    profiles/r06_graph_replay_determinism.txt).  (The input race round 6 fixed -- asynchronous copies from PAGEABLE host memory
+    reading a batch the loop had already refilled, train_step._async_ok / synthetic.to_device -- is timing dependent and does
+    not show in 40 steps of this loop; tools/probe/graph_input_race.py and op_h2d_race.py provoke it directly.)"""
+    from glue_factory_amd.optim import FusedAdam
+    from glue_factory_amd.train_step import TrainStep
+
+    def run():
+        model = _model(kind)
+        step = TrainStep(model, FusedAdam(model.parameters(), lr=lc.LR[kind]), amp_dtype=torch.bfloat16, graph=True, graph_warmup=2)
+        losses = []
+        for i in range(40):
+            out = step(_batch(kind, 2000 + i))             # (the device batch is dropped right away: its memory is reused)
+            losses.append(out["total"].clone())             # device-side: no host synchronisation in the loop
+        torch.cuda.synchronize()
+        assert step.skipped == 0
+        state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        step.close()
+        return torch.stack([v.float().mean() for v in losses]), state
+
+    (la, sa), (lb, sb) = run(), run()
+    assert torch.equal(la, lb), (la - lb).abs().max()
+    assert all(torch.equal(sa[k], sb[k]) for k in sa), [k for k in sa if not torch.equal(sa[k], sb[k])][:5]
