@@ -290,7 +290,15 @@ def test_nonfree_superpoint_randomized_keypoints_in_training_mode():
         b = model({"image": image})
         model.eval()
         e1, e2 = model({"image": image}), model({"image": image})
-    torch.testing.assert_close(e1["keypoints"], e2["keypoints"])                      # eval: deterministic top-k
+    # eval: the top-k, not a draw.  Two calls agree up to near-ties at the k-th score: the stock library convolutions of the 128 /
+    # 256-channel blocks (MIOpen, as in the reference) are not bit-reproducible from call to call -- fp32 outputs move by ~5e-7,
+    # the score map by ~1e-8 (tools/probe/conv_determinism.py, sp_eval_determinism.py) -- which swaps the 64th and 65th candidate of
+    # this sharpened detector once in a hundred calls (the exact comparison that stood here failed one suite run in ~10)
+    torch.testing.assert_close(e1["keypoint_scores"], e2["keypoint_scores"], rtol=0, atol=1e-6)
+    for i in range(image.shape[0]):
+        k1 = {tuple(k) for k in e1["keypoints"][i].round().long().tolist()}
+        k2 = {tuple(k) for k in e2["keypoints"][i].round().long().tolist()}
+        assert len(k1 & k2) >= 62, (i, len(k1 & k2))
     assert not torch.equal(a["keypoints"], b["keypoints"])                           # training: a draw per call
     for i in range(image.shape[0]):
         dets = {tuple(k) for k, s in zip(pool["keypoints"][i].round().long().tolist(), pool["keypoint_scores"][i].tolist()) if s > 0}
