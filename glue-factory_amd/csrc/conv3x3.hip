@@ -58,7 +58,8 @@ template <typename V> __device__ __forceinline__ void c3_tie(V& v) { asm volatil
 struct C3Params {
     const bf16_t* x; const bf16_t* w;        // x [B,H,W,64]; w [9][64 cout][64 cin]
     const float* bias; const float* scale; const float* shift;
-    bf16_t* y;                               // [B,H,W,64] or pooled [B,H/2,W/2,64]
+    bf16_t* y;                               // [B,H,W,64] or pooled [B,H/2,W/2,64]; pixel stride ldy >= 64 elements (a 64-channel
+    int ldy;                                 // slice of a wider channels-last tensor: one half of a 64 -> 128 block's output)
     int B, H, W, relu;
 };
 
@@ -152,14 +153,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c64_kernel(C3Params p) {
     constexpr int NSTORE = POOL ? 4 : 8;                    // store steps per thread and tile
     // element offset of this thread's 16-byte chunk inside its tile (step 0) -- a per-lane constant; step k adds whole
     // output rows (one, or two pooled ones), the tile's origin is uniform: one 32-bit add per store instead of ~8 instructions
-    const int st_off0 = POOL ? ((int)(threadIdx.x >> 7) * (p.W / 2) + ((int)(threadIdx.x >> 3) & 15)) * 64 + ((int)threadIdx.x & 7) * 8
-                             : ((int)(threadIdx.x >> 3)) * 64 + ((int)threadIdx.x & 7) * 8;
+    const int st_off0 = POOL ? ((int)(threadIdx.x >> 7) * (p.W / 2) + ((int)(threadIdx.x >> 3) & 15)) * p.ldy + ((int)threadIdx.x & 7) * 8
+                             : ((int)(threadIdx.x >> 3)) * p.ldy + ((int)threadIdx.x & 7) * 8;
     auto store_addr = [&](const Tile& t, int k) -> bf16_t* {
         if (!POOL) {
-            bf16_t* base = p.y + (((int64_t)t.b * p.H + t.y0 + k) * p.W + t.x0) * 64;                      // (uniform)
+            bf16_t* base = p.y + (((int64_t)t.b * p.H + t.y0 + k) * p.W + t.x0) * p.ldy;                   // (uniform)
             return base + st_off0;
         }
-        bf16_t* base = p.y + (((int64_t)t.b * (p.H / 2) + t.y0 / 2 + 2 * k) * (p.W / 2) + t.x0 / 2) * 64;   // (uniform)
+        bf16_t* base = p.y + (((int64_t)t.b * (p.H / 2) + t.y0 / 2 + 2 * k) * (p.W / 2) + t.x0 / 2) * p.ldy;   // (uniform)
         return base + st_off0;
     };
     // LDS byte address of (staging buffer sb, pixel opx, logical chunk c)
@@ -330,15 +331,23 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c64_kernel(C3Params p) {
 
 }  // namespace
 
+extern "C" int gf_conv3x3_c64_ld(const void* x, const void* w, const float* bias, const float* scale, const float* shift,
+                                 void* y, int64_t ldy, int B, int H, int W, int relu, int pool, int dtype, void* stream);
 extern "C" int gf_conv3x3_c64(const void* x, const void* w, const float* bias, const float* scale, const float* shift,
                               void* y, int B, int H, int W, int relu, int pool, int dtype, void* stream) {
+    return gf_conv3x3_c64_ld(x, w, bias, scale, shift, y, 64, B, H, W, relu, pool, dtype, stream);
+}
+extern "C" int gf_conv3x3_c64_ld(const void* x, const void* w, const float* bias, const float* scale, const float* shift,
+                                 void* y, int64_t ldy, int B, int H, int W, int relu, int pool, int dtype, void* stream) {
     if (B <= 0 || H <= 0 || W <= 0) return GF_ERR_SHAPE;
     if (dtype != GF_BF16) return GF_ERR_DTYPE;
     if (H % C3_TH || W % C3_TW) return GF_ERR_UNSUPPORTED;
     if ((int64_t)H * W * 128 >= (1ll << 31)) return GF_ERR_UNSUPPORTED;      // 32-bit byte offsets inside one image (buffer loads)
+    if (ldy < 64 || ldy % 8) return GF_ERR_ALIGN;                            // whole 16-byte chunks of a pixel
+    if ((int64_t)H * W * ldy >= (1ll << 31)) return GF_ERR_UNSUPPORTED;      // (32-bit element offsets inside one output image)
     C3Params p;
     p.x = static_cast<const bf16_t*>(x); p.w = static_cast<const bf16_t*>(w); p.bias = bias; p.scale = scale; p.shift = shift;
-    p.y = static_cast<bf16_t*>(y); p.B = B; p.H = H; p.W = W; p.relu = relu;
+    p.y = static_cast<bf16_t*>(y); p.ldy = (int)ldy; p.B = B; p.H = H; p.W = W; p.relu = relu;
     const size_t lds = C3_LDS;
     const int tiles = (W / C3_TW) * (H / C3_TH) * B;
     const int grid = tiles < 256 ? tiles : 256;            // one persistent workgroup per CU

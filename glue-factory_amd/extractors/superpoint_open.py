@@ -29,6 +29,9 @@ import torch.nn.functional as F
 from ..base_model import BaseModel, BatchedExtractionUnsupported
 
 
+WIDE64 = True       # the 64 -> 128 block on gf_conv3x3_c64_ld (two launches) instead of the library convolution + tail pass (A/B switch)
+
+
 def sample_descriptors(keypoints, descriptors, s=8):
     """Bilinear sampling of the dense descriptor map at keypoint locations, then L2 norm."""
     b, c, h, w = descriptors.shape
@@ -162,6 +165,12 @@ class SuperPoint(BaseModel):
                 if dtype == torch.bfloat16 and tuple(blk.conv.weight.shape) == (64, 64, 3, 3):
                     # [tap][c_out][c_in] for the register-resident weights of gf_conv3x3_c64
                     out[name + "/taps"] = blk.conv.weight.detach().permute(2, 3, 0, 1).to(dtype).contiguous()
+                if dtype == torch.bfloat16 and tuple(blk.conv.weight.shape) == (128, 64, 3, 3):
+                    # 64 -> 128 (backbone.2.0): the same kernel once per half of the output channels (gf_conv3x3_c64_ld)
+                    t = blk.conv.weight.detach().permute(2, 3, 0, 1).to(dtype)                  # [3, 3, 128, 64]
+                    out[name + "/taps2"] = [(t[:, :, 64 * h:64 * h + 64].contiguous(), out[name][1][64 * h:64 * h + 64].contiguous(),
+                                             scale[64 * h:64 * h + 64].contiguous(), shift[64 * h:64 * h + 64].contiguous())
+                                            for h in range(2)]
         caches[dtype] = (key, out)
         return out
 
@@ -202,6 +211,24 @@ class SuperPoint(BaseModel):
             x.data_ptr(), params[name + "/taps"].data_ptr(), bias.data_ptr(), scale.data_ptr(), shift.data_ptr(),
             out.data_ptr(), b, h, wd, int(isinstance(blk.activation, nn.ReLU)), int(pool), 1,
             torch.cuda.current_stream().cuda_stream), "gf_conv3x3_c64")
+        return out
+
+    def _conv64_wide_block(self, name, blk, x, params, pool):
+        """64 -> 128 channel 3x3 block in bf16 (backbone.2.0): gf_conv3x3_c64's kernel once per half of the output channels,
+        each writing its 64-channel slice of the [B, h, w, 128] output with the tail (bias, ReLU, BatchNorm(eval), pool)
+        fused -- instead of the library convolution + a tail pass over the output."""
+        from .. import lib as _lib
+        b, _, h, wd = x.shape
+        if not x.is_contiguous(memory_format=torch.channels_last):
+            x = x.contiguous(memory_format=torch.channels_last)
+        out = torch.empty((b, 128, h // 2, wd // 2) if pool else (b, 128, h, wd), dtype=x.dtype, device=x.device,
+                          memory_format=torch.channels_last)
+        relu = int(isinstance(blk.activation, nn.ReLU))
+        for half, (taps, bias, scale, shift) in enumerate(params[name + "/taps2"]):
+            _lib.check(_lib.load().gf_conv3x3_c64_ld(
+                x.data_ptr(), taps.data_ptr(), bias.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                out.data_ptr() + 64 * half * out.element_size(), 128, b, h, wd, relu, int(pool), 1,
+                torch.cuda.current_stream().cuda_stream), "gf_conv3x3_c64_ld")
         return out
 
     def _first_block(self, name, blk, x, params):
@@ -257,6 +284,9 @@ class SuperPoint(BaseModel):
                 elif name + "/taps" in params and x.shape[2] % 8 == 0 and x.shape[3] % 32 == 0 \
                         and x.shape[2] * x.shape[3] * 128 < 2 ** 31 and blk.conv.padding == (1, 1) and blk.conv.stride == (1, 1):
                     x = self._conv64_block(name, blk, x, params, pool)
+                elif WIDE64 and name + "/taps2" in params and x.shape[1] == 64 and x.shape[2] % 8 == 0 and x.shape[3] % 32 == 0 \
+                        and x.shape[2] * x.shape[3] * 256 < 2 ** 31 and blk.conv.padding == (1, 1) and blk.conv.stride == (1, 1):
+                    x = self._conv64_wide_block(name, blk, x, params, pool)
                 else:
                     x = self._fused_block(name, blk, x, params, pool=pool)
         (d0n, d0), (d1n, d1) = self._heads()[0]

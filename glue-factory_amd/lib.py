@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgf_amd.so")
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 16      # == GF_AMD_ABI_VERSION in include/gf_amd.h (bumped with every signature / workspace change)
+ABI_VERSION = 17      # == GF_AMD_ABI_VERSION in include/gf_amd.h (bumped with every signature / workspace change)
 
 _c = ctypes
 _P, _I, _F, _L, _D = _c.c_void_p, _c.c_int, _c.c_float, _c.c_int64, _c.c_double
@@ -80,6 +80,7 @@ SIGNATURES = {
     "gf_bias_act_bn_nhwc": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "gf_conv1_bias_act_bn": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "gf_conv3x3_c64": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "gf_conv3x3_c64_ld": [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P],
     "gf_nms_scores": [_P, _P, _I, _I, _I, _I, _I, _P],
     "gf_nms_candidates": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "gf_nms_candidates_cap": [_I, _I, _I],

@@ -36,8 +36,8 @@ extern "C" {
 #define GF_ERR_ALIGN (-3)
 #define GF_ERR_DTYPE (-4)
 
-/* ABI version; bumped on any signature or workspace-size change (2: gf_attn_bwd's delta workspace doubled; 3: line head + gf_bgemm; 4: smallops; 5: gf_attn_bwd_acc; 9: cast entries with leading dimensions, gf_fold_linear_*, double betas in gf_multi_adam; 10: gf_attn_fwd_ex / GF_ATTN_SPLIT, gf_topk_candidates; 14: gf_sinkhorn_* take `schedule`, gf_sinkhorn_mode removed, gf_probe_hold_cus, gf_linear_dw2, gf_gemm_res2, gf_rowdot2_*; gf_rowdot_fwd / gf_rotary_qk_bwd take a device bias / a base sum; 16: the test diagnostic gf_probe_hold_cus left the product ABI for tests/csrc/gf_test_probe.hip). */
-#define GF_AMD_ABI_VERSION 16
+/* ABI version; bumped on any signature or workspace-size change (2: gf_attn_bwd's delta workspace doubled; 3: line head + gf_bgemm; 4: smallops; 5: gf_attn_bwd_acc; 9: cast entries with leading dimensions, gf_fold_linear_*, double betas in gf_multi_adam; 10: gf_attn_fwd_ex / GF_ATTN_SPLIT, gf_topk_candidates; 14: gf_sinkhorn_* take `schedule`, gf_sinkhorn_mode removed, gf_probe_hold_cus, gf_linear_dw2, gf_gemm_res2, gf_rowdot2_*; gf_rowdot_fwd / gf_rotary_qk_bwd take a device bias / a base sum; 16: the test diagnostic gf_probe_hold_cus left the product ABI for tests/csrc/gf_test_probe.hip; 17: gf_conv3x3_c64_ld). */
+#define GF_AMD_ABI_VERSION 17
 int gf_abi_version(void);
 
 /* ---- multi-head attention over keypoints --------------------------------------------------
@@ -421,6 +421,12 @@ int gf_conv1_bias_act_bn(const void* img, const void* w, const float* bias, cons
  *   (GF_ERR_UNSUPPORTED: the caller uses the library convolution + gf_bias_act_bn_nhwc). */
 int gf_conv3x3_c64(const void* x, const void* w, const float* bias, const float* scale, const float* shift, void* y,
                    int B, int H, int W, int relu, int pool, int dtype, void* stream);
+/* gf_conv3x3_c64_ld (ABI 17): the same with the output's pixel stride ldy (elements, >= 64, % 8 == 0) as an argument: the kernel
+ *   writes the 64 channels of each pixel into a slice of a WIDER channels-last tensor -- a 64 -> 128 block (backbone.2.0,
+ *   superpoint_open.py:101-103) is two calls, one per half of the output channels (w / bias / scale / shift of that half,
+ *   y + 64 * half), tail fused, instead of the library convolution + a tail pass. */
+int gf_conv3x3_c64_ld(const void* x, const void* w, const float* bias, const float* scale, const float* shift, void* y,
+                      int64_t ldy, int B, int H, int W, int relu, int pool, int dtype, void* stream);
 int gf_nms_scores(const float* scores, float* out, int B, int H, int W, int radius, int border, void* stream);
 /* gf_nms_candidates: the same NMS, but instead of the dense map the surviving maxima with a POSITIVE score outside the
  * border go to per-image lists cand_scores / cand_idx [B, cap] (flat pixel index y W + x), cap = gf_nms_candidates_cap(H, W,

@@ -211,6 +211,38 @@ def test_conv3x3_c64_kernel(shape, pool):
     torch.testing.assert_close(out.float(), ref, rtol=8e-3, atol=8e-3)
 
 
+@pytest.mark.parametrize("pool", [False, True])
+@pytest.mark.parametrize("shape", [(2, 16, 96), (1, 256, 288)])
+def test_conv3x3_c64_into_a_wider_output(shape, pool):
+    """gf_conv3x3_c64_ld: a 64 -> 128 block (backbone.2.0, superpoint_open.py:101-103) as two launches of the 64 -> 64 kernel,
+    each writing its 64-channel slice of the [B, h, w, 128] channels-last output with the tail fused -- vs the stock fp32 ops
+    on the same bf16 inputs; the other half of every pixel must stay untouched by each launch."""
+    from glue_factory_amd import lib as L_
+    B, H, W = shape
+    g = torch.Generator(device="cuda").manual_seed(H * 5 + W)
+    x = torch.randn(B, 64, H, W, device="cuda", generator=g).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(128, 64, 3, 3, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+    bias, scale, shift = (torch.randn(128, device="cuda", generator=g) for _ in range(3))
+    ref = torch.nn.functional.conv2d(x.float(), w.float(), bias, padding=1)
+    ref = torch.relu(ref) * scale.view(1, 128, 1, 1) + shift.view(1, 128, 1, 1)
+    if pool:
+        ref = torch.nn.functional.max_pool2d(ref, 2, 2)
+    out = torch.full(ref.shape, 777.0, dtype=torch.bfloat16, device="cuda").contiguous(memory_format=torch.channels_last)
+    st = torch.cuda.current_stream().cuda_stream
+    for half in range(2):
+        sl = slice(64 * half, 64 * half + 64)
+        taps = w[sl].permute(2, 3, 0, 1).contiguous()
+        L_.check(L_.load().gf_conv3x3_c64_ld(x.data_ptr(), taps.data_ptr(), bias[sl].contiguous().data_ptr(),
+                                             scale[sl].contiguous().data_ptr(), shift[sl].contiguous().data_ptr(),
+                                             out.data_ptr() + 128 * half, 128, B, H, W, 1, int(pool), 1, st), "gf_conv3x3_c64_ld")
+        if half == 0:
+            assert bool((out[:, 64:] == 777.0).all())              # the other half of every pixel: not written
+    torch.testing.assert_close(out.float(), ref, rtol=8e-3, atol=8e-3)
+    z = torch.zeros(8, device="cuda")
+    assert L_.load().gf_conv3x3_c64_ld(z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(),
+                                       60, 1, 8, 32, 1, 0, 1, st) == -3            # GF_ERR_ALIGN: a pixel stride below 64 channels
+
+
 def test_conv3x3_c64_rejects():
     from glue_factory_amd import lib as L_
     z = torch.zeros(64, device="cuda")
