@@ -98,55 +98,102 @@ __global__ __launch_bounds__(256) void bias_act_bn_pool_kernel(const T* __restri
 // per-channel bias / scale / shift in registers; a wave's store covers 8 pixels x 128 contiguous bytes (C = 64 bf16).
 // The products are fp32 on the T-rounded image and weights (what the library computes from the same operands);
 // bias, ReLU and the batch-norm affine act on the fp32 sum -- one rounding.
+#ifndef C1_TY
+#define C1_TY 64            // tile rows and 32-pixel passes per row of a workgroup (tools/probe/time_conv1.py, 64 x 1024^2: 32x1 1.67 ms, 64x1 1.59, 128x1 1.60, 256x1 1.63, 8x4 1.75, 2x16 1.81)
+#endif
+#ifndef C1_NX
+#define C1_NX 1
+#endif
 template <typename T, bool RELU, int C>
 __global__ __launch_bounds__(256) void conv1_fused_kernel(const T* __restrict__ img, const T* __restrict__ wgt,
                                                           const float* __restrict__ bias, const float* __restrict__ scale,
                                                           const float* __restrict__ shift, T* __restrict__ out, int H, int W) {
     constexpr int CG = C / 8;                 // lanes per pixel (8 channels each)
-    constexpr int PX = 256 / CG;              // pixels per workgroup row
-    constexpr int TY = 32;
-    __shared__ float tile[(TY + 2) * (PX + 2)];
-    const int b = blockIdx.z, y0 = blockIdx.y * TY, x0 = blockIdx.x * PX;
+    constexpr int PX = 256 / CG;              // pixels per pass of the workgroup (32)
+    constexpr int TY = C1_TY, NX = C1_NX, TW = PX * NX;      // tile: TY rows x NX passes of PX pixels
+    __shared__ float tile[(TY + 2) * (TW + 2)];
+    const int b = blockIdx.z, y0 = blockIdx.y * TY, x0 = blockIdx.x * TW;
     const T* im = img + (int64_t)b * H * W;
-    for (int i = threadIdx.x; i < (TY + 2) * (PX + 2); i += 256) {
-        const int y = y0 - 1 + i / (PX + 2), x = x0 - 1 + i % (PX + 2);
+    for (int i = threadIdx.x; i < (TY + 2) * (TW + 2); i += 256) {
+        const int y = y0 - 1 + i / (TW + 2), x = x0 - 1 + i % (TW + 2);
         tile[i] = (y >= 0 && y < H && x >= 0 && x < W) ? to_f32(im[(int64_t)y * W + x]) : 0.f;
     }
     const int cg = threadIdx.x % CG, px = threadIdx.x / CG;
-    float w[8][9], bi[8], sc[8], sh[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-#pragma unroll
-        for (int t = 0; t < 9; ++t) w[c][t] = to_f32(wgt[(8 * cg + c) * 9 + t]);
-        bi[c] = bias[8 * cg + c];
-        sc[c] = scale[8 * cg + c];
-        sh[c] = shift[8 * cg + c];
-    }
-    __syncthreads();
-    const int x = x0 + px;
-    for (int ly = 0; ly < TY; ++ly) {
-        const int y = y0 + ly;
-        if (y >= H) break;
-        float v[9];
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-            for (int dx = 0; dx < 3; ++dx) v[3 * dy + dx] = tile[(ly + dy) * (PX + 2) + px + dx];
-        float o[8];
+    if constexpr (sizeof(T) == 2) {
+        // bf16: the nine products of a channel as five v_dot2c_f32_bf16 (pairs of taps; image and weights ARE bf16, the products
+        // are exact and the sums fp32 as before) on the bias as the initial value: 7 VALU instructions per output value where
+        // the fma form took 12.  Measured at 64 x 1024^2 (8.6 GB written; the box fills at 6.9 TB/s = 1.25 ms): 1.75 -> 1.67 ms,
+        // with 64-row tiles 1.59 ms = 5.4 TB/s -- the kernel is bound by its store stream, not by these instructions
+        typedef __bf16 c1_bf16x2 __attribute__((ext_vector_type(2)));
+        c1_bf16x2 wp[8][5];
+        float bi[8], sc[8], sh[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-            float a = 0.f;
+            const T* wc = wgt + (8 * cg + c) * 9;
 #pragma unroll
-            for (int t = 0; t < 9; ++t) a = fmaf(w[c][t], v[t], a);
-            a += bi[c];
-            if (RELU) a = fmaxf(a, 0.f);
-            o[c] = fmaf(a, sc[c], sh[c]);
+            for (int j = 0; j < 4; ++j) wp[c][j] = c1_bf16x2{wc[2 * j], wc[2 * j + 1]};
+            wp[c][4] = c1_bf16x2{wc[8], (T)0.f};
+            bi[c] = bias[8 * cg + c];
+            sc[c] = scale[8 * cg + c];
+            sh[c] = shift[8 * cg + c];
         }
-        if (x < W) {
-            T* dst = out + (((int64_t)b * H + y) * W + x) * C + 8 * cg;
-            if constexpr (sizeof(T) == 2) {
-                st_vec<T>(dst, o);
-            } else {
+        __syncthreads();
+        for (int it = 0; it < TY * NX; ++it) {
+            const int ly = it / NX, lx = (it % NX) * PX + px;
+            const int y = y0 + ly, x = x0 + lx;
+            if (y >= H) break;
+            float v[10];
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) v[3 * dy + dx] = tile[(ly + dy) * (TW + 2) + lx + dx];
+            v[9] = 0.f;
+            c1_bf16x2 vp[5];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) vp[j] = c1_bf16x2{(T)v[2 * j], (T)v[2 * j + 1]};     // exact: the tile holds bf16 values
+            float o[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                float a = bi[c];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) a = __builtin_amdgcn_fdot2_f32_bf16(wp[c][j], vp[j], a, false);
+                if (RELU) a = fmaxf(a, 0.f);
+                o[c] = fmaf(a, sc[c], sh[c]);
+            }
+            if (x < W) st_vec<T>(out + (((int64_t)b * H + y) * W + x) * C + 8 * cg, o);
+        }
+    } else {
+        float w[8][9], bi[8], sc[8], sh[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) w[c][t] = to_f32(wgt[(8 * cg + c) * 9 + t]);
+            bi[c] = bias[8 * cg + c];
+            sc[c] = scale[8 * cg + c];
+            sh[c] = shift[8 * cg + c];
+        }
+        __syncthreads();
+        for (int it = 0; it < TY * NX; ++it) {
+            const int ly = it / NX, lx = (it % NX) * PX + px;
+            const int y = y0 + ly, x = x0 + lx;
+            if (y >= H) break;
+            float v[9];
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) v[3 * dy + dx] = tile[(ly + dy) * (TW + 2) + lx + dx];
+            float o[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                float a = 0.f;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) a = fmaf(w[c][t], v[t], a);
+                a += bi[c];
+                if (RELU) a = fmaxf(a, 0.f);
+                o[c] = fmaf(a, sc[c], sh[c]);
+            }
+            if (x < W) {
+                T* dst = out + (((int64_t)b * H + y) * W + x) * C + 8 * cg;
                 st4(dst, o[0], o[1], o[2], o[3]);
                 st4(dst + 4, o[4], o[5], o[6], o[7]);
             }
@@ -573,7 +620,7 @@ extern "C" int gf_conv1_bias_act_bn(const void* img, const void* w, const float*
     if (C != 64) return GF_ERR_UNSUPPORTED;
     if (dtype != GF_F32 && dtype != GF_BF16) return GF_ERR_DTYPE;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    const dim3 grid((W + 31) / 32, (H + 31) / 32, B);
+    const dim3 grid((W + 32 * C1_NX - 1) / (32 * C1_NX), (H + C1_TY - 1) / C1_TY, B);
 #define GF_C1(T, RELU) conv1_fused_kernel<T, RELU, 64><<<grid, 256, 0, st>>>((const T*)img, (const T*)w, bias, scale, shift, (T*)out, H, W)
     if (dtype == GF_BF16) { if (relu) GF_C1(bf16_t, true); else GF_C1(bf16_t, false); }
     else { if (relu) GF_C1(float, true); else GF_C1(float, false); }
