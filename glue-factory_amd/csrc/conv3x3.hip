@@ -71,6 +71,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c64_kernel(C3Params p) {
     const int l31 = lane & 31, hi = lane >> 5;
     const int tx_n = p.W / C3_TW, ty_n = p.H / C3_TH;
     const int tiles = tx_n * ty_n * p.B;
+#ifndef C3_SKEW32
+#define C3_SKEW32 5         // (3 ... 17 measure the same, 4.88-4.94 ms; skews of the 16-tile rows of the 512^2 blocks: no gain)
+#endif
+    const int skew = tx_n % 32 == 0 ? C3_SKEW32 : 0;
 
     // ---- weights: A operands, lane = output channel 32 nt + l31, elements cin 16 ks + 8 hi .. + 8 of tap t
     // (all 72 fragments = 288 registers stay resident: 192 in the AGPRs next to the 64 accumulator registers, 96 in VGPRs)
@@ -106,7 +110,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_c64_kernel(C3Params p) {
         t.b = tile / (tx_n * ty_n);
         const int r = tile - t.b * (tx_n * ty_n);
         const int ty = r / tx_n;
-        t.y0 = ty * C3_TH; t.x0 = (r - ty * tx_n) * C3_TW;
+        // tile columns skewed by the tile row when a tile row is a multiple of 32 tiles (W = 1024: 128 KB per pixel row): with the
+        // plain order workgroup j -- XCD j % 8 -- works on tile column j % 32 for ever, i.e. every XCD reads the same 4 KB blocks
+        // of every row; measured 5.35 -> 4.92 ms at 64 x 1024^2 (and 4.74 on a 33-tile row), neutral or slightly worse for the
+        // 16- and 8-tile rows of the later blocks (tools/probe/time_conv3x3_shapes.py, -DC3_ORDER=...)
+        const int tx = (r - ty * tx_n + skew * ty) % tx_n;
+        t.y0 = ty * C3_TH; t.x0 = tx * C3_TW;
         return t;
     };
     // ---- input window DMA: piece q = wave + 4 i = LDS chunk positions [64 q, 64 q + 64) = window pixels 8 q .. 8 q + 7; the lane
